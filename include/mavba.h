@@ -1,0 +1,284 @@
+/*
+ * mavba.h — C ABI of the MI355X-native bundle-adjustment backend for MAVMAP.
+ *
+ * This is the drop-in boundary. The reference has exactly one function boundary
+ * for this path:
+ *
+ *   double bundle_adjustment(FeatureManager&, free_ids, fixed_ids, fixed_x_ids,
+ *                            options, point3D_errors, rotation_constraints,
+ *                            gcp_ids)        reference src/base3d/bundle_adjustment.h:221-230
+ *   double pose_refinement(rvec, tvec, camera_params, points2D, points3D,
+ *                          inlier_mask, options)  reference src/base3d/bundle_adjustment.h:212-218
+ *
+ * Both are C++ functions over Eigen/STL containers; everything below them is
+ * Ceres. A replacement translation unit (shim/base3d/bundle_adjustment.cc in
+ * this repo) flattens FeatureManager into the plain arrays declared here,
+ * calls mavba_solve()/mavba_pose_refine(), and writes the results back in
+ * place. No exceptions, no C++ types and no torch types cross this ABI.
+ *
+ * All floating point is FP64 (the reference is `double` throughout). Indices
+ * are 0-based int32 (the shim maps FeatureManager's 1-based size_t ids).
+ *
+ * The implementation behind this header is HIP for gfx950 only. There is no
+ * CPU fallback: every compute entry point returns MAVBA_ERR_NO_DEVICE when no
+ * GPU is present.
+ */
+#ifndef MAVBA_H_
+#define MAVBA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAVBA_VERSION 1
+
+/* Camera model codes — identical to the reference's CameraModel::code values
+ * (reference src/base3d/camera_models.h:106-109, 165-168, 272-275). */
+#define MAVBA_MODEL_PINHOLE 1 /* K = 4: fx fy cx cy                */
+#define MAVBA_MODEL_OPENCV 2  /* K = 8: fx fy cx cy k1 k2 p1 p2    */
+#define MAVBA_MODEL_CATA 3    /* K = 9: fx fy cx cy k1 k2 p1 p2 xi */
+#define MAVBA_MAX_INTR 9      /* stride of the intrinsics table    */
+
+/* Per-image constancy bitmask. The reference splits a pose into the Ceres
+ * parameter blocks rvec(3), tx(1), ty(1), tz(1) so that BA_POSE_FIXED_X can
+ * freeze tx alone (reference src/base3d/bundle_adjustment.h:125-128,
+ * bundle_adjustment.cc:361-385). */
+#define MAVBA_CONST_RVEC 1u
+#define MAVBA_CONST_TX 2u
+#define MAVBA_CONST_TY 4u
+#define MAVBA_CONST_TZ 8u
+#define MAVBA_CONST_POSE 15u /* BA_POSE_FIXED   */
+/* BA_POSE_FIXED_X == MAVBA_CONST_TX, BA_POSE_FREE == 0 */
+
+/* Return codes (negative = error). */
+#define MAVBA_OK 0
+#define MAVBA_ERR_INVALID_ARGUMENT (-1)
+#define MAVBA_ERR_NO_DEVICE (-2)   /* no gfx950 device / HIP runtime failure at init */
+#define MAVBA_ERR_HIP (-3)         /* a HIP call failed mid-flight (message via mavba_last_error) */
+#define MAVBA_ERR_OUT_OF_MEMORY (-4)
+#define MAVBA_ERR_BAD_INDEX (-5)   /* obs/image/camera index out of range */
+#define MAVBA_ERR_BAD_MODEL (-6)   /* camera model code not in {1,2,3}     */
+
+/* Termination types, mirroring the subset of ceres::SolverTerminationType the
+ * trust-region minimizer can produce (Ceres 1.8 semantics). */
+#define MAVBA_TERM_NO_CONVERGENCE 0      /* max_num_iterations reached      */
+#define MAVBA_TERM_FUNCTION_TOLERANCE 1
+#define MAVBA_TERM_GRADIENT_TOLERANCE 2
+#define MAVBA_TERM_PARAMETER_TOLERANCE 3 /* step or trust-region radius too small */
+#define MAVBA_TERM_NUMERICAL_FAILURE 4   /* too many consecutive invalid steps    */
+#define MAVBA_TERM_RUNNING (-1)          /* session only: not terminated yet       */
+
+/*
+ * The flattened problem. Caller owns every array. `poses`, `intrinsics` and
+ * `points` are read AND written in place (the reference hands Ceres raw
+ * double* into FeatureManager's hash-map nodes, bundle_adjustment.cc:311-317).
+ *
+ * Observations must already be filtered (min_track_len) and are given in the
+ * reference's residual-block order (FREE images, FIXED images, FIXED_X images;
+ * inside an image the image_to_points2D order — bundle_adjustment.cc:511-533).
+ * The order only fixes the meaning of `point_error` accumulation and the
+ * summation order of the CPU oracle; the device path re-sorts internally.
+ */
+typedef struct mavba_problem {
+  int32_t num_images;
+  int32_t num_cameras;
+  int32_t num_points;
+  int64_t num_obs;
+
+  double* poses;               /* [num_images][6]  rvec(3) then tvec(3); in/out   */
+  const uint8_t* pose_const;   /* [num_images]     MAVBA_CONST_* bitmask          */
+  const int32_t* image_camera; /* [num_images]     physical camera of each image  */
+
+  double* intrinsics;          /* [num_cameras][MAVBA_MAX_INTR]; first K used; in/out */
+  const int32_t* camera_model; /* [num_cameras]    MAVBA_MODEL_*                  */
+  const uint8_t* intr_const;   /* [num_cameras]    1 = intrinsics held constant   */
+
+  double* points;              /* [num_points][3]; in/out                         */
+  const uint8_t* point_const;  /* [num_points] 1 = held constant (GCP); may be NULL */
+
+  const double* obs_uv;        /* [num_obs][2]     measured pixel                 */
+  const int32_t* obs_image;    /* [num_obs]                                        */
+  const int32_t* obs_point;    /* [num_obs]                                        */
+
+  /* Rotation-prior residuals, one scalar residual per listed image, NULL loss
+   * (reference BARotationConstraintCostFunction, bundle_adjustment.cc:57-111,
+   * added for FREE images only at :428-444). */
+  int32_t num_rot_priors;
+  const int32_t* rot_prior_image; /* [num_rot_priors]                             */
+  const double* rot_prior_rvec;   /* [num_rot_priors][3]  rvec0                   */
+  double rot_prior_weight;
+} mavba_problem;
+
+/*
+ * Solver options. The first block mirrors BundleAdjustmentOptions
+ * (reference src/base3d/bundle_adjustment.h:38-114); the second block are the
+ * Ceres-Solver defaults the reference never overrides, kept
+ * here so tests can pin them. Always start from mavba_options_init().
+ */
+typedef struct mavba_options {
+  int32_t max_num_iterations;   /* 100  */
+  double function_tolerance;    /* 1e-4 */
+  double gradient_tolerance;    /* 1e-8 (relative to the initial max|g|)          */
+  double loss_scale_factor;     /* 1.0  Cauchy scale a; rho(s) = a^2 log(1+s/a^2)  */
+  int32_t update_point_errors;  /* 0    fill point_error (needs non-NULL array)   */
+  int32_t print_progress;       /* 0    per-iteration table on stdout              */
+
+  double parameter_tolerance;               /* 1e-8  */
+  double initial_trust_region_radius;       /* 1e4   */
+  double max_trust_region_radius;           /* 1e16  */
+  double min_trust_region_radius;           /* 1e-32 */
+  double min_relative_decrease;             /* 1e-3  */
+  double min_lm_diagonal;                   /* 1e-6  */
+  double max_lm_diagonal;                   /* 1e32  */
+  int32_t max_num_consecutive_invalid_steps; /* 10 (bundle_adjustment.cc:559)      */
+  int32_t jacobi_scaling;                   /* 1     */
+
+  int32_t device;               /* HIP device ordinal; -1 = current device         */
+  int32_t profile_kernels;      /* 1 = bracket kernels with HIP events (bench)     */
+} mavba_options;
+
+typedef struct mavba_result {
+  double initial_cost;           /* 1/2 sum rho(|r|^2), incl. fixed cost           */
+  double final_cost;
+  double fixed_cost;             /* cost of residual blocks with no free parameter */
+  int64_t num_residuals;         /* 2*num_obs + num_rot_priors                     */
+  int64_t num_residuals_reduced;
+  int64_t num_parameters_reduced;
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t termination;           /* MAVBA_TERM_*                                   */
+  double final_gradient_max_norm;
+  double final_trust_region_radius;
+  double setup_seconds;          /* host indexing + upload                          */
+  double solve_seconds;          /* LM loop                                         */
+} mavba_result;
+
+void mavba_options_init(mavba_options* opt);
+
+/* Human-readable message of the last failing call on this thread. */
+const char* mavba_last_error(void);
+
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int mavba_device_count(void);
+
+/*
+ * One-shot global/local BA: upload, solve, write parameters back into
+ * problem->poses/intrinsics/points. `point_error` (may be NULL) receives, for
+ * every point, sum over its observations of |r_raw| / (number of its
+ * observations in the problem) — bundle_adjustment.cc:575-598 — and is left
+ * untouched for points without observations.
+ * Replaces: the body of bundle_adjustment(), bundle_adjustment.cc:473-612.
+ */
+int mavba_solve(const mavba_problem* problem, const mavba_options* options,
+                mavba_result* result, double* point_error);
+
+/*
+ * Single-camera 6-DoF refinement with points and intrinsics held constant.
+ * `uv` [n][2], `xyz` [n][3], `inlier_mask` [n] (NULL = all inliers).
+ * Replaces: pose_refinement(), bundle_adjustment.cc:139-225.
+ */
+int mavba_pose_refine(double rvec[3], double tvec[3], const double* intrinsics,
+                      int32_t camera_model, const double* uv, const double* xyz,
+                      const uint8_t* inlier_mask, int64_t n,
+                      const mavba_options* options, mavba_result* result);
+
+/* ------------------------------------------------------------------------
+ * Session API: the same solver with device-resident state, for callers that
+ * iterate (local BA after every image), for the parity tests (intermediate
+ * quantities) and for bench.py (inputs resident in HBM before timing starts).
+ * ---------------------------------------------------------------------- */
+typedef struct mavba_session mavba_session;
+
+int mavba_session_create(const mavba_problem* problem,
+                         const mavba_options* options, mavba_session** out);
+void mavba_session_destroy(mavba_session* s);
+
+/* Restore the parameters given at creation and reset the LM state. */
+int mavba_session_reset(mavba_session* s);
+
+/* Run LM iterations until termination or until `max_iters` more iterations
+ * have been done; returns the number done in *iters_done. A terminated
+ * session does nothing until reset. */
+int mavba_session_iterate(mavba_session* s, int32_t max_iters,
+                          int32_t* iters_done, int32_t* termination);
+
+/* Summary so far (costs, counts, termination). */
+int mavba_session_result(mavba_session* s, mavba_result* result);
+
+/* Copy current parameters to the host arrays (any may be NULL). */
+int mavba_session_get_params(mavba_session* s, double* poses,
+                             double* intrinsics, double* points);
+
+/* Per-point mean raw reprojection error at the current parameters. */
+int mavba_session_point_errors(mavba_session* s, double* point_error);
+
+/*
+ * Multi-GPU hook. When the points are sharded over several processes (one
+ * per GPU), every rank holds all cameras and a disjoint subset of points and
+ * observations; the reduced camera system and a handful of scalars must be
+ * summed over ranks once per linear solve. The session calls `fn` with a
+ * device pointer to `count` contiguous doubles that must be all-reduced in
+ * place (op 0 = sum, 1 = max) before `fn` returns. The stream the session
+ * works on is idle while `fn` runs. With no hook set the session is
+ * single-rank.
+ */
+typedef int (*mavba_allreduce_fn)(void* ctx, void* device_ptr, int64_t count,
+                                  int32_t op);
+int mavba_session_set_allreduce(mavba_session* s, mavba_allreduce_fn fn,
+                                void* ctx, int32_t rank, int32_t world_size);
+
+/* ---- probes used by tests/ and bench.py -------------------------------- */
+
+/* Evaluate residuals + Jacobians at the current parameters (the Jacobian
+ * sweep) and download them in the caller's observation order:
+ *   r  [num_obs][2]        loss-corrected residual
+ *   Jc [num_obs][2][6]     d r / d (rvec, t)
+ *   Jp [num_obs][2][3]     d r / d point
+ *   Jk [num_obs][2][9]     d r / d intrinsics (columns >= K are 0)
+ * Any output may be NULL. *cost receives 1/2 sum rho. */
+int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r,
+                                double* Jc, double* Jp, double* Jk);
+
+/* Build the reduced camera system for the current Jacobian and trust-region
+ * radius and download it: S [n][n] row-major (both triangles), v [n], with
+ * n = mavba_session_reduced_dim(). Column j of image i's pose is 6*i+j,
+ * intrinsic k of camera c is 6*num_images + 9*c + k; constant / unused
+ * columns have S_jj = 1, v_j = 0. */
+int mavba_session_reduced_dim(mavba_session* s);
+int mavba_session_reduced_system(mavba_session* s, double radius, double* S,
+                                 double* v);
+
+/* Solve the current LM linear system at `radius` and download the
+ * (Jacobi-unscaled) step: d_poses [num_images][6], d_intr [num_cameras][9],
+ * d_points [num_points][3]; *model_cost_change as used by the step test. */
+int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses,
+                              double* d_intr, double* d_points,
+                              double* model_cost_change);
+
+/* Time `reps` back-to-back launches of the Jacobian-sweep kernel alone with
+ * HIP events on the session's stream; *ms_avg = average per launch. */
+int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg);
+
+/* Per-kernel event timings accumulated while options.profile_kernels != 0.
+ * Returns the number of kernels; fills up to `cap` entries. */
+typedef struct mavba_kernel_stat {
+  char name[48];
+  int64_t launches;
+  double total_ms;
+} mavba_kernel_stat;
+int mavba_session_kernel_stats(mavba_session* s, mavba_kernel_stat* out,
+                               int32_t cap);
+
+/* Dense SPD solve used for the reduced camera system, exposed for tests:
+ * solves A x = b, A [n][n] row-major symmetric positive definite (host
+ * arrays). Returns MAVBA_ERR_INVALID_ARGUMENT if A is not numerically SPD. */
+int mavba_dense_spd_solve(int32_t n, const double* A, const double* b,
+                          double* x, int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAVBA_H_ */
