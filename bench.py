@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py — LM iterations / second of the MI355X bundle-adjustment backend.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3]
+
+A "step" is ONE Levenberg-Marquardt iteration of the reference's global BA (Jacobian sweep when the
+previous step was accepted, Schur complement, dense reduced solve, back-substitution, candidate
+cost, accept/reject) on the synthetic configuration named in `config.workload`. The session keeps
+the problem resident in HBM; when a solve terminates inside the timed region the parameters are
+reset to the perturbed start (a device-to-device copy) and the next solve begins, so every timed
+step is a real iteration of a real solve. With N > 1 the 3-D points (and their observations) are
+sharded over the ranks and the reduced camera system is all-reduced over RCCL once per iteration.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak
+
+WORKLOADS = {
+    "C2": "C2: 100 images / 30000 points / 300000 obs global BA, PINHOLE, 1 shared camera",
+    "C3": "C3: 500 images / 200000 points / 2000000 obs global BA, PINHOLE+OPENCV, 2 shared cameras",
+    "C5": "C5: 2000 images / 1000000 points / ~10M obs global BA, PINHOLE+OPENCV, rotation priors, long tracks",
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_work(stats_name, prob, sess_info):
+    """(bound, amount per launch, unit) of one kernel — SURVEY.md §8(d) figures, stated in DESIGN.md."""
+    from mavmap_amd import _abi as A
+    n_obs, n_pts = prob.num_obs, prob.num_points
+    K = np.array([A.MODEL_NUM_PARAMS[int(m)] for m in prob.camera_model])
+    k_obs = K[prob.image_camera[prob.obs_image]]
+    if stats_name == "jacobian_sweep":
+        return "hbm", float(np.sum(48 + 16 + 2 * (9 + k_obs) * 8)), "B"
+    if stats_name == "cost_only":
+        return "hbm", 48.0 * n_obs, "B"
+    if stats_name == "point_sums":
+        return "hbm", 64.0 * n_obs + 72.0 * n_pts, "B"
+    if stats_name == "camera_sweep":
+        return "hbm", 44.0 * n_obs, "B"
+    if stats_name == "entries_pose":
+        return "hbm", (96 + 48 + 8 + 192.0) * n_obs, "B"
+    if stats_name == "backsub_points":
+        return "hbm", 192.0 * n_obs + 48.0 * n_pts, "B"
+    if stats_name == "schur_chunks_pp":
+        return "hbm", 296.0 * sess_info["terms_pp"], "B"
+    if stats_name == "dense_cholesky":
+        n = sess_info["n_reduced"]
+        return "mfma", n ** 3 / 3.0 + 2.0 * n * n, "FLOP"
+    return None, 0.0, ""
+
+
+def count_pp_terms(prob):
+    """Number of (observation, observation) pairs inside a point with image(a) >= image(b)."""
+    order = np.argsort(prob.obs_point, kind="stable")
+    cnt = np.bincount(prob.obs_point, minlength=prob.num_points).astype(np.int64)
+    return int(np.sum(cnt * (cnt + 1) // 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--config", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        log("bench.py: no GPU visible — the mavba backend has no CPU path")
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import mavmap_amd
+    from mavmap_amd import synth, _abi as A
+    mavmap_amd.load()
+
+    t0 = time.time()
+    full = synth.make_config(args.config, scale=args.scale)
+    prob, _ = full.shard_by_point(rank, world)
+    log(f"[rank {rank}] scene {args.config}: {full.num_images} images / {full.num_points} points / "
+        f"{full.num_obs} obs (this rank: {prob.num_points} points / {prob.num_obs} obs), generated in {time.time() - t0:.1f}s")
+
+    opts = dict(max_num_iterations=200, function_tolerance=1e-6, gradient_tolerance=1e-10,  # mapper.cc:170-174
+                device=local_rank, profile_kernels=1)
+    sess = mavmap_amd.Session(prob, opts)
+
+    hip = None
+    stage = {}
+    if world > 1:
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        hip.hipMemcpy.restype = ctypes.c_int
+
+        def allreduce(ptr, count, op):
+            buf = stage.get(count)
+            if buf is None:
+                buf = stage[count] = torch.empty(count, dtype=torch.float64, device=f"cuda:{local_rank}")
+            assert hip.hipMemcpy(buf.data_ptr(), ptr, count * 8, 3) == 0
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            assert hip.hipMemcpy(ptr, buf.data_ptr(), count * 8, 3) == 0
+
+        sess.set_allreduce(allreduce, rank, world)
+
+    def run_steps(k):
+        remaining, solves, idle = k, 0, 0
+        while remaining > 0:
+            done, term = sess.iterate(remaining)
+            remaining -= done
+            idle = idle + 1 if done == 0 else 0
+            if idle > 2:
+                raise RuntimeError("bench: solver makes no progress")
+            if term != A.TERM_RUNNING:
+                solves += 1
+                if remaining > 0:
+                    sess.reset()
+        return solves
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    stats0 = sess.kernel_stats()
+    barrier()
+    t_start = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats1 = sess.kernel_stats()
+
+    # one complete solve for the record (RMSE, iteration count, setup time)
+    sess.reset()
+    final = sess.solve()
+    rmse = float(np.sqrt(final["final_cost"] / max(final["num_residuals"], 1)))
+
+    if rank == 0:
+        per = {}
+        for name, s1 in stats1.items():
+            s0 = stats0.get(name, dict(launches=0, total_ms=0.0))
+            n, ms = s1["launches"] - s0["launches"], s1["total_ms"] - s0["total_ms"]
+            if n > 0:
+                per[name] = dict(launches=n, total_ms=ms, avg_ms=ms / n)
+        info = dict(n_reduced=6 * prob.num_images + 9 * prob.num_cameras - 7, terms_pp=count_pp_terms(prob))
+        tot_ms = sum(v["total_ms"] for v in per.values()) or 1.0
+        table = []
+        for name, v in sorted(per.items(), key=lambda kv: -kv[1]["total_ms"]):
+            bound, amount, unit = algorithmic_work(name, prob, info)
+            row = dict(kernel=name, launches=v["launches"], avg_ms=round(v["avg_ms"], 5),
+                       share=round(v["total_ms"] / tot_ms, 4))
+            if bound == "hbm":
+                ach = amount / (v["avg_ms"] * 1e-3) / 1e9
+                row.update(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                           frac=round(ach / HBM_PEAK_GBS, 4), algorithmic_bytes=amount)
+            elif bound == "mfma":
+                ach = amount / (v["avg_ms"] * 1e-3) / 1e12
+                row.update(bound="mfma", achieved=round(ach, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                           frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), algorithmic_flops=amount)
+            table.append(row)
+            log("  {kernel:18s} n={launches:5d} avg={avg_ms:9.4f} ms share={share:6.1%}  ".format(**row) +
+                (f"{row['achieved']} {row['unit']} ({row['frac']:.1%} of {row['bound']} peak)" if bound else ""))
+        dominant = next((r for r in table if r.get("bound")), None)
+        roofline = None
+        if dominant:
+            roofline = dict(kernel=dominant["kernel"], bound=dominant["bound"], achieved=dominant["achieved"],
+                            peak=dominant["peak"], unit=dominant["unit"], frac=dominant["frac"], traffic=None)
+        sweep = next((r for r in table if r["kernel"] == "jacobian_sweep"), None)
+
+        cpu_baseline = None
+        if world == 1 and not args.no_cpu_baseline:
+            from tests import oracle_lib
+            cores = oracle_lib.max_threads()
+            oracle_lib.set_threads(cores)
+            q = full.copy()
+            o = oracle_lib.options(max_num_iterations=args.cpu_iters, function_tolerance=1e-6, gradient_tolerance=1e-10)
+            tc = time.time()
+            ro, _ = oracle_lib.solve(q, o, jac_mode=1)
+            its = ro["num_successful_steps"] + ro["num_unsuccessful_steps"]
+            cpu_baseline = dict(value=round(its / ro["solve_seconds"], 4), unit="iter/s", cores=cores, kind="port",
+                                sample=f"first {its} LM iterations of the same {args.config} solve by the CPU oracle "
+                                       f"(analytic Jacobians, OpenMP, dense Schur + Cholesky), {ro['solve_seconds']:.1f}s "
+                                       f"of {time.time() - tc:.1f}s wall")
+            log("cpu_baseline:", cpu_baseline)
+
+        value = args.steps / elapsed
+        out = {
+            "metric": "global-BA LM iterations/sec", "value": round(value, 3), "unit": "iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.config] + ("" if args.scale == 1.0 else f" (scaled x{args.scale})"),
+                       "images": full.num_images, "points": full.num_points, "observations": full.num_obs,
+                       "parallelism": "single GPU" if world == 1 else f"points sharded over {world} ranks, "
+                       "RCCL all-reduce of the reduced camera system",
+                       "options": "max_iter 200, ftol 1e-6, gtol 1e-10, ptol 1e-8, Cauchy a=1, refine intrinsics"},
+            "roofline": roofline,
+            "jacobian_sweep": None if not sweep else {
+                "obs_per_sec": round(prob.num_obs / (sweep["avg_ms"] * 1e-3), 1), "avg_ms": sweep["avg_ms"],
+                "bound": "hbm", "achieved": sweep["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": sweep["frac"], "note": "algorithmic bytes 48 + 16 + 2*(9+K)*8 per observation, this rank"},
+            "cpu_baseline": cpu_baseline,
+            "kernels": table,
+            "solve": {"iterations": final["num_successful_steps"] + final["num_unsuccessful_steps"],
+                      "termination": final["termination_name"], "rmse_px": round(rmse, 6),
+                      "solve_seconds": round(final["solve_seconds"], 4), "setup_seconds": round(final["setup_seconds"], 4)},
+        }
+        print(json.dumps(out), flush=True)
+    sess.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,9 @@
+"""mavmap_amd — MI355X-native bundle-adjustment backend for MAVMAP (hot path only).
+
+Only what the path needs lives here: csrc/ (HIP kernels + the C ABI of include/mavba.h),
+the ctypes binding (api), the flat problem container and the synthetic scene generator.
+"""
+from . import _abi  # noqa: F401
+from .problem import BAProblem  # noqa: F401
+from .api import (BundleAdjustmentOptions, MavbaError, Session, bundle_adjustment,  # noqa: F401
+                  pose_refinement, device_count, dense_spd_solve, load, lib_path)

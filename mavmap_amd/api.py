@@ -1,0 +1,304 @@
+"""Python binding of the C ABI in include/mavba.h (ctypes; no torch types at the boundary).
+
+Host-side mirror of the reference's bundle-adjustment interface
+(reference src/base3d/bundle_adjustment.h:38-114, 212-230):
+
+    BundleAdjustmentOptions      -> options dict / mavmap_amd.BundleAdjustmentOptions
+    bundle_adjustment(...)       -> bundle_adjustment(problem, options)   (flat problem instead
+                                    of FeatureManager; the C++ shim does the flattening for MAVMAP)
+    pose_refinement(...)         -> pose_refinement(rvec, tvec, camera_params, points2D, points3D,
+                                    inlier_mask, options)
+
+There is no CPU fallback: without the built HIP library, or without a GPU, every compute call
+raises MavbaError.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _abi as A
+from .problem import BAProblem
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmavba.so")
+_lib = None
+
+EXPORTED_SYMBOLS = [
+    "mavba_options_init", "mavba_last_error", "mavba_device_count", "mavba_solve", "mavba_pose_refine",
+    "mavba_session_create", "mavba_session_destroy", "mavba_session_reset", "mavba_session_iterate",
+    "mavba_session_result", "mavba_session_get_params", "mavba_session_point_errors",
+    "mavba_session_set_allreduce", "mavba_session_eval_jacobian", "mavba_session_reduced_dim",
+    "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian",
+    "mavba_session_kernel_stats", "mavba_dense_spd_solve",
+]
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+
+
+class MavbaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mavba error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libmavba.so (raises MavbaError if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MavbaError(A.ERR_NO_DEVICE, f"{_LIB_PATH} is missing: run `python -m mavmap_amd.build` "
+                                          "(the HIP extension is mandatory, there is no CPU fallback)")
+    L = C.CDLL(_LIB_PATH)
+    dp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    pp, op, rp = C.POINTER(A.CProblem), C.POINTER(A.COptions), C.POINTER(A.CResult)
+    sp = C.c_void_p
+    L.mavba_options_init.argtypes = [op]
+    L.mavba_options_init.restype = None
+    L.mavba_last_error.restype = C.c_char_p
+    L.mavba_device_count.restype = C.c_int
+    L.mavba_solve.argtypes = [pp, op, rp, dp]
+    L.mavba_pose_refine.argtypes = [dp, dp, dp, C.c_int32, dp, dp, bp, C.c_int64, op, rp]
+    L.mavba_session_create.argtypes = [pp, op, C.POINTER(sp)]
+    L.mavba_session_destroy.argtypes = [sp]
+    L.mavba_session_destroy.restype = None
+    L.mavba_session_reset.argtypes = [sp]
+    L.mavba_session_iterate.argtypes = [sp, C.c_int32, ip, ip]
+    L.mavba_session_result.argtypes = [sp, rp]
+    L.mavba_session_get_params.argtypes = [sp, dp, dp, dp]
+    L.mavba_session_point_errors.argtypes = [sp, dp]
+    L.mavba_session_set_allreduce.argtypes = [sp, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32]
+    L.mavba_session_eval_jacobian.argtypes = [sp, dp, dp, dp, dp, dp]
+    L.mavba_session_reduced_dim.argtypes = [sp]
+    L.mavba_session_reduced_system.argtypes = [sp, C.c_double, dp, dp]
+    L.mavba_session_linear_step.argtypes = [sp, C.c_double, dp, dp, dp, dp]
+    L.mavba_session_time_jacobian.argtypes = [sp, C.c_int32, C.POINTER(C.c_float)]
+    L.mavba_session_kernel_stats.argtypes = [sp, C.POINTER(A.CKernelStat), C.c_int32]
+    L.mavba_dense_spd_solve.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
+    for f in EXPORTED_SYMBOLS:
+        if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy"):
+            getattr(L, f).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != A.OK:
+        raise MavbaError(rc, load().mavba_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return int(load().mavba_device_count())
+
+
+def _d(a):
+    return A.ptr(a, C.c_double)
+
+
+@dataclass
+class BundleAdjustmentOptions:
+    """Field-for-field mirror of the reference struct (bundle_adjustment.h:38-114)."""
+    max_num_iterations: int = 100
+    function_tolerance: float = 1e-4
+    gradient_tolerance: float = 1e-8
+    update_point3D_errors: bool = False
+    min_track_len: int = 2
+    loss_scale_factor: float = 1.0
+    constrain_rotation: bool = False
+    constrain_rotation_weight: float = 0.0
+    refine_camera_params: bool = False
+    print_progress: bool = False
+    print_summary: bool = True
+
+    @staticmethod
+    def global_ba():
+        """The values mapper.cc forces for global BA (reference src/mapper.cc:170-174, 878-881)."""
+        return BundleAdjustmentOptions(max_num_iterations=200, function_tolerance=1e-6,
+                                       gradient_tolerance=1e-10, update_point3D_errors=True,
+                                       refine_camera_params=True, print_summary=False)
+
+
+def make_options(opts=None, **kw):
+    """COptions from a BundleAdjustmentOptions / dict plus overrides of the C-level fields."""
+    o = A.COptions()
+    load().mavba_options_init(C.byref(o))
+    if isinstance(opts, BundleAdjustmentOptions):
+        o.max_num_iterations = int(opts.max_num_iterations)
+        o.function_tolerance = float(opts.function_tolerance)
+        o.gradient_tolerance = float(opts.gradient_tolerance)
+        o.loss_scale_factor = float(opts.loss_scale_factor)
+        o.update_point_errors = int(bool(opts.update_point3D_errors))
+        o.print_progress = int(bool(opts.print_progress))
+    elif isinstance(opts, dict):
+        kw = {**opts, **kw}
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
+def print_report(res, title="Bundle Adjustment Report"):
+    """stdout report in the reference's format (_print_report, bundle_adjustment.cc:114-136)."""
+    n = max(res["num_residuals"], 1)
+    print(title)
+    print("-" * len(title))
+    print(f"{'Residuals : ':>18}{res['num_residuals_reduced']}")
+    print(f"{'Parameters : ':>18}{res['num_parameters_reduced']}")
+    print(f"{'Iterations : ':>18}{res['num_successful_steps'] + res['num_unsuccessful_steps']}")
+    print(f"{'Initial cost : ':>18}{np.sqrt(res['initial_cost'] / n):.6g} [px]")
+    print(f"{'Final cost : ':>18}{np.sqrt(res['final_cost'] / n):.6g} [px]")
+    print()
+
+
+def bundle_adjustment(problem: BAProblem, options=None, point3D_errors=None, **kw):
+    """Solve IN PLACE on `problem` (the reference mutates FeatureManager in place).
+
+    Returns (final_cost_px, result) where final_cost_px = sqrt(final_cost / num_residuals)
+    (the reference's return value, bundle_adjustment.cc:610) and `result` the summary dict.
+    `point3D_errors`: optional float64 array [num_points], updated like the reference's map when
+    options.update_point3D_errors is set.
+    """
+    if isinstance(options, BundleAdjustmentOptions):
+        if options.min_track_len < 2:
+            raise ValueError("Minimum track length must be >= 2 in order build valid bundle adjustment problem.")
+    copt = make_options(options, **kw)
+    res = A.CResult()
+    cp = problem.c_struct()
+    perr = None
+    if point3D_errors is not None:
+        copt.update_point_errors = 1
+        perr = _d(point3D_errors)
+    _check(load().mavba_solve(C.byref(cp), C.byref(copt), C.byref(res), perr))
+    out = res.as_dict()
+    if isinstance(options, BundleAdjustmentOptions) and options.print_summary:
+        print_report(out)
+    return float(np.sqrt(out["final_cost"] / out["num_residuals"])) if out["num_residuals"] else float("nan"), out
+
+
+def pose_refinement(rvec, tvec, camera_params, points2D, points3D, inlier_mask=None, options=None, **kw):
+    """Mirror of pose_refinement() (bundle_adjustment.h:212-218). `camera_params` carries the model
+    code as its last element, exactly like FeatureManager.camera_params
+    (reference src/sfm/sequential_mapper.cc:958-967). rvec/tvec are updated in place."""
+    camera_params = np.asarray(camera_params, float)
+    model = int(camera_params[-1])
+    intr = A.as_f64(np.pad(camera_params[:-1], (0, 9 - (len(camera_params) - 1))))
+    uv, xyz = A.as_f64(points2D, (-1, 2)), A.as_f64(points3D, (-1, 3))
+    mask = None if inlier_mask is None else np.ascontiguousarray(inlier_mask, dtype=np.uint8)
+    rv, tv = A.as_f64(rvec), A.as_f64(tvec)
+    copt = make_options(options, **kw)
+    res = A.CResult()
+    _check(load().mavba_pose_refine(_d(rv), _d(tv), _d(intr), model, _d(uv), _d(xyz),
+                                    A.ptr(mask, C.c_uint8), len(uv), C.byref(copt), C.byref(res)))
+    np.asarray(rvec)[...] = rv
+    np.asarray(tvec)[...] = tv
+    out = res.as_dict()
+    return float(np.sqrt(out["final_cost"] / out["num_residuals"])) if out["num_residuals"] else float("nan"), out
+
+
+class Session:
+    """Device-resident solver state (mavba_session_*)."""
+
+    def __init__(self, problem: BAProblem, options=None, **kw):
+        self.problem = problem
+        self.copt = make_options(options, **kw)
+        self._cp = problem.c_struct()
+        self._h = C.c_void_p()
+        self._cb = None
+        _check(load().mavba_session_create(C.byref(self._cp), C.byref(self.copt), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().mavba_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def reset(self):
+        _check(load().mavba_session_reset(self._h))
+
+    def iterate(self, max_iters=1):
+        done, term = C.c_int32(), C.c_int32()
+        _check(load().mavba_session_iterate(self._h, int(max_iters), C.byref(done), C.byref(term)))
+        return done.value, term.value
+
+    def solve(self):
+        self.iterate(self.copt.max_num_iterations + 1)
+        return self.result()
+
+    def result(self):
+        r = A.CResult()
+        _check(load().mavba_session_result(self._h, C.byref(r)))
+        return r.as_dict()
+
+    def get_params(self):
+        p = self.problem
+        poses, intr, pts = np.zeros((p.num_images, 6)), np.zeros((p.num_cameras, 9)), np.zeros((p.num_points, 3))
+        _check(load().mavba_session_get_params(self._h, _d(poses), _d(intr), _d(pts)))
+        return poses, intr, pts
+
+    def point_errors(self):
+        e = np.full(self.problem.num_points, np.nan)
+        _check(load().mavba_session_point_errors(self._h, _d(e)))
+        return e
+
+    def set_allreduce(self, fn, rank, world_size):
+        """fn(device_ptr:int, count:int, op:int) -> None; must all-reduce in place and return when done."""
+        def trampoline(_ctx, ptr, count, op):
+            try:
+                fn(ptr, count, op)
+                return 0
+            except Exception as e:  # noqa: BLE001 - must not unwind through C
+                print("all-reduce hook raised:", repr(e), flush=True)
+                return 1
+        self._cb = ALLREDUCE_FN(trampoline)
+        _check(load().mavba_session_set_allreduce(self._h, self._cb, None, rank, world_size))
+
+    def eval_jacobian(self):
+        n = self.problem.num_obs
+        r, Jc, Jp, Jk = np.zeros((n, 2)), np.zeros((n, 2, 6)), np.zeros((n, 2, 3)), np.zeros((n, 2, 9))
+        cost = C.c_double()
+        _check(load().mavba_session_eval_jacobian(self._h, C.byref(cost), _d(r), _d(Jc), _d(Jp), _d(Jk)))
+        return cost.value, r, Jc, Jp, Jk
+
+    def reduced_system(self, radius):
+        n = load().mavba_session_reduced_dim(self._h)
+        S, v = np.zeros((n, n)), np.zeros(n)
+        _check(load().mavba_session_reduced_system(self._h, float(radius), _d(S), _d(v)))
+        return S, v
+
+    def linear_step(self, radius):
+        p = self.problem
+        dp, di, dx = np.zeros((p.num_images, 6)), np.zeros((p.num_cameras, 9)), np.zeros((p.num_points, 3))
+        mcc = C.c_double()
+        _check(load().mavba_session_linear_step(self._h, float(radius), _d(dp), _d(di), _d(dx), C.byref(mcc)))
+        return dict(d_poses=dp, d_intr=di, d_points=dx, model_cost_change=mcc.value)
+
+    def time_jacobian(self, reps=20):
+        ms = C.c_float()
+        _check(load().mavba_session_time_jacobian(self._h, int(reps), C.byref(ms)))
+        return float(ms.value)
+
+    def kernel_stats(self):
+        buf = (A.CKernelStat * 64)()
+        n = load().mavba_session_kernel_stats(self._h, buf, 64)
+        return {buf[i].name.decode(): dict(launches=int(buf[i].launches), total_ms=float(buf[i].total_ms))
+                for i in range(min(n, 64))}
+
+
+def dense_spd_solve(Amat, b, device=-1):
+    Amat, b = A.as_f64(Amat), A.as_f64(b)
+    x = np.zeros_like(b)
+    _check(load().mavba_dense_spd_solve(len(b), _d(Amat), _d(b), _d(x), device))
+    return x

@@ -1,0 +1,59 @@
+"""Builds libmavba.so (HIP, gfx950 only) in-tree: mavmap_amd/lib/libmavba.so.
+
+hipcc cross-compiles without a GPU, so this runs on the CPU-only build container as well as on
+the MI355X box. The built library is git-ignored but travels with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(ROOT, "csrc")
+LIBDIR = os.path.join(ROOT, "lib")
+LIB = os.path.join(LIBDIR, "libmavba.so")
+OBJDIR = os.path.join(LIBDIR, "obj")
+SOURCES = ["kernels.hip", "dense_chol.hip", "session.hip"]
+HEADERS = ["ba_math.h", "internal.h", os.path.join("..", "..", "include", "mavba.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall",
+         "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libmavba.so)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    hipcc = _hipcc()
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if force or _stale(obj, [sp] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

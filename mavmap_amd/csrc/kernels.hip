@@ -1,0 +1,1017 @@
+// kernels.hip — hand-written gfx950 kernels of the bundle-adjustment hot path.
+//
+// Data layout in HBM (all FP64):
+//   observations  point-major (all observations of a 3-D point contiguous), uv as double2
+//   Jacobian      structure-of-arrays planes of length Nstride: R[2], Jp[6], Jc[12], Jk[2*KMAX]
+//                 -> every wave store is 64 lanes x 16 B contiguous
+//   per point     planes of length NPs: Cu[6] (J_p^T J_p), gu[3] (J_p^T r), Gi[6], h[3]
+//   Schur entries array-of-records (24 / 36 doubles) because the pair kernel gathers them
+//   S             dense (n_pad + 64) x n_pad row-major; row n_pad is the right-hand side
+//
+// Every reduction is a fixed-shape tree (per-thread -> wave shuffle -> LDS -> per-block
+// partial -> single-block final pass), so results are bit-reproducible run to run.
+#include "internal.h"
+#include "ba_math.h"
+
+namespace mavba {
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+// Block-wide sum for 256-thread blocks; `scratch` = 4 doubles of LDS. Result in thread 0.
+__device__ __forceinline__ double block_sum_256(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wv] = v;
+  __syncthreads();
+  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+__device__ __forceinline__ double block_max_256(double v, double* scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wv] = v;
+  __syncthreads();
+  return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+}
+
+// ---------------------------------------------------------------------------
+// K0: camera records (hoists sin/cos out of the per-observation work)
+// ---------------------------------------------------------------------------
+__global__ void k_cam_prepare(int NI, const double* __restrict__ poses, double* __restrict__ camrec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NI) return;
+  double rec[9];
+  cam_prepare(poses + 6 * i, rec);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) camrec[9 * i + k] = rec[k];
+}
+void launch_cam_prepare(hipStream_t st, int NI, const double* poses, double* camrec) {
+  if (NI <= 0) return;
+  hipLaunchKernelGGL(k_cam_prepare, dim3((NI + 127) / 128), dim3(128), 0, st, NI, poses, camrec);
+}
+
+// ---------------------------------------------------------------------------
+// K1: the Jacobian sweep. Persistent 256-thread blocks; the whole camera table
+// (72 B / image + intrinsics) is staged in LDS once per block; each lane owns
+// TWO consecutive observations so that every plane store is 16 B per lane.
+// Algorithmic bytes per observation: 48 read + 16 + 2*(9+K)*8 written.
+// ---------------------------------------------------------------------------
+constexpr int kSweepObsPerBlock = 512;
+constexpr int kSweepMaxGrid = 1024;
+int jacobian_sweep_grid(int N) {
+  int g = (N + kSweepObsPerBlock - 1) / kSweepObsPerBlock;
+  if (g < 1) g = 1;
+  return g > kSweepMaxGrid ? kSweepMaxGrid : g;
+}
+
+struct CamTables {
+  const double* rec; const double* intr; const int* img_cam; const int* model;
+};
+
+template <bool LDS_CAM>
+__device__ __forceinline__ CamTables stage_cameras(double* smem, int NI, int NC,
+                                                   const double* camrec, const double* intr,
+                                                   const int* img_cam, const int* cam_model) {
+  CamTables t;
+  if constexpr (LDS_CAM) {
+    double* s_rec = smem + 4;
+    double* s_intr = s_rec + 9 * NI;
+    int* s_cam = reinterpret_cast<int*>(s_intr + 9 * NC);
+    int* s_model = s_cam + NI;
+    for (int i = threadIdx.x; i < 9 * NI; i += blockDim.x) s_rec[i] = camrec[i];
+    for (int i = threadIdx.x; i < 9 * NC; i += blockDim.x) s_intr[i] = intr[i];
+    for (int i = threadIdx.x; i < NI; i += blockDim.x) s_cam[i] = img_cam[i];
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) s_model[i] = cam_model[i];
+    __syncthreads();
+    t.rec = s_rec; t.intr = s_intr; t.img_cam = s_cam; t.model = s_model;
+  } else {
+    t.rec = camrec; t.intr = intr; t.img_cam = img_cam; t.model = cam_model;
+  }
+  return t;
+}
+static size_t camera_lds_bytes(int NI, int NC) {
+  size_t b = (size_t)(4 + 9 * NI + 9 * NC) * 8 + (size_t)(NI + NC) * 4;
+  return (b + 15) & ~(size_t)15;
+}
+constexpr size_t kCamLdsLimit = 150 * 1024;  // of the 160 KiB per CU
+
+template <int KMAX, bool LDS_CAM>
+__global__ void __launch_bounds__(256) k_jacobian_sweep(SweepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const CamTables T = stage_cameras<LDS_CAM>(smem, a.NI, a.NC, a.camrec, a.intr, a.img_cam, a.cam_model);
+  constexpr int NOUT = 2 + 6 + 12 + 2 * KMAX;
+  const int tid = threadIdx.x;
+  const long long N = a.N, S = a.Nstride;
+  double cost = 0.0;
+  for (long long base = (long long)blockIdx.x * kSweepObsPerBlock; base < N;
+       base += (long long)gridDim.x * kSweepObsPerBlock) {
+    const long long o0 = base + 2 * tid;
+    if (o0 >= N) continue;
+    const bool two = (o0 + 1 < N);
+    int im[2], pt[2];
+    double uo[2], vo[2];
+    if (two) {
+      const int2 i2 = *reinterpret_cast<const int2*>(a.obs_img + o0);
+      const int2 p2 = *reinterpret_cast<const int2*>(a.obs_pt + o0);
+      const double2 m0 = a.uv[o0], m1 = a.uv[o0 + 1];
+      im[0] = i2.x; im[1] = i2.y; pt[0] = p2.x; pt[1] = p2.y;
+      uo[0] = m0.x; vo[0] = m0.y; uo[1] = m1.x; vo[1] = m1.y;
+    } else {
+      im[0] = im[1] = a.obs_img[o0]; pt[0] = pt[1] = a.obs_pt[o0];
+      const double2 m0 = a.uv[o0];
+      uo[0] = uo[1] = m0.x; vo[0] = vo[1] = m0.y;
+    }
+    double out[2][NOUT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cam = T.img_cam[im[j]];
+      const int model = T.model[cam];
+      double rec[9], kin[9], X[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) rec[k] = T.rec[9 * im[j] + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) kin[k] = T.intr[9 * cam + k];
+      X[0] = a.points[3 * (long long)pt[j]]; X[1] = a.points[3 * (long long)pt[j] + 1];
+      X[2] = a.points[3 * (long long)pt[j] + 2];
+      double r[2], Jc[12], Jp[6], Jk[18];
+      obs_jacobian(model, rec, kin, X, uo[j], vo[j], r, Jc, Jp, Jk);
+      double w, half_rho;
+      cauchy_weight(r[0] * r[0] + r[1] * r[1], a.loss_b, a.loss_inv_b, w, half_rho);
+      if (j == 0 || two) cost += half_rho;
+      out[j][0] = w * r[0]; out[j][1] = w * r[1];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) out[j][2 + e] = w * Jp[e];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) out[j][8 + e] = w * Jc[e];
+#pragma unroll
+      for (int row = 0; row < 2; ++row)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) out[j][20 + row * KMAX + k] = w * Jk[row * 9 + k];
+    }
+    // plane e of the concatenated [R | Jp | Jc | Jk] output
+    auto plane = [&](int e) -> double* {
+      if (e < 2) return a.R + (long long)e * S;
+      if (e < 8) return a.Jp + (long long)(e - 2) * S;
+      if (e < 20) return a.Jc + (long long)(e - 8) * S;
+      return a.Jk + (long long)(e - 20) * S;
+    };
+    if (two) {
+#pragma unroll
+      for (int e = 0; e < NOUT; ++e)
+        *reinterpret_cast<double2*>(plane(e) + o0) = make_double2(out[0][e], out[1][e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < NOUT; ++e) plane(e)[o0] = out[0][e];
+    }
+  }
+  const double tot = block_sum_256(cost, smem);
+  if (tid == 0) a.cost_partial[blockIdx.x] = tot;
+}
+
+template <bool LDS_CAM>
+__global__ void __launch_bounds__(256) k_cost_only(SweepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const CamTables T = stage_cameras<LDS_CAM>(smem, a.NI, a.NC, a.camrec, a.intr, a.img_cam, a.cam_model);
+  const long long N = a.N;
+  double cost = 0.0;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < N; o += (long long)gridDim.x * 256) {
+    const int im = a.obs_img[o], pt = a.obs_pt[o];
+    const double2 m = a.uv[o];
+    const int cam = T.img_cam[im];
+    double rec[9], kin[9], X[3], r[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rec[k] = T.rec[9 * im + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) kin[k] = T.intr[9 * cam + k];
+    X[0] = a.points[3 * (long long)pt]; X[1] = a.points[3 * (long long)pt + 1]; X[2] = a.points[3 * (long long)pt + 2];
+    obs_residual(T.model[cam], rec, kin, X, m.x, m.y, r);
+    double w, half_rho;
+    cauchy_weight(r[0] * r[0] + r[1] * r[1], a.loss_b, a.loss_inv_b, w, half_rho);
+    cost += half_rho;
+  }
+  const double tot = block_sum_256(cost, smem);
+  if (threadIdx.x == 0) a.cost_partial[blockIdx.x] = tot;
+}
+
+// |r_raw| per observation (trivial loss) for the point-error report.
+__global__ void __launch_bounds__(256) k_raw_residual_norm(SweepArgs a, double* __restrict__ out) {
+  const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= a.N) return;
+  const int im = a.obs_img[o], pt = a.obs_pt[o];
+  const double2 m = a.uv[o];
+  const int cam = a.img_cam[im];
+  double r[2];
+  obs_residual(a.cam_model[cam], a.camrec + 9 * im, a.intr + 9 * cam, a.points + 3 * (long long)pt, m.x, m.y, r);
+  out[o] = sqrt(r[0] * r[0] + r[1] * r[1]);
+}
+
+void launch_jacobian_sweep(hipStream_t st, const SweepArgs& a) {
+  if (a.N <= 0) return;
+  const int grid = jacobian_sweep_grid(a.N);
+  const size_t lds = camera_lds_bytes(a.NI, a.NC);
+  const bool use_lds = lds <= kCamLdsLimit;
+  const size_t shm = use_lds ? lds : 64;
+#define MAVBA_SWEEP(K)                                                                              \
+  if (use_lds) hipLaunchKernelGGL((k_jacobian_sweep<K, true>), dim3(grid), dim3(256), shm, st, a);  \
+  else hipLaunchKernelGGL((k_jacobian_sweep<K, false>), dim3(grid), dim3(256), shm, st, a);
+  if (a.KMAX <= 4) { MAVBA_SWEEP(4) } else if (a.KMAX <= 8) { MAVBA_SWEEP(8) } else { MAVBA_SWEEP(9) }
+#undef MAVBA_SWEEP
+}
+void launch_cost_only(hipStream_t st, const SweepArgs& a) {
+  if (a.N <= 0) return;
+  const int grid = jacobian_sweep_grid(a.N);  // same partial count as the sweep
+  const size_t lds = camera_lds_bytes(a.NI, a.NC);
+  const bool use_lds = lds <= kCamLdsLimit;
+  if (use_lds) hipLaunchKernelGGL((k_cost_only<true>), dim3(grid), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((k_cost_only<false>), dim3(grid), dim3(256), 64, st, a);
+}
+void launch_raw_residual_norm(hipStream_t st, const SweepArgs& a, double* out_norm) {
+  if (a.N <= 0) return;
+  hipLaunchKernelGGL(k_raw_residual_norm, dim3((a.N + 255) / 256), dim3(256), 0, st, a, out_norm);
+}
+
+// ---------------------------------------------------------------------------
+// K3: per-point sums C_p = sum J_p^T J_p (sym 6), g_p = sum J_p^T r. One lane per
+// point walking its contiguous observations; neighbouring lanes read neighbouring
+// lines, so the planes are streamed once through L1/L2.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_point_sums(int NP, int NPs, int Nstride,
+                                                    const int* __restrict__ pt_start,
+                                                    const double* __restrict__ R,
+                                                    const double* __restrict__ Jp,
+                                                    double* __restrict__ Cu, double* __restrict__ gu) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= NP) return;
+  const int b = pt_start[p], e = pt_start[p + 1];
+  double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2 = 0;
+  const long long S = Nstride;
+  for (int o = b; o < e; ++o) {
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+      const double x = Jp[(row * 3 + 0) * S + o], y = Jp[(row * 3 + 1) * S + o], z = Jp[(row * 3 + 2) * S + o];
+      const double r = R[row * S + o];
+      c0 += x * x; c1 += x * y; c2 += x * z; c3 += y * y; c4 += y * z; c5 += z * z;
+      g0 += x * r; g1 += y * r; g2 += z * r;
+    }
+  }
+  Cu[0 * NPs + p] = c0; Cu[1 * NPs + p] = c1; Cu[2 * NPs + p] = c2;
+  Cu[3 * NPs + p] = c3; Cu[4 * NPs + p] = c4; Cu[5 * NPs + p] = c5;
+  gu[0 * NPs + p] = g0; gu[1 * NPs + p] = g1; gu[2 * NPs + p] = g2;
+}
+void launch_point_sums(hipStream_t st, int NP, int NPs, int Nstride, const int* pt_start,
+                       const double* R, const double* Jp, double* Cu, double* gu) {
+  if (NP <= 0) return;
+  hipLaunchKernelGGL(k_point_sums, dim3((NP + 255) / 256), dim3(256), 0, st, NP, NPs, Nstride, pt_start, R, Jp, Cu, gu);
+}
+
+// ---------------------------------------------------------------------------
+// K4: camera sweep. Image-major pass that RECOMPUTES each observation's camera-
+// side Jacobian (cheaper than gathering 2x(6+K) doubles through a permutation:
+// 28 B of input per observation) and reduces, per image chunk,
+//   PP = Jc^T Jc, Pg = Jc^T r, PI = Jc^T Jk, II = Jk^T Jk, Ig = Jk^T r.
+// One block per chunk; the image's camera record is block-uniform.
+// ---------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256) k_camera_sweep(CamSweepArgs a) {
+  __shared__ double s_red[4 * kSweepAcc];
+  const SweepChunk ch = a.chunks[blockIdx.x];
+  const int cam = a.img_cam[ch.image];
+  const int model = a.cam_model[cam];
+  double rec[9], kin[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rec[k] = a.camrec[9 * ch.image + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) kin[k] = a.intr[9 * cam + k];
+  constexpr int KK = K > 0 ? K : 1;
+  double aPP[21], aPg[6], aPI[6 * KK], aII[KK * (KK + 1) / 2], aIg[KK];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) aPP[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) aPg[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6 * KK; ++i) aPI[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < KK * (KK + 1) / 2; ++i) aII[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < KK; ++i) aIg[i] = 0.0;
+
+  for (int o = ch.begin + threadIdx.x; o < ch.end; o += 256) {
+    const double2 m = a.im_uv[o];
+    const int pt = a.im_pt[o];
+    double X[3] = {a.points[3 * (long long)pt], a.points[3 * (long long)pt + 1], a.points[3 * (long long)pt + 2]};
+    double r[2], Jc[12], Jp[6], Jk[18];
+    obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
+    double w, half_rho;
+    cauchy_weight(r[0] * r[0] + r[1] * r[1], a.loss_b, a.loss_inv_b, w, half_rho);
+    const double w2 = w * w;  // every product below carries two weighted factors
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+#pragma unroll
+      for (int y = x; y < 6; ++y)
+        aPP[sym_idx(x, y, 6)] += w2 * (Jc[x] * Jc[y] + Jc[6 + x] * Jc[6 + y]);
+      aPg[x] += w2 * (Jc[x] * r[0] + Jc[6 + x] * r[1]);
+    }
+    if constexpr (K > 0) {
+#pragma unroll
+      for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int k = 0; k < K; ++k) aPI[x * K + k] += w2 * (Jc[x] * Jk[k] + Jc[6 + x] * Jk[9 + k]);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int l = k; l < K; ++l) aII[sym_idx(k, l, K)] += w2 * (Jk[k] * Jk[l] + Jk[9 + k] * Jk[9 + l]);
+        aIg[k] += w2 * (Jk[k] * r[0] + Jk[9 + k] * r[1]);
+      }
+    }
+  }
+  // block reduction into the fixed 135-slot layout
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * kSweepAcc; i += 256) s_red[i] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 21; ++i) { const double v = wave_sum(aPP[i]); if (lane == 0) s_red[wv * kSweepAcc + i] = v; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const double v = wave_sum(aPg[i]); if (lane == 0) s_red[wv * kSweepAcc + 21 + i] = v; }
+  if constexpr (K > 0) {
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int k = 0; k < K; ++k) { const double v = wave_sum(aPI[x * K + k]); if (lane == 0) s_red[wv * kSweepAcc + 27 + x * 9 + k] = v; }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int l = k; l < K; ++l) { const double v = wave_sum(aII[sym_idx(k, l, K)]); if (lane == 0) s_red[wv * kSweepAcc + 81 + sym_idx(k, l, 9)] = v; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const double v = wave_sum(aIg[k]); if (lane == 0) s_red[wv * kSweepAcc + 126 + k] = v; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSweepAcc; i += 256)
+    a.partial[(size_t)blockIdx.x * kSweepAcc + i] =
+        (s_red[i] + s_red[kSweepAcc + i]) + (s_red[2 * kSweepAcc + i] + s_red[3 * kSweepAcc + i]);
+}
+void launch_camera_sweep(hipStream_t st, const CamSweepArgs& a, int kmax, bool any_intr_free) {
+  if (a.num_chunks <= 0) return;
+  const dim3 g(a.num_chunks), b(256);
+  if (!any_intr_free) hipLaunchKernelGGL((k_camera_sweep<0>), g, b, 0, st, a);
+  else if (kmax <= 4) hipLaunchKernelGGL((k_camera_sweep<4>), g, b, 0, st, a);
+  else if (kmax <= 8) hipLaunchKernelGGL((k_camera_sweep<8>), g, b, 0, st, a);
+  else hipLaunchKernelGGL((k_camera_sweep<9>), g, b, 0, st, a);
+}
+
+// Rotation priors: one lane per prior (reference bundle_adjustment.cc:72-111, :428-444).
+__global__ void k_rot_prior(int n, const int* __restrict__ prior_img, const double* __restrict__ R0,
+                            double w, const double* __restrict__ poses, double* __restrict__ res,
+                            double* __restrict__ jac, double* __restrict__ cost_partial) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  double r, j[3];
+  rot_prior_eval(poses + 6 * prior_img[q], R0 + 9 * q, w, r, j);
+  res[q] = r; jac[3 * q] = j[0]; jac[3 * q + 1] = j[1]; jac[3 * q + 2] = j[2];
+  cost_partial[q] = 0.5 * r * r;
+}
+void launch_rot_prior(hipStream_t st, int n, const int* prior_img, const double* prior_R0, double w,
+                      const double* poses, double* res, double* jac, double* cost_partial) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_rot_prior, dim3((n + 127) / 128), dim3(128), 0, st, n, prior_img, prior_R0, w, poses, res, jac, cost_partial);
+}
+
+// Per image: sum its chunks (fixed order) + its rotation priors -> img_rec[81] and
+// the image's intrinsics part -> img_intr_tmp[54]. One 64-lane group per image.
+__global__ void __launch_bounds__(64) k_camera_reduce_img(
+    int NI, const int* __restrict__ img_chunk_start, const double* __restrict__ partial,
+    const int* __restrict__ prior_start, const double* __restrict__ prior_res,
+    const double* __restrict__ prior_jac, double* __restrict__ img_rec, double* __restrict__ img_intr_tmp) {
+  const int i = blockIdx.x;
+  const int c0 = img_chunk_start[i], c1 = img_chunk_start[i + 1];
+  for (int e = threadIdx.x; e < kSweepAcc; e += 64) {
+    double s = 0.0;
+    for (int c = c0; c < c1; ++c) s += partial[(size_t)c * kSweepAcc + e];
+    if (e < 27 && prior_start) {
+      for (int q = prior_start[i]; q < prior_start[i + 1]; ++q) {
+        const double* j = prior_jac + 3 * q;
+        if (e < 21) {
+          // PP upper-triangle slots touching the rvec block: (x,y) with y < 3
+          int x = 0, rem = e;
+          while (rem >= 6 - x) { rem -= 6 - x; ++x; }
+          const int y = x + rem;
+          if (y < 3) s += j[x] * j[y];
+        } else if (e - 21 < 3) {
+          s += j[e - 21] * prior_res[q];
+        }
+      }
+    }
+    if (e < kImgRec) img_rec[(size_t)i * kImgRec + e] = s;
+    else img_intr_tmp[(size_t)i * kCamRec + (e - kImgRec)] = s;
+  }
+}
+// Per camera: sum the intrinsics parts of its images in image order.
+__global__ void __launch_bounds__(64) k_camera_reduce_cam(
+    const int* __restrict__ cam_img_start, const int* __restrict__ cam_imgs,
+    const double* __restrict__ img_intr_tmp, double* __restrict__ cam_rec) {
+  const int c = blockIdx.x;
+  const int e = threadIdx.x;
+  if (e >= kCamRec) return;
+  double s = 0.0;
+  for (int t = cam_img_start[c]; t < cam_img_start[c + 1]; ++t) s += img_intr_tmp[(size_t)cam_imgs[t] * kCamRec + e];
+  cam_rec[(size_t)c * kCamRec + e] = s;
+}
+void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_start,
+                          const double* partial, const int* prior_start, const double* prior_res,
+                          const double* prior_jac, const int* cam_img_start, const int* cam_imgs,
+                          double* img_rec, double* cam_rec, double* img_intr_tmp) {
+  if (NI > 0)
+    hipLaunchKernelGGL(k_camera_reduce_img, dim3(NI), dim3(64), 0, st, NI, img_chunk_start, partial,
+                       prior_start, prior_res, prior_jac, img_rec, img_intr_tmp);
+  if (NC > 0)
+    hipLaunchKernelGGL(k_camera_reduce_cam, dim3(NC), dim3(64), 0, st, cam_img_start, cam_imgs, img_intr_tmp, cam_rec);
+}
+
+// ---------------------------------------------------------------------------
+// Jacobi scaling (ceres EstimateScale): s_j = 1 / (1 + |J_:j|), 0 for constant columns.
+// scale_cam is indexed like S: 6*i+e for poses, 6*NI + 9*c + k for intrinsics.
+// ---------------------------------------------------------------------------
+__global__ void k_scales(int NI, int NC, int NP, int NPs, int jacobi,
+                         const unsigned char* __restrict__ pose_free,
+                         const unsigned char* __restrict__ intr_free,
+                         const unsigned char* __restrict__ pt_free, const double* __restrict__ img_rec,
+                         const double* __restrict__ cam_rec, const double* __restrict__ Cu,
+                         double* __restrict__ scale_cam, double* __restrict__ scale_pt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncam = 6 * NI + 9 * NC;
+  if (t < ncam) {
+    double n2; bool fr;
+    if (t < 6 * NI) {
+      const int i = t / 6, e = t % 6;
+      n2 = img_rec[(size_t)i * kImgRec + sym_idx(e, e, 6)];
+      fr = pose_free[t] != 0;
+    } else {
+      const int c = (t - 6 * NI) / 9, k = (t - 6 * NI) % 9;
+      n2 = cam_rec[(size_t)c * kCamRec + sym_idx(k, k, 9)];
+      fr = intr_free[9 * c + k] != 0;
+    }
+    scale_cam[t] = fr ? (jacobi ? 1.0 / (1.0 + sqrt(n2)) : 1.0) : 0.0;
+  }
+  if (t < NP) {
+    const bool fr = pt_free[t] != 0;
+    const int d[3] = {0, 3, 5};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      scale_pt[k * NPs + t] = fr ? (jacobi ? 1.0 / (1.0 + sqrt(Cu[d[k] * NPs + t])) : 1.0) : 0.0;
+  }
+}
+void launch_scales(hipStream_t st, int NI, int NC, int NP, int NPs, int jacobi,
+                   const unsigned char* pose_free, const unsigned char* intr_free,
+                   const unsigned char* pt_free, const double* img_rec, const double* cam_rec,
+                   const double* Cu, double* scale_cam, double* scale_pt) {
+  const int n = max(6 * NI + 9 * NC, NP);
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_scales, dim3((n + 255) / 256), dim3(256), 0, st, NI, NC, NP, NPs, jacobi, pose_free,
+                     intr_free, pt_free, img_rec, cam_rec, Cu, scale_cam, scale_pt);
+}
+
+// max |g| and |x|^2 over the free parameters. partial[b][0] = max, [b][1] = sum.
+// Blocks [0, gp) cover points; the last block covers the camera columns.
+__global__ void __launch_bounds__(256) k_state_norms(
+    int NI, int NC, int NP, int NPs, int gp, int cam_part, const unsigned char* __restrict__ pose_free,
+    const unsigned char* __restrict__ intr_free, const unsigned char* __restrict__ pt_free,
+    const double* __restrict__ poses, const double* __restrict__ intr, const double* __restrict__ points,
+    const double* __restrict__ img_rec, const double* __restrict__ cam_rec, const double* __restrict__ gu,
+    double* __restrict__ partial) {
+  __shared__ double s_red[4];
+  double gmax = 0.0, x2 = 0.0;
+  if ((int)blockIdx.x < gp) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < NP; p += gp * 256) {
+      if (!pt_free[p]) continue;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gmax = fmax(gmax, fabs(gu[k * NPs + p]));
+        const double x = points[3 * (size_t)p + k];
+        x2 += x * x;
+      }
+    }
+  } else {
+    const int ncam = 6 * NI + 9 * NC;
+    for (int t = threadIdx.x; t < ncam; t += 256) {
+      double g, x; bool fr;
+      if (t < 6 * NI) {
+        fr = pose_free[t] != 0; g = img_rec[(size_t)(t / 6) * kImgRec + 21 + t % 6]; x = poses[t];
+      } else {
+        const int c = (t - 6 * NI) / 9, k = (t - 6 * NI) % 9;
+        fr = intr_free[9 * c + k] != 0; g = cam_rec[(size_t)c * kCamRec + 45 + k]; x = intr[9 * c + k];
+      }
+      if (!fr) continue;
+      gmax = fmax(gmax, fabs(g));        // gradient is global after the camera-sum all-reduce
+      if (cam_part) x2 += x * x;         // counted on one rank only
+    }
+  }
+  const double m = block_max_256(gmax, s_red);
+  const double s = block_sum_256(x2, s_red);
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = m; partial[2 * blockIdx.x + 1] = s; }
+}
+void launch_state_norms(hipStream_t st, int NI, int NC, int NP, int NPs, bool cam_part,
+                        const unsigned char* pose_free, const unsigned char* intr_free,
+                        const unsigned char* pt_free, const double* poses, const double* intr,
+                        const double* points, const double* img_rec, const double* cam_rec,
+                        const double* gu, double* partial, int* grid_out) {
+  int gp = (NP + 255) / 256;
+  if (gp > 512) gp = 512;
+  hipLaunchKernelGGL(k_state_norms, dim3(gp + 1), dim3(256), 0, st, NI, NC, NP, NPs, gp, cam_part ? 1 : 0,
+                     pose_free, intr_free, pt_free, poses, intr, points, img_rec, cam_rec, gu, partial);
+  *grid_out = gp + 1;
+}
+
+// ---------------------------------------------------------------------------
+// Point factor: C_p = S_p Cu S_p + D_p^2, C_p = G G^T, Gi = G^-1, h = Gi (S_p gu).
+// (Schur eliminator e-block step; D^2 = clamp(diag(Js^T Js)) / radius.)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_point_factor(
+    int NP, int NPs, double radius, double dmin, double dmax, const unsigned char* __restrict__ pt_free,
+    const double* __restrict__ Cu, const double* __restrict__ gu, const double* __restrict__ scale_pt,
+    double* __restrict__ Gi, double* __restrict__ h, double* __restrict__ fail) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= NP) return;
+  double G[6] = {0, 0, 0, 0, 0, 0}, hh[3] = {0, 0, 0};
+  if (pt_free[p]) {
+    const double s0 = scale_pt[p], s1 = scale_pt[NPs + p], s2 = scale_pt[2 * NPs + p];
+    double C[6];
+    C[0] = s0 * s0 * Cu[p];           C[1] = s0 * s1 * Cu[NPs + p];     C[2] = s0 * s2 * Cu[2 * NPs + p];
+    C[3] = s1 * s1 * Cu[3 * NPs + p]; C[4] = s1 * s2 * Cu[4 * NPs + p]; C[5] = s2 * s2 * Cu[5 * NPs + p];
+    C[0] += clampd(C[0], dmin, dmax) / radius;
+    C[3] += clampd(C[3], dmin, dmax) / radius;
+    C[5] += clampd(C[5], dmin, dmax) / radius;
+    const bool ok = chol3_inv(C, G);
+    const double gs[3] = {s0 * gu[p], s1 * gu[NPs + p], s2 * gu[2 * NPs + p]};
+    gi_mul(G, gs, hh);
+    bool fin = ok;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fin = fin && isfinite(G[k]);
+    if (!fin) atomicAdd(fail, 1.0);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Gi[k * NPs + p] = G[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h[k * NPs + p] = hh[k];
+}
+void launch_point_factor(hipStream_t st, int NP, int NPs, double radius, double dmin, double dmax,
+                         const unsigned char* pt_free, const double* Cu, const double* gu,
+                         const double* scale_pt, double* Gi, double* h, double* fail) {
+  if (NP <= 0) return;
+  hipLaunchKernelGGL(k_point_factor, dim3((NP + 255) / 256), dim3(256), 0, st, NP, NPs, radius, dmin, dmax,
+                     pt_free, Cu, gu, scale_pt, Gi, h, fail);
+}
+
+// ---------------------------------------------------------------------------
+// Pose entries: U_a = (Jc' ^T Jp') Gi^T (6x3), e_a = U_a h. One lane per
+// observation; records are transposed through LDS so the 192-byte records leave
+// the block as one contiguous, fully coalesced 48 KB store.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_entries_pose(
+    int N, int Nstride, int NPs, const int* __restrict__ obs_img, const int* __restrict__ obs_pt,
+    const unsigned char* __restrict__ pt_free, const double* __restrict__ Jc, const double* __restrict__ Jp,
+    const double* __restrict__ scale_cam, const double* __restrict__ scale_pt, const double* __restrict__ Gi,
+    const double* __restrict__ h, double* __restrict__ Epose) {
+  __shared__ double s_rec[256 * 25];
+  const long long S = Nstride;
+  const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+  double rec[kPoseRec];
+#pragma unroll
+  for (int k = 0; k < kPoseRec; ++k) rec[k] = 0.0;
+  if (o < N) {
+    const int p = obs_pt[o];
+    if (pt_free[p]) {
+      const int im = obs_img[o];
+      double sp[3], G[6], hh[3], jp[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { sp[k] = scale_pt[k * NPs + p]; hh[k] = h[k * NPs + p]; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) G[k] = Gi[k * NPs + p];
+#pragma unroll
+      for (int row = 0; row < 2; ++row)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) jp[row * 3 + k] = Jp[(row * 3 + k) * S + o] * sp[k];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const double sc = scale_cam[6 * im + e];
+        const double j0 = Jc[e * S + o] * sc, j1 = Jc[(6 + e) * S + o] * sc;
+        const double w0 = j0 * jp[0] + j1 * jp[3], w1 = j0 * jp[1] + j1 * jp[4], w2 = j0 * jp[2] + j1 * jp[5];
+        // U = W Gi^T : U[k] = sum_{m<=k} W[m] Gi[k][m]
+        const double u0 = w0 * G[0];
+        const double u1 = w0 * G[1] + w1 * G[2];
+        const double u2 = w0 * G[3] + w1 * G[4] + w2 * G[5];
+        rec[3 * e] = u0; rec[3 * e + 1] = u1; rec[3 * e + 2] = u2;
+        rec[18 + e] = u0 * hh[0] + u1 * hh[1] + u2 * hh[2];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kPoseRec; ++k) s_rec[threadIdx.x * 25 + k] = rec[k];
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * 256 * kPoseRec;
+  const long long lim = (long long)N * kPoseRec;
+  for (int i = threadIdx.x; i < 256 * kPoseRec; i += 256) {
+    const int t = i / kPoseRec, k = i - t * kPoseRec;
+    if (base + i < lim) Epose[base + i] = s_rec[t * 25 + k];
+  }
+}
+void launch_entries_pose(hipStream_t st, int N, int Nstride, int NPs, const int* obs_img,
+                         const int* obs_pt, const unsigned char* pt_free, const double* Jc,
+                         const double* Jp, const double* scale_cam, const double* scale_pt,
+                         const double* Gi, const double* h, double* Epose) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_entries_pose, dim3((N + 255) / 256), dim3(256), 0, st, N, Nstride, NPs, obs_img, obs_pt,
+                     pt_free, Jc, Jp, scale_cam, scale_pt, Gi, h, Epose);
+}
+
+// Intrinsics entries: one per (free point p, free camera c seen by p):
+//   Uk = (sum_{a in p, cam(a)=c} Jk'_a^T Jp'_a) Gi^T  (9x3),  ek = Uk h.
+template <int KMAX>
+__global__ void __launch_bounds__(128) k_entries_intr(
+    int Q, int NI, int Nstride, int NPs, const int* __restrict__ q_pt, const int* __restrict__ q_cam,
+    const int* __restrict__ pt_start, const int* __restrict__ obs_img, const int* __restrict__ img_cam,
+    const double* __restrict__ Jk, const double* __restrict__ Jp, const double* __restrict__ scale_cam,
+    const double* __restrict__ scale_pt, const double* __restrict__ Gi, const double* __restrict__ h,
+    double* __restrict__ Eintr) {
+  const int q = blockIdx.x * 128 + threadIdx.x;
+  if (q >= Q) return;
+  const long long S = Nstride;
+  const int p = q_pt[q], c = q_cam[q];
+  double sp[3], G[6], hh[3], sk[KMAX], W[KMAX * 3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { sp[k] = scale_pt[k * NPs + p]; hh[k] = h[k * NPs + p]; }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) G[k] = Gi[k * NPs + p];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { sk[k] = scale_cam[6 * NI + 9 * c + k]; W[3 * k] = W[3 * k + 1] = W[3 * k + 2] = 0.0; }
+  for (int o = pt_start[p]; o < pt_start[p + 1]; ++o) {
+    if (img_cam[obs_img[o]] != c) continue;
+    double jp[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) jp[e] = Jp[e * S + o];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const double j0 = Jk[k * S + o], j1 = Jk[(KMAX + k) * S + o];
+      W[3 * k] += j0 * jp[0] + j1 * jp[3];
+      W[3 * k + 1] += j0 * jp[1] + j1 * jp[4];
+      W[3 * k + 2] += j0 * jp[2] + j1 * jp[5];
+    }
+  }
+  double* out = Eintr + (size_t)q * kIntrRec;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+    if (k < KMAX) {
+      const double w0 = W[3 * k] * sk[k] * sp[0], w1 = W[3 * k + 1] * sk[k] * sp[1], w2 = W[3 * k + 2] * sk[k] * sp[2];
+      u0 = w0 * G[0];
+      u1 = w0 * G[1] + w1 * G[2];
+      u2 = w0 * G[3] + w1 * G[4] + w2 * G[5];
+    }
+    out[3 * k] = u0; out[3 * k + 1] = u1; out[3 * k + 2] = u2;
+    out[27 + k] = u0 * hh[0] + u1 * hh[1] + u2 * hh[2];
+  }
+}
+void launch_entries_intr(hipStream_t st, int Q, int KMAX, int NI, int Nstride, int NPs, const int* q_pt,
+                         const int* q_cam, const int* pt_start, const int* obs_img,
+                         const int* img_cam, const double* Jk, const double* Jp,
+                         const double* scale_cam, const double* scale_pt, const double* Gi,
+                         const double* h, double* Eintr) {
+  if (Q <= 0) return;
+  const dim3 g((Q + 127) / 128), b(128);
+#define MAVBA_EI(K) hipLaunchKernelGGL((k_entries_intr<K>), g, b, 0, st, Q, NI, Nstride, NPs, q_pt, q_cam, pt_start, \
+                                       obs_img, img_cam, Jk, Jp, scale_cam, scale_pt, Gi, h, Eintr)
+  if (KMAX <= 4) MAVBA_EI(4); else if (KMAX <= 8) MAVBA_EI(8); else MAVBA_EI(9);
+#undef MAVBA_EI
+}
+
+// ---------------------------------------------------------------------------
+// Schur chunks: one wave per chunk of (x, y) entry pairs of one block of S;
+// partial[chunk] = sum U_x U_y^T  (+ sum e_x over x == y terms for diagonal kinds).
+// Every block of S is produced by exactly one finalize group from its chunk
+// partials in order: no atomics, bit-reproducible.
+// ---------------------------------------------------------------------------
+template <int RX, int RY, int SX, int SY, bool DIAG>
+__global__ void __launch_bounds__(256) k_schur_chunks(int num_chunks, const SchurChunk* __restrict__ chunks,
+                                                      const int2* __restrict__ terms,
+                                                      const double* __restrict__ EX,
+                                                      const double* __restrict__ EY,
+                                                      double* __restrict__ partial) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cid = blockIdx.x * 4 + wv;
+  if (cid >= num_chunks) return;
+  const SchurChunk ch = chunks[cid];
+  constexpr int NA = RX * RY;
+  constexpr int PS = NA + (DIAG ? RX : 0);
+  double acc[NA], ev[RX];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < RX; ++i) ev[i] = 0.0;
+  for (int t = ch.begin + lane; t < ch.end; t += 64) {
+    const int2 xy = terms[t];
+    const double* px = EX + (size_t)xy.x * SX;
+    const double* py = EY + (size_t)xy.y * SY;
+    double ux[RX * 3], uy[RY * 3];
+#pragma unroll
+    for (int i = 0; i < RX * 3; i += 2) {  // RX*3 is even for RX = 6; odd tail handled below
+      if (i + 1 < RX * 3) { const double2 v = *reinterpret_cast<const double2*>(px + i); ux[i] = v.x; ux[i + 1] = v.y; }
+      else ux[i] = px[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RY * 3; i += 2) {
+      if (i + 1 < RY * 3) { const double2 v = *reinterpret_cast<const double2*>(py + i); uy[i] = v.x; uy[i + 1] = v.y; }
+      else uy[i] = py[i];
+    }
+#pragma unroll
+    for (int r = 0; r < RX; ++r)
+#pragma unroll
+      for (int c = 0; c < RY; ++c)
+        acc[r * RY + c] += ux[3 * r] * uy[3 * c] + ux[3 * r + 1] * uy[3 * c + 1] + ux[3 * r + 2] * uy[3 * c + 2];
+    if (DIAG && xy.x == xy.y) {
+#pragma unroll
+      for (int r = 0; r < RX; ++r) ev[r] += px[RX * 3 + r];
+    }
+  }
+  double* out = partial + (size_t)cid * PS;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) { const double v = wave_sum(acc[i]); if (lane == 0) out[i] = v; }
+  if (DIAG) {
+#pragma unroll
+    for (int r = 0; r < RX; ++r) { const double v = wave_sum(ev[r]); if (lane == 0) out[NA + r] = v; }
+  }
+}
+int schur_partial_stride(int kind) { return kind == BLK_PP ? 42 : kind == BLK_IP ? 54 : 90; }
+void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurChunk* chunks,
+                         const int2* terms, const double* Epose, const double* Eintr, double* partial) {
+  if (num_chunks <= 0) return;
+  const dim3 g((num_chunks + 3) / 4), b(256);
+  if (kind == BLK_PP)
+    hipLaunchKernelGGL((k_schur_chunks<6, 6, kPoseRec, kPoseRec, true>), g, b, 0, st, num_chunks, chunks, terms, Epose, Epose, partial);
+  else if (kind == BLK_IP)
+    hipLaunchKernelGGL((k_schur_chunks<9, 6, kIntrRec, kPoseRec, false>), g, b, 0, st, num_chunks, chunks, terms, Eintr, Epose, partial);
+  else
+    hipLaunchKernelGGL((k_schur_chunks<9, 9, kIntrRec, kIntrRec, true>), g, b, 0, st, num_chunks, chunks, terms, Eintr, Eintr, partial);
+}
+
+// Finalize: one 64-lane group per block of S.
+//   S_blk = base - sum_chunks partial,   v_rows = base_g - sum_chunks e   (diagonal kinds)
+// base (only when add_base, i.e. on one rank): scaled F^T F + D^2 from the camera sums.
+__global__ void __launch_bounds__(256) k_schur_finalize(
+    int num_blocks, const SchurBlock* __restrict__ blocks, const double* __restrict__ part_pp,
+    const double* __restrict__ part_ip, const double* __restrict__ part_ii, int NI, int NC, int ld,
+    int add_base, double radius, double dmin, double dmax, const int* __restrict__ img_cam,
+    const double* __restrict__ img_rec, const double* __restrict__ cam_rec,
+    const double* __restrict__ scale_cam, double* __restrict__ S, double* __restrict__ v) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bid = blockIdx.x * 4 + wv;
+  if (bid >= num_blocks) return;
+  const SchurBlock B = blocks[bid];
+  const int RX = B.kind == BLK_PP ? 6 : 9, RY = B.kind == BLK_II ? 9 : 6;
+  const int NA = RX * RY;
+  const bool diag_kind = B.kind != BLK_IP;
+  const int PS = NA + (diag_kind ? RX : 0);
+  const double* part = B.kind == BLK_PP ? part_pp : B.kind == BLK_IP ? part_ip : part_ii;
+  const int row0 = B.kind == BLK_PP ? 6 * B.row_ent : 6 * NI + 9 * B.row_ent;
+  const int col0 = B.kind == BLK_II ? 6 * NI + 9 * B.col_ent : 6 * B.col_ent;
+  const bool is_diag = diag_kind && B.row_ent == B.col_ent;
+  for (int idx = lane; idx < PS; idx += 64) {
+    double s = 0.0;
+    for (int c = B.chunk_begin; c < B.chunk_end; ++c) s += part[(size_t)c * PS + idx];
+    if (idx < NA) {
+      const int r = idx / RY, c = idx - r * RY;
+      const int gr = row0 + r, gc = col0 + c;
+      double base = 0.0;
+      if (add_base) {
+        const double sr = scale_cam[gr], sc = scale_cam[gc];
+        if (B.kind == BLK_PP && is_diag) {
+          const int x = r < c ? r : c, y = r < c ? c : r;
+          base = sr * sc * img_rec[(size_t)B.row_ent * kImgRec + sym_idx(x, y, 6)];
+          if (r == c && sr != 0.0) base += clampd(base, dmin, dmax) / radius;
+        } else if (B.kind == BLK_IP && img_cam[B.col_ent] == B.row_ent) {
+          base = sr * sc * img_rec[(size_t)B.col_ent * kImgRec + 27 + c * 9 + r];  // PI[pose c][intr r]
+        } else if (B.kind == BLK_II && is_diag) {
+          const int x = r < c ? r : c, y = r < c ? c : r;
+          base = sr * sc * cam_rec[(size_t)B.row_ent * kCamRec + sym_idx(x, y, 9)];
+          if (r == c && sr != 0.0) base += clampd(base, dmin, dmax) / radius;
+        }
+      }
+      const double val = base - s;
+      if (!is_diag || gr >= gc) {
+        S[(size_t)gr * ld + gc] = val;
+        S[(size_t)gc * ld + gr] = val;
+      }
+    } else if (is_diag) {
+      const int r = idx - NA;
+      const int gr = row0 + r;
+      double base = 0.0;
+      if (add_base) {
+        const double g = B.kind == BLK_PP ? img_rec[(size_t)B.row_ent * kImgRec + 21 + r]
+                                          : cam_rec[(size_t)B.row_ent * kCamRec + 45 + r];
+        base = scale_cam[gr] * g;
+      }
+      v[gr] = base - s;
+    }
+  }
+}
+void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blocks,
+                           const double* part_pp, const double* part_ip, const double* part_ii,
+                           int NI, int NC, int ld, bool add_base, double radius, double dmin,
+                           double dmax, const int* img_cam, const double* img_rec,
+                           const double* cam_rec, const double* scale_cam, double* S, double* v) {
+  if (num_blocks <= 0) return;
+  hipLaunchKernelGGL(k_schur_finalize, dim3((num_blocks + 3) / 4), dim3(256), 0, st, num_blocks, blocks, part_pp,
+                     part_ip, part_ii, NI, NC, ld, add_base ? 1 : 0, radius, dmin, dmax, img_cam, img_rec, cam_rec,
+                     scale_cam, S, v);
+}
+// Constant / unused / padding columns: unit diagonal (their rows and columns are zero).
+__global__ void k_fix_diag(int n_full, int n_pad, int ld, int add_one, const double* __restrict__ scale_cam,
+                           double* __restrict__ S) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_pad) return;
+  if (j >= n_full || scale_cam[j] == 0.0) S[(size_t)j * ld + j] = add_one ? 1.0 : 0.0;
+}
+void launch_fix_diag(hipStream_t st, int n_full, int n_pad, int ld, bool add_one, const double* scale_cam, double* S) {
+  hipLaunchKernelGGL(k_fix_diag, dim3((n_pad + 255) / 256), dim3(256), 0, st, n_full, n_pad, ld, add_one ? 1 : 0, scale_cam, S);
+}
+
+// ---------------------------------------------------------------------------
+// Back-substitution and candidate point update (one lane per point):
+//   y_p = Gi^T ( h - sum_a U_a^T y_cam(a) - sum_q Uk_q^T y_intr(q) ),  step = -y,
+//   delta = s_p * step,  X_cand = X + delta.
+// partial[b] = { |delta|^2, model-change part, |X_cand|^2 } over free points, where the
+// model cost change is 1/2 sum_j y_j (g_j + D_j^2 y_j)  (== -(J step).(r + J step/2) when
+// (J^T J + D^2) y = g, which the direct solve guarantees to round-off).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_backsub_points(
+    int NP, int NPs, int NI, int gp, double radius, double dmin, double dmax, const int* __restrict__ pt_start,
+    const int* __restrict__ obs_img, const int* __restrict__ q_start, const int* __restrict__ q_cam,
+    const unsigned char* __restrict__ pt_free, const double* __restrict__ Epose, const double* __restrict__ Eintr,
+    const double* __restrict__ y, const double* __restrict__ Gi, const double* __restrict__ h,
+    const double* __restrict__ Cu, const double* __restrict__ gu, const double* __restrict__ scale_pt,
+    const double* __restrict__ points, double* __restrict__ cand_points, double* __restrict__ delta_points,
+    double* __restrict__ partial) {
+  __shared__ double s_red[4];
+  double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < NP; p += gp * 256) {
+    double X[3] = {points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2]};
+    double d[3] = {0, 0, 0};
+    if (pt_free[p]) {
+      double t[3] = {h[p], h[NPs + p], h[2 * NPs + p]};
+      for (int o = pt_start[p]; o < pt_start[p + 1]; ++o) {
+        const double* U = Epose + (size_t)o * kPoseRec;
+        const double* yc = y + 6 * obs_img[o];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double yr = yc[r];
+          t[0] -= U[3 * r] * yr; t[1] -= U[3 * r + 1] * yr; t[2] -= U[3 * r + 2] * yr;
+        }
+      }
+      for (int q = q_start[p]; q < q_start[p + 1]; ++q) {
+        const double* U = Eintr + (size_t)q * kIntrRec;
+        const double* yc = y + 6 * NI + 9 * q_cam[q];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+          const double yr = yc[r];
+          t[0] -= U[3 * r] * yr; t[1] -= U[3 * r + 1] * yr; t[2] -= U[3 * r + 2] * yr;
+        }
+      }
+      const double G[6] = {Gi[p], Gi[NPs + p], Gi[2 * NPs + p], Gi[3 * NPs + p], Gi[4 * NPs + p], Gi[5 * NPs + p]};
+      double yp[3];
+      git_mul(G, t, yp);
+      const int dg[3] = {0, 3, 5};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double s = scale_pt[k * NPs + p];
+        const double D2 = clampd(s * s * Cu[dg[k] * NPs + p], dmin, dmax) / radius;
+        const double gs = s * gu[k * NPs + p];
+        a_model += 0.5 * yp[k] * (gs + D2 * yp[k]);
+        d[k] = -yp[k] * s;
+        a_step += d[k] * d[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double xn = X[k] + d[k];
+      cand_points[3 * (size_t)p + k] = xn;
+      delta_points[3 * (size_t)p + k] = d[k];
+      if (pt_free[p]) a_x2 += xn * xn;
+    }
+  }
+  const double s0 = block_sum_256(a_step, s_red);
+  const double s1 = block_sum_256(a_model, s_red);
+  const double s2 = block_sum_256(a_x2, s_red);
+  if (threadIdx.x == 0) { partial[3 * blockIdx.x] = s0; partial[3 * blockIdx.x + 1] = s1; partial[3 * blockIdx.x + 2] = s2; }
+}
+void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radius, double dmin,
+                           double dmax, const int* pt_start, const int* obs_img, const int* q_start,
+                           const int* q_cam, const unsigned char* pt_free, const double* Epose,
+                           const double* Eintr, const double* y, const double* Gi, const double* h,
+                           const double* Cu, const double* gu, const double* scale_pt,
+                           const double* points, double* cand_points, double* delta_points,
+                           double* partial, int* grid_out) {
+  int gp = (NP + 255) / 256;
+  if (gp > 1024) gp = 1024;
+  if (gp < 1) gp = 1;
+  hipLaunchKernelGGL(k_backsub_points, dim3(gp), dim3(256), 0, st, NP, NPs, NI, gp, radius, dmin, dmax, pt_start,
+                     obs_img, q_start, q_cam, pt_free, Epose, Eintr, y, Gi, h, Cu, gu, scale_pt, points, cand_points,
+                     delta_points, partial);
+  *grid_out = gp;
+}
+
+// Camera columns: step = -y, delta = s * step, candidate parameters; one block.
+__global__ void __launch_bounds__(256) k_update_cameras(
+    int NI, int NC, int cam_part, double radius, double dmin, double dmax, const double* __restrict__ y,
+    const double* __restrict__ scale_cam, const double* __restrict__ img_rec, const double* __restrict__ cam_rec,
+    const double* __restrict__ poses, const double* __restrict__ intr, double* __restrict__ cand_poses,
+    double* __restrict__ cand_intr, double* __restrict__ delta_cam, double* __restrict__ partial3) {
+  __shared__ double s_red[4];
+  const int ncam = 6 * NI + 9 * NC;
+  double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
+  for (int t = threadIdx.x; t < ncam; t += 256) {
+    const double s = scale_cam[t];
+    double n2, g, x;
+    if (t < 6 * NI) {
+      const int i = t / 6, e = t % 6;
+      n2 = img_rec[(size_t)i * kImgRec + sym_idx(e, e, 6)]; g = img_rec[(size_t)i * kImgRec + 21 + e]; x = poses[t];
+    } else {
+      const int c = (t - 6 * NI) / 9, k = (t - 6 * NI) % 9;
+      n2 = cam_rec[(size_t)c * kCamRec + sym_idx(k, k, 9)]; g = cam_rec[(size_t)c * kCamRec + 45 + k]; x = intr[9 * c + k];
+    }
+    double d = 0.0;
+    if (s != 0.0) {
+      const double yy = y[t];
+      const double D2 = clampd(s * s * n2, dmin, dmax) / radius;
+      d = -yy * s;
+      if (cam_part) { a_model += 0.5 * yy * (s * g + D2 * yy); a_step += d * d; }
+    }
+    const double xn = x + d;
+    if (s != 0.0 && cam_part) a_x2 += xn * xn;
+    delta_cam[t] = d;
+    if (t < 6 * NI) cand_poses[t] = xn; else cand_intr[t - 6 * NI] = xn;
+  }
+  const double s0 = block_sum_256(a_step, s_red);
+  const double s1 = block_sum_256(a_model, s_red);
+  const double s2 = block_sum_256(a_x2, s_red);
+  if (threadIdx.x == 0) { partial3[0] = s0; partial3[1] = s1; partial3[2] = s2; }
+}
+void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double radius, double dmin,
+                           double dmax, const double* y, const double* scale_cam,
+                           const double* img_rec, const double* cam_rec, const double* poses,
+                           const double* intr, double* cand_poses, double* cand_intr,
+                           double* delta_cam, double* partial3) {
+  hipLaunchKernelGGL(k_update_cameras, dim3(1), dim3(256), 0, st, NI, NC, cam_part ? 1 : 0, radius, dmin, dmax, y,
+                     scale_cam, img_rec, cam_rec, poses, intr, cand_poses, cand_intr, delta_cam, partial3);
+}
+
+// out[c] (op)= reduce over rows of partial[row*stride + c]; single block, fixed order.
+__global__ void __launch_bounds__(256) k_reduce_cols(const double* __restrict__ partial, int rows, int cols,
+                                                     int stride, unsigned max_mask, double* __restrict__ out,
+                                                     int accumulate) {
+  __shared__ double s_red[4];
+  for (int c = 0; c < cols; ++c) {
+    const bool mx = (max_mask >> c) & 1u;
+    double v = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      const double x = partial[(size_t)r * stride + c];
+      v = mx ? fmax(v, x) : v + x;
+    }
+    const double t = mx ? block_max_256(v, s_red) : block_sum_256(v, s_red);
+    if (threadIdx.x == 0) {
+      if (accumulate) out[c] = mx ? fmax(out[c], t) : out[c] + t;
+      else out[c] = t;
+    }
+    __syncthreads();
+  }
+}
+void launch_reduce_cols(hipStream_t st, const double* partial, int rows, int cols, int stride,
+                        unsigned max_mask, double* out, bool accumulate) {
+  hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(256), 0, st, partial, rows, cols, stride, max_mask, out, accumulate ? 1 : 0);
+}
+
+// point3D_errors: sum |r_raw| / count over a point's observations (bundle_adjustment.cc:590-596)
+__global__ void k_point_errors(int NP, const int* __restrict__ pt_start, const double* __restrict__ rnorm,
+                               const int* __restrict__ pt_count, double* __restrict__ perr) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= NP) return;
+  const double cnt = (double)pt_count[p];
+  double s = 0.0;
+  for (int o = pt_start[p]; o < pt_start[p + 1]; ++o) s += rnorm[o] / cnt;
+  perr[p] = s;
+}
+void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,
+                         const int* pt_count, double* perr) {
+  if (NP <= 0) return;
+  hipLaunchKernelGGL(k_point_errors, dim3((NP + 255) / 256), dim3(256), 0, st, NP, pt_start, rnorm, pt_count, perr);
+}
+
+}  // namespace mavba

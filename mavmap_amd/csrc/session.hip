@@ -1,0 +1,1081 @@
+// session.hip — host side of the MI355X bundle-adjustment backend: problem indexing,
+// device state, the Levenberg-Marquardt trust-region loop, and the C ABI of include/mavba.h.
+//
+// The LM loop runs on the host in C++ and drives the HIP kernels of kernels.hip /
+// dense_chol.hip through one stream; one 128-byte scalar read-back per evaluation and per
+// candidate step is the only device->host traffic inside the loop.
+//
+// Semantics restated (reference file:line, /root/reference):
+//   src/base3d/bundle_adjustment.cc:553-569  ceres::Solve, LM + SPARSE_SCHUR, options
+//   Ceres 1.8 trust_region_minimizer.cc / levenberg_marquardt_strategy.cc  
+//   src/base3d/bundle_adjustment.cc:575-598  point3D_errors
+//   src/base3d/bundle_adjustment.cc:139-225  pose_refinement
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mavba.h"
+#include "ba_math.h"
+#include "internal.h"
+
+namespace mavba {
+
+static thread_local std::string g_last_error;
+
+struct Failure : std::runtime_error {
+  int code;
+  Failure(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+#define HIP_OK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      throw Failure(e_ == hipErrorOutOfMemory ? MAVBA_ERR_OUT_OF_MEMORY : MAVBA_ERR_HIP, \
+                    std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  void alloc(size_t count) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    if (count) HIP_OK(hipMalloc(&p, count * sizeof(T)));
+  }
+  void upload(const std::vector<T>& h, hipStream_t st) {
+    alloc(std::max<size_t>(h.size(), 1));
+    if (!h.empty()) HIP_OK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+  void zero(hipStream_t st) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
+};
+
+static inline int model_k(int m) { return m == MAVBA_MODEL_PINHOLE ? 4 : m == MAVBA_MODEL_OPENCV ? 8 : 9; }
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct KernelTimer { std::string name; long long launches = 0; double total_ms = 0.0; };
+
+}  // namespace mavba
+
+using namespace mavba;
+
+struct mavba_session {
+  mavba_options opt;
+  int device = 0;
+  hipStream_t st = nullptr;
+  // sizes
+  int NI = 0, NC = 0, NP = 0, N = 0, Nstride = 32, NPs = 32, KMAX = 4, n_full = 0, n_pad = 64, Q = 0;
+  long long NO_all = 0;
+  bool any_intr_free = false;
+  // host-side copies
+  std::vector<double> h_poses0, h_intr0, h_points0;
+  std::vector<int> h_cam_model, h_img_cam, h_pt_start, h_oimg;
+  std::vector<long long> perm;      // point-major position -> caller observation index
+  std::vector<int> h_pt_count_all;  // observations per point in the caller's problem
+  std::vector<unsigned char> h_pose_const, h_intr_const_in, h_pt_const_in;
+  std::vector<unsigned char> h_img_used, h_cam_used, h_pt_used;
+  std::vector<unsigned char> h_pose_free, h_intr_free, h_pt_free;
+  double fixed_cost = 0.0;
+  long long num_residuals = 0, num_residuals_reduced = 0, num_parameters_reduced = 0;
+  int num_priors = 0;
+  double prior_weight = 0.0;
+  double setup_seconds = 0.0, solve_seconds = 0.0;
+
+  // ---- device: static problem data ----
+  DevBuf<double2> d_uv, d_im_uv;
+  DevBuf<int> d_obs_img, d_obs_pt, d_pt_start, d_im_pt, d_img_cam, d_cam_model, d_img_chunk_start,
+      d_cam_img_start, d_cam_imgs, d_prior_img, d_prior_start, d_q_pt, d_q_cam, d_q_start, d_pt_count;
+  DevBuf<SweepChunk> d_sweep_chunks;
+  int num_sweep_chunks = 0;
+  DevBuf<unsigned char> d_pose_free, d_intr_free, d_pt_free;
+  DevBuf<double> d_prior_R0;
+  DevBuf<SchurBlock> d_blocks;
+  DevBuf<SchurChunk> d_chunks[3];
+  DevBuf<int2> d_terms[3];
+  int num_blocks = 0, num_chunks[3] = {0, 0, 0};
+  long long num_terms[3] = {0, 0, 0};
+  // ---- device: parameters (current x, candidate, initial) ----
+  DevBuf<double> d_poses, d_intr, d_points, d_cposes, d_cintr, d_cpoints, d_poses0, d_intr0, d_points0;
+  DevBuf<double> d_camrec, d_ccamrec;
+  // ---- device: linearisation ----
+  DevBuf<double> d_R, d_Jp, d_Jc, d_Jk, d_Cu, d_gu, d_Gi, d_h, d_scale_cam, d_scale_pt;
+  DevBuf<double> d_sweep_partial, d_camsum /* img_rec | cam_rec */, d_img_intr_tmp, d_cam_partial;
+  DevBuf<double> d_prior_res, d_prior_jac, d_prior_cost;
+  DevBuf<double> d_Epose, d_Eintr, d_part[3];
+  DevBuf<double> d_M, d_y, d_diag_ws, d_delta_cam, d_delta_pts, d_norm_partial, d_step_partial, d_scal;
+  DevBuf<double> d_rnorm, d_perr;
+  double* d_img_rec = nullptr;
+  double* d_cam_rec = nullptr;
+
+  // ---- LM state (Ceres TrustRegionMinimizer / LevenbergMarquardtStrategy) ----
+  bool evaluated = false, scales_ready = false, started = false, assembled = false;
+  double radius = 1e4, decrease_factor = 2.0;
+  double cost = 0.0, x_norm = 0.0, grad_max = 0.0, abs_gtol = 0.0, initial_cost = 0.0;
+  int iteration = 0, invalid_steps = 0, n_success = 0, n_fail = 0;
+  int termination = MAVBA_TERM_RUNNING;
+
+  // ---- multi-GPU ----
+  mavba_allreduce_fn ar_fn = nullptr;
+  void* ar_ctx = nullptr;
+  int rank = 0, world = 1;
+
+  // ---- profiling ----
+  std::vector<KernelTimer> timers;
+  struct Pending { int idx; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+
+  ~mavba_session() {
+    for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& e : ev_pool) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+  }
+
+  int timer_index(const char* name) {
+    for (size_t i = 0; i < timers.size(); ++i) if (timers[i].name == name) return (int)i;
+    timers.push_back(KernelTimer{name, 0, 0.0});
+    return (int)timers.size() - 1;
+  }
+  hipEvent_t get_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e; HIP_OK(hipEventCreate(&e)); return e;
+  }
+  template <typename F>
+  void timed(const char* name, F&& f) {
+    if (!opt.profile_kernels) { f(); return; }
+    Pending p; p.idx = timer_index(name); p.a = get_event(); p.b = get_event();
+    HIP_OK(hipEventRecord(p.a, st));
+    f();
+    HIP_OK(hipEventRecord(p.b, st));
+    pending.push_back(p);
+  }
+  void flush_timers() {  // only after a stream synchronisation
+    for (auto& p : pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { timers[p.idx].launches++; timers[p.idx].total_ms += ms; }
+      ev_pool.push_back(p.a); ev_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+  void sync() { HIP_OK(hipStreamSynchronize(st)); HIP_OK(hipGetLastError()); flush_timers(); }
+
+  void allreduce(double* dptr, long long count, int op) {
+    if (!ar_fn || world <= 1) return;
+    sync();
+    if (ar_fn(ar_ctx, dptr, count, op) != 0) throw Failure(MAVBA_ERR_HIP, "all-reduce hook failed");
+  }
+
+  SweepArgs sweep_args(const double* camrec, const double* intr, const double* points) {
+    SweepArgs a;
+    a.N = N; a.Nstride = Nstride; a.NI = NI; a.NC = NC; a.KMAX = KMAX;
+    a.uv = d_uv.p; a.obs_img = d_obs_img.p; a.obs_pt = d_obs_pt.p;
+    a.camrec = camrec; a.intr = intr; a.img_cam = d_img_cam.p; a.cam_model = d_cam_model.p;
+    a.points = points;
+    a.loss_b = opt.loss_scale_factor * opt.loss_scale_factor; a.loss_inv_b = 1.0 / a.loss_b;
+    a.R = d_R.p; a.Jp = d_Jp.p; a.Jc = d_Jc.p; a.Jk = d_Jk.p; a.cost_partial = d_sweep_partial.p;
+    return a;
+  }
+  void read_scalars(double* h) {
+    HIP_OK(hipMemcpyAsync(h, d_scal.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+    sync();
+  }
+
+  void build(const mavba_problem* P);
+  void derive_free_flags();
+  void finish_structure();
+  void reset_state();
+  void evaluate();
+  void assemble(double r);
+  void solve_linear(double r);
+  void candidate(double r, double* h_scal);
+  void start();
+  int iterate(int max_iters, int* done);
+  void point_errors(double* out);
+  void fill_result(mavba_result* r);
+};
+
+// ===========================================================================
+// Problem indexing (host) — the device-side counterpart of
+// _bundle_adjustment_extract_data / _fill_problem (bundle_adjustment.cc:228-387): the shim
+// has already selected images and observations; here they are re-ordered point-major and
+// the block structure of the reduced camera system is enumerated.
+// ===========================================================================
+void mavba_session::derive_free_flags() {
+  h_pose_free.assign((size_t)NI * 6, 0);
+  h_intr_free.assign((size_t)NC * 9, 0);
+  h_pt_free.assign(NP, 0);
+  for (int i = 0; i < NI; ++i) {
+    if (!h_img_used[i]) continue;
+    const unsigned m = h_pose_const[i];
+    for (int e = 0; e < 6; ++e) {
+      const bool c = e < 3 ? (m & MAVBA_CONST_RVEC) != 0 : (m & (MAVBA_CONST_TX << (e - 3))) != 0;
+      h_pose_free[(size_t)i * 6 + e] = c ? 0 : 1;
+    }
+  }
+  any_intr_free = false;
+  for (int c = 0; c < NC; ++c) {
+    if (!h_cam_used[c] || h_intr_const_in[c]) continue;
+    for (int k = 0; k < model_k(h_cam_model[c]); ++k) h_intr_free[(size_t)c * 9 + k] = 1;
+    any_intr_free = true;
+  }
+  for (int p = 0; p < NP; ++p) h_pt_free[p] = (h_pt_used[p] && !h_pt_const_in[p]) ? 1 : 0;
+  long long np = 0;
+  for (unsigned char f : h_pose_free) np += f;
+  for (unsigned char f : h_intr_free) np += f;
+  for (unsigned char f : h_pt_free) np += 3 * f;
+  num_parameters_reduced = np;
+}
+
+void mavba_session::build(const mavba_problem* P) {
+  const double t0 = now_s();
+  NI = P->num_images; NC = P->num_cameras; NP = P->num_points; NO_all = P->num_obs;
+  if (NI < 0 || NC < 0 || NP < 0 || NO_all < 0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "negative size");
+  if (NO_all >= (1ll << 31) - 64) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 observations per session");
+  if (NI > 16000) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 16000 images per session (dense block index)");
+  if (!(opt.loss_scale_factor > 0.0)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "loss_scale_factor must be > 0");
+  if (NI > 0 && (!P->poses || !P->image_camera)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null pose arrays");
+  if (NC > 0 && (!P->intrinsics || !P->camera_model)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null camera arrays");
+  if (NP > 0 && !P->points) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null point array");
+  if (NO_all > 0 && (!P->obs_uv || !P->obs_image || !P->obs_point)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null observation arrays");
+  h_cam_model.assign(P->camera_model, P->camera_model + NC);
+  h_img_cam.assign(P->image_camera, P->image_camera + NI);
+  int kmax = 4;
+  for (int c = 0; c < NC; ++c) {
+    if (h_cam_model[c] < 1 || h_cam_model[c] > 3) throw Failure(MAVBA_ERR_BAD_MODEL, "camera model code not in {1,2,3}");
+    kmax = std::max(kmax, model_k(h_cam_model[c]));
+  }
+  KMAX = kmax;  // 4, 8 or 9: number of intrinsics columns the Jacobian planes carry
+  for (int i = 0; i < NI; ++i)
+    if (h_img_cam[i] < 0 || h_img_cam[i] >= NC) throw Failure(MAVBA_ERR_BAD_INDEX, "image_camera out of range");
+  for (long long o = 0; o < NO_all; ++o)
+    if (P->obs_image[o] < 0 || P->obs_image[o] >= NI || P->obs_point[o] < 0 || P->obs_point[o] >= NP)
+      throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
+  for (int q = 0; q < P->num_rot_priors; ++q)
+    if (P->rot_prior_image[q] < 0 || P->rot_prior_image[q] >= NI) throw Failure(MAVBA_ERR_BAD_INDEX, "rot_prior_image out of range");
+
+  h_poses0.assign(P->poses, P->poses + (size_t)NI * 6);
+  h_intr0.assign(P->intrinsics, P->intrinsics + (size_t)NC * 9);
+  h_points0.assign(P->points, P->points + (size_t)NP * 3);
+  h_pose_const.assign(NI, 0); h_intr_const_in.assign(NC, 0); h_pt_const_in.assign(NP, 0);
+  if (P->pose_const) h_pose_const.assign(P->pose_const, P->pose_const + NI);
+  if (P->intr_const) h_intr_const_in.assign(P->intr_const, P->intr_const + NC);
+  if (P->point_const) h_pt_const_in.assign(P->point_const, P->point_const + NP);
+
+  // Residual blocks without a free parameter block leave the program (ceres
+  // RemoveFixedBlocksFromProgram); their cost is the fixed cost.
+  h_pt_count_all.assign(NP, 0);
+  std::vector<long long> kept;
+  kept.reserve((size_t)NO_all);
+  fixed_cost = 0.0;
+  const double b = opt.loss_scale_factor * opt.loss_scale_factor;
+  h_img_used.assign(NI, 0); h_cam_used.assign(NC, 0); h_pt_used.assign(NP, 0);
+  for (long long o = 0; o < NO_all; ++o) {
+    const int i = P->obs_image[o], p = P->obs_point[o], c = h_img_cam[i];
+    h_pt_count_all[p]++;
+    if ((h_pose_const[i] & 15u) == 15u && h_intr_const_in[c] && h_pt_const_in[p]) {
+      double rec[9], r[2], w, hr;
+      cam_prepare(&h_poses0[(size_t)i * 6], rec);
+      obs_residual(h_cam_model[c], rec, &h_intr0[(size_t)c * 9], &h_points0[(size_t)p * 3], P->obs_uv[2 * o],
+                   P->obs_uv[2 * o + 1], r);
+      cauchy_weight(r[0] * r[0] + r[1] * r[1], b, 1.0 / b, w, hr);
+      fixed_cost += hr;
+      continue;
+    }
+    kept.push_back(o);
+    h_img_used[i] = 1; h_cam_used[c] = 1; h_pt_used[p] = 1;
+  }
+  N = (int)kept.size();
+  Nstride = std::max(32, round_up(N, 32));
+  NPs = std::max(32, round_up(NP, 32));
+
+  // rotation priors: kept when the image's rvec block is free, sorted by image
+  std::vector<std::pair<int, int>> pri;  // (image, index)
+  for (int q = 0; q < P->num_rot_priors; ++q) {
+    const int i = P->rot_prior_image[q];
+    if (h_pose_const[i] & MAVBA_CONST_RVEC) {
+      double R0[9], r, j[3];
+      rot_matrix_colmajor(&P->rot_prior_rvec[3 * q], R0);
+      rot_prior_eval(&h_poses0[(size_t)i * 6], R0, P->rot_prior_weight, r, j);
+      fixed_cost += 0.5 * r * r;
+      continue;
+    }
+    pri.push_back({i, q});
+    h_img_used[i] = 1;
+  }
+  std::stable_sort(pri.begin(), pri.end());
+  num_priors = (int)pri.size();
+  prior_weight = P->rot_prior_weight;
+  num_residuals = 2 * NO_all + P->num_rot_priors;
+  num_residuals_reduced = 2ll * N + num_priors;
+
+  // ---- point-major order (stable counting sort by point) ----
+  h_pt_start.assign(NP + 1, 0);
+  for (int k = 0; k < N; ++k) h_pt_start[P->obs_point[kept[k]] + 1]++;
+  for (int p = 0; p < NP; ++p) h_pt_start[p + 1] += h_pt_start[p];
+  perm.assign(N, 0);
+  {
+    std::vector<int> cur(h_pt_start.begin(), h_pt_start.end() - 1);
+    for (int k = 0; k < N; ++k) perm[cur[P->obs_point[kept[k]]]++] = kept[k];
+  }
+  std::vector<double2> uv(N);
+  std::vector<int> opt_(N);
+  h_oimg.assign(N, 0);
+  for (int a = 0; a < N; ++a) {
+    const long long o = perm[a];
+    uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
+    h_oimg[a] = P->obs_image[o]; opt_[a] = P->obs_point[o];
+  }
+
+  // ---- image-major view for the camera sweep ----
+  std::vector<int> img_start(NI + 1, 0);
+  for (int a = 0; a < N; ++a) img_start[h_oimg[a] + 1]++;
+  for (int i = 0; i < NI; ++i) img_start[i + 1] += img_start[i];
+  std::vector<double2> im_uv(N);
+  std::vector<int> im_pt(N);
+  {
+    std::vector<int> cur(img_start.begin(), img_start.end() - 1);
+    for (int a = 0; a < N; ++a) { const int t = cur[h_oimg[a]]++; im_uv[t] = uv[a]; im_pt[t] = opt_[a]; }
+  }
+  const int kSweepChunk = 2048;
+  std::vector<SweepChunk> sweep_chunks;
+  std::vector<int> img_chunk_start(NI + 1, 0);
+  for (int i = 0; i < NI; ++i) {
+    img_chunk_start[i] = (int)sweep_chunks.size();
+    for (int b0 = img_start[i]; b0 < img_start[i + 1]; b0 += kSweepChunk)
+      sweep_chunks.push_back(SweepChunk{i, b0, std::min(b0 + kSweepChunk, img_start[i + 1])});
+  }
+  img_chunk_start[NI] = (int)sweep_chunks.size();
+  num_sweep_chunks = (int)sweep_chunks.size();
+  std::vector<int> cam_img_start(NC + 1, 0), cam_imgs(std::max(NI, 1));
+  for (int i = 0; i < NI; ++i) cam_img_start[h_img_cam[i] + 1]++;
+  for (int c = 0; c < NC; ++c) cam_img_start[c + 1] += cam_img_start[c];
+  {
+    std::vector<int> cur(cam_img_start.begin(), cam_img_start.end() - 1);
+    for (int i = 0; i < NI; ++i) cam_imgs[cur[h_img_cam[i]]++] = i;
+  }
+  std::vector<int> prior_img(num_priors), prior_start(NI + 1, 0);
+  std::vector<double> prior_R0((size_t)num_priors * 9);
+  for (int k = 0; k < num_priors; ++k) {
+    prior_img[k] = pri[k].first;
+    prior_start[pri[k].first + 1]++;
+    rot_matrix_colmajor(&P->rot_prior_rvec[3 * pri[k].second], &prior_R0[(size_t)k * 9]);
+  }
+  for (int i = 0; i < NI; ++i) prior_start[i + 1] += prior_start[i];
+
+  n_full = 6 * NI + 9 * NC;
+  n_pad = std::max(64, round_up(n_full, 64));
+
+  // ---- uploads of the static data ----
+  d_uv.upload(uv, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload(opt_, st); d_pt_start.upload(h_pt_start, st);
+  d_im_uv.upload(im_uv, st); d_im_pt.upload(im_pt, st);
+  d_img_cam.upload(h_img_cam, st); d_cam_model.upload(h_cam_model, st);
+  d_sweep_chunks.upload(sweep_chunks, st); d_img_chunk_start.upload(img_chunk_start, st);
+  d_cam_img_start.upload(cam_img_start, st); d_cam_imgs.upload(cam_imgs, st);
+  d_prior_img.upload(prior_img, st); d_prior_start.upload(prior_start, st); d_prior_R0.upload(prior_R0, st);
+  d_pt_count.upload(h_pt_count_all, st);
+  d_poses0.upload(h_poses0, st); d_intr0.upload(h_intr0, st); d_points0.upload(h_points0, st);
+  const size_t nI = std::max(NI, 1), nC = std::max(NC, 1), nP = std::max(NP, 1);
+  d_poses.alloc(nI * 6); d_intr.alloc(nC * 9); d_points.alloc(nP * 3);
+  d_cposes.alloc(nI * 6); d_cintr.alloc(nC * 9); d_cpoints.alloc(nP * 3);
+  d_camrec.alloc(nI * 9); d_ccamrec.alloc(nI * 9);
+  d_R.alloc((size_t)2 * Nstride); d_Jp.alloc((size_t)6 * Nstride); d_Jc.alloc((size_t)12 * Nstride);
+  d_Jk.alloc((size_t)2 * KMAX * Nstride);
+  d_Cu.alloc((size_t)6 * NPs); d_gu.alloc((size_t)3 * NPs); d_Gi.alloc((size_t)6 * NPs); d_h.alloc((size_t)3 * NPs);
+  d_scale_cam.alloc((size_t)n_pad); d_scale_pt.alloc((size_t)3 * NPs);
+  d_scale_cam.zero(st); d_scale_pt.zero(st);
+  d_sweep_partial.alloc((size_t)jacobian_sweep_grid(std::max(N, 1)) + 8);
+  d_camsum.alloc(nI * kImgRec + nC * kCamRec);
+  d_camsum.zero(st);
+  d_img_rec = d_camsum.p; d_cam_rec = d_camsum.p + (size_t)NI * kImgRec;
+  d_img_intr_tmp.alloc(nI * kCamRec);
+  d_cam_partial.alloc((size_t)std::max(num_sweep_chunks, 1) * kSweepAcc);
+  d_prior_res.alloc(std::max(num_priors, 1)); d_prior_jac.alloc((size_t)std::max(num_priors, 1) * 3);
+  d_prior_cost.alloc(std::max(num_priors, 1));
+  d_Epose.alloc((size_t)std::max(N, 1) * kPoseRec);
+  d_M.alloc((size_t)(n_pad + 64) * n_pad); d_y.alloc(n_pad); d_diag_ws.alloc((size_t)n_pad * 64);
+  d_delta_cam.alloc(n_pad); d_delta_pts.alloc(nP * 3);
+  d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + 2) * 3);
+  d_scal.alloc(SC_COUNT); d_scal.zero(st);
+  d_rnorm.alloc(std::max(N, 1)); d_perr.alloc(nP);
+
+  derive_free_flags();
+  finish_structure();
+  reset_state();
+  sync();
+  setup_seconds = now_s() - t0;
+}
+
+// Everything that depends on which parameter blocks are free: flags on the device, the
+// intrinsics entries (one per free point x free camera seen by it) and the term / chunk /
+// block lists of the Schur complement.
+void mavba_session::finish_structure() {
+  d_pose_free.upload(h_pose_free, st); d_intr_free.upload(h_intr_free, st); d_pt_free.upload(h_pt_free, st);
+  std::vector<unsigned char> img_active(NI, 0), cam_active(NC, 0);
+  for (int i = 0; i < NI; ++i) for (int e = 0; e < 6; ++e) img_active[i] |= h_pose_free[(size_t)i * 6 + e];
+  for (int c = 0; c < NC; ++c) for (int k = 0; k < 9; ++k) cam_active[c] |= h_intr_free[(size_t)c * 9 + k];
+
+  // intrinsics entries
+  std::vector<int> q_start(NP + 1, 0), q_pt, q_cam;
+  {
+    std::vector<int> seen;
+    for (int p = 0; p < NP; ++p) {
+      q_start[p] = (int)q_pt.size();
+      if (!h_pt_free[p]) continue;
+      seen.clear();
+      for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
+        const int c = h_img_cam[h_oimg[a]];
+        if (cam_active[c] && std::find(seen.begin(), seen.end(), c) == seen.end()) seen.push_back(c);
+      }
+      std::sort(seen.begin(), seen.end());
+      for (int c : seen) { q_pt.push_back(p); q_cam.push_back(c); }
+    }
+    q_start[NP] = (int)q_pt.size();
+  }
+  Q = (int)q_pt.size();
+  d_q_start.upload(q_start, st); d_q_pt.upload(q_pt, st); d_q_cam.upload(q_cam, st);
+  d_Eintr.alloc((size_t)std::max(Q, 1) * kIntrRec);
+
+  // term enumeration: f(kind, row_ent, col_ent, x, y)
+  auto enumerate = [&](auto&& f) {
+    for (int p = 0; p < NP; ++p) {
+      if (!h_pt_free[p]) continue;
+      const int a0 = h_pt_start[p], a1 = h_pt_start[p + 1], q0 = q_start[p], q1 = q_start[p + 1];
+      for (int a = a0; a < a1; ++a) {
+        const int i = h_oimg[a];
+        if (!img_active[i]) continue;
+        for (int bq = a0; bq < a1; ++bq) {
+          const int j = h_oimg[bq];
+          if (img_active[j] && i >= j) f(BLK_PP, i, j, a, bq);
+        }
+      }
+      for (int q = q0; q < q1; ++q) {
+        for (int a = a0; a < a1; ++a)
+          if (img_active[h_oimg[a]]) f(BLK_IP, q_cam[q], h_oimg[a], q, a);
+        for (int q2 = q0; q2 <= q; ++q2) f(BLK_II, q_cam[q], q_cam[q2], q, q2);
+      }
+    }
+  };
+  const long long ncols[3] = {NI, NI, NC};
+  const long long nrows[3] = {NI, NC, NC};
+  std::vector<int> count[3];
+  std::vector<unsigned char> mandatory[3];
+  for (int k = 0; k < 3; ++k) { count[k].assign((size_t)(nrows[k] * ncols[k]), 0); mandatory[k].assign(count[k].size(), 0); }
+  for (int i = 0; i < NI; ++i) {
+    if (!img_active[i]) continue;
+    mandatory[BLK_PP][(size_t)i * NI + i] = 1;
+    if (cam_active[h_img_cam[i]]) mandatory[BLK_IP][(size_t)h_img_cam[i] * NI + i] = 1;
+  }
+  for (int c = 0; c < NC; ++c) if (cam_active[c]) mandatory[BLK_II][(size_t)c * NC + c] = 1;
+  long long tot[3] = {0, 0, 0};
+  enumerate([&](int kind, int r, int c, int, int) { count[kind][(size_t)r * ncols[kind] + c]++; tot[kind]++; });
+  for (int k = 0; k < 3; ++k)
+    if (tot[k] >= (1ll << 31) - 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 Schur terms of one kind");
+  const int kChunkTerms = 2048;
+  std::vector<SchurBlock> blocks;
+  std::vector<SchurChunk> chunks[3];
+  std::vector<int> cursor[3];
+  for (int k = 0; k < 3; ++k) {
+    cursor[k].assign(count[k].size(), 0);
+    int off = 0;
+    for (size_t key = 0; key < count[k].size(); ++key) {
+      const int cnt = count[k][key];
+      if (cnt == 0 && !mandatory[k][key]) continue;
+      SchurBlock B;
+      B.kind = k; B.row_ent = (int)(key / ncols[k]); B.col_ent = (int)(key % ncols[k]);
+      B.chunk_begin = (int)chunks[k].size();
+      for (int b0 = off; b0 < off + cnt; b0 += kChunkTerms)
+        chunks[k].push_back(SchurChunk{b0, std::min(b0 + kChunkTerms, off + cnt)});
+      B.chunk_end = (int)chunks[k].size();
+      blocks.push_back(B);
+      cursor[k][key] = off;
+      off += cnt;
+    }
+  }
+  std::vector<int2> terms[3];
+  for (int k = 0; k < 3; ++k) terms[k].resize((size_t)tot[k]);
+  enumerate([&](int kind, int r, int c, int x, int y) {
+    terms[kind][(size_t)cursor[kind][(size_t)r * ncols[kind] + c]++] = make_int2(x, y);
+  });
+  num_blocks = (int)blocks.size();
+  d_blocks.upload(blocks, st);
+  for (int k = 0; k < 3; ++k) {
+    num_chunks[k] = (int)chunks[k].size();
+    num_terms[k] = tot[k];
+    d_chunks[k].upload(chunks[k], st);
+    d_terms[k].upload(terms[k], st);
+    d_part[k].alloc((size_t)std::max(num_chunks[k], 1) * schur_partial_stride(k));
+  }
+  sync();
+}
+
+void mavba_session::reset_state() {
+  HIP_OK(hipMemcpyAsync(d_poses.p, d_poses0.p, (size_t)NI * 6 * 8, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(d_intr.p, d_intr0.p, (size_t)NC * 9 * 8, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(d_points.p, d_points0.p, (size_t)NP * 3 * 8, hipMemcpyDeviceToDevice, st));
+  evaluated = scales_ready = started = assembled = false;
+  radius = opt.initial_trust_region_radius; decrease_factor = 2.0;
+  cost = x_norm = grad_max = abs_gtol = initial_cost = 0.0;
+  iteration = invalid_steps = n_success = n_fail = 0;
+  termination = MAVBA_TERM_RUNNING;
+  solve_seconds = 0.0;
+}
+
+// ===========================================================================
+// Evaluation at the current x: residuals, Jacobian, cost, gradient norm (ceres
+// Evaluator::Evaluate with jacobian != NULL).
+// ===========================================================================
+void mavba_session::evaluate() {
+  timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
+  SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
+  timed("jacobian_sweep", [&] { launch_jacobian_sweep(st, a); });
+  timed("point_sums", [&] { launch_point_sums(st, NP, NPs, Nstride, d_pt_start.p, d_R.p, d_Jp.p, d_Cu.p, d_gu.p); });
+  CamSweepArgs c;
+  c.NI = NI; c.NC = NC; c.chunks = d_sweep_chunks.p; c.num_chunks = num_sweep_chunks;
+  c.im_uv = d_im_uv.p; c.im_pt = d_im_pt.p; c.camrec = d_camrec.p; c.intr = d_intr.p;
+  c.img_cam = d_img_cam.p; c.cam_model = d_cam_model.p; c.points = d_points.p;
+  c.loss_b = a.loss_b; c.loss_inv_b = a.loss_inv_b; c.partial = d_cam_partial.p;
+  timed("camera_sweep", [&] { launch_camera_sweep(st, c, KMAX, any_intr_free); });
+  if (num_priors > 0)
+    timed("rot_prior", [&] {
+      launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_poses.p, d_prior_res.p,
+                       d_prior_jac.p, d_prior_cost.p);
+    });
+  timed("camera_reduce", [&] {
+    launch_camera_reduce(st, NI, NC, d_img_chunk_start.p, d_cam_partial.p, num_priors > 0 ? d_prior_start.p : nullptr,
+                         d_prior_res.p, d_prior_jac.p, d_cam_img_start.p, d_cam_imgs.p, d_img_rec, d_cam_rec,
+                         d_img_intr_tmp.p);
+  });
+  allreduce(d_camsum.p, (long long)NI * kImgRec + (long long)NC * kCamRec, 0);
+  if (!scales_ready) {
+    timed("scales", [&] {
+      launch_scales(st, NI, NC, NP, NPs, opt.jacobi_scaling, d_pose_free.p, d_intr_free.p, d_pt_free.p, d_img_rec,
+                    d_cam_rec, d_Cu.p, d_scale_cam.p, d_scale_pt.p);
+    });
+    scales_ready = true;
+  }
+  int rows = 0;
+  timed("state_norms", [&] {
+    launch_state_norms(st, NI, NC, NP, NPs, rank == 0, d_pose_free.p, d_intr_free.p, d_pt_free.p, d_poses.p,
+                       d_intr.p, d_points.p, d_img_rec, d_cam_rec, d_gu.p, d_norm_partial.p, &rows);
+  });
+  timed("reduce", [&] {
+    launch_reduce_cols(st, d_norm_partial.p, rows, 1, 2, 1u, d_scal.p + SC_GRAD_MAX, false);
+    launch_reduce_cols(st, d_norm_partial.p + 1, rows, 1, 2, 0u, d_scal.p + SC_XNORM2, false);
+    launch_reduce_cols(st, d_sweep_partial.p, N > 0 ? jacobian_sweep_grid(N) : 0, 1, 1, 0u, d_scal.p + SC_COST, false);
+    if (num_priors > 0) launch_reduce_cols(st, d_prior_cost.p, num_priors, 1, 1, 0u, d_scal.p + SC_COST, true);
+  });
+  if (world > 1) {
+    allreduce(d_scal.p, SC_NUM_SUMS, 0);
+    allreduce(d_scal.p + SC_GRAD_MAX, 1, 1);
+  }
+  double h[SC_COUNT];
+  read_scalars(h);
+  cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]);
+  evaluated = true; assembled = false;
+}
+
+// Schur complement for the current Jacobian at trust-region radius r:
+// rows [0, n_pad) of d_M <- S, row n_pad <- v   (SchurEliminator::Eliminate).
+void mavba_session::assemble(double r) {
+  const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
+  HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, sizeof(double), st));
+  timed("point_factor", [&] {
+    launch_point_factor(st, NP, NPs, r, dmin, dmax, d_pt_free.p, d_Cu.p, d_gu.p, d_scale_pt.p, d_Gi.p, d_h.p,
+                        d_scal.p + SC_FAIL);
+  });
+  timed("entries_pose", [&] {
+    launch_entries_pose(st, N, Nstride, NPs, d_obs_img.p, d_obs_pt.p, d_pt_free.p, d_Jc.p, d_Jp.p, d_scale_cam.p,
+                        d_scale_pt.p, d_Gi.p, d_h.p, d_Epose.p);
+  });
+  timed("entries_intr", [&] {
+    launch_entries_intr(st, Q, KMAX, NI, Nstride, NPs, d_q_pt.p, d_q_cam.p, d_pt_start.p, d_obs_img.p, d_img_cam.p,
+                        d_Jk.p, d_Jp.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p, d_Eintr.p);
+  });
+  timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_pad + 64) * n_pad * sizeof(double), st)); });
+  timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
+  timed("schur_chunks_ip", [&] { launch_schur_chunks(st, BLK_IP, num_chunks[1], d_chunks[1].p, d_terms[1].p, d_Epose.p, d_Eintr.p, d_part[1].p); });
+  timed("schur_chunks_ii", [&] { launch_schur_chunks(st, BLK_II, num_chunks[2], d_chunks[2].p, d_terms[2].p, d_Epose.p, d_Eintr.p, d_part[2].p); });
+  double* v = d_M.p + (size_t)n_pad * n_pad;
+  timed("schur_finalize", [&] {
+    launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, n_pad, rank == 0,
+                          r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_M.p, v);
+    launch_fix_diag(st, n_full, n_pad, n_pad, rank == 0, d_scale_cam.p, d_M.p);
+  });
+  allreduce(d_M.p, (long long)(n_pad + 1) * n_pad, 0);
+  assembled = true;
+}
+
+void mavba_session::solve_linear(double r) {
+  assemble(r);
+  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_pad, d_y.p, d_scal.p + SC_FAIL, d_diag_ws.p); });
+  assembled = false;  // the factorisation overwrote S
+}
+
+// Back-substitution, candidate x + delta, and its cost. Leaves the scalars on the host.
+void mavba_session::candidate(double r, double* h) {
+  const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
+  int rows = 0;
+  timed("backsub_points", [&] {
+    launch_backsub_points(st, NP, NPs, NI, r, dmin, dmax, d_pt_start.p, d_obs_img.p, d_q_start.p, d_q_cam.p,
+                          d_pt_free.p, d_Epose.p, d_Eintr.p, d_y.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p,
+                          d_points.p, d_cpoints.p, d_delta_pts.p, d_step_partial.p, &rows);
+  });
+  timed("update_cameras", [&] {
+    launch_update_cameras(st, NI, NC, rank == 0, r, dmin, dmax, d_y.p, d_scale_cam.p, d_img_rec, d_cam_rec,
+                          d_poses.p, d_intr.p, d_cposes.p, d_cintr.p, d_delta_cam.p, d_step_partial.p + 3 * (size_t)rows);
+  });
+  timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_cposes.p, d_ccamrec.p); });
+  SweepArgs a = sweep_args(d_ccamrec.p, d_cintr.p, d_cpoints.p);
+  timed("cost_only", [&] { launch_cost_only(st, a); });
+  if (num_priors > 0)
+    timed("rot_prior", [&] {
+      launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_cposes.p, d_prior_res.p,
+                       d_prior_jac.p, d_prior_cost.p);
+    });
+  timed("reduce", [&] {
+    launch_reduce_cols(st, d_step_partial.p, rows + 1, 1, 3, 0u, d_scal.p + SC_STEP_NORM2, false);
+    launch_reduce_cols(st, d_step_partial.p + 1, rows + 1, 1, 3, 0u, d_scal.p + SC_MODEL_CHANGE, false);
+    launch_reduce_cols(st, d_step_partial.p + 2, rows + 1, 1, 3, 0u, d_scal.p + SC_CAND_XNORM2, false);
+    launch_reduce_cols(st, d_sweep_partial.p, N > 0 ? jacobian_sweep_grid(N) : 0, 1, 1, 0u, d_scal.p + SC_NEW_COST, false);
+    if (num_priors > 0) launch_reduce_cols(st, d_prior_cost.p, num_priors, 1, 1, 0u, d_scal.p + SC_NEW_COST, true);
+  });
+  if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS, 0);
+  read_scalars(h);
+}
+
+void mavba_session::start() {
+  evaluate();
+  initial_cost = cost + fixed_cost;
+  const double g0 = std::max(grad_max, std::numeric_limits<double>::epsilon());
+  abs_gtol = opt.gradient_tolerance * g0;
+  started = true;
+  if (num_residuals_reduced == 0 || num_parameters_reduced == 0) { termination = MAVBA_TERM_FUNCTION_TOLERANCE; return; }
+  if (grad_max <= abs_gtol) { termination = MAVBA_TERM_GRADIENT_TOLERANCE; return; }
+  if (opt.print_progress) {
+    std::printf("%4s %14s %12s %10s %10s %10s %10s\n", "iter", "cost", "cost_change", "|gradient|", "|step|", "tr_ratio", "tr_radius");
+    std::printf("%4d %14.6e %12.2e %10.2e %10.2e %10.2e %10.2e\n", 0, cost + fixed_cost, 0.0, grad_max, 0.0, 0.0, radius);
+  }
+}
+
+// TrustRegionMinimizer::Minimize main loop (Ceres 1.8), one pass per LM iteration.
+int mavba_session::iterate(int max_iters, int* done) {
+  const double t0 = now_s();
+  int n = 0;
+  if (!started) start();
+  while (termination == MAVBA_TERM_RUNNING && n < max_iters) {
+    if (iteration >= opt.max_num_iterations) { termination = MAVBA_TERM_NO_CONVERGENCE; break; }
+    ++iteration; ++n;
+    solve_linear(radius);
+    double h[SC_COUNT];
+    candidate(radius, h);
+    const double mcc = h[SC_MODEL_CHANGE];
+    const bool solved = h[SC_FAIL] == 0.0 && std::isfinite(mcc) && std::isfinite(h[SC_STEP_NORM2]);
+    const bool valid = solved && !(mcc < 0.0);
+    bool successful = false;
+    double rel = 0.0, step_norm = 0.0, cost_change = 0.0;
+    if (!valid) {
+      if (++invalid_steps >= opt.max_num_consecutive_invalid_steps) { termination = MAVBA_TERM_NUMERICAL_FAILURE; ++n_fail; break; }
+    } else {
+      invalid_steps = 0;
+      step_norm = std::sqrt(h[SC_STEP_NORM2]);
+      const double new_cost = h[SC_NEW_COST];
+      if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { termination = MAVBA_TERM_PARAMETER_TOLERANCE; break; }
+      cost_change = cost - new_cost;
+      if (std::fabs(cost_change) < opt.function_tolerance * cost) { termination = MAVBA_TERM_FUNCTION_TOLERANCE; break; }
+      rel = cost_change / mcc;
+      successful = rel > opt.min_relative_decrease;
+    }
+    if (successful) {
+      ++n_success;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+      radius = std::min(opt.max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
+      evaluate();
+      if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+    } else {
+      ++n_fail;
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+    }
+    if (opt.print_progress)
+      std::printf("%4d %14.6e %12.2e %10.2e %10.2e %10.2e %10.2e\n", iteration, cost + fixed_cost, successful ? cost_change : 0.0,
+                  grad_max, step_norm, rel, radius);
+    if (termination == MAVBA_TERM_RUNNING && radius < opt.min_trust_region_radius) termination = MAVBA_TERM_PARAMETER_TOLERANCE;
+  }
+  if (termination == MAVBA_TERM_RUNNING && iteration >= opt.max_num_iterations) termination = MAVBA_TERM_NO_CONVERGENCE;
+  if (done) *done = n;
+  solve_seconds += now_s() - t0;
+  return MAVBA_OK;
+}
+
+void mavba_session::point_errors(double* out) {
+  launch_cam_prepare(st, NI, d_poses.p, d_camrec.p);
+  SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
+  launch_raw_residual_norm(st, a, d_rnorm.p);
+  launch_point_errors(st, NP, d_pt_start.p, d_rnorm.p, d_pt_count.p, d_perr.p);
+  std::vector<double> h(NP);
+  if (NP) HIP_OK(hipMemcpyAsync(h.data(), d_perr.p, (size_t)NP * 8, hipMemcpyDeviceToHost, st));
+  sync();
+  evaluated = false;  // camrec still matches x, but keep the contract simple
+  // Only points that have observations in the problem are touched (bundle_adjustment.cc:578-581);
+  // observations dropped as all-constant blocks still count (they are residual blocks there).
+  for (int p = 0; p < NP; ++p)
+    if (h_pt_count_all[p] > 0) out[p] = h[p];
+}
+
+void mavba_session::fill_result(mavba_result* r) {
+  std::memset(r, 0, sizeof(*r));
+  r->initial_cost = initial_cost;
+  r->final_cost = cost + fixed_cost;
+  r->fixed_cost = fixed_cost;
+  r->num_residuals = num_residuals;
+  r->num_residuals_reduced = num_residuals_reduced;
+  r->num_parameters_reduced = num_parameters_reduced;
+  r->num_successful_steps = n_success;
+  r->num_unsuccessful_steps = n_fail;
+  r->termination = termination;
+  r->final_gradient_max_norm = grad_max;
+  r->final_trust_region_radius = radius;
+  r->setup_seconds = setup_seconds;
+  r->solve_seconds = solve_seconds;
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+#define MAVBA_TRY try {
+#define MAVBA_CATCH                                                              \
+  }                                                                              \
+  catch (const Failure& f) { g_last_error = f.what(); return f.code; }           \
+  catch (const std::bad_alloc&) { g_last_error = "host out of memory"; return MAVBA_ERR_OUT_OF_MEMORY; } \
+  catch (const std::exception& e) { g_last_error = e.what(); return MAVBA_ERR_HIP; }
+
+extern "C" {
+
+void mavba_options_init(mavba_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 100;       // bundle_adjustment.h:40
+  o->function_tolerance = 1e-4;      // :41
+  o->gradient_tolerance = 1e-8;      // :42
+  o->loss_scale_factor = 1.0;        // :45
+  o->update_point_errors = 0;        // :43
+  o->print_progress = 0;             // :49
+  o->parameter_tolerance = 1e-8;     // Ceres 1.8 Solver::Options defaults below
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 10;  // bundle_adjustment.cc:559
+  o->jacobi_scaling = 1;
+  o->device = -1;
+  o->profile_kernels = 0;
+}
+
+const char* mavba_last_error(void) { return g_last_error.c_str(); }
+
+int mavba_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int mavba_session_create(const mavba_problem* problem, const mavba_options* options, mavba_session** out) {
+  if (!problem || !options || !out) { g_last_error = "null argument"; return MAVBA_ERR_INVALID_ARGUMENT; }
+  *out = nullptr;
+  if (mavba_device_count() <= 0) {
+    g_last_error = "no HIP device: the mavba backend has no CPU path";
+    return MAVBA_ERR_NO_DEVICE;
+  }
+  mavba_session* s = nullptr;
+  MAVBA_TRY
+  s = new mavba_session();
+  s->opt = *options;
+  if (options->device >= 0) HIP_OK(hipSetDevice(options->device));
+  HIP_OK(hipGetDevice(&s->device));
+  HIP_OK(hipStreamCreate(&s->st));
+  s->build(problem);
+  *out = s;
+  return MAVBA_OK;
+  }
+  catch (const Failure& f) { g_last_error = f.what(); delete s; return f.code; }
+  catch (const std::bad_alloc&) { g_last_error = "host out of memory"; delete s; return MAVBA_ERR_OUT_OF_MEMORY; }
+  catch (const std::exception& e) { g_last_error = e.what(); delete s; return MAVBA_ERR_HIP; }
+}
+
+void mavba_session_destroy(mavba_session* s) { delete s; }
+
+int mavba_session_reset(mavba_session* s) {
+  MAVBA_TRY
+  s->reset_state();
+  s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_iterate(mavba_session* s, int32_t max_iters, int32_t* iters_done, int32_t* termination) {
+  MAVBA_TRY
+  int done = 0;
+  s->iterate(max_iters, &done);
+  if (iters_done) *iters_done = done;
+  if (termination) *termination = s->termination;
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_result(mavba_session* s, mavba_result* result) {
+  MAVBA_TRY
+  s->fill_result(result);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_get_params(mavba_session* s, double* poses, double* intrinsics, double* points) {
+  MAVBA_TRY
+  if (poses && s->NI) HIP_OK(hipMemcpyAsync(poses, s->d_poses.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
+  if (intrinsics && s->NC) HIP_OK(hipMemcpyAsync(intrinsics, s->d_intr.p, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
+  if (points && s->NP) HIP_OK(hipMemcpyAsync(points, s->d_points.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st));
+  s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_point_errors(mavba_session* s, double* point_error) {
+  MAVBA_TRY
+  if (!point_error) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null point_error");
+  s->point_errors(point_error);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_set_allreduce(mavba_session* s, mavba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world_size) {
+  MAVBA_TRY
+  if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_allreduce must precede the first iteration");
+  s->ar_fn = fn; s->ar_ctx = ctx; s->rank = rank; s->world = world_size;
+  if (fn && world_size > 1) {
+    // A camera block is in the problem if ANY rank has a residual block on it; the counts
+    // reported in mavba_result become global.
+    const size_t n = (size_t)s->NI + s->NC + 4;
+    std::vector<double> h(n, 0.0);
+    for (int i = 0; i < s->NI; ++i) h[i] = s->h_img_used[i];
+    for (int c = 0; c < s->NC; ++c) h[s->NI + c] = s->h_cam_used[c];
+    DevBuf<double> d;
+    d.upload(h, s->st);
+    s->allreduce(d.p, (long long)s->NI + s->NC, 1);
+    std::vector<double> g(4, 0.0);
+    long long free_pts = 0;
+    for (unsigned char f : s->h_pt_free) free_pts += f;
+    g[0] = s->fixed_cost; g[1] = (double)s->num_residuals; g[2] = (double)s->num_residuals_reduced; g[3] = (double)free_pts;
+    HIP_OK(hipMemcpyAsync(d.p + s->NI + s->NC, g.data(), 32, hipMemcpyHostToDevice, s->st));
+    s->allreduce(d.p + s->NI + s->NC, 4, 0);
+    HIP_OK(hipMemcpyAsync(h.data(), d.p, n * 8, hipMemcpyDeviceToHost, s->st));
+    s->sync();
+    for (int i = 0; i < s->NI; ++i) s->h_img_used[i] = h[i] != 0.0;
+    for (int c = 0; c < s->NC; ++c) s->h_cam_used[c] = h[s->NI + c] != 0.0;
+    s->derive_free_flags();
+    long long cam_params = 0;
+    for (unsigned char f : s->h_pose_free) cam_params += f;
+    for (unsigned char f : s->h_intr_free) cam_params += f;
+    s->fixed_cost = h[s->NI + s->NC];
+    s->num_residuals = (long long)h[s->NI + s->NC + 1];
+    s->num_residuals_reduced = (long long)h[s->NI + s->NC + 2];
+    s->num_parameters_reduced = cam_params + 3 * (long long)h[s->NI + s->NC + 3];
+    s->finish_structure();
+  }
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, double* Jc, double* Jp, double* Jk) {
+  MAVBA_TRY
+  s->evaluate();
+  if (cost) *cost = s->cost + s->fixed_cost;
+  const size_t S = s->Nstride, N = s->N;
+  auto pull = [&](const double* dev, int planes, std::vector<double>& h) {
+    h.resize((size_t)planes * S);
+    HIP_OK(hipMemcpyAsync(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost, s->st));
+  };
+  std::vector<double> hR, hJp, hJc, hJk;
+  pull(s->d_R.p, 2, hR); pull(s->d_Jp.p, 6, hJp); pull(s->d_Jc.p, 12, hJc); pull(s->d_Jk.p, 2 * s->KMAX, hJk);
+  s->sync();
+  const size_t NO = (size_t)s->NO_all;
+  if (r) std::memset(r, 0, NO * 2 * 8);
+  if (Jc) std::memset(Jc, 0, NO * 12 * 8);
+  if (Jp) std::memset(Jp, 0, NO * 6 * 8);
+  if (Jk) std::memset(Jk, 0, NO * 18 * 8);
+  for (size_t a = 0; a < N; ++a) {
+    const size_t o = (size_t)s->perm[a];
+    if (r) for (int e = 0; e < 2; ++e) r[o * 2 + e] = hR[e * S + a];
+    if (Jp) for (int e = 0; e < 6; ++e) Jp[o * 6 + e] = hJp[e * S + a];
+    if (Jc) for (int e = 0; e < 12; ++e) Jc[o * 12 + e] = hJc[e * S + a];
+    if (Jk)
+      for (int row = 0; row < 2; ++row)
+        for (int k = 0; k < s->KMAX; ++k) Jk[o * 18 + row * 9 + k] = hJk[(size_t)(row * s->KMAX + k) * S + a];
+  }
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_reduced_dim(mavba_session* s) { return s ? s->n_full : 0; }
+
+int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, double* vout) {
+  MAVBA_TRY
+  if (!s->evaluated) s->evaluate();
+  s->assemble(radius);
+  const int n = s->n_full, ld = s->n_pad;
+  if (Sout && n)
+    HIP_OK(hipMemcpy2DAsync(Sout, (size_t)n * 8, s->d_M.p, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, s->st));
+  if (vout && n)
+    HIP_OK(hipMemcpyAsync(vout, s->d_M.p + (size_t)s->n_pad * ld, (size_t)n * 8, hipMemcpyDeviceToHost, s->st));
+  s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, double* d_intr, double* d_points,
+                              double* model_cost_change) {
+  MAVBA_TRY
+  if (!s->evaluated) s->evaluate();
+  s->solve_linear(radius);
+  double h[SC_COUNT];
+  s->candidate(radius, h);
+  if (model_cost_change) *model_cost_change = h[SC_MODEL_CHANGE];
+  if (d_poses && s->NI) HIP_OK(hipMemcpyAsync(d_poses, s->d_delta_cam.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
+  if (d_intr && s->NC) HIP_OK(hipMemcpyAsync(d_intr, s->d_delta_cam.p + 6 * (size_t)s->NI, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
+  if (d_points && s->NP) HIP_OK(hipMemcpyAsync(d_points, s->d_delta_pts.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st));
+  s->sync();
+  if (h[SC_FAIL] != 0.0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "linear solve failed (matrix not positive definite)");
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
+  MAVBA_TRY
+  if (reps < 1) reps = 1;
+  launch_cam_prepare(s->st, s->NI, s->d_poses.p, s->d_camrec.p);
+  SweepArgs a = s->sweep_args(s->d_camrec.p, s->d_intr.p, s->d_points.p);
+  launch_jacobian_sweep(s->st, a);  // warm-up
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, s->st));
+  for (int i = 0; i < reps; ++i) launch_jacobian_sweep(s->st, a);
+  HIP_OK(hipEventRecord(e1, s->st));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms_avg) *ms_avg = ms / reps;
+  s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_kernel_stats(mavba_session* s, mavba_kernel_stat* out, int32_t cap) {
+  if (!s) return 0;
+  const int n = (int)s->timers.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    std::memset(&out[i], 0, sizeof(out[i]));
+    std::strncpy(out[i].name, s->timers[i].name.c_str(), sizeof(out[i].name) - 1);
+    out[i].launches = s->timers[i].launches;
+    out[i].total_ms = s->timers[i].total_ms;
+  }
+  return n;
+}
+
+int mavba_solve(const mavba_problem* problem, const mavba_options* options, mavba_result* result, double* point_error) {
+  mavba_session* s = nullptr;
+  int rc = mavba_session_create(problem, options, &s);
+  if (rc != MAVBA_OK) return rc;
+  int done = 0, term = 0;
+  rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &term);
+  if (rc == MAVBA_OK && result) rc = mavba_session_result(s, result);
+  // ceres leaves the user's parameter blocks untouched after NUMERICAL_FAILURE
+  if (rc == MAVBA_OK && term != MAVBA_TERM_NUMERICAL_FAILURE)
+    rc = mavba_session_get_params(s, problem->poses, problem->intrinsics, problem->points);
+  if (rc == MAVBA_OK && point_error && options->update_point_errors) rc = mavba_session_point_errors(s, point_error);
+  mavba_session_destroy(s);
+  return rc;
+}
+
+int mavba_pose_refine(double rvec[3], double tvec[3], const double* intrinsics, int32_t camera_model,
+                      const double* uv, const double* xyz, const uint8_t* inlier_mask, int64_t n,
+                      const mavba_options* options, mavba_result* result) {
+  if (!rvec || !tvec || !intrinsics || !options || n < 0 || (n > 0 && (!uv || !xyz))) {
+    g_last_error = "null argument"; return MAVBA_ERR_INVALID_ARGUMENT;
+  }
+  if (camera_model < 1 || camera_model > 3) { g_last_error = "bad camera model"; return MAVBA_ERR_BAD_MODEL; }
+  // One image, one (constant) camera, every inlier a constant point: pose_refinement(),
+  // bundle_adjustment.cc:160-193.
+  std::vector<double> pose = {rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]};
+  std::vector<double> intr(9, 0.0), pts, obs;
+  for (int k = 0; k < model_k(camera_model); ++k) intr[k] = intrinsics[k];
+  std::vector<int32_t> oi, op;
+  for (int64_t i = 0; i < n; ++i) {
+    if (inlier_mask && !inlier_mask[i]) continue;
+    op.push_back((int32_t)(pts.size() / 3)); oi.push_back(0);
+    pts.insert(pts.end(), xyz + 3 * i, xyz + 3 * i + 3);
+    obs.insert(obs.end(), uv + 2 * i, uv + 2 * i + 2);
+  }
+  const int32_t np = (int32_t)(pts.size() / 3);
+  std::vector<uint8_t> pconst(std::max(np, 1), 1);
+  uint8_t pose_const = 0, intr_const = 1;
+  int32_t img_cam = 0, model = camera_model;
+  mavba_problem P;
+  std::memset(&P, 0, sizeof(P));
+  P.num_images = 1; P.num_cameras = 1; P.num_points = np; P.num_obs = np;
+  P.poses = pose.data(); P.pose_const = &pose_const; P.image_camera = &img_cam;
+  P.intrinsics = intr.data(); P.camera_model = &model; P.intr_const = &intr_const;
+  P.points = pts.data(); P.point_const = pconst.data();
+  P.obs_uv = obs.data(); P.obs_image = oi.data(); P.obs_point = op.data();
+  mavba_result local;
+  const int rc = mavba_solve(&P, options, result ? result : &local, nullptr);
+  if (rc == MAVBA_OK) { for (int k = 0; k < 3; ++k) { rvec[k] = pose[k]; tvec[k] = pose[3 + k]; } }
+  return rc;
+}
+
+int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x, int32_t device) {
+  if (n <= 0 || !A || !b || !x) { g_last_error = "bad argument"; return MAVBA_ERR_INVALID_ARGUMENT; }
+  if (mavba_device_count() <= 0) { g_last_error = "no HIP device: the mavba backend has no CPU path"; return MAVBA_ERR_NO_DEVICE; }
+  MAVBA_TRY
+  if (device >= 0) HIP_OK(hipSetDevice(device));
+  hipStream_t st;
+  HIP_OK(hipStreamCreate(&st));
+  const int n_pad = std::max(64, round_up(n, 64));
+  std::vector<double> M((size_t)(n_pad + 64) * n_pad, 0.0);
+  for (int i = 0; i < n_pad; ++i) M[(size_t)i * n_pad + i] = 1.0;
+  for (int i = 0; i < n; ++i) std::memcpy(&M[(size_t)i * n_pad], &A[(size_t)i * n], (size_t)n * 8);
+  std::memcpy(&M[(size_t)n_pad * n_pad], b, (size_t)n * 8);
+  int rc = MAVBA_OK;
+  {
+    DevBuf<double> dM, dy, dws, dfail;
+    dM.upload(M, st); dy.alloc(n_pad); dws.alloc((size_t)n_pad * 64); dfail.alloc(1); dfail.zero(st);
+    dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p);
+    std::vector<double> y(n_pad);
+    double fail = 0.0;
+    HIP_OK(hipMemcpyAsync(y.data(), dy.p, (size_t)n_pad * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&fail, dfail.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::memcpy(x, y.data(), (size_t)n * 8);
+    if (fail != 0.0) { g_last_error = "matrix is not positive definite"; rc = MAVBA_ERR_INVALID_ARGUMENT; }
+  }
+  (void)hipStreamDestroy(st);
+  return rc;
+  MAVBA_CATCH
+}
+
+}  // extern "C"

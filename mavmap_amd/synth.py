@@ -133,12 +133,19 @@ def make_scene(num_images, num_points, track_len, models, seed, rot_priors=False
     tree = cKDTree(centres[:, :2])
     pts, obs_img, obs_pt = [], [], []
     n_long = int(round(long_track_frac * num_points))
+    track_len = min(track_len, NI)
+    long_track_len = min(long_track_len, NI)
     want_len = np.full(num_points, track_len)
     if n_long:
         want_len[rng.choice(num_points, n_long, replace=False)] = long_track_len
     done = 0
+    stalled = 0
     kq = min(NI, max(4 * max(track_len, long_track_len), 48))
     while done < num_points:
+        before = done
+        if stalled > 50:
+            raise RuntimeError("scene generator: no point is visible in enough cameras "
+                               f"(images={NI}, track_len={track_len}, spacing={spacing})")
         m = min(max(2 * (num_points - done), 1024), 400000)
         xy = rng.uniform(lo, hi, (m, 2))
         z = 2.0 * np.sin(xy[:, 0] / 17.0) * np.cos(xy[:, 1] / 23.0) + rng.normal(0, 0.5, m)
@@ -173,6 +180,7 @@ def make_scene(num_images, num_points, track_len, models, seed, rot_priors=False
             obs_img.extend(chosen.tolist())
             obs_pt.extend([done] * L)
             done += 1
+        stalled = stalled + 1 if done == before else 0
     X_true = np.array(pts)
     obs_img = np.array(obs_img, np.int32)
     obs_pt = np.array(obs_pt, np.int32)

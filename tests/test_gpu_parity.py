@@ -1,0 +1,255 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (north star: final RMSE / cameras / points within 1e-6 relative of the CPU path):
+  single evaluation (residuals, Jacobians, cost)      1e-11 relative
+  reduced camera system, LM step                      1e-9  relative
+  full solve: final cost, parameters                  1e-6  relative
+"""
+import numpy as np
+import pytest
+
+from mavmap_amd import _abi as A
+from mavmap_amd import synth
+from tests.conftest import global_opts, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(kind):
+    if kind == "pinhole":
+        return synth.make_config("C2", scale=0.03, seed=11)
+    if kind == "mixed":
+        return synth.make_config("C3", scale=0.01, seed=12)
+    if kind == "cata":
+        return synth.make_scene(num_images=6, num_points=400, track_len=4,
+                                models=[A.MODEL_CATA, A.MODEL_OPENCV, A.MODEL_PINHOLE], seed=13)
+    if kind == "priors":
+        return synth.make_scene(num_images=8, num_points=500, track_len=4,
+                                models=[A.MODEL_PINHOLE], seed=14, rot_priors=True)
+    if kind == "fixed_intr":
+        return synth.make_scene(num_images=8, num_points=500, track_len=4,
+                                models=[A.MODEL_OPENCV], seed=15, refine_camera_params=False)
+    if kind == "gcp":
+        p = synth.make_scene(num_images=8, num_points=500, track_len=4, models=[A.MODEL_PINHOLE], seed=16)
+        p.point_const[::7] = 1
+        p.points[::7] = p.truth["points"][::7]
+        return p
+    raise KeyError(kind)
+
+
+KINDS = ["pinhole", "mixed", "cata", "priors", "fixed_intr", "gcp"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_jacobian_sweep_matches_oracle(mavba, oracle, kind):
+    p = _scene(kind)
+    c0, r0, Jc0, Jp0, Jk0 = oracle.eval_jacobian(p, jac_mode=0)
+    with mavba.Session(p) as s:
+        c, r, Jc, Jp, Jk = s.eval_jacobian()
+    assert abs(c - c0) <= 1e-11 * abs(c0)
+    for name, a, b in (("r", r, r0), ("Jc", Jc, Jc0), ("Jp", Jp, Jp0), ("Jk", Jk, Jk0)):
+        assert rel_err(a, b) < 1e-11, (kind, name, rel_err(a, b))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_reduced_system_and_step_match_oracle(mavba, oracle, kind):
+    p = _scene(kind)
+    for radius in (1e4, 3.0):
+        ref = oracle.linear_step(p, radius)
+        with mavba.Session(p) as s:
+            S, v = s.reduced_system(radius)
+            st = s.linear_step(radius)
+        assert rel_err(S, ref["S"]) < 1e-9, (kind, radius)
+        assert np.abs(S - S.T).max() == 0.0
+        assert rel_err(v, ref["v"]) < 1e-9
+        assert rel_err(st["d_poses"], ref["d_poses"]) < 1e-8
+        assert rel_err(st["d_intr"], ref["d_intr"]) < 1e-8
+        assert rel_err(st["d_points"], ref["d_points"]) < 1e-8
+        assert abs(st["model_cost_change"] - ref["model_cost_change"]) < 1e-9 * abs(ref["model_cost_change"])
+
+
+def _solve_both(mavba, oracle, p, **optkw):
+    po, pg = p.copy(), p.copy()
+    ro, eo = oracle.solve(po, oracle.options(**optkw), want_point_errors=True)
+    eg = np.full(p.num_points, np.nan)
+    _, rg = mavba.bundle_adjustment(pg, dict(optkw), point3D_errors=eg)
+    return po, ro, eo, pg, rg, eg
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_full_solve_matches_oracle(mavba, oracle, kind):
+    p = _scene(kind)
+    po, ro, eo, pg, rg, eg = _solve_both(mavba, oracle, p, **global_opts())
+    assert rg["termination"] == ro["termination"]
+    assert rg["num_successful_steps"] == ro["num_successful_steps"]
+    assert rg["num_unsuccessful_steps"] == ro["num_unsuccessful_steps"]
+    for k in ("num_residuals", "num_residuals_reduced", "num_parameters_reduced"):
+        assert rg[k] == ro[k], k
+    assert abs(rg["initial_cost"] - ro["initial_cost"]) <= 1e-10 * ro["initial_cost"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+    rmse_g = np.sqrt(rg["final_cost"] / rg["num_residuals"])
+    rmse_o = np.sqrt(ro["final_cost"] / ro["num_residuals"])
+    assert abs(rmse_g - rmse_o) <= 1e-6 * rmse_o
+    assert rel_err(pg.poses, po.poses) < 1e-6
+    assert rel_err(pg.points, po.points) < 1e-6
+    assert rel_err(pg.intrinsics, po.intrinsics) < 1e-6
+    m = ~np.isnan(eo)
+    assert np.array_equal(m, ~np.isnan(eg))
+    assert rel_err(eg[m], eo[m]) < 1e-6
+    # constant blocks really stay put
+    assert np.array_equal(pg.poses[0], p.poses[0])
+    assert pg.poses[1, 3] == p.poses[1, 3]
+    if kind == "gcp":
+        assert np.array_equal(pg.points[::7], p.points[::7])
+    if kind == "fixed_intr":
+        assert np.array_equal(pg.intrinsics, p.intrinsics)
+
+
+def test_local_ba_windows_c1(mavba, oracle):
+    """Config C1: the reference's local-BA window [FIXED, FIXED, FREE x 6] slid over 10 images."""
+    g = synth.make_config("C1")
+    for first in range(0, g.num_images - 7):
+        p = synth.local_ba_window(g, first)
+        p.intr_const[:] = 0  # mapper.cc:882-886: refine_camera_params defaults to true for local BA
+        po, ro, _, pg, rg, _ = _solve_both(mavba, oracle, p)  # BundleAdjustmentOptions defaults
+        assert rg["termination"] == ro["termination"]
+        assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+        assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+        # images outside the window are not part of the problem and must not move
+        out = np.setdiff1d(np.arange(g.num_images), np.arange(first, first + 8))
+        assert np.array_equal(pg.poses[out], p.poses[out])
+
+
+def test_pose_refinement_matches_oracle(mavba, oracle):
+    g = synth.make_scene(num_images=4, num_points=300, track_len=3, models=[A.MODEL_OPENCV], seed=21)
+    sel = g.obs_image == 2
+    uv, xyz = g.obs_uv[sel], g.truth["points"][g.obs_point[sel]]
+    mask = np.ones(len(uv), np.uint8)
+    mask[::9] = 0
+    rvec, tvec = g.poses[2, :3].copy(), g.poses[2, 3:].copy()
+    cam = np.concatenate([g.truth["intrinsics"][g.image_camera[2]][:8], [float(A.MODEL_OPENCV)]])
+    cost, res = mavba.pose_refinement(rvec, tvec, cam, uv, xyz, mask)
+    # oracle: same thing as a flat problem
+    from mavmap_amd.problem import BAProblem
+    keep = mask.astype(bool)
+    q = BAProblem(poses=g.poses[2:3].copy(), pose_const=[0], image_camera=[0],
+                  intrinsics=g.truth["intrinsics"][g.image_camera[2]][None].copy(), camera_model=[A.MODEL_OPENCV],
+                  intr_const=[1], points=xyz[keep].copy(), point_const=np.ones(keep.sum(), np.uint8),
+                  obs_uv=uv[keep].copy(), obs_image=np.zeros(keep.sum(), np.int32),
+                  obs_point=np.arange(keep.sum(), dtype=np.int32))
+    ro, _ = oracle.solve(q)
+    assert res["termination"] == ro["termination"]
+    assert abs(res["final_cost"] - ro["final_cost"]) <= 1e-6 * max(ro["final_cost"], 1e-12)
+    assert rel_err(np.concatenate([rvec, tvec]), q.poses[0]) < 1e-6
+    assert abs(cost - np.sqrt(ro["final_cost"] / ro["num_residuals"])) < 1e-6 * cost
+
+
+@pytest.mark.parametrize("n", [5, 64, 65, 200, 777])
+def test_dense_spd_solve(mavba, n):
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, n))
+    Amat = B @ B.T + n * np.eye(n)
+    # asymmetric-by-construction right-hand side and matrix: catches transposed MFMA tiles
+    Amat[np.arange(n), np.arange(n)] += np.arange(n) * 0.5
+    b = rng.normal(size=n)
+    x = mavba.dense_spd_solve(Amat, b)
+    x0 = np.linalg.solve(Amat, b)
+    assert rel_err(x, x0) < 1e-10
+    with pytest.raises(mavba.MavbaError):
+        mavba.dense_spd_solve(-Amat, b)
+
+
+def test_edge_cases(mavba, oracle):
+    # empty problem: returns immediately, cost 0 (the reference prints a warning and returns NaN
+    # = sqrt(0/0); the shim computes that from these numbers)
+    from mavmap_amd.problem import BAProblem
+    e = BAProblem(poses=np.zeros((2, 6)), pose_const=[15, 2], image_camera=[0, 0], intrinsics=np.zeros((1, 9)),
+                  camera_model=[1], intr_const=[0], points=np.zeros((0, 3)), point_const=[], obs_uv=np.zeros((0, 2)),
+                  obs_image=[], obs_point=[])
+    e.intrinsics[0, :4] = [600, 600, 376, 240]
+    cost, res = mavba.bundle_adjustment(e)
+    assert res["num_residuals"] == 0 and res["final_cost"] == 0.0 and np.isnan(cost)
+    # a ragged problem: one point seen once (L = 1), an image without observations, a camera without images
+    p = synth.make_scene(num_images=6, num_points=120, track_len=3, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=31)
+    keep = np.ones(p.num_obs, bool)
+    first_of_pt5 = np.nonzero(p.obs_point == 5)[0]
+    keep[first_of_pt5[1:]] = False
+    keep[p.obs_image == 4] = False
+    p.obs_uv, p.obs_image, p.obs_point = p.obs_uv[keep], p.obs_image[keep], p.obs_point[keep]
+    po, ro, eo, pg, rg, eg = _solve_both(mavba, oracle, p, **global_opts())
+    assert rg["termination"] == ro["termination"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+    assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+    assert np.array_equal(pg.poses[4], p.poses[4])
+    # bad inputs are rejected with the documented codes
+    bad = p.copy(); bad.obs_image[0] = 99
+    with pytest.raises(mavba.MavbaError) as ei:
+        mavba.bundle_adjustment(bad)
+    assert ei.value.code == A.ERR_BAD_INDEX
+    bad = p.copy(); bad.camera_model[0] = 7
+    with pytest.raises(mavba.MavbaError) as ei:
+        mavba.bundle_adjustment(bad)
+    assert ei.value.code == A.ERR_BAD_MODEL
+
+
+def test_fixed_cost_blocks(mavba, oracle):
+    """Residual blocks whose parameter blocks are all constant leave the program (fixed cost)."""
+    p = synth.make_scene(num_images=6, num_points=200, track_len=3, models=[A.MODEL_PINHOLE], seed=41,
+                         refine_camera_params=False)
+    seen0 = np.unique(p.obs_point[p.obs_image == 0])
+    p.point_const[seen0[:20]] = 1
+    po, ro, _, pg, rg, _ = _solve_both(mavba, oracle, p, **global_opts())
+    assert ro["fixed_cost"] > 0
+    assert abs(rg["fixed_cost"] - ro["fixed_cost"]) <= 1e-12 * ro["fixed_cost"]
+    assert rg["num_residuals_reduced"] == ro["num_residuals_reduced"] < ro["num_residuals"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+
+
+def test_session_iterate_reset_and_determinism(mavba):
+    p = synth.make_config("C2", scale=0.05, seed=51)
+    with mavba.Session(p, global_opts()) as s:
+        r1 = s.solve()
+        x1 = s.get_params()
+        s.reset()
+        n = 0
+        while True:
+            done, term = s.iterate(1)
+            n += done
+            if term != A.TERM_RUNNING:
+                break
+        r2 = s.result()
+        x2 = s.get_params()
+    assert n == r1["num_successful_steps"] + r1["num_unsuccessful_steps"]
+    # fixed-shape reduction trees: bit-identical run to run
+    assert r1["final_cost"] == r2["final_cost"]
+    for a, b in zip(x1, x2):
+        assert np.array_equal(a, b)
+
+
+def test_full_size_c2_properties(mavba):
+    """BASELINE config C2 at full size (100 images / 30k points / 300k observations): properties that
+    do not need the oracle — monotone cost, first-order optimality, ground-truth recovery on clean data."""
+    p = synth.make_config("C2")
+    assert (p.num_images, p.num_points, p.num_obs) == (100, 30000, 300000)
+    q = p.copy()
+    cost, res = mavba.bundle_adjustment(q, global_opts())
+    assert res["termination"] in (A.TERM_FUNCTION_TOLERANCE, A.TERM_GRADIENT_TOLERANCE, A.TERM_PARAMETER_TOLERANCE)
+    assert res["final_cost"] < 0.2 * res["initial_cost"]
+    # noise-free observations from the perturbed start -> exact recovery up to the datum
+    clean = synth.make_scene(num_images=100, num_points=30000, track_len=10, models=[A.MODEL_PINHOLE], seed=1002,
+                             noise_px=0.0, outlier_frac=0.0)
+    c = clean.copy()
+    cost, res = mavba.bundle_adjustment(c, global_opts(function_tolerance=1e-14, gradient_tolerance=1e-14))
+    assert cost < 1e-6
+    uv = _reproject(c)
+    assert np.abs(uv - clean.truth["uv_clean"]).max() < 1e-5
+
+
+def _reproject(p):
+    R = synth.rodrigues(p.poses[:, :3])
+    Xc = np.einsum("nij,nj->ni", R[p.obs_image], p.points[p.obs_point]) + p.poses[p.obs_image, 3:]
+    uv = np.zeros((p.num_obs, 2))
+    for c in range(p.num_cameras):
+        sel = p.image_camera[p.obs_image] == c
+        uv[sel] = synth.project(int(p.camera_model[c]), p.intrinsics[c], Xc[sel])
+    return uv
