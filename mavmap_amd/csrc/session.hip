@@ -483,7 +483,10 @@ void mavba_session::finish_structure() {
   enumerate([&](int kind, int r, int c, int, int) { count[kind][(size_t)r * ncols[kind] + c]++; tot[kind]++; });
   for (int k = 0; k < 3; ++k)
     if (tot[k] >= (1ll << 31) - 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 Schur terms of one kind");
-  const int kChunkTerms = 2048;
+  // One wave per chunk: aim for a few thousand chunks per kind so that a single long block (the
+  // intrinsics-intrinsics block has one term per point) still fills the chip.
+  int chunk_terms[3];
+  for (int k = 0; k < 3; ++k) chunk_terms[k] = (int)std::min<long long>(2048, std::max<long long>(128, tot[k] / 4096));
   std::vector<SchurBlock> blocks;
   std::vector<SchurChunk> chunks[3];
   std::vector<int> cursor[3];
@@ -496,8 +499,8 @@ void mavba_session::finish_structure() {
       SchurBlock B;
       B.kind = k; B.row_ent = (int)(key / ncols[k]); B.col_ent = (int)(key % ncols[k]);
       B.chunk_begin = (int)chunks[k].size();
-      for (int b0 = off; b0 < off + cnt; b0 += kChunkTerms)
-        chunks[k].push_back(SchurChunk{b0, std::min(b0 + kChunkTerms, off + cnt)});
+      for (int b0 = off; b0 < off + cnt; b0 += chunk_terms[k])
+        chunks[k].push_back(SchurChunk{b0, std::min(b0 + chunk_terms[k], off + cnt)});
       B.chunk_end = (int)chunks[k].size();
       blocks.push_back(B);
       cursor[k][key] = off;

@@ -29,7 +29,7 @@ if has bench; then
 fi
 if has prof; then
   rm -rf $OUT/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 60 --warmup 6 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof_bench.log)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 60 --warmup 6 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof_bench.log)
   echo "rocprof exit $?"
   find $OUT/prof -name "*stats*" | head; find $OUT/prof -name "*kernel_stats*.csv" -exec head -30 {} \;
   # keep only the summaries (the raw trace can be large)

@@ -219,7 +219,9 @@ def test_session_iterate_reset_and_determinism(mavba):
                 break
         r2 = s.result()
         x2 = s.get_params()
-    assert n == r1["num_successful_steps"] + r1["num_unsuccessful_steps"]
+    # the iteration that trips a tolerance is started but never counted (ceres returns before the
+    # step is judged), hence the possible +1
+    assert n - (r1["num_successful_steps"] + r1["num_unsuccessful_steps"]) in (0, 1)
     # fixed-shape reduction trees: bit-identical run to run
     assert r1["final_cost"] == r2["final_cost"]
     for a, b in zip(x1, x2):
