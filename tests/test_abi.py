@@ -1,0 +1,98 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol include/mavba.h declares,
+its structs match the ctypes mirror byte for byte, and compute calls fail loudly without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from mavmap_amd import _abi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mavba.h")
+
+
+def _declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(mavba_[a-z0-9_]+)\s*\(", text))
+    names.discard("mavba_allreduce_fn")
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(mavba):
+    from mavmap_amd import api
+    L = mavba.load()
+    declared = _declared_functions()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(api.EXPORTED_SYMBOLS) == declared
+
+
+def test_struct_layouts_match_the_header():
+    src = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "mavba.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\n", sizeof(mavba_problem), sizeof(mavba_options), sizeof(mavba_result), sizeof(mavba_kernel_stat));
+  printf("%zu %zu %zu %zu\n", offsetof(mavba_problem, obs_uv), offsetof(mavba_problem, rot_prior_weight),
+         offsetof(mavba_options, parameter_tolerance), offsetof(mavba_result, termination));
+  return 0;
+}"""
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.c"), "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(td, "t.c"), "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = [C.sizeof(A.CProblem), C.sizeof(A.COptions), C.sizeof(A.CResult), C.sizeof(A.CKernelStat)]
+    offs = [A.CProblem.obs_uv.offset, A.CProblem.rot_prior_weight.offset, A.COptions.parameter_tolerance.offset,
+            A.CResult.termination.offset]
+    assert [int(x) for x in out[:4]] == sizes
+    assert [int(x) for x in out[4:]] == offs
+
+
+def test_options_defaults_are_the_reference_and_ceres_defaults(mavba):
+    o = mavba.api.make_options()
+    # BundleAdjustmentOptions() — reference src/base3d/bundle_adjustment.h:40-50
+    assert (o.max_num_iterations, o.function_tolerance, o.gradient_tolerance, o.loss_scale_factor) == (100, 1e-4, 1e-8, 1.0)
+    # Ceres 1.8 Solver::Options defaults the reference relies on
+    assert (o.parameter_tolerance, o.initial_trust_region_radius, o.max_trust_region_radius) == (1e-8, 1e4, 1e16)
+    assert (o.min_trust_region_radius, o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-32, 1e-3, 1e-6, 1e32)
+    assert o.max_num_consecutive_invalid_steps == 10 and o.jacobi_scaling == 1
+    g = mavba.BundleAdjustmentOptions.global_ba()  # reference src/mapper.cc:170-174
+    assert (g.max_num_iterations, g.function_tolerance, g.gradient_tolerance) == (200, 1e-6, 1e-10)
+
+
+def test_compute_calls_fail_loudly_without_a_device(mavba):
+    if mavba.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from mavmap_amd import synth
+    p = synth.make_config("C1")
+    before = p.poses.copy()
+    for call in (lambda: mavba.bundle_adjustment(p), lambda: mavba.Session(p),
+                 lambda: mavba.dense_spd_solve(np.eye(3), np.ones(3)),
+                 lambda: mavba.pose_refinement(np.zeros(3), np.zeros(3), [600, 600, 376, 240, 1.0], np.zeros((4, 2)),
+                                               np.ones((4, 3)))):
+        with pytest.raises(mavba.MavbaError) as ei:
+            call()
+        assert ei.value.code == A.ERR_NO_DEVICE
+        assert "no CPU path" in str(ei.value)
+    assert np.array_equal(p.poses, before)
+
+
+def test_product_code_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under mavmap_amd/ or shim/ may reference it."""
+    bad = []
+    for base in ("mavmap_amd", "shim", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".cc")):
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    if re.search(r"oracle_lib|ba_oracle|libba_oracle|from tests|import tests", text):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -197,7 +197,7 @@ def test_solver_reaches_the_same_minimum_as_scipy(oracle):
 
 def test_ground_truth_recovery_on_clean_data(oracle):
     p = synth.make_scene(num_images=6, num_points=150, track_len=4, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV],
-                         seed=9, noise_px=0.0, outlier_frac=0.0, refine_camera_params=False)
+                         seed=9, noise_px=0.0, outlier_frac=0.0)
     q = p.copy()
     res, _ = oracle.solve(q, oracle.options(**global_opts(function_tolerance=1e-16, gradient_tolerance=1e-16)))
     assert res["final_cost"] < 1e-12 * res["initial_cost"]
