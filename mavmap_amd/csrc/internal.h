@@ -150,7 +150,7 @@ void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const doub
 // SPD matrix (lower triangle is read), row n_pad holds the right-hand side.
 // On return y[0..n_pad) = A^-1 b; M is overwritten by the factor. *fail
 // (device double) is incremented if a pivot is not positive.
-// diag_ws: workspace of n_pad * 64 doubles (the factor's diagonal tiles).
+// diag_ws: workspace of 2 * n_pad * 64 doubles (the factor's diagonal tiles and their inverses).
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws);
 

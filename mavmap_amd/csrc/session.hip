@@ -405,7 +405,7 @@ void mavba_session::build(const mavba_problem* P) {
   d_prior_res.alloc(std::max(num_priors, 1)); d_prior_jac.alloc((size_t)std::max(num_priors, 1) * 3);
   d_prior_cost.alloc(std::max(num_priors, 1));
   d_Epose.alloc((size_t)std::max(N, 1) * kPoseRec);
-  d_M.alloc((size_t)(n_pad + 64) * n_pad); d_y.alloc(n_pad); d_diag_ws.alloc((size_t)n_pad * 64);
+  d_M.alloc((size_t)(n_pad + 64) * n_pad); d_y.alloc(n_pad); d_diag_ws.alloc((size_t)2 * n_pad * 64);
   d_delta_cam.alloc(n_pad); d_delta_pts.alloc(nP * 3);
   d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + 2) * 3);
   d_scal.alloc(SC_COUNT); d_scal.zero(st);
@@ -483,10 +483,14 @@ void mavba_session::finish_structure() {
   enumerate([&](int kind, int r, int c, int, int) { count[kind][(size_t)r * ncols[kind] + c]++; tot[kind]++; });
   for (int k = 0; k < 3; ++k)
     if (tot[k] >= (1ll << 31) - 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 Schur terms of one kind");
-  // One wave per chunk: aim for a few thousand chunks per kind so that a single long block (the
-  // intrinsics-intrinsics block has one term per point) still fills the chip.
-  int chunk_terms[3];
-  for (int k = 0; k < 3; ++k) chunk_terms[k] = (int)std::min<long long>(2048, std::max<long long>(128, tot[k] / 4096));
+  // One wave per chunk. A block gets ceil(terms / 1024) chunks but never more than 64, so the
+  // finalize pass (which adds a block's chunk partials in order) stays short even for the
+  // intrinsics-intrinsics block, whose term list has one entry per point.
+  auto block_chunk_terms = [](int cnt) {
+    int nch = (cnt + 1023) / 1024;
+    nch = std::max(1, std::min(nch, 64));
+    return std::max(1, (cnt + nch - 1) / nch);
+  };
   std::vector<SchurBlock> blocks;
   std::vector<SchurChunk> chunks[3];
   std::vector<int> cursor[3];
@@ -499,8 +503,9 @@ void mavba_session::finish_structure() {
       SchurBlock B;
       B.kind = k; B.row_ent = (int)(key / ncols[k]); B.col_ent = (int)(key % ncols[k]);
       B.chunk_begin = (int)chunks[k].size();
-      for (int b0 = off; b0 < off + cnt; b0 += chunk_terms[k])
-        chunks[k].push_back(SchurChunk{b0, std::min(b0 + chunk_terms[k], off + cnt)});
+      const int ct = block_chunk_terms(cnt);
+      for (int b0 = off; b0 < off + cnt; b0 += ct)
+        chunks[k].push_back(SchurChunk{b0, std::min(b0 + ct, off + cnt)});
       B.chunk_end = (int)chunks[k].size();
       blocks.push_back(B);
       cursor[k][key] = off;
@@ -1066,7 +1071,7 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
   int rc = MAVBA_OK;
   {
     DevBuf<double> dM, dy, dws, dfail;
-    dM.upload(M, st); dy.alloc(n_pad); dws.alloc((size_t)n_pad * 64); dfail.alloc(1); dfail.zero(st);
+    dM.upload(M, st); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
     dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p);
     std::vector<double> y(n_pad);
     double fail = 0.0;
