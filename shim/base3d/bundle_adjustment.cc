@@ -1,0 +1,357 @@
+// bundle_adjustment.cc — replacement translation unit for MAVMAP's
+// src/base3d/bundle_adjustment.cc: same two functions, no Ceres. It restates the reference's
+// problem construction (which images / observations / constant blocks enter the problem) on
+// the host and hands the flattened problem to the MI355X library through include/mavba.h.
+//
+// Restated (reference file:line, /root/reference):
+//   validation                     src/base3d/bundle_adjustment.cc:459-471
+//   observation selection + order  :228-286 (extract), :289-387 (fill), :493-533 (call order)
+//   constancy per pose state       :361-385  (only when the image contributed > 1 residual)
+//   rotation priors + pre-rotation :390-446  (+ src/base3d/projection.cc:12-23,
+//                                   src/base3d/similarity_transform.cc:90-122)
+//   GCP points                     :545-549
+//   point3D_errors                 :575-598
+//   report / return value          :114-136, :600-612
+//   pose_refinement                :139-225
+#include "base3d/bundle_adjustment.h"
+
+#include <cmath>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <string>
+
+#include "mavba.h"
+
+namespace {
+
+const double kEps = std::numeric_limits<double>::epsilon();
+
+// ---- small SO(3) helpers on plain doubles (row-major 3x3) -------------------------------
+// angle_axis_from_rvec(rvec).toRotationMatrix()  (projection.cc:12-23)
+void rotation_from_rvec(const double* w, double* R) {
+  double angle = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double ax[3] = {0, 0, 1};
+  if (angle < kEps) {
+    angle = 0;
+  } else {
+    for (int i = 0; i < 3; ++i) ax[i] = w[i] / angle;
+  }
+  const double c = std::cos(angle), s = std::sin(angle), t = 1 - c;
+  R[0] = c + t * ax[0] * ax[0];         R[1] = t * ax[0] * ax[1] - s * ax[2]; R[2] = t * ax[0] * ax[2] + s * ax[1];
+  R[3] = t * ax[0] * ax[1] + s * ax[2]; R[4] = c + t * ax[1] * ax[1];         R[5] = t * ax[1] * ax[2] - s * ax[0];
+  R[6] = t * ax[0] * ax[2] - s * ax[1]; R[7] = t * ax[1] * ax[2] + s * ax[0]; R[8] = c + t * ax[2] * ax[2];
+}
+
+// Eigen::AngleAxisd(matrix): matrix -> quaternion -> (angle in [0, pi], axis); returns angle*axis.
+void rvec_from_rotation(const double* R, double* w) {
+  double q[4];  // w, x, y, z
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) {
+    double t = std::sqrt(tr + 1.0);
+    q[0] = 0.5 * t; t = 0.5 / t;
+    q[1] = (R[7] - R[5]) * t; q[2] = (R[2] - R[6]) * t; q[3] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    q[1 + i] = 0.5 * t; t = 0.5 / t;
+    q[0] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[1 + j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[1 + k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+  double n = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n != 0.0) {
+    const double angle = 2.0 * std::atan2(n, std::fabs(q[0]));
+    if (q[0] < 0) n = -n;
+    for (int i = 0; i < 3; ++i) w[i] = angle * q[1 + i] / n;
+  } else {
+    w[0] = w[1] = w[2] = 0.0;
+  }
+}
+
+void matmul3(const double* A, const double* B, double* C) {  // C = A B
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+
+int model_num_params(int code) {
+  switch (code) {
+    case MAVBA_MODEL_PINHOLE: return 4;
+    case MAVBA_MODEL_OPENCV: return 8;
+    case MAVBA_MODEL_CATA: return 9;
+  }
+  return -1;
+}
+
+void fill_options(const BundleAdjustmentOptions& o, mavba_options* m) {
+  mavba_options_init(m);
+  m->max_num_iterations = (int32_t)o.max_num_iterations;
+  m->function_tolerance = o.function_tolerance;
+  m->gradient_tolerance = o.gradient_tolerance;
+  m->loss_scale_factor = o.loss_scale_factor;
+  m->update_point_errors = o.update_point3D_errors ? 1 : 0;
+  m->print_progress = o.print_progress ? 1 : 0;
+}
+
+[[noreturn]] void raise(int code) {
+  const std::string msg = std::string("mavba: ") + mavba_last_error();
+  if (code == MAVBA_ERR_INVALID_ARGUMENT || code == MAVBA_ERR_BAD_INDEX || code == MAVBA_ERR_BAD_MODEL)
+    throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+
+// _print_report (bundle_adjustment.cc:114-136)
+void print_report(const mavba_result& s) {
+  std::cout << std::right << std::setw(18) << "Residuals : " << std::left << s.num_residuals_reduced << std::endl;
+  std::cout << std::right << std::setw(18) << "Parameters : " << std::left << s.num_parameters_reduced << std::endl;
+  std::cout << std::right << std::setw(18) << "Iterations : " << std::left
+            << s.num_successful_steps + s.num_unsuccessful_steps << std::endl;
+  std::cout << std::right << std::setw(18) << "Initial cost : " << std::right << std::setprecision(6)
+            << std::sqrt(s.initial_cost / s.num_residuals) << " [px]" << std::endl;
+  std::cout << std::right << std::setw(18) << "Final cost : " << std::right << std::setprecision(6)
+            << std::sqrt(s.final_cost / s.num_residuals) << " [px]" << std::endl;
+  std::cout << std::endl;
+}
+
+}  // namespace
+
+double pose_refinement(Eigen::Vector3d& rvec, Eigen::Vector3d& tvec, std::vector<double>& camera_params,
+                       const std::vector<Eigen::Vector2d>& points2D, std::vector<Eigen::Vector3d>& points3D,
+                       const std::vector<bool>& inlier_mask, const BundleAdjustmentOptions& options) {
+  const int model = (int)camera_params.back();
+  const size_t n = points2D.size();
+  std::vector<double> uv(2 * n), xyz(3 * n);
+  std::vector<uint8_t> mask(n);
+  for (size_t i = 0; i < n; ++i) {
+    uv[2 * i] = points2D[i](0); uv[2 * i + 1] = points2D[i](1);
+    xyz[3 * i] = points3D[i](0); xyz[3 * i + 1] = points3D[i](1); xyz[3 * i + 2] = points3D[i](2);
+    mask[i] = inlier_mask[i] ? 1 : 0;
+  }
+  mavba_options mo;
+  fill_options(options, &mo);
+  mavba_result res;
+  const int rc = mavba_pose_refine(rvec.data(), tvec.data(), camera_params.data(), model, uv.data(), xyz.data(),
+                                   mask.data(), (int64_t)n, &mo, &res);
+  if (rc != MAVBA_OK) raise(rc);
+  if (options.print_progress) std::cout << std::endl;
+  if (options.print_summary) {
+    std::cout << "Pose Refinement Report" << std::endl;
+    std::cout << "----------------------" << std::endl;
+    print_report(res);
+  }
+  return std::sqrt(res.final_cost / res.num_residuals);
+}
+
+double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_image_ids,
+                         const std::vector<size_t>& fixed_image_ids, const std::vector<size_t>& fixed_x_image_ids,
+                         const BundleAdjustmentOptions& options, std::unordered_map<size_t, double>& point3D_errors,
+                         const std::unordered_map<size_t, Eigen::Vector3d>& rotation_constraints,
+                         const std::set<size_t>& gcp_ids) {
+  const size_t num_fixed_params = fixed_image_ids.size() * 6 + fixed_x_image_ids.size() + gcp_ids.size() * 3;
+  if (num_fixed_params < 7) {
+    throw std::invalid_argument("At least 7 parameters should be set as fixed to avoid datum defects resulting in a "
+                                "singular Jacobian.");
+  }
+  if (options.min_track_len < 2) {
+    throw std::invalid_argument("Minimum track length must be >= 2 in order build valid bundle adjustment problem.");
+  }
+
+  // Rotation priors: the reference first rotates EVERY pose and point of the feature manager so
+  // that the first fixed image agrees with its prior (bundle_adjustment.cc:399-425).
+  if (options.constrain_rotation) {
+    if (fixed_image_ids.empty())
+      throw std::out_of_range("constrain_rotation needs a fixed image (the reference reads fixed_image_ids[0])");
+    const size_t ref_id = fixed_image_ids[0];
+    double R_fm[9], R_c[9], S[9], R_fm_t[9];
+    rotation_from_rvec(fm.rvecs.at(ref_id).data(), R_fm);
+    rotation_from_rvec(rotation_constraints.at(ref_id).data(), R_c);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R_fm_t[i * 3 + j] = R_fm[j * 3 + i];
+    matmul3(R_fm_t, R_c, S);  // rotation from the SfM to the constraint frame
+    double St[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) St[i * 3 + j] = S[j * 3 + i];
+    for (auto it = fm.rvecs.begin(); it != fm.rvecs.end(); ++it) {
+      // transform_pose: [R | t] S^-1; S is a pure rotation, so t is unchanged
+      double R[9], Rn[9];
+      rotation_from_rvec(it->second.data(), R);
+      matmul3(R, St, Rn);
+      rvec_from_rotation(Rn, it->second.data());
+    }
+    for (auto it = fm.points3D.begin(); it != fm.points3D.end(); ++it) {
+      double* X = it->second.data();
+      const double x = X[0], y = X[1], z = X[2];
+      X[0] = S[0] * x + S[1] * y + S[2] * z;
+      X[1] = S[3] * x + S[4] * y + S[5] * z;
+      X[2] = S[6] * x + S[7] * y + S[8] * z;
+    }
+  }
+
+  // ---- which observations enter (extract_data, :228-286): count, per 3-D point, its
+  // observations inside the selected image set
+  std::unordered_map<size_t, size_t> point3D_num_points2D;
+  const std::vector<size_t>* extract_order[3] = {&free_image_ids, &fixed_x_image_ids, &fixed_image_ids};
+  for (int l = 0; l < 3; ++l) {
+    for (size_t image_id : *extract_order[l]) {
+      const std::vector<size_t>& p2d = fm.image_to_points2D[image_id];
+      for (size_t point2D_id : p2d) {
+        auto it = fm.point2D_to_point3D.find(point2D_id);
+        if (it == fm.point2D_to_point3D.end()) continue;
+        point3D_num_points2D[it->second] += 1;
+      }
+    }
+  }
+
+  // ---- flatten in the reference's residual-block order: FREE, FIXED, FIXED_X (:511-533)
+  std::vector<size_t> image_ids, camera_ids, point_ids;           // flat index -> feature-manager id
+  std::unordered_map<size_t, int32_t> image_index, camera_index, point_index;
+  std::vector<double> poses, intrinsics, points, obs_uv;
+  std::vector<uint8_t> pose_const, intr_const, point_const;
+  std::vector<int32_t> image_camera, camera_model, obs_image, obs_point;
+  const std::vector<size_t>* fill_order[3] = {&free_image_ids, &fixed_image_ids, &fixed_x_image_ids};
+  const int fill_state[3] = {BA_POSE_FREE, BA_POSE_FIXED, BA_POSE_FIXED_X};
+  for (int l = 0; l < 3; ++l) {
+    for (size_t image_id : *fill_order[l]) {
+      const size_t camera_id = fm.image_to_camera[image_id];
+      std::vector<double>& cam = fm.camera_params[camera_id];
+      const int model = (int)cam.back();
+      const int K = model_num_params(model);
+      if (K < 0) throw std::invalid_argument("unknown camera model code");
+      size_t num_residuals = 0;
+      int32_t img = -1;
+      const std::vector<size_t>& p2d = fm.image_to_points2D[image_id];
+      for (size_t point2D_id : p2d) {
+        auto it3 = fm.point2D_to_point3D.find(point2D_id);
+        if (it3 == fm.point2D_to_point3D.end()) continue;
+        const size_t point3D_id = it3->second;
+        if (point3D_num_points2D[point3D_id] < options.min_track_len) continue;   // :330
+        if (img < 0) {
+          // first residual of this image: register the image (and its camera)
+          auto ic = camera_index.find(camera_id);
+          if (ic == camera_index.end()) {
+            ic = camera_index.emplace(camera_id, (int32_t)camera_ids.size()).first;
+            camera_ids.push_back(camera_id);
+            camera_model.push_back(model);
+            intr_const.push_back(0);
+            for (int k = 0; k < MAVBA_MAX_INTR; ++k) intrinsics.push_back(k < K ? cam[k] : 0.0);
+          }
+          img = (int32_t)image_ids.size();
+          image_index[image_id] = img;
+          image_ids.push_back(image_id);
+          image_camera.push_back(ic->second);
+          pose_const.push_back(0);
+          const double* r = fm.rvecs[image_id].data();
+          const double* t = fm.tvecs[image_id].data();
+          poses.insert(poses.end(), r, r + 3);
+          poses.insert(poses.end(), t, t + 3);
+        }
+        auto ip = point_index.find(point3D_id);
+        if (ip == point_index.end()) {
+          ip = point_index.emplace(point3D_id, (int32_t)point_ids.size()).first;
+          point_ids.push_back(point3D_id);
+          const double* X = fm.points3D[point3D_id].data();
+          points.insert(points.end(), X, X + 3);
+          point_const.push_back(gcp_ids.count(point3D_id) ? 1 : 0);  // :545-549
+        }
+        const double* xy = fm.points2D[point2D_id].data();
+        obs_uv.push_back(xy[0]); obs_uv.push_back(xy[1]);
+        obs_image.push_back(img);
+        obs_point.push_back(ip->second);
+        ++num_residuals;
+      }
+      // Constancy is applied only if the image contributed more than one residual (:361).
+      if (num_residuals > 1) {
+        if (fill_state[l] == BA_POSE_FIXED) pose_const[img] = MAVBA_CONST_POSE;
+        if (fill_state[l] == BA_POSE_FIXED_X) pose_const[img] = MAVBA_CONST_TX;
+        if (!options.refine_camera_params) intr_const[image_camera[img]] = 1;
+      }
+    }
+  }
+
+  // rotation-prior residuals for the FREE images (:428-444)
+  std::vector<int32_t> prior_image;
+  std::vector<double> prior_rvec;
+  if (options.constrain_rotation) {
+    for (size_t image_id : free_image_ids) {
+      const Eigen::Vector3d& rvec0 = rotation_constraints.at(image_id);
+      auto ii = image_index.find(image_id);
+      if (ii == image_index.end()) {
+        // an image without residual blocks still gets its prior in the reference
+        const size_t camera_id = fm.image_to_camera[image_id];
+        std::vector<double>& cam = fm.camera_params[camera_id];
+        const int model = (int)cam.back();
+        const int K = model_num_params(model);
+        if (K < 0) throw std::invalid_argument("unknown camera model code");
+        auto ic = camera_index.find(camera_id);
+        if (ic == camera_index.end()) {
+          ic = camera_index.emplace(camera_id, (int32_t)camera_ids.size()).first;
+          camera_ids.push_back(camera_id);
+          camera_model.push_back(model);
+          intr_const.push_back(1);  // no residual touches it through this image
+          for (int k = 0; k < MAVBA_MAX_INTR; ++k) intrinsics.push_back(k < K ? cam[k] : 0.0);
+        }
+        ii = image_index.emplace(image_id, (int32_t)image_ids.size()).first;
+        image_ids.push_back(image_id);
+        image_camera.push_back(ic->second);
+        pose_const.push_back(MAVBA_CONST_TX | MAVBA_CONST_TY | MAVBA_CONST_TZ);  // only rvec is in the problem
+        const double* r = fm.rvecs[image_id].data();
+        const double* t = fm.tvecs[image_id].data();
+        poses.insert(poses.end(), r, r + 3);
+        poses.insert(poses.end(), t, t + 3);
+      }
+      prior_image.push_back(ii->second);
+      prior_rvec.push_back(rvec0(0)); prior_rvec.push_back(rvec0(1)); prior_rvec.push_back(rvec0(2));
+    }
+  }
+
+  mavba_problem P;
+  P.num_images = (int32_t)image_ids.size();
+  P.num_cameras = (int32_t)camera_ids.size();
+  P.num_points = (int32_t)point_ids.size();
+  P.num_obs = (int64_t)obs_image.size();
+  P.poses = poses.data(); P.pose_const = pose_const.data(); P.image_camera = image_camera.data();
+  P.intrinsics = intrinsics.data(); P.camera_model = camera_model.data(); P.intr_const = intr_const.data();
+  P.points = points.data(); P.point_const = point_const.data();
+  P.obs_uv = obs_uv.data(); P.obs_image = obs_image.data(); P.obs_point = obs_point.data();
+  P.num_rot_priors = (int32_t)prior_image.size();
+  P.rot_prior_image = prior_image.data(); P.rot_prior_rvec = prior_rvec.data();
+  P.rot_prior_weight = options.constrain_rotation_weight;
+
+  mavba_options mo;
+  fill_options(options, &mo);
+  std::vector<double> perr(point_ids.size(), 0.0);
+  mavba_result res;
+  const int rc = mavba_solve(&P, &mo, &res, options.update_point3D_errors ? perr.data() : nullptr);
+  if (rc != MAVBA_OK) raise(rc);
+
+  // ---- write back in place (the reference lets Ceres write through raw pointers)
+  for (size_t i = 0; i < image_ids.size(); ++i) {
+    double* r = fm.rvecs[image_ids[i]].data();
+    double* t = fm.tvecs[image_ids[i]].data();
+    for (int k = 0; k < 3; ++k) { r[k] = poses[6 * i + k]; t[k] = poses[6 * i + 3 + k]; }
+  }
+  for (size_t c = 0; c < camera_ids.size(); ++c) {
+    std::vector<double>& cam = fm.camera_params[camera_ids[c]];
+    const int K = model_num_params(camera_model[c]);
+    for (int k = 0; k < K; ++k) cam[k] = intrinsics[MAVBA_MAX_INTR * c + k];  // the model code (last slot) is never written
+  }
+  for (size_t p = 0; p < point_ids.size(); ++p) {
+    double* X = fm.points3D[point_ids[p]].data();
+    for (int k = 0; k < 3; ++k) X[k] = points[3 * p + k];
+  }
+
+  if (obs_image.empty()) {
+    std::cout << "No observations in bundle adjustment. Consider relaxing the constraints." << std::endl;
+  }
+  if (options.update_point3D_errors) {
+    for (size_t p = 0; p < point_ids.size(); ++p) point3D_errors[point_ids[p]] = perr[p];
+  }
+  if (options.print_progress) std::cout << std::endl;
+  if (options.print_summary) {
+    std::cout << "Bundle Adjustment Report" << std::endl;
+    std::cout << "------------------------" << std::endl;
+    print_report(res);
+  }
+  return std::sqrt(res.final_cost / res.num_residuals);
+}
