@@ -50,7 +50,7 @@ def algorithmic_work(stats_name, prob, sess_info):
         return "hbm", float(np.sum(48 + 16 + 2 * (9 + k_obs) * 8)), "B"
     if stats_name == "cost_only":
         return "hbm", 48.0 * n_obs, "B"
-    if stats_name == "point_sums":
+    if stats_name in ("point_sums", "point_reduce"):
         return "hbm", 64.0 * n_obs + 72.0 * n_pts, "B"
     if stats_name == "camera_sweep":
         return "hbm", 44.0 * n_obs, "B"

@@ -34,72 +34,135 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 
-// Factorise the SPD tile in T (LDS, pitch GLD) and invert the factor:
-//   T    <- L   (lower; strict upper zeroed),   Ti <- L^-1 (lower).
-// Executed by wave 0 of a 256-thread work-group; every thread must call it (uniform
-// barriers). scr = 192 doubles of LDS scratch (two column buffers + reciprocal diagonal).
-// Right-looking with the lane's row in registers: per column one pivot broadcast, one
-// rsqrt, one LDS column exchange, then 63-j INDEPENDENT fused multiply-adds.
-// Returns false in wave 0 if a pivot is not positive.
-__device__ __forceinline__ bool tile_potrf_inv(double* T, double* Ti, double* scr, int tid) {
-  const bool w0 = tid < 64;
-  const int lane = tid & 63;
-  double* rd = scr + 128;
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// 16x16 SPD block: Cholesky factor AND its inverse in one 16-step sweep, in the registers of
+// lanes 0..15 (lane = row). In: a[k] = row `lane` of the block. Out: a[k] = L[lane][k],
+// x[k] = (L^-1)[lane][k] (zero above the diagonal). Elimination of column j also applies the same
+// row operations to the identity, so L^-1 is finished with L. Broadcasts are v_readlane (SGPR),
+// no LDS round trips on the critical path.
+__device__ __forceinline__ bool potrf_inv16(double* a, double* x, int lane) {
   bool ok = true;
-  double reg[NB];  // wave 0: row `lane` of the (partially updated) tile, later column `lane` of L^-1
-  if (w0) {
 #pragma unroll
-    for (int k = 0; k < NB; k += 2) {
-      const double2 v = *reinterpret_cast<const double2*>(T + lane * GLD + k);
-      reg[k] = v.x; reg[k + 1] = v.y;
+  for (int k = 0; k < 16; ++k) x[k] = (k == lane) ? 1.0 : 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double piv = readlane_d(a[j], j);
+    if (!(piv > 0.0) || !isfinite(piv)) { ok = false; piv = 1.0; }
+    const double rs = rsqrt_nr(piv);
+    a[j] = lane > j ? a[j] * rs : (lane == j ? piv * rs : 0.0);
+    if (lane == j) {
+#pragma unroll
+      for (int c = 0; c <= j; ++c) x[c] *= rs;
     }
-  }
+    const double m = lane > j ? a[j] : 0.0;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double* col = scr + (j & 1) * NB;
-    if (w0) {
-      double piv = __shfl(reg[j], j, 64);
-      if (!(piv > 0.0) || !isfinite(piv)) { ok = false; piv = 1.0; }
-      const double rs = rsqrt_nr(piv);
-      const double l = lane == j ? piv * rs : (lane > j ? reg[j] * rs : 0.0);
-      reg[j] = l;
-      col[lane] = l;
-      if (lane == j) rd[j] = rs;
+    for (int k = j + 1; k < 16; ++k) a[k] -= m * readlane_d(a[j], k);
+#pragma unroll
+    for (int c = 0; c <= j; ++c) x[c] -= m * readlane_d(x[c], j);
+  }
+  return ok;
+}
+
+// acc += A(16x16, row-major lda) * B^T  (NT)   or   A * B (NN), K = 16, operands in LDS.
+// v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][k = l >> 4], B[k = l >> 4][l & 15];
+// reg r of lane l holds D[(l >> 4) + 4 r][l & 15].
+__device__ __forceinline__ d4 gemm16(const double* A, int lda, const double* B, int ldb, bool transB,
+                                     double sign, d4 acc, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 4) {
+    const double av = sign * A[li * lda + kk + lk];
+    const double bv = transB ? B[li * ldb + kk + lk] : B[(kk + lk) * ldb + li];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ d4 load_d16(const double* C, int ldc, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = C[(lk + 4 * r) * ldc + li];
+  return v;
+}
+__device__ __forceinline__ void store_d16(double* C, int ldc, d4 v, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) C[(lk + 4 * r) * ldc + li] = v[r];
+}
+
+// Factorise the SPD tile in T (LDS, pitch GLD) and invert the factor, blocked 4 x 4 in 16x16:
+//   T  <- L on and below the diagonal blocks,   Ti <- L^-1 (lower; Ti must come in zeroed).
+// Per 16-column block: the diagonal block is factored + inverted in registers by 16 lanes
+// (potrf_inv16); the panel below it, the trailing update inside the tile and the assembly of
+// the off-diagonal blocks of L^-1 are 16x16x16 FP64-MFMA products spread over the 4 waves.
+// All 256 threads must call it (uniform barriers). scr: 4 * 16 * 18 doubles of LDS.
+// Returns false (in thread 0) if a pivot is not positive.
+constexpr int MLD = 18;
+constexpr int kFuseBelow = 12;  // fuse the panel solve into the update when <= this many row blocks remain
+__device__ __forceinline__ bool tile_potrf_inv(double* T, double* Ti, double* scr, int tid) {
+  const int wv = tid >> 6, lane = tid & 63;
+  bool ok = true;
+  for (int cb = 0; cb < 4; ++cb) {
+    double* D = T + (16 * cb) * GLD + 16 * cb;
+    double* Di = Ti + (16 * cb) * GLD + 16 * cb;
+    if (wv == 0 && lane < 16) {
+      double a[16], x[16];
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(D + lane * GLD + k);
+        a[k] = v.x; a[k + 1] = v.y;
+      }
+      ok = potrf_inv16(a, x, lane) && ok;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { D[lane * GLD + k] = k <= lane ? a[k] : 0.0; Di[lane * GLD + k] = k <= lane ? x[k] : 0.0; }
     }
     __syncthreads();
-    if (w0) {
-      const double l = reg[j];
-#pragma unroll
-      for (int k = j + 1; k < NB; ++k) {
-        reg[k] -= l * col[k];
-      }
+    const int nt = 3 - cb;  // 16-row blocks below the diagonal block
+    if (wv < nt) {          // panel: P = T[rt, cb] * Dinv^T
+      double* P = T + (16 * (cb + 1 + wv)) * GLD + 16 * cb;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      acc = gemm16(P, GLD, Di, GLD, true, 1.0, acc, lane);
+      store_d16(P, GLD, acc, lane);
     }
-  }
-  if (w0) {
-#pragma unroll
-    for (int k = 0; k < NB; ++k) T[lane * GLD + k] = k <= lane ? reg[k] : 0.0;
-  }
-  __syncthreads();
-  // column `lane` of X = L^-1:  x_r = (delta_rc - sum_{m<r} L[r][m] x_m) / L[r][r]
-  if (w0) {
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      const double* rr = T + r * GLD;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-      for (int m = 0; m + 3 < r; m += 4) {
-        const double2 b0 = *reinterpret_cast<const double2*>(rr + m);
-        const double2 b1 = *reinterpret_cast<const double2*>(rr + m + 2);
-        s0 += b0.x * reg[m]; s1 += b0.y * reg[m + 1];
-        s2 += b1.x * reg[m + 2]; s3 += b1.y * reg[m + 3];
-      }
-#pragma unroll
-      for (int m = (r / 4) * 4; m < r; ++m) s0 += rr[m] * reg[m];
-      reg[r] = ((r == lane ? 1.0 : 0.0) - ((s0 + s1) + (s2 + s3))) * rd[r];
-      Ti[r * GLD + lane] = reg[r];
+    __syncthreads();
+    // trailing update inside the tile: T[i, j] -= P_i P_j^T for cb < j <= i <= 3
+    const int npairs = nt * (nt + 1) / 2;
+    for (int p = wv; p < npairs; p += 4) {
+      int i = 0, q = p;
+      while (q > i) { q -= i + 1; ++i; }   // p -> (i, q) with q <= i
+      const int bi = cb + 1 + i, bj = cb + 1 + q;
+      double* C = T + (16 * bi) * GLD + 16 * bj;
+      d4 acc = load_d16(C, GLD, lane);
+      acc = gemm16(T + (16 * bi) * GLD + 16 * cb, GLD, T + (16 * bj) * GLD + 16 * cb, GLD, true, -1.0, acc, lane);
+      store_d16(C, GLD, acc, lane);
     }
+    __syncthreads();
   }
-  __syncthreads();
+  // off-diagonal blocks of X = L^-1:  X_ij = -Dinv_i * sum_{k=j}^{i-1} L_ik X_kj,  by distance d = i - j
+  double* Ms = scr + wv * 16 * MLD;
+  for (int d = 1; d < 4; ++d) {
+    const bool mine = wv < 4 - d;
+    const int i = d + wv, j = wv;
+    if (mine) {
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int k = j; k < i; ++k)
+        acc = gemm16(T + (16 * i) * GLD + 16 * k, GLD, Ti + (16 * k) * GLD + 16 * j, GLD, false, 1.0, acc, lane);
+      store_d16(Ms, MLD, acc, lane);
+    }
+    __syncthreads();
+    if (mine) {
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      acc = gemm16(Ti + (16 * i) * GLD + 16 * i, GLD, Ms, MLD, false, -1.0, acc, lane);
+      store_d16(Ti + (16 * i) * GLD + 16 * j, GLD, acc, lane);
+    }
+    __syncthreads();
+  }
+  // thread 0 is in wave 0 lanes < 16: it carries the pivot verdict
   return ok;
 }
 
@@ -150,7 +213,7 @@ __global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M
                                                     double* __restrict__ fail) {
   __shared__ __attribute__((aligned(16))) double T[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Ti[NB * GLD];
-  __shared__ __attribute__((aligned(16))) double rd[3 * NB];
+  __shared__ __attribute__((aligned(16))) double rd[4 * 16 * MLD];
   const int tid = threadIdx.x;
   load_tile(M, ld, T, tid);
   for (int i = tid; i < NB * GLD; i += 256) Ti[i] = 0.0;
@@ -163,14 +226,15 @@ __global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M
 
 // Panel k: row block k+1+blockIdx.x (the last one is the right-hand-side block) of panel k
 //   A_ik <- A_ik L_kk^-T = A_ik (L_kk^-1)^T
-__global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ M, int ld, int k,
+__global__ void __launch_bounds__(256) k_chol_trsm(const double* __restrict__ M, double* __restrict__ Lout, int ld, int k,
                                                    const double* __restrict__ inv) {
   __shared__ __attribute__((aligned(16))) double As[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * GLD];
   const int tid = threadIdx.x;
   const int i = k + 1 + blockIdx.x;
-  double* A = M + (size_t)i * NB * ld + (size_t)k * NB;
-  load_tile(A, ld, As, tid);
+  const double* Ain = M + (size_t)i * NB * ld + (size_t)k * NB;
+  double* A = Lout + (size_t)i * NB * ld + (size_t)k * NB;
+  load_tile(Ain, ld, As, tid);
   load_tile(inv + (size_t)k * NB * NB, NB, Bs, tid);
   __syncthreads();
   const int wv = tid >> 6, lane = tid & 63;
@@ -188,24 +252,61 @@ __global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ M, int l
         A[(size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li] = acc[m][n][r];
 }
 
-// Trailing update, panel k: tile (i, j) -= A_ik A_jk^T for k < j <= i (i may be the
-// right-hand-side block). The owner of tile (k+1, k+1) then factorises + inverts it.
-__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, int ld, int k,
+// store the wave's 2x2 MFMA tiles (D layout) of a 64x64 product into an LDS tile (pitch GLD)
+__device__ __forceinline__ void quadrant_to_lds(double* S, int wr, int wc, int lane, const d4 acc[2][2]) {
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(wr + 16 * m + lk + 4 * r) * GLD + wc + 16 * n + li] = acc[m][n][r];
+}
+
+// Panel k, fused triangular solve + trailing update. Work-group (i, j), k < j <= i (i may be the
+// right-hand-side block):
+//   P_i = A_ik L_kk^-T,  P_j = A_jk L_kk^-T   (re-derived here from the raw panel tiles: two
+//                                               extra 64^3 MFMA products instead of a launch)
+//   tile (i, j) -= P_i P_j^T
+// Column j == k+1 work-groups store P_i (the final L_ik, needed by the backward substitution);
+// the owner of tile (k+1, k+1) then factorises + inverts it for the next panel.
+template <bool FUSED>
+__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, double* __restrict__ Lout, int ld, int k,
                                                      double* __restrict__ diag, double* __restrict__ inv,
                                                      double* __restrict__ fail) {
   const int j = k + 1 + blockIdx.x, i = k + 1 + blockIdx.y;
   if (j > i) return;
   __shared__ __attribute__((aligned(16))) double As[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * GLD];
-  __shared__ __attribute__((aligned(16))) double rd[3 * NB];
+  __shared__ __attribute__((aligned(16))) double Cs[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double rd[4 * 16 * MLD];
   const int tid = threadIdx.x;
-  load_tile(M + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
-  load_tile(M + (size_t)j * NB * ld + (size_t)k * NB, ld, Bs, tid);
-  __syncthreads();
   const int wv = tid >> 6, lane = tid & 63;
   const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
   d4 acc[2][2];
-  mfma_quadrant_nt(As, Bs, wr, wc, lane, acc);
+  if constexpr (FUSED) {
+    load_tile(M + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
+    load_tile(inv + (size_t)k * NB * NB, NB, Bs, tid);
+    if (i != j) load_tile(M + (size_t)j * NB * ld + (size_t)k * NB, ld, Cs, tid);
+    __syncthreads();
+    mfma_quadrant_nt(As, Bs, wr, wc, lane, acc);      // P_i
+    d4 accj[2][2];
+    if (i != j) mfma_quadrant_nt(Cs, Bs, wr, wc, lane, accj);  // P_j
+    __syncthreads();
+    quadrant_to_lds(As, wr, wc, lane, acc);
+    if (i != j) quadrant_to_lds(Cs, wr, wc, lane, accj);
+    __syncthreads();
+    // L_ik is final; it goes to the second matrix (the raw tile is still being read by the
+    // other work-groups of this launch)
+    if (blockIdx.x == 0) store_tile(Lout + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
+  } else {
+    // panel tiles were already solved by k_chol_trsm into the second matrix
+    load_tile(Lout + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
+    if (i != j) load_tile(Lout + (size_t)j * NB * ld + (size_t)k * NB, ld, Cs, tid);
+    __syncthreads();
+  }
+  const double* Pj = (i != j) ? Cs : As;
+  mfma_quadrant_nt(As, Pj, wr, wc, lane, acc);
   const int li = lane & 15, lk = lane >> 4;
   double* C = M + (size_t)i * NB * ld + (size_t)j * NB;
   const bool next_diag = (blockIdx.x == 0 && blockIdx.y == 0);
@@ -222,7 +323,7 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, int
     return;
   }
   // tile (k+1, k+1): keep the updated tile in LDS, factorise + invert it for the next panel
-  __syncthreads();  // everyone is done reading As / Bs
+  __syncthreads();  // everyone is done reading As
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -230,14 +331,16 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wr + 16 * m + lk + 4 * r, col = wc + 16 * n + li;
-        As[row * GLD + col] = C[(size_t)row * ld + col] - acc[m][n][r];
+        Cs[row * GLD + col] = C[(size_t)row * ld + col] - acc[m][n][r];
       }
-  for (int t = tid; t < NB * GLD; t += 256) Bs[t] = 0.0;
+  double* Ti = As;  // the plain variant has no third tile: reuse As (its reads ended at the barrier above)
+  if constexpr (FUSED) Ti = Bs;
+  for (int t = tid; t < NB * GLD; t += 256) Ti[t] = 0.0;
   __syncthreads();
-  const bool ok = tile_potrf_inv(As, Bs, rd, tid);
+  const bool ok = tile_potrf_inv(Cs, Ti, rd, tid);
   if (tid == 0 && !ok) atomicAdd(fail, 1.0);
-  store_tile(diag + (size_t)(k + 1) * NB * NB, NB, As, tid);
-  store_tile(inv + (size_t)(k + 1) * NB * NB, NB, Bs, tid);
+  store_tile(diag + (size_t)(k + 1) * NB * NB, NB, Cs, tid);
+  store_tile(inv + (size_t)(k + 1) * NB * NB, NB, Ti, tid);
 }
 
 // Backward substitution, tile k: y_k = L_kk^-T z_k; then z_j -= L_kj^T y_k for j < k.
@@ -272,22 +375,32 @@ __global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict_
   z[j * NB + lane] -= a0 + a1;
 }
 
-// diag_ws: 2 * n_pad * 64 doubles (factor tiles, then their inverses).
+// diag_ws: 2 * n_pad * 64 doubles (factor tiles, then their inverses); L: second
+// (n_pad + 64) x n_pad matrix receiving the factor's off-diagonal tiles and the
+// forward-substituted right-hand side.
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
-                            double* diag_ws) {
+                            double* diag_ws, double* L) {
   const int nb = n_pad / NB, ld = n_pad;
   double* diag = diag_ws;
   double* inv = diag_ws + (size_t)n_pad * NB;
   hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, diag, inv, fail);
   for (int k = 0; k < nb; ++k) {
     const int below = nb - 1 - k;  // real row blocks below tile k
-    hipLaunchKernelGGL(k_chol_trsm, dim3(below + 1), dim3(256), 0, st, M, ld, k, inv);
-    if (below > 0)
-      hipLaunchKernelGGL(k_chol_update, dim3(below, below + 1), dim3(256), 0, st, M, ld, k, diag, inv, fail);
+    if (below > kFuseBelow) {
+      // large trailing matrix: one panel solve, then a lean update (2 work-groups per CU)
+      hipLaunchKernelGGL(k_chol_trsm, dim3(below + 1), dim3(256), 0, st, M, L, ld, k, inv);
+      hipLaunchKernelGGL((k_chol_update<false>), dim3(below, below + 1), dim3(256), 0, st, M, L, ld, k, diag, inv, fail);
+    } else if (below > 0) {
+      // small trailing matrix: latency matters, fold the panel solve into the update launch
+      hipLaunchKernelGGL((k_chol_update<true>), dim3(below, below + 1), dim3(256), 0, st, M, L, ld, k, diag, inv, fail);
+    } else {
+      // last tile: only the right-hand-side block is left
+      hipLaunchKernelGGL(k_chol_trsm, dim3(1), dim3(256), 0, st, M, L, ld, k, inv);
+    }
   }
-  double* z = M + (size_t)n_pad * ld;
+  double* z = L + (size_t)n_pad * ld;
   for (int k = nb - 1; k >= 0; --k)
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(k + 1), dim3(64), 0, st, M, ld, k, inv, z, y);
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(k + 1), dim3(64), 0, st, L, ld, k, inv, z, y);
 }
 
 }  // namespace mavba

@@ -68,8 +68,10 @@ void launch_jacobian_sweep(hipStream_t st, const SweepArgs& a);
 void launch_cost_only(hipStream_t st, const SweepArgs& a);  // uses uv/obs/points/camrec/intr, writes cost_partial
 void launch_raw_residual_norm(hipStream_t st, const SweepArgs& a, double* out_norm);  // |r_raw| per obs
 
-void launch_point_sums(hipStream_t st, int NP, int NPs, int Nstride, const int* pt_start,
-                       const double* R, const double* Jp, double* Cu, double* gu);
+void launch_point_reduce(hipStream_t st, int NP, int NPs, int Nstride, int KMAX, const int* pt_start,
+                         const int* q_start, const int* q_cam, const int* obs_img, const int* img_cam,
+                         const double* R, const double* Jp, const double* Jk, double* Cu, double* gu,
+                         double* Wk /*[Q][27]*/);
 
 struct CamSweepArgs {
   int NI, NC;
@@ -106,11 +108,9 @@ void launch_entries_pose(hipStream_t st, int N, int Nstride, int NPs, const int*
                          const int* obs_pt, const unsigned char* pt_free, const double* Jc,
                          const double* Jp, const double* scale_cam, const double* scale_pt,
                          const double* Gi, const double* h, double* Epose);
-void launch_entries_intr(hipStream_t st, int Q, int KMAX, int NI, int Nstride, int NPs, const int* q_pt,
-                         const int* q_cam, const int* pt_start, const int* obs_img,
-                         const int* img_cam, const double* Jk, const double* Jp,
-                         const double* scale_cam, const double* scale_pt, const double* Gi,
-                         const double* h, double* Eintr);
+void launch_entries_intr(hipStream_t st, int Q, int NI, int NPs, const int* q_pt, const int* q_cam,
+                         const double* Wk, const double* scale_cam, const double* scale_pt,
+                         const double* Gi, const double* h, double* Eintr);
 
 void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurChunk* chunks,
                          const int2* terms, const double* Epose, const double* Eintr,
@@ -151,8 +151,9 @@ void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const doub
 // On return y[0..n_pad) = A^-1 b; M is overwritten by the factor. *fail
 // (device double) is incremented if a pivot is not positive.
 // diag_ws: workspace of 2 * n_pad * 64 doubles (the factor's diagonal tiles and their inverses).
+// L: scratch matrix of the same shape as M (receives the factor).
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
-                            double* diag_ws);
+                            double* diag_ws, double* L);
 
 }  // namespace mavba
 #endif

@@ -243,37 +243,95 @@ void launch_raw_residual_norm(hipStream_t st, const SweepArgs& a, double* out_no
 }
 
 // ---------------------------------------------------------------------------
-// K3: per-point sums C_p = sum J_p^T J_p (sym 6), g_p = sum J_p^T r. One lane per
-// point walking its contiguous observations; neighbouring lanes read neighbouring
-// lines, so the planes are streamed once through L1/L2.
+// K3: per-point reductions, once per Jacobian evaluation. 16 lanes per 3-D point (4 points per
+// wave): the lanes stride over the point's contiguous observations (coalesced 128-byte runs per
+// plane) and combine with DPP row rotations — "wavefront reductions for the 3x3 point blocks".
+//   Cu = sum Jp^T Jp (sym 6),  gu = sum Jp^T r,
+//   Wk[q] = sum_{obs of camera q_cam[q]} Jk^T Jp  (KMAX x 3, unscaled) for each free camera
+//           the point is seen by (the radius-independent part of the intrinsics Schur entries).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_point_sums(int NP, int NPs, int Nstride,
-                                                    const int* __restrict__ pt_start,
-                                                    const double* __restrict__ R,
-                                                    const double* __restrict__ Jp,
-                                                    double* __restrict__ Cu, double* __restrict__ gu) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= NP) return;
-  const int b = pt_start[p], e = pt_start[p + 1];
-  double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2 = 0;
+__device__ __forceinline__ double row16_sum(double v) {
+  // all-reduce inside each 16-lane DPP row: rotate right by 8, 4, 2, 1
+#define MAVBA_ROR_ADD(N)                                                                                   \
+  {                                                                                                        \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 | (N), 0xf, 0xf, false);        \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 | (N), 0xf, 0xf, false);        \
+    v += __hiloint2double(hi, lo);                                                                         \
+  }
+  MAVBA_ROR_ADD(8) MAVBA_ROR_ADD(4) MAVBA_ROR_ADD(2) MAVBA_ROR_ADD(1)
+#undef MAVBA_ROR_ADD
+  return v;
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(256) k_point_reduce(
+    int NP, int NPs, int Nstride, const int* __restrict__ pt_start, const int* __restrict__ q_start,
+    const int* __restrict__ q_cam, const int* __restrict__ obs_img, const int* __restrict__ img_cam,
+    const double* __restrict__ R, const double* __restrict__ Jp, const double* __restrict__ Jk,
+    double* __restrict__ Cu, double* __restrict__ gu, double* __restrict__ Wk) {
+  const int g = threadIdx.x & 15;
+  const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (p >= NP) return;  // whole 16-lane row leaves together
   const long long S = Nstride;
-  for (int o = b; o < e; ++o) {
+  const int b = pt_start[p], e = pt_start[p + 1];
+  double c[6] = {0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0};
+  for (int o = b + g; o < e; o += 16) {
 #pragma unroll
     for (int row = 0; row < 2; ++row) {
       const double x = Jp[(row * 3 + 0) * S + o], y = Jp[(row * 3 + 1) * S + o], z = Jp[(row * 3 + 2) * S + o];
       const double r = R[row * S + o];
-      c0 += x * x; c1 += x * y; c2 += x * z; c3 += y * y; c4 += y * z; c5 += z * z;
-      g0 += x * r; g1 += y * r; g2 += z * r;
+      c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
+      gg[0] += x * r; gg[1] += y * r; gg[2] += z * r;
     }
   }
-  Cu[0 * NPs + p] = c0; Cu[1 * NPs + p] = c1; Cu[2 * NPs + p] = c2;
-  Cu[3 * NPs + p] = c3; Cu[4 * NPs + p] = c4; Cu[5 * NPs + p] = c5;
-  gu[0 * NPs + p] = g0; gu[1 * NPs + p] = g1; gu[2 * NPs + p] = g2;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) c[k] = row16_sum(c[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gg[k] = row16_sum(gg[k]);
+  if (g == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Cu[k * NPs + p] = c[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gu[k * NPs + p] = gg[k];
+  }
+  for (int q = q_start[p]; q < q_start[p + 1]; ++q) {
+    const int cam = q_cam[q];
+    double W[KMAX * 3];
+#pragma unroll
+    for (int k = 0; k < KMAX * 3; ++k) W[k] = 0.0;
+    for (int o = b + g; o < e; o += 16) {
+      if (img_cam[obs_img[o]] != cam) continue;
+      double jp[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) jp[t] = Jp[t * S + o];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const double j0 = Jk[k * S + o], j1 = Jk[(KMAX + k) * S + o];
+        W[3 * k] += j0 * jp[0] + j1 * jp[3];
+        W[3 * k + 1] += j0 * jp[1] + j1 * jp[4];
+        W[3 * k + 2] += j0 * jp[2] + j1 * jp[5];
+      }
+    }
+    double* out = Wk + (size_t)q * 27;
+#pragma unroll
+    for (int k = 0; k < KMAX * 3; ++k) {
+      const double v = row16_sum(W[k]);
+      if (g == (k & 15)) out[k] = v;
+    }
+    if (KMAX < 9 && g < 27 - KMAX * 3) out[KMAX * 3 + g] = 0.0;
+    if (KMAX < 9 && g + 16 < 27 - KMAX * 3) out[KMAX * 3 + g + 16] = 0.0;
+  }
 }
-void launch_point_sums(hipStream_t st, int NP, int NPs, int Nstride, const int* pt_start,
-                       const double* R, const double* Jp, double* Cu, double* gu) {
+void launch_point_reduce(hipStream_t st, int NP, int NPs, int Nstride, int KMAX, const int* pt_start,
+                         const int* q_start, const int* q_cam, const int* obs_img, const int* img_cam,
+                         const double* R, const double* Jp, const double* Jk, double* Cu, double* gu,
+                         double* Wk) {
   if (NP <= 0) return;
-  hipLaunchKernelGGL(k_point_sums, dim3((NP + 255) / 256), dim3(256), 0, st, NP, NPs, Nstride, pt_start, R, Jp, Cu, gu);
+  const dim3 g((NP + 15) / 16), b(256);
+#define MAVBA_PR(K) hipLaunchKernelGGL((k_point_reduce<K>), g, b, 0, st, NP, NPs, Nstride, pt_start, q_start, q_cam, \
+                                       obs_img, img_cam, R, Jp, Jk, Cu, gu, Wk)
+  if (KMAX <= 4) MAVBA_PR(4); else if (KMAX <= 8) MAVBA_PR(8); else MAVBA_PR(9);
+#undef MAVBA_PR
 }
 
 // ---------------------------------------------------------------------------
@@ -416,16 +474,26 @@ __global__ void __launch_bounds__(64) k_camera_reduce_img(
     else img_intr_tmp[(size_t)i * kCamRec + (e - kImgRec)] = s;
   }
 }
-// Per camera: sum the intrinsics parts of its images in image order.
-__global__ void __launch_bounds__(64) k_camera_reduce_cam(
+// Per camera: sum the intrinsics parts of its images (fixed order: 16 interleaved partial sums
+// per element, then a fixed tree) — one 1024-thread block per camera.
+__global__ void __launch_bounds__(1024) k_camera_reduce_cam(
     const int* __restrict__ cam_img_start, const int* __restrict__ cam_imgs,
     const double* __restrict__ img_intr_tmp, double* __restrict__ cam_rec) {
+  __shared__ double s_part[16][64];
   const int c = blockIdx.x;
-  const int e = threadIdx.x;
-  if (e >= kCamRec) return;
+  const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
   double s = 0.0;
-  for (int t = cam_img_start[c]; t < cam_img_start[c + 1]; ++t) s += img_intr_tmp[(size_t)cam_imgs[t] * kCamRec + e];
-  cam_rec[(size_t)c * kCamRec + e] = s;
+  if (e < kCamRec)
+    for (int t = cam_img_start[c] + part; t < cam_img_start[c + 1]; t += 16)
+      s += img_intr_tmp[(size_t)cam_imgs[t] * kCamRec + e];
+  s_part[part][e] = s;
+  __syncthreads();
+  if (part == 0 && e < kCamRec) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += s_part[k][e];
+    cam_rec[(size_t)c * kCamRec + e] = tot;
+  }
 }
 void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_start,
                           const double* partial, const int* prior_start, const double* prior_res,
@@ -435,7 +503,7 @@ void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_s
     hipLaunchKernelGGL(k_camera_reduce_img, dim3(NI), dim3(64), 0, st, NI, img_chunk_start, partial,
                        prior_start, prior_res, prior_jac, img_rec, img_intr_tmp);
   if (NC > 0)
-    hipLaunchKernelGGL(k_camera_reduce_cam, dim3(NC), dim3(64), 0, st, cam_img_start, cam_imgs, img_intr_tmp, cam_rec);
+    hipLaunchKernelGGL(k_camera_reduce_cam, dim3(NC), dim3(1024), 0, st, cam_img_start, cam_imgs, img_intr_tmp, cam_rec);
 }
 
 // ---------------------------------------------------------------------------
@@ -634,64 +702,39 @@ void launch_entries_pose(hipStream_t st, int N, int Nstride, int NPs, const int*
                      pt_free, Jc, Jp, scale_cam, scale_pt, Gi, h, Epose);
 }
 
-// Intrinsics entries: one per (free point p, free camera c seen by p):
-//   Uk = (sum_{a in p, cam(a)=c} Jk'_a^T Jp'_a) Gi^T  (9x3),  ek = Uk h.
-template <int KMAX>
+// Intrinsics entries, per linear solve: one lane per (free point p, free camera c seen by p):
+//   Uk = (s_k * Wk * s_p) Gi^T  (9x3),  ek = Uk h,   Wk from k_point_reduce.
 __global__ void __launch_bounds__(128) k_entries_intr(
-    int Q, int NI, int Nstride, int NPs, const int* __restrict__ q_pt, const int* __restrict__ q_cam,
-    const int* __restrict__ pt_start, const int* __restrict__ obs_img, const int* __restrict__ img_cam,
-    const double* __restrict__ Jk, const double* __restrict__ Jp, const double* __restrict__ scale_cam,
-    const double* __restrict__ scale_pt, const double* __restrict__ Gi, const double* __restrict__ h,
-    double* __restrict__ Eintr) {
+    int Q, int NI, int NPs, const int* __restrict__ q_pt, const int* __restrict__ q_cam,
+    const double* __restrict__ Wk, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
+    const double* __restrict__ Gi, const double* __restrict__ h, double* __restrict__ Eintr) {
   const int q = blockIdx.x * 128 + threadIdx.x;
   if (q >= Q) return;
-  const long long S = Nstride;
   const int p = q_pt[q], c = q_cam[q];
-  double sp[3], G[6], hh[3], sk[KMAX], W[KMAX * 3];
+  double sp[3], G[6], hh[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { sp[k] = scale_pt[k * NPs + p]; hh[k] = h[k * NPs + p]; }
 #pragma unroll
   for (int k = 0; k < 6; ++k) G[k] = Gi[k * NPs + p];
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) { sk[k] = scale_cam[6 * NI + 9 * c + k]; W[3 * k] = W[3 * k + 1] = W[3 * k + 2] = 0.0; }
-  for (int o = pt_start[p]; o < pt_start[p + 1]; ++o) {
-    if (img_cam[obs_img[o]] != c) continue;
-    double jp[6];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) jp[e] = Jp[e * S + o];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const double j0 = Jk[k * S + o], j1 = Jk[(KMAX + k) * S + o];
-      W[3 * k] += j0 * jp[0] + j1 * jp[3];
-      W[3 * k + 1] += j0 * jp[1] + j1 * jp[4];
-      W[3 * k + 2] += j0 * jp[2] + j1 * jp[5];
-    }
-  }
+  const double* W = Wk + (size_t)q * 27;
   double* out = Eintr + (size_t)q * kIntrRec;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
-    double u0 = 0.0, u1 = 0.0, u2 = 0.0;
-    if (k < KMAX) {
-      const double w0 = W[3 * k] * sk[k] * sp[0], w1 = W[3 * k + 1] * sk[k] * sp[1], w2 = W[3 * k + 2] * sk[k] * sp[2];
-      u0 = w0 * G[0];
-      u1 = w0 * G[1] + w1 * G[2];
-      u2 = w0 * G[3] + w1 * G[4] + w2 * G[5];
-    }
+    const double sk = scale_cam[6 * NI + 9 * c + k];
+    const double w0 = W[3 * k] * sk * sp[0], w1 = W[3 * k + 1] * sk * sp[1], w2 = W[3 * k + 2] * sk * sp[2];
+    const double u0 = w0 * G[0];
+    const double u1 = w0 * G[1] + w1 * G[2];
+    const double u2 = w0 * G[3] + w1 * G[4] + w2 * G[5];
     out[3 * k] = u0; out[3 * k + 1] = u1; out[3 * k + 2] = u2;
     out[27 + k] = u0 * hh[0] + u1 * hh[1] + u2 * hh[2];
   }
 }
-void launch_entries_intr(hipStream_t st, int Q, int KMAX, int NI, int Nstride, int NPs, const int* q_pt,
-                         const int* q_cam, const int* pt_start, const int* obs_img,
-                         const int* img_cam, const double* Jk, const double* Jp,
-                         const double* scale_cam, const double* scale_pt, const double* Gi,
-                         const double* h, double* Eintr) {
+void launch_entries_intr(hipStream_t st, int Q, int NI, int NPs, const int* q_pt, const int* q_cam,
+                         const double* Wk, const double* scale_cam, const double* scale_pt,
+                         const double* Gi, const double* h, double* Eintr) {
   if (Q <= 0) return;
-  const dim3 g((Q + 127) / 128), b(128);
-#define MAVBA_EI(K) hipLaunchKernelGGL((k_entries_intr<K>), g, b, 0, st, Q, NI, Nstride, NPs, q_pt, q_cam, pt_start, \
-                                       obs_img, img_cam, Jk, Jp, scale_cam, scale_pt, Gi, h, Eintr)
-  if (KMAX <= 4) MAVBA_EI(4); else if (KMAX <= 8) MAVBA_EI(8); else MAVBA_EI(9);
-#undef MAVBA_EI
+  hipLaunchKernelGGL(k_entries_intr, dim3((Q + 127) / 128), dim3(128), 0, st, Q, NI, NPs, q_pt, q_cam, Wk, scale_cam,
+                     scale_pt, Gi, h, Eintr);
 }
 
 // ---------------------------------------------------------------------------

@@ -114,8 +114,8 @@ struct mavba_session {
   DevBuf<double> d_R, d_Jp, d_Jc, d_Jk, d_Cu, d_gu, d_Gi, d_h, d_scale_cam, d_scale_pt;
   DevBuf<double> d_sweep_partial, d_camsum /* img_rec | cam_rec */, d_img_intr_tmp, d_cam_partial;
   DevBuf<double> d_prior_res, d_prior_jac, d_prior_cost;
-  DevBuf<double> d_Epose, d_Eintr, d_part[3];
-  DevBuf<double> d_M, d_y, d_diag_ws, d_delta_cam, d_delta_pts, d_norm_partial, d_step_partial, d_scal;
+  DevBuf<double> d_Epose, d_Eintr, d_Wk, d_part[3];
+  DevBuf<double> d_M, d_L, d_y, d_diag_ws, d_delta_cam, d_delta_pts, d_norm_partial, d_step_partial, d_scal;
   DevBuf<double> d_rnorm, d_perr;
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
@@ -405,7 +405,7 @@ void mavba_session::build(const mavba_problem* P) {
   d_prior_res.alloc(std::max(num_priors, 1)); d_prior_jac.alloc((size_t)std::max(num_priors, 1) * 3);
   d_prior_cost.alloc(std::max(num_priors, 1));
   d_Epose.alloc((size_t)std::max(N, 1) * kPoseRec);
-  d_M.alloc((size_t)(n_pad + 64) * n_pad); d_y.alloc(n_pad); d_diag_ws.alloc((size_t)2 * n_pad * 64);
+  d_M.alloc((size_t)(n_pad + 64) * n_pad); d_L.alloc((size_t)(n_pad + 64) * n_pad); d_y.alloc(n_pad); d_diag_ws.alloc((size_t)2 * n_pad * 64);
   d_delta_cam.alloc(n_pad); d_delta_pts.alloc(nP * 3);
   d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + 2) * 3);
   d_scal.alloc(SC_COUNT); d_scal.zero(st);
@@ -447,6 +447,7 @@ void mavba_session::finish_structure() {
   Q = (int)q_pt.size();
   d_q_start.upload(q_start, st); d_q_pt.upload(q_pt, st); d_q_cam.upload(q_cam, st);
   d_Eintr.alloc((size_t)std::max(Q, 1) * kIntrRec);
+  d_Wk.alloc((size_t)std::max(Q, 1) * 27);
 
   // term enumeration: f(kind, row_ent, col_ent, x, y)
   auto enumerate = [&](auto&& f) {
@@ -483,12 +484,12 @@ void mavba_session::finish_structure() {
   enumerate([&](int kind, int r, int c, int, int) { count[kind][(size_t)r * ncols[kind] + c]++; tot[kind]++; });
   for (int k = 0; k < 3; ++k)
     if (tot[k] >= (1ll << 31) - 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 Schur terms of one kind");
-  // One wave per chunk. A block gets ceil(terms / 1024) chunks but never more than 64, so the
+  // One wave per chunk. A block gets ceil(terms / 1024) chunks but never more than 256, so the
   // finalize pass (which adds a block's chunk partials in order) stays short even for the
   // intrinsics-intrinsics block, whose term list has one entry per point.
   auto block_chunk_terms = [](int cnt) {
     int nch = (cnt + 1023) / 1024;
-    nch = std::max(1, std::min(nch, 64));
+    nch = std::max(1, std::min(nch, 256));
     return std::max(1, (cnt + nch - 1) / nch);
   };
   std::vector<SchurBlock> blocks;
@@ -549,7 +550,10 @@ void mavba_session::evaluate() {
   timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
   SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
   timed("jacobian_sweep", [&] { launch_jacobian_sweep(st, a); });
-  timed("point_sums", [&] { launch_point_sums(st, NP, NPs, Nstride, d_pt_start.p, d_R.p, d_Jp.p, d_Cu.p, d_gu.p); });
+  timed("point_reduce", [&] {
+    launch_point_reduce(st, NP, NPs, Nstride, KMAX, d_pt_start.p, d_q_start.p, d_q_cam.p, d_obs_img.p, d_img_cam.p,
+                        d_R.p, d_Jp.p, d_Jk.p, d_Cu.p, d_gu.p, d_Wk.p);
+  });
   CamSweepArgs c;
   c.NI = NI; c.NC = NC; c.chunks = d_sweep_chunks.p; c.num_chunks = num_sweep_chunks;
   c.im_uv = d_im_uv.p; c.im_pt = d_im_pt.p; c.camrec = d_camrec.p; c.intr = d_intr.p;
@@ -609,8 +613,8 @@ void mavba_session::assemble(double r) {
                         d_scale_pt.p, d_Gi.p, d_h.p, d_Epose.p);
   });
   timed("entries_intr", [&] {
-    launch_entries_intr(st, Q, KMAX, NI, Nstride, NPs, d_q_pt.p, d_q_cam.p, d_pt_start.p, d_obs_img.p, d_img_cam.p,
-                        d_Jk.p, d_Jp.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p, d_Eintr.p);
+    launch_entries_intr(st, Q, NI, NPs, d_q_pt.p, d_q_cam.p, d_Wk.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p,
+                        d_Eintr.p);
   });
   timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_pad + 64) * n_pad * sizeof(double), st)); });
   timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
@@ -628,7 +632,7 @@ void mavba_session::assemble(double r) {
 
 void mavba_session::solve_linear(double r) {
   assemble(r);
-  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_pad, d_y.p, d_scal.p + SC_FAIL, d_diag_ws.p); });
+  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_pad, d_y.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p); });
   assembled = false;  // the factorisation overwrote S
 }
 
@@ -1070,9 +1074,9 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
   std::memcpy(&M[(size_t)n_pad * n_pad], b, (size_t)n * 8);
   int rc = MAVBA_OK;
   {
-    DevBuf<double> dM, dy, dws, dfail;
-    dM.upload(M, st); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
-    dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p);
+    DevBuf<double> dM, dL, dy, dws, dfail;
+    dM.upload(M, st); dL.alloc(M.size()); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
+    dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p, dL.p);
     std::vector<double> y(n_pad);
     double fail = 0.0;
     HIP_OK(hipMemcpyAsync(y.data(), dy.p, (size_t)n_pad * 8, hipMemcpyDeviceToHost, st));

@@ -34,10 +34,15 @@ def _scene(kind):
         p.point_const[::7] = 1
         p.points[::7] = p.truth["points"][::7]
         return p
+    if kind == "long_tracks":
+        # BASELINE config C5 in miniature: mixed models, rotation priors, 5 % long loop-closure tracks
+        # (track length 36 > 2 x 16: exercises the strided loops of the 16-lane point reductions)
+        return synth.make_scene(num_images=40, num_points=1500, track_len=10, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV],
+                                seed=17, rot_priors=True, long_track_frac=0.05, long_track_len=36, spacing=5.0)
     raise KeyError(kind)
 
 
-KINDS = ["pinhole", "mixed", "cata", "priors", "fixed_intr", "gcp"]
+KINDS = ["pinhole", "mixed", "cata", "priors", "fixed_intr", "gcp", "long_tracks"]
 
 
 @pytest.mark.parametrize("kind", KINDS)
