@@ -274,14 +274,33 @@ __global__ void __launch_bounds__(256) k_point_reduce(
   if (p >= NP) return;  // whole 16-lane row leaves together
   const long long S = Nstride;
   const int b = pt_start[p], e = pt_start[p + 1];
+  const int q0 = q_start[p], nq = q_start[p + 1] - q0;
+  const int cam0 = nq > 0 ? q_cam[q0] : -1, cam1 = nq > 1 ? q_cam[q0 + 1] : -1;
   double c[6] = {0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0};
-  for (int o = b + g; o < e; o += 16) {
+  double W0[KMAX * 3], W1[KMAX * 3];
 #pragma unroll
-    for (int row = 0; row < 2; ++row) {
-      const double x = Jp[(row * 3 + 0) * S + o], y = Jp[(row * 3 + 1) * S + o], z = Jp[(row * 3 + 2) * S + o];
-      const double r = R[row * S + o];
-      c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
-      gg[0] += x * r; gg[1] += y * r; gg[2] += z * r;
+  for (int k = 0; k < KMAX * 3; ++k) { W0[k] = 0.0; W1[k] = 0.0; }
+  // one pass: point block sums + the intrinsics products of the first two cameras of the point
+  for (int o = b + g; o < e; o += 16) {
+    double jp[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) jp[t] = Jp[t * S + o];
+    const double r0 = R[o], r1 = R[S + o];
+    c[0] += jp[0] * jp[0] + jp[3] * jp[3]; c[1] += jp[0] * jp[1] + jp[3] * jp[4]; c[2] += jp[0] * jp[2] + jp[3] * jp[5];
+    c[3] += jp[1] * jp[1] + jp[4] * jp[4]; c[4] += jp[1] * jp[2] + jp[4] * jp[5]; c[5] += jp[2] * jp[2] + jp[5] * jp[5];
+    gg[0] += jp[0] * r0 + jp[3] * r1; gg[1] += jp[1] * r0 + jp[4] * r1; gg[2] += jp[2] * r0 + jp[5] * r1;
+    if (nq > 0) {
+      const int cam = img_cam[obs_img[o]];
+      const double s0 = cam == cam0 ? 1.0 : 0.0, s1 = cam == cam1 ? 1.0 : 0.0;
+      if (cam == cam0 || cam == cam1) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          const double j0 = Jk[k * S + o], j1 = Jk[(KMAX + k) * S + o];
+          const double w0 = j0 * jp[0] + j1 * jp[3], w1 = j0 * jp[1] + j1 * jp[4], w2 = j0 * jp[2] + j1 * jp[5];
+          W0[3 * k] += s0 * w0; W0[3 * k + 1] += s0 * w1; W0[3 * k + 2] += s0 * w2;
+          W1[3 * k] += s1 * w0; W1[3 * k + 1] += s1 * w1; W1[3 * k + 2] += s1 * w2;
+        }
+      }
     }
   }
 #pragma unroll
@@ -294,24 +313,7 @@ __global__ void __launch_bounds__(256) k_point_reduce(
 #pragma unroll
     for (int k = 0; k < 3; ++k) gu[k * NPs + p] = gg[k];
   }
-  for (int q = q_start[p]; q < q_start[p + 1]; ++q) {
-    const int cam = q_cam[q];
-    double W[KMAX * 3];
-#pragma unroll
-    for (int k = 0; k < KMAX * 3; ++k) W[k] = 0.0;
-    for (int o = b + g; o < e; o += 16) {
-      if (img_cam[obs_img[o]] != cam) continue;
-      double jp[6];
-#pragma unroll
-      for (int t = 0; t < 6; ++t) jp[t] = Jp[t * S + o];
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        const double j0 = Jk[k * S + o], j1 = Jk[(KMAX + k) * S + o];
-        W[3 * k] += j0 * jp[0] + j1 * jp[3];
-        W[3 * k + 1] += j0 * jp[1] + j1 * jp[4];
-        W[3 * k + 2] += j0 * jp[2] + j1 * jp[5];
-      }
-    }
+  auto emit = [&](int q, double* W) {
     double* out = Wk + (size_t)q * 27;
 #pragma unroll
     for (int k = 0; k < KMAX * 3; ++k) {
@@ -320,6 +322,28 @@ __global__ void __launch_bounds__(256) k_point_reduce(
     }
     if (KMAX < 9 && g < 27 - KMAX * 3) out[KMAX * 3 + g] = 0.0;
     if (KMAX < 9 && g + 16 < 27 - KMAX * 3) out[KMAX * 3 + g + 16] = 0.0;
+  };
+  if (nq > 0) emit(q0, W0);
+  if (nq > 1) emit(q0 + 1, W1);
+  // points seen by more than two free cameras: one extra pass per further camera
+  for (int q = q0 + 2; q < q0 + nq; ++q) {
+    const int cam = q_cam[q];
+#pragma unroll
+    for (int k = 0; k < KMAX * 3; ++k) W0[k] = 0.0;
+    for (int o = b + g; o < e; o += 16) {
+      if (img_cam[obs_img[o]] != cam) continue;
+      double jp[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) jp[t] = Jp[t * S + o];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const double j0 = Jk[k * S + o], j1 = Jk[(KMAX + k) * S + o];
+        W0[3 * k] += j0 * jp[0] + j1 * jp[3];
+        W0[3 * k + 1] += j0 * jp[1] + j1 * jp[4];
+        W0[3 * k + 2] += j0 * jp[2] + j1 * jp[5];
+      }
+    }
+    emit(q, W0);
   }
 }
 void launch_point_reduce(hipStream_t st, int NP, int NPs, int Nstride, int KMAX, const int* pt_start,
@@ -750,7 +774,12 @@ __global__ void __launch_bounds__(256) k_schur_chunks(int num_chunks, const Schu
                                                       const double* __restrict__ EY,
                                                       double* __restrict__ partial) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cid = blockIdx.x * 4 + wv;
+  // XCD-aware order: work-group b runs on XCD b % 8 (observed dispatch, used for speed only), so
+  // give every XCD one CONTIGUOUS run of chunks — neighbouring blocks share entry records and then
+  // find them in the same L2.
+  const int per_xcd = (gridDim.x + 7) >> 3;
+  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int cid = wg * 4 + wv;
   if (cid >= num_chunks) return;
   const SchurChunk ch = chunks[cid];
   constexpr int NA = RX * RY;
@@ -797,7 +826,7 @@ int schur_partial_stride(int kind) { return kind == BLK_PP ? 42 : kind == BLK_IP
 void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurChunk* chunks,
                          const int2* terms, const double* Epose, const double* Eintr, double* partial) {
   if (num_chunks <= 0) return;
-  const dim3 g((num_chunks + 3) / 4), b(256);
+  const dim3 g((((num_chunks + 3) / 4) + 7) / 8 * 8), b(256);  // multiple of 8: one contiguous run per XCD
   if (kind == BLK_PP)
     hipLaunchKernelGGL((k_schur_chunks<6, 6, kPoseRec, kPoseRec, true>), g, b, 0, st, num_chunks, chunks, terms, Epose, Epose, partial);
   else if (kind == BLK_IP)
@@ -827,9 +856,7 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
   const int row0 = B.kind == BLK_PP ? 6 * B.row_ent : 6 * NI + 9 * B.row_ent;
   const int col0 = B.kind == BLK_II ? 6 * NI + 9 * B.col_ent : 6 * B.col_ent;
   const bool is_diag = diag_kind && B.row_ent == B.col_ent;
-  for (int idx = lane; idx < PS; idx += 64) {
-    double s = 0.0;
-    for (int c = B.chunk_begin; c < B.chunk_end; ++c) s += part[(size_t)c * PS + idx];
+  auto apply = [&](int idx, double s) {
     if (idx < NA) {
       const int r = idx / RY, c = idx - r * RY;
       const int gr = row0 + r, gc = col0 + c;
@@ -864,6 +891,18 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
       }
       v[gr] = base - s;
     }
+  };
+  // one lane per element; the block's chunk partials are added in a fixed order, eight independent
+  // running sums so that the (dependent-latency) loads of a long chunk list overlap
+  for (int idx = lane; idx < PS; idx += 64) {
+    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int c = B.chunk_begin;
+    for (; c + 8 <= B.chunk_end; c += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s8[u] += part[(size_t)(c + u) * PS + idx];
+    }
+    for (; c < B.chunk_end; ++c) s8[0] += part[(size_t)c * PS + idx];
+    apply(idx, ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7])));
   }
 }
 void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blocks,

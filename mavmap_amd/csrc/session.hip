@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -495,12 +496,31 @@ void mavba_session::finish_structure() {
   std::vector<SchurBlock> blocks;
   std::vector<SchurChunk> chunks[3];
   std::vector<int> cursor[3];
+  // Block order = launch order of the chunk kernels. Pose-pose blocks are visited in 2-D tiles of
+  // kTile x kTile images so that the entry records of ~2*kTile images (a few MB) stay in one XCD's
+  // L2 while all blocks among them are accumulated; the other kinds are ordered by image.
+  int kTile = 4;
+  if (const char* e = std::getenv("MAVBA_PP_TILE")) kTile = std::max(1, std::atoi(e));  // tuning knob
   for (int k = 0; k < 3; ++k) {
     cursor[k].assign(count[k].size(), 0);
+    std::vector<size_t> keys;
+    for (size_t key = 0; key < count[k].size(); ++key)
+      if (count[k][key] != 0 || mandatory[k][key]) keys.push_back(key);
+    if (k == BLK_PP) {
+      const long long nc = ncols[k];
+      std::stable_sort(keys.begin(), keys.end(), [&](size_t a, size_t b) {
+        const long long ia = a / nc, ja = a % nc, ib = b / nc, jb = b % nc;
+        if (ia / kTile != ib / kTile) return ia / kTile < ib / kTile;
+        if (ja / kTile != jb / kTile) return ja / kTile < jb / kTile;
+        return a < b;
+      });
+    } else if (k == BLK_IP) {
+      const long long nc = ncols[k];
+      std::stable_sort(keys.begin(), keys.end(), [&](size_t a, size_t b) { return a % nc < b % nc; });
+    }
     int off = 0;
-    for (size_t key = 0; key < count[k].size(); ++key) {
+    for (size_t key : keys) {
       const int cnt = count[k][key];
-      if (cnt == 0 && !mandatory[k][key]) continue;
       SchurBlock B;
       B.kind = k; B.row_ent = (int)(key / ncols[k]); B.col_ent = (int)(key % ncols[k]);
       B.chunk_begin = (int)chunks[k].size();
