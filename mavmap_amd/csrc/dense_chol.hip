@@ -40,31 +40,58 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// 16x16 SPD block: Cholesky factor AND its inverse in one 16-step sweep, in the registers of
-// lanes 0..15 (lane = row). In: a[k] = row `lane` of the block. Out: a[k] = L[lane][k],
-// x[k] = (L^-1)[lane][k] (zero above the diagonal). Elimination of column j also applies the same
-// row operations to the identity, so L^-1 is finished with L. Broadcasts are v_readlane (SGPR),
-// no LDS round trips on the critical path.
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {  // value held by lane Q of the caller's quad
+  constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_fetch(double v, int src_lane) {  // per-lane source (ds_bpermute)
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// 16x16 SPD block: Cholesky factor AND its inverse in one 16-step sweep over a whole wave.
+// Lane l owns row i = l >> 2 and the four columns 4q..4q+3 (q = l & 3) of both the block (a[])
+// and the identity that is transformed into L^-1 (x[]). Eliminating column j applies the same
+// row operations to both, so L^-1 is finished together with L. Per step: one pivot broadcast
+// (v_readlane), one quad broadcast (DPP) of the row multiplier, and 8 per-lane fetches
+// (ds_bpermute) feeding 8 independent FMAs per lane — no LDS memory round trips, no barriers.
+template <int J>
+__device__ __forceinline__ void potrf_inv16_step(double* a, double* x, int i, int q, bool& ok) {
+  constexpr int QJ = J >> 2, JJ = J & 3;
+  double piv = readlane_d(a[JJ], 4 * J + QJ);
+  if (!(piv > 0.0) || !isfinite(piv)) { ok = false; piv = 1.0; }
+  const double rs = rsqrt_nr(piv);
+  if (q == QJ) a[JJ] = i > J ? a[JJ] * rs : (i == J ? piv * rs : 0.0);
+  if (i == J) { x[0] *= rs; x[1] *= rs; x[2] *= rs; x[3] *= rs; }
+  double m = quad_bcast<QJ>(a[JJ]);   // l_iJ of this lane's row
+  m = i > J ? m : 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = 4 * q + c;          // column of a[c]; l_kJ lives in lane (k, QJ), register a[JJ]
+    double lk = lane_fetch(a[JJ], 4 * k + QJ);
+    lk = k > J ? lk : 0.0;
+    a[c] -= m * lk;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) x[c] -= m * lane_fetch(x[c], 4 * J + q);  // row J of the (scaled) inverse
+}
 __device__ __forceinline__ bool potrf_inv16(double* a, double* x, int lane) {
+  const int i = lane >> 2, q = lane & 3;
   bool ok = true;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) x[k] = (k == lane) ? 1.0 : 0.0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double piv = readlane_d(a[j], j);
-    if (!(piv > 0.0) || !isfinite(piv)) { ok = false; piv = 1.0; }
-    const double rs = rsqrt_nr(piv);
-    a[j] = lane > j ? a[j] * rs : (lane == j ? piv * rs : 0.0);
-    if (lane == j) {
-#pragma unroll
-      for (int c = 0; c <= j; ++c) x[c] *= rs;
-    }
-    const double m = lane > j ? a[j] : 0.0;
-#pragma unroll
-    for (int k = j + 1; k < 16; ++k) a[k] -= m * readlane_d(a[j], k);
-#pragma unroll
-    for (int c = 0; c <= j; ++c) x[c] -= m * readlane_d(x[c], j);
-  }
+  for (int c = 0; c < 4; ++c) x[c] = (4 * q + c == i) ? 1.0 : 0.0;
+  potrf_inv16_step<0>(a, x, i, q, ok);  potrf_inv16_step<1>(a, x, i, q, ok);
+  potrf_inv16_step<2>(a, x, i, q, ok);  potrf_inv16_step<3>(a, x, i, q, ok);
+  potrf_inv16_step<4>(a, x, i, q, ok);  potrf_inv16_step<5>(a, x, i, q, ok);
+  potrf_inv16_step<6>(a, x, i, q, ok);  potrf_inv16_step<7>(a, x, i, q, ok);
+  potrf_inv16_step<8>(a, x, i, q, ok);  potrf_inv16_step<9>(a, x, i, q, ok);
+  potrf_inv16_step<10>(a, x, i, q, ok); potrf_inv16_step<11>(a, x, i, q, ok);
+  potrf_inv16_step<12>(a, x, i, q, ok); potrf_inv16_step<13>(a, x, i, q, ok);
+  potrf_inv16_step<14>(a, x, i, q, ok); potrf_inv16_step<15>(a, x, i, q, ok);
   return ok;
 }
 
@@ -98,7 +125,7 @@ __device__ __forceinline__ void store_d16(double* C, int ldc, d4 v, int lane) {
 // Factorise the SPD tile in T (LDS, pitch GLD) and invert the factor, blocked 4 x 4 in 16x16:
 //   T  <- L on and below the diagonal blocks,   Ti <- L^-1 (lower; Ti must come in zeroed).
 // Per 16-column block: the diagonal block is factored + inverted in registers by 16 lanes
-// (potrf_inv16); the panel below it, the trailing update inside the tile and the assembly of
+// (potrf_inv16, one wave); the panel below it, the trailing update inside the tile and the assembly of
 // the off-diagonal blocks of L^-1 are 16x16x16 FP64-MFMA products spread over the 4 waves.
 // All 256 threads must call it (uniform barriers). scr: 4 * 16 * 18 doubles of LDS.
 // Returns false (in thread 0) if a pivot is not positive.
@@ -110,16 +137,18 @@ __device__ __forceinline__ bool tile_potrf_inv(double* T, double* Ti, double* sc
   for (int cb = 0; cb < 4; ++cb) {
     double* D = T + (16 * cb) * GLD + 16 * cb;
     double* Di = Ti + (16 * cb) * GLD + 16 * cb;
-    if (wv == 0 && lane < 16) {
-      double a[16], x[16];
-#pragma unroll
-      for (int k = 0; k < 16; k += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(D + lane * GLD + k);
-        a[k] = v.x; a[k + 1] = v.y;
-      }
+    if (wv == 0) {
+      const int i = lane >> 2, q = lane & 3;
+      double a[4], x[4];
+      const double2 v0 = *reinterpret_cast<const double2*>(D + i * GLD + 4 * q);
+      const double2 v1 = *reinterpret_cast<const double2*>(D + i * GLD + 4 * q + 2);
+      a[0] = v0.x; a[1] = v0.y; a[2] = v1.x; a[3] = v1.y;
       ok = potrf_inv16(a, x, lane) && ok;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { D[lane * GLD + k] = k <= lane ? a[k] : 0.0; Di[lane * GLD + k] = k <= lane ? x[k] : 0.0; }
+      for (int c = 0; c < 4; ++c) {
+        D[i * GLD + 4 * q + c] = (4 * q + c <= i) ? a[c] : 0.0;
+        Di[i * GLD + 4 * q + c] = x[c];
+      }
     }
     __syncthreads();
     const int nt = 3 - cb;  // 16-row blocks below the diagonal block
