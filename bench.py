@@ -66,6 +66,30 @@ def algorithmic_work(stats_name, prob, sess_info):
     return None, 0.0, ""
 
 
+PMC_KERNEL = {  # bench timer name -> rocprofv3 kernel-name prefix in profiles/*pmc_traffic*.json
+    "jacobian_sweep": "k_jacobian_sweep", "cost_only": "k_cost_only", "point_reduce": "k_point_reduce",
+    "camera_sweep": "k_camera_sweep", "entries_pose": "k_entries_pose", "entries_intr": "k_entries_intr",
+    "backsub_points": "k_backsub_points", "schur_chunks_pp": "k_schur_chunks<6, 6", "schur_chunks_ip": "k_schur_chunks<9, 6",
+    "schur_chunks_ii": "k_schur_chunks<9, 9", "schur_finalize": "k_schur_finalize", "point_factor": "k_point_factor",
+}
+
+
+def pmc_traffic(name, config, scale, world):
+    """HBM bytes per launch of one bench kernel from the committed rocprofv3 --pmc passes (separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, scripts/pmc_traffic.sh), or None."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{config}.json")
+    if scale != 1.0 or world != 1 or not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"]
+    if name == "dense_cholesky":
+        chol = {n: v for n, v in k.items() if n.startswith("k_chol_")}
+        solves = max((v["launches"] for n, v in chol.items() if n.startswith("k_chol_diag0")), default=0)
+        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in chol.values()) / solves if solves else None
+    pre = PMC_KERNEL.get(name)
+    hit = [v for n, v in k.items() if pre and n.startswith(pre)]
+    return hit[0]["hbm_bytes_per_launch"] if hit else None
+
+
 def count_pp_terms(prob):
     """Number of (observation, observation) pairs inside a point with image(a) >= image(b)."""
     order = np.argsort(prob.obs_point, kind="stable")
@@ -199,7 +223,8 @@ def main():
         roofline = None
         if dominant:
             roofline = dict(kernel=dominant["kernel"], bound=dominant["bound"], achieved=dominant["achieved"],
-                            peak=dominant["peak"], unit=dominant["unit"], frac=dominant["frac"], traffic=None)
+                            peak=dominant["peak"], unit=dominant["unit"], frac=dominant["frac"],
+                            traffic=pmc_traffic(dominant["kernel"], args.config, args.scale, world))
         sweep = next((r for r in table if r["kernel"] == "jacobian_sweep"), None)
 
         cpu_baseline = None
@@ -233,7 +258,9 @@ def main():
             "jacobian_sweep": None if not sweep else {
                 "obs_per_sec": round(prob.num_obs / (sweep["avg_ms"] * 1e-3), 1), "avg_ms": sweep["avg_ms"],
                 "bound": "hbm", "achieved": sweep["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": sweep["frac"], "note": "algorithmic bytes 48 + 16 + 2*(9+K)*8 per observation, this rank"},
+                "frac": sweep["frac"], "traffic": pmc_traffic("jacobian_sweep", args.config, args.scale, world),
+                "note": "algorithmic bytes 48 + 16 + 2*(9+K)*8 per observation, this rank; traffic = HBM bytes per "
+                        "launch from rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes in profiles/"},
             "cpu_baseline": cpu_baseline,
             "kernels": table,
             "solve": {"iterations": final["num_successful_steps"] + final["num_unsuccessful_steps"],
