@@ -14,7 +14,6 @@ sharded over the ranks and the reduced camera system is all-reduced over RCCL on
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -120,10 +119,12 @@ def main():
     if not torch.cuda.is_available():
         log("bench.py: no GPU visible — the mavba backend has no CPU path")
         sys.exit(3)
+    # one process per GPU; MAVBA_DIST_BACKEND=gloo lets several ranks share one GPU (testing only)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("MAVBA_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     import mavmap_amd
     from mavmap_amd import synth, _abi as A
@@ -139,23 +140,9 @@ def main():
                 device=local_rank, profile_kernels=1)
     sess = mavmap_amd.Session(prob, opts)
 
-    hip = None
-    stage = {}
     if world > 1:
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        hip.hipMemcpy.restype = ctypes.c_int
-
-        def allreduce(ptr, count, op):
-            buf = stage.get(count)
-            if buf is None:
-                buf = stage[count] = torch.empty(count, dtype=torch.float64, device=f"cuda:{local_rank}")
-            assert hip.hipMemcpy(buf.data_ptr(), ptr, count * 8, 3) == 0
-            dist.all_reduce(buf, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-            assert hip.hipMemcpy(ptr, buf.data_ptr(), count * 8, 3) == 0
-
-        sess.set_allreduce(allreduce, rank, world)
+        from mavmap_amd.dist import make_allreduce
+        sess.set_allreduce(make_allreduce(torch.device(f"cuda:{local_rank}")), rank, world)
 
     def run_steps(k):
         remaining, solves, idle = k, 0, 0

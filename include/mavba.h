@@ -221,7 +221,8 @@ int mavba_session_point_errors(mavba_session* s, double* point_error);
  * observations; the reduced camera system and a handful of scalars must be
  * summed over ranks once per linear solve. The session calls `fn` with a
  * device pointer to `count` contiguous doubles that must be all-reduced in
- * place (op 0 = sum, 1 = max) before `fn` returns. The stream the session
+ * place (op 0 = sum, 1 = max, 2 = sum for the first count-1 doubles and max
+ * for the last one) before `fn` returns. The stream the session
  * works on is idle while `fn` runs. With no hook set the session is
  * single-rank.
  */

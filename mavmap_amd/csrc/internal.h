@@ -48,7 +48,7 @@ enum {
   SC_CAND_XNORM2,     // |x + delta|^2
   SC_FAIL,            // > 0: linear solve failed (non-SPD point block or pivot)
   SC_NUM_SUMS,
-  SC_GRAD_MAX = 8,    // max |g_j| over free parameters (unscaled gradient)
+  SC_GRAD_MAX = SC_NUM_SUMS,  // max |g_j| over free parameters (unscaled gradient); directly after the sums
   SC_COUNT = 16
 };
 

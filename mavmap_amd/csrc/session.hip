@@ -609,10 +609,7 @@ void mavba_session::evaluate() {
     launch_reduce_cols(st, d_sweep_partial.p, N > 0 ? jacobian_sweep_grid(N) : 0, 1, 1, 0u, d_scal.p + SC_COST, false);
     if (num_priors > 0) launch_reduce_cols(st, d_prior_cost.p, num_priors, 1, 1, 0u, d_scal.p + SC_COST, true);
   });
-  if (world > 1) {
-    allreduce(d_scal.p, SC_NUM_SUMS, 0);
-    allreduce(d_scal.p + SC_GRAD_MAX, 1, 1);
-  }
+  if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS + 1, 2);  // sums, then max|g| in the last slot
   double h[SC_COUNT];
   read_scalars(h);
   cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]);

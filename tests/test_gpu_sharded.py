@@ -33,6 +33,8 @@ class InProcessAllReduce:
             self.bar.wait()
             stack = np.stack(self.bufs)                                            # fixed rank order
             tot = stack.max(0) if op == 1 else stack.sum(0)
+            if op == 2:                                                            # sums, last element max
+                tot[-1] = stack[:, -1].max()
             self.bar.wait()
             assert self.hip.hipMemcpy(ptr, tot.ctypes.data, count * 8, 1) == 0     # host -> device
             if rank == 0:
@@ -109,3 +111,21 @@ def test_rank_without_observations_of_an_image_keeps_it_free(mavba):
     out, _ = solve_sharded(mavba, full, 2, opts)
     assert abs(out[0][0]["final_cost"] - r1["final_cost"]) <= 1e-9 * r1["final_cost"]
     assert rel_err(out[0][1], single.poses) < 1e-8
+
+
+def test_torch_zero_copy_view_of_a_device_pointer(mavba):
+    """bench.py's RCCL hook wraps the session's raw device pointer as a torch tensor (CUDA array
+    interface). Check that the view aliases the memory (no copy) on this GPU."""
+    torch = pytest.importorskip("torch")
+    from mavmap_amd.dist import tensor_from_ptr
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    base = torch.arange(16, dtype=torch.float64, device="cuda:0")
+    view = tensor_from_ptr(base.data_ptr() + 4 * 8, 8, torch.device("cuda:0"))
+    assert view.data_ptr() == base.data_ptr() + 32 and view.dtype == torch.float64
+    view.mul_(2.0)
+    torch.cuda.synchronize()
+    host = np.zeros(16)
+    assert hip.hipMemcpy(host.ctypes.data, base.data_ptr(), 16 * 8, 2) == 0
+    expect = np.arange(16.0); expect[4:12] *= 2
+    assert np.array_equal(host, expect)

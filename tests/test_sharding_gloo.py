@@ -55,7 +55,11 @@ def _worker(rank, world, port, q):
         buf = torch.from_numpy(local.copy())
 
         def hook(tensor, count, op):  # same contract as the device hook: in place, blocking
-            dist.all_reduce(tensor[:count], op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+            if op == 2:
+                dist.all_reduce(tensor[:count - 1], op=dist.ReduceOp.SUM)
+                dist.all_reduce(tensor[count - 1:count], op=dist.ReduceOp.MAX)
+            else:
+                dist.all_reduce(tensor[:count], op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
 
         hook(buf, buf.numel(), 0)
         ref = _camera_sums(full, O)
@@ -67,6 +71,9 @@ def _worker(rank, world, port, q):
         used[np.unique(shard.obs_image)] = 1.0
         hook(used, used.numel(), 1)
         assert used.min().item() == 1.0
+        mixed = torch.tensor([1.0 + rank, 10.0 * (rank + 1), 5.0 - rank], dtype=torch.float64)
+        hook(mixed, 3, 2)  # op 2: sums, then max in the last slot
+        assert mixed.tolist() == [3.0, 30.0, 5.0]
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))
