@@ -18,10 +18,23 @@ namespace mavba {
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
+// Sum over the 64 lanes, result in EVERY lane: DPP row rotations (8, 4, 2, 1) give each 16-lane row
+// its total, four v_readlane pairs combine the rows in a fixed order. No LDS traffic.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;  // valid in lane 0
+#define MAVBA_ROR_ADD(N)                                                                                   \
+  {                                                                                                        \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 | (N), 0xf, 0xf, false);        \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 | (N), 0xf, 0xf, false);        \
+    v += __hiloint2double(hi, lo);                                                                         \
+  }
+  MAVBA_ROR_ADD(8) MAVBA_ROR_ADD(4) MAVBA_ROR_ADD(2) MAVBA_ROR_ADD(1)
+#undef MAVBA_ROR_ADD
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -943,50 +956,63 @@ __global__ void __launch_bounds__(256) k_backsub_points(
     const double* __restrict__ points, double* __restrict__ cand_points, double* __restrict__ delta_points,
     double* __restrict__ partial) {
   __shared__ double s_red[4];
+  // 16 lanes per point: lane g takes observation b + g, b + g + 16, ... (consecutive 192-byte records
+  // -> the row reads one contiguous run), then a DPP row reduction of the three sums.
+  const int g = threadIdx.x & 15;
   double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
-  for (int p = blockIdx.x * 256 + threadIdx.x; p < NP; p += gp * 256) {
-    double X[3] = {points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2]};
-    double d[3] = {0, 0, 0};
-    if (pt_free[p]) {
-      double t[3] = {h[p], h[NPs + p], h[2 * NPs + p]};
-      for (int o = pt_start[p]; o < pt_start[p + 1]; ++o) {
-        const double* U = Epose + (size_t)o * kPoseRec;
+  for (int p = blockIdx.x * 16 + (threadIdx.x >> 4); p < NP; p += gp * 16) {
+    const bool fr = pt_free[p] != 0;
+    double t[3] = {0, 0, 0};
+    if (fr) {
+      for (int o = pt_start[p] + g; o < pt_start[p + 1]; o += 16) {
+        const double2* U = reinterpret_cast<const double2*>(Epose + (size_t)o * kPoseRec);
         const double* yc = y + 6 * obs_img[o];
+        double u[18];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const double2 v = U[k]; u[2 * k] = v.x; u[2 * k + 1] = v.y; }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
           const double yr = yc[r];
-          t[0] -= U[3 * r] * yr; t[1] -= U[3 * r + 1] * yr; t[2] -= U[3 * r + 2] * yr;
+          t[0] += u[3 * r] * yr; t[1] += u[3 * r + 1] * yr; t[2] += u[3 * r + 2] * yr;
         }
       }
-      for (int q = q_start[p]; q < q_start[p + 1]; ++q) {
+      for (int q = q_start[p] + g; q < q_start[p + 1]; q += 16) {
         const double* U = Eintr + (size_t)q * kIntrRec;
         const double* yc = y + 6 * NI + 9 * q_cam[q];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
           const double yr = yc[r];
-          t[0] -= U[3 * r] * yr; t[1] -= U[3 * r + 1] * yr; t[2] -= U[3 * r + 2] * yr;
+          t[0] += U[3 * r] * yr; t[1] += U[3 * r + 1] * yr; t[2] += U[3 * r + 2] * yr;
         }
       }
-      const double G[6] = {Gi[p], Gi[NPs + p], Gi[2 * NPs + p], Gi[3 * NPs + p], Gi[4 * NPs + p], Gi[5 * NPs + p]};
-      double yp[3];
-      git_mul(G, t, yp);
-      const int dg[3] = {0, 3, 5};
+    }
+    t[0] = row16_sum(t[0]); t[1] = row16_sum(t[1]); t[2] = row16_sum(t[2]);
+    if (g == 0) {
+      double X[3] = {points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2]};
+      double d[3] = {0, 0, 0};
+      if (fr) {
+        const double tt[3] = {h[p] - t[0], h[NPs + p] - t[1], h[2 * NPs + p] - t[2]};
+        const double G[6] = {Gi[p], Gi[NPs + p], Gi[2 * NPs + p], Gi[3 * NPs + p], Gi[4 * NPs + p], Gi[5 * NPs + p]};
+        double yp[3];
+        git_mul(G, tt, yp);
+        const int dg[3] = {0, 3, 5};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double s = scale_pt[k * NPs + p];
+          const double D2 = clampd(s * s * Cu[dg[k] * NPs + p], dmin, dmax) / radius;
+          const double gs = s * gu[k * NPs + p];
+          a_model += 0.5 * yp[k] * (gs + D2 * yp[k]);
+          d[k] = -yp[k] * s;
+          a_step += d[k] * d[k];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const double s = scale_pt[k * NPs + p];
-        const double D2 = clampd(s * s * Cu[dg[k] * NPs + p], dmin, dmax) / radius;
-        const double gs = s * gu[k * NPs + p];
-        a_model += 0.5 * yp[k] * (gs + D2 * yp[k]);
-        d[k] = -yp[k] * s;
-        a_step += d[k] * d[k];
+        const double xn = X[k] + d[k];
+        cand_points[3 * (size_t)p + k] = xn;
+        delta_points[3 * (size_t)p + k] = d[k];
+        if (fr) a_x2 += xn * xn;
       }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double xn = X[k] + d[k];
-      cand_points[3 * (size_t)p + k] = xn;
-      delta_points[3 * (size_t)p + k] = d[k];
-      if (pt_free[p]) a_x2 += xn * xn;
     }
   }
   const double s0 = block_sum_256(a_step, s_red);
@@ -1001,7 +1027,7 @@ void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radiu
                            const double* Cu, const double* gu, const double* scale_pt,
                            const double* points, double* cand_points, double* delta_points,
                            double* partial, int* grid_out) {
-  int gp = (NP + 255) / 256;
+  int gp = (NP + 15) / 16;
   if (gp > 1024) gp = 1024;
   if (gp < 1) gp = 1;
   hipLaunchKernelGGL(k_backsub_points, dim3(gp), dim3(256), 0, st, NP, NPs, NI, gp, radius, dmin, dmax, pt_start,
