@@ -40,58 +40,46 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-template <int Q>
-__device__ __forceinline__ double quad_bcast(double v) {  // value held by lane Q of the caller's quad
-  constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_fetch(double v, int src_lane) {  // per-lane source (ds_bpermute)
-  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
-  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
-// 16x16 SPD block: Cholesky factor AND its inverse in one 16-step sweep over a whole wave.
-// Lane l owns row i = l >> 2 and the four columns 4q..4q+3 (q = l & 3) of both the block (a[])
-// and the identity that is transformed into L^-1 (x[]). Eliminating column j applies the same
-// row operations to both, so L^-1 is finished together with L. Per step: one pivot broadcast
-// (v_readlane), one quad broadcast (DPP) of the row multiplier, and 8 per-lane fetches
-// (ds_bpermute) feeding 8 independent FMAs per lane — no LDS memory round trips, no barriers.
+// 16x16 SPD block: Cholesky factor AND the inverse of the factor, 16 pivot steps, the whole block
+// living in ONE wave's MFMA accumulator layout (reg r of lane l = element [(l >> 4) + 4 r][l & 15]).
+//
+// Right-looking on the full symmetric block: at step J the scaled row J (u = a_J / sqrt(a_JJ),
+// = column J of L by symmetry) sits in the 16 lanes of group t = J & 3, register J >> 2 — exactly
+// where v_mfma_f64_16x16x4_f64 expects the k = t slice of both of its operands. So the rank-1
+// update  A -= u u^T  is ONE matrix instruction whose operands are each lane's own (masked) value:
+// no shuffles, no LDS, no per-column FMAs. The same instruction with the scaled row J of the
+// running inverse as second operand applies the row operations to the identity, so X = L^-1 is
+// finished together with the factor:  X -= u x_J^T.
+// In: acc = the block (both triangles). Out: xacc = L^-1 (lower). Returns false on a bad pivot.
 template <int J>
-__device__ __forceinline__ void potrf_inv16_step(double* a, double* x, int i, int q, bool& ok) {
-  constexpr int QJ = J >> 2, JJ = J & 3;
-  double piv = readlane_d(a[JJ], 4 * J + QJ);
+__device__ __forceinline__ void potrf_inv16_step(d4& acc, d4& xacc, int lane, bool& ok) {
+  constexpr int T4 = J & 3, RR = J >> 2;
+  double piv = readlane_d(acc[RR], 16 * T4 + J);
   if (!(piv > 0.0) || !isfinite(piv)) { ok = false; piv = 1.0; }
   const double rs = rsqrt_nr(piv);
-  if (q == QJ) a[JJ] = i > J ? a[JJ] * rs : (i == J ? piv * rs : 0.0);
-  if (i == J) { x[0] *= rs; x[1] *= rs; x[2] *= rs; x[3] *= rs; }
-  double m = quad_bcast<QJ>(a[JJ]);   // l_iJ of this lane's row
-  m = i > J ? m : 0.0;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int k = 4 * q + c;          // column of a[c]; l_kJ lives in lane (k, QJ), register a[JJ]
-    double lk = lane_fetch(a[JJ], 4 * k + QJ);
-    lk = k > J ? lk : 0.0;
-    a[c] -= m * lk;
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) x[c] -= m * lane_fetch(x[c], 4 * J + q);  // row J of the (scaled) inverse
+  const bool in_row = (lane >> 4) == T4;
+  const bool live = in_row && (lane & 15) >= J;
+  const double u = live ? acc[RR] * rs : 0.0;      // row J of L^T (zero left of the diagonal)
+  const double xj = in_row ? xacc[RR] * rs : 0.0;  // row J of the inverse, scaled
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, u, acc, 0, 0, 0);
+  xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, xj, xacc, 0, 0, 0);
+  // the instruction also hit row J itself; put the finished rows back
+  acc[RR] = live ? u : acc[RR];
+  xacc[RR] = in_row ? xj : xacc[RR];
 }
-__device__ __forceinline__ bool potrf_inv16(double* a, double* x, int lane) {
-  const int i = lane >> 2, q = lane & 3;
+__device__ __forceinline__ bool potrf_inv16(d4& acc, d4& xacc, int lane) {
   bool ok = true;
+  const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) x[c] = (4 * q + c == i) ? 1.0 : 0.0;
-  potrf_inv16_step<0>(a, x, i, q, ok);  potrf_inv16_step<1>(a, x, i, q, ok);
-  potrf_inv16_step<2>(a, x, i, q, ok);  potrf_inv16_step<3>(a, x, i, q, ok);
-  potrf_inv16_step<4>(a, x, i, q, ok);  potrf_inv16_step<5>(a, x, i, q, ok);
-  potrf_inv16_step<6>(a, x, i, q, ok);  potrf_inv16_step<7>(a, x, i, q, ok);
-  potrf_inv16_step<8>(a, x, i, q, ok);  potrf_inv16_step<9>(a, x, i, q, ok);
-  potrf_inv16_step<10>(a, x, i, q, ok); potrf_inv16_step<11>(a, x, i, q, ok);
-  potrf_inv16_step<12>(a, x, i, q, ok); potrf_inv16_step<13>(a, x, i, q, ok);
-  potrf_inv16_step<14>(a, x, i, q, ok); potrf_inv16_step<15>(a, x, i, q, ok);
+  for (int r = 0; r < 4; ++r) xacc[r] = (lk + 4 * r == li) ? 1.0 : 0.0;
+  potrf_inv16_step<0>(acc, xacc, lane, ok);  potrf_inv16_step<1>(acc, xacc, lane, ok);
+  potrf_inv16_step<2>(acc, xacc, lane, ok);  potrf_inv16_step<3>(acc, xacc, lane, ok);
+  potrf_inv16_step<4>(acc, xacc, lane, ok);  potrf_inv16_step<5>(acc, xacc, lane, ok);
+  potrf_inv16_step<6>(acc, xacc, lane, ok);  potrf_inv16_step<7>(acc, xacc, lane, ok);
+  potrf_inv16_step<8>(acc, xacc, lane, ok);  potrf_inv16_step<9>(acc, xacc, lane, ok);
+  potrf_inv16_step<10>(acc, xacc, lane, ok); potrf_inv16_step<11>(acc, xacc, lane, ok);
+  potrf_inv16_step<12>(acc, xacc, lane, ok); potrf_inv16_step<13>(acc, xacc, lane, ok);
+  potrf_inv16_step<14>(acc, xacc, lane, ok); potrf_inv16_step<15>(acc, xacc, lane, ok);
   return ok;
 }
 
@@ -123,7 +111,8 @@ __device__ __forceinline__ void store_d16(double* C, int ldc, d4 v, int lane) {
 }
 
 // Factorise the SPD tile in T (LDS, pitch GLD) and invert the factor, blocked 4 x 4 in 16x16:
-//   T  <- L on and below the diagonal blocks,   Ti <- L^-1 (lower; Ti must come in zeroed).
+//   T  <- L below the diagonal blocks (the diagonal blocks themselves are consumed),
+//   Ti <- L^-1 (lower; Ti must come in zeroed).
 // Per 16-column block: the diagonal block is factored + inverted in registers by 16 lanes
 // (potrf_inv16, one wave); the panel below it, the trailing update inside the tile and the assembly of
 // the off-diagonal blocks of L^-1 are 16x16x16 FP64-MFMA products spread over the 4 waves.
@@ -138,17 +127,9 @@ __device__ __forceinline__ bool tile_potrf_inv(double* T, double* Ti, double* sc
     double* D = T + (16 * cb) * GLD + 16 * cb;
     double* Di = Ti + (16 * cb) * GLD + 16 * cb;
     if (wv == 0) {
-      const int i = lane >> 2, q = lane & 3;
-      double a[4], x[4];
-      const double2 v0 = *reinterpret_cast<const double2*>(D + i * GLD + 4 * q);
-      const double2 v1 = *reinterpret_cast<const double2*>(D + i * GLD + 4 * q + 2);
-      a[0] = v0.x; a[1] = v0.y; a[2] = v1.x; a[3] = v1.y;
-      ok = potrf_inv16(a, x, lane) && ok;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        D[i * GLD + 4 * q + c] = (4 * q + c <= i) ? a[c] : 0.0;
-        Di[i * GLD + 4 * q + c] = x[c];
-      }
+      d4 acc = load_d16(D, GLD, lane), xacc;
+      ok = potrf_inv16(acc, xacc, lane) && ok;
+      store_d16(Di, GLD, xacc, lane);  // the diagonal block of L itself is not needed again
     }
     __syncthreads();
     const int nt = 3 - cb;  // 16-row blocks below the diagonal block
