@@ -52,34 +52,36 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // finished together with the factor:  X -= u x_J^T.
 // In: acc = the block (both triangles). Out: xacc = L^-1 (lower). Returns false on a bad pivot.
 template <int J>
-__device__ __forceinline__ void potrf_inv16_step(d4& acc, d4& xacc, int lane, bool& ok) {
+__device__ __forceinline__ void potrf_inv16_step(d4& acc, d4& xacc, d4& xfin, int lane, bool& ok) {
   constexpr int T4 = J & 3, RR = J >> 2;
-  double piv = readlane_d(acc[RR], 16 * T4 + J);
-  if (!(piv > 0.0) || !isfinite(piv)) { ok = false; piv = 1.0; }
+  const double piv = readlane_d(acc[RR], 16 * T4 + J);
+  ok = ok && (piv > 0.0);  // recorded, not repaired: a bad pivot just propagates NaNs and the solve is rejected
   const double rs = rsqrt_nr(piv);
   const bool in_row = (lane >> 4) == T4;
   const bool live = in_row && (lane & 15) >= J;
   const double u = live ? acc[RR] * rs : 0.0;      // row J of L^T (zero left of the diagonal)
-  const double xj = in_row ? xacc[RR] * rs : 0.0;  // row J of the inverse, scaled
+  const double xj = in_row ? xacc[RR] * rs : 0.0;  // row J of the inverse, scaled = final
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, u, acc, 0, 0, 0);
   xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, xj, xacc, 0, 0, 0);
-  // the instruction also hit row J itself; put the finished rows back
-  acc[RR] = live ? u : acc[RR];
-  xacc[RR] = in_row ? xj : xacc[RR];
+  // Row J of acc / xacc is garbage now, but never read again: later steps only touch rows > J.
+  // The finished inverse row is collected on the side (off the matrix-core dependency chain).
+  xfin[RR] = in_row ? xj : xfin[RR];
 }
 __device__ __forceinline__ bool potrf_inv16(d4& acc, d4& xacc, int lane) {
   bool ok = true;
   const int li = lane & 15, lk = lane >> 4;
+  d4 xfin = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) xacc[r] = (lk + 4 * r == li) ? 1.0 : 0.0;
-  potrf_inv16_step<0>(acc, xacc, lane, ok);  potrf_inv16_step<1>(acc, xacc, lane, ok);
-  potrf_inv16_step<2>(acc, xacc, lane, ok);  potrf_inv16_step<3>(acc, xacc, lane, ok);
-  potrf_inv16_step<4>(acc, xacc, lane, ok);  potrf_inv16_step<5>(acc, xacc, lane, ok);
-  potrf_inv16_step<6>(acc, xacc, lane, ok);  potrf_inv16_step<7>(acc, xacc, lane, ok);
-  potrf_inv16_step<8>(acc, xacc, lane, ok);  potrf_inv16_step<9>(acc, xacc, lane, ok);
-  potrf_inv16_step<10>(acc, xacc, lane, ok); potrf_inv16_step<11>(acc, xacc, lane, ok);
-  potrf_inv16_step<12>(acc, xacc, lane, ok); potrf_inv16_step<13>(acc, xacc, lane, ok);
-  potrf_inv16_step<14>(acc, xacc, lane, ok); potrf_inv16_step<15>(acc, xacc, lane, ok);
+  potrf_inv16_step<0>(acc, xacc, xfin, lane, ok);  potrf_inv16_step<1>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_step<2>(acc, xacc, xfin, lane, ok);  potrf_inv16_step<3>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_step<4>(acc, xacc, xfin, lane, ok);  potrf_inv16_step<5>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_step<6>(acc, xacc, xfin, lane, ok);  potrf_inv16_step<7>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_step<8>(acc, xacc, xfin, lane, ok);  potrf_inv16_step<9>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_step<10>(acc, xacc, xfin, lane, ok); potrf_inv16_step<11>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_step<12>(acc, xacc, xfin, lane, ok); potrf_inv16_step<13>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_step<14>(acc, xacc, xfin, lane, ok); potrf_inv16_step<15>(acc, xacc, xfin, lane, ok);
+  xacc = xfin;
   return ok;
 }
 
