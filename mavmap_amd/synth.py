@@ -131,13 +131,9 @@ def make_scene(num_images, num_points, track_len, models, seed, rot_priors=False
     if np.any(hi <= lo):
         lo, hi = centres[:, :2].min(0) - 5.0, centres[:, :2].max(0) + 5.0
     tree = cKDTree(centres[:, :2])
-    pts, obs_img, obs_pt = [], [], []
-    n_long = int(round(long_track_frac * num_points))
+    pts, obs_img_l, obs_pt_l = [], [], []
     track_len = min(track_len, NI)
     long_track_len = min(long_track_len, NI)
-    want_len = np.full(num_points, track_len)
-    if n_long:
-        want_len[rng.choice(num_points, n_long, replace=False)] = long_track_len
     done = 0
     stalled = 0
     kq = min(NI, max(4 * max(track_len, long_track_len), 48))
@@ -150,12 +146,20 @@ def make_scene(num_images, num_points, track_len, models, seed, rot_priors=False
         xy = rng.uniform(lo, hi, (m, 2))
         z = 2.0 * np.sin(xy[:, 0] / 17.0) * np.cos(xy[:, 1] / 23.0) + rng.normal(0, 0.5, m)
         X = np.column_stack([xy, z])
+        is_long = rng.random(m) < long_track_frac if long_track_frac > 0 else np.zeros(m, bool)
         _, nn = tree.query(xy, k=kq)
         nn = nn.reshape(m, -1)
         vis = np.zeros(nn.shape, bool)
+        cnt = np.zeros(m, np.int64)
+        need = np.where(is_long, max(long_track_len, track_len), track_len)
+        rows = np.arange(m)
         for j in range(nn.shape[1]):
-            ci = nn[:, j]
-            Xc = np.einsum("nij,nj->ni", R_wc[ci], X) + t_wc[ci]
+            # columns are sorted by distance: rows that already see enough cameras drop out
+            rows = rows[cnt[rows] < need[rows]]
+            if len(rows) == 0:
+                break
+            ci = nn[rows, j]
+            Xc = np.einsum("nij,nj->ni", R_wc[ci], X[rows]) + t_wc[ci]
             ok = Xc[:, 2] > 1.0
             for c in range(NC):
                 sel = ok & (image_camera[ci] == c)
@@ -163,27 +167,34 @@ def make_scene(num_images, num_points, track_len, models, seed, rot_priors=False
                     continue
                 uv = project(camera_model[c], intr_true[c], Xc[sel])
                 inside = (uv[:, 0] > 2) & (uv[:, 0] < IMAGE_W - 2) & (uv[:, 1] > 2) & (uv[:, 1] < IMAGE_H - 2)
-                idx = np.nonzero(sel)[0]
-                vis[idx[inside], j] = True
-        for r in range(m):
-            if done == num_points:
-                break
-            L = want_len[done]
-            cand = nn[r, vis[r]]
-            if len(cand) < L:
-                continue
-            if L > track_len:
-                # long "loop-closure" track: spread over the visible set instead of the nearest
-                cand = cand[np.linspace(0, len(cand) - 1, L).astype(int)]
-            chosen = np.sort(cand[:L])
-            pts.append(X[r])
-            obs_img.extend(chosen.tolist())
-            obs_pt.extend([done] * L)
-            done += 1
+                hit = rows[np.nonzero(sel)[0][inside]]
+                vis[hit, j] = True
+                cnt[hit] += 1
+        accept = np.nonzero(cnt >= track_len)[0][: num_points - done]
+        if len(accept):
+            # columns of `nn` are sorted by distance: a stable sort on "not visible" lists the visible
+            # cameras of every row first, nearest first
+            first_vis = np.argsort(~vis[accept], axis=1, kind="stable")
+            normal = ~is_long[accept]
+            rows_n = accept[normal]
+            cams_n = np.sort(np.take_along_axis(nn[rows_n], first_vis[normal][:, :track_len], axis=1), axis=1)
+            ids = done + np.arange(len(accept))
+            obs_img_l.append(cams_n.ravel())
+            obs_pt_l.append(np.repeat(ids[normal], track_len))
+            # long "loop-closure" tracks: as many views as exist (up to long_track_len), spread over
+            # the visible set instead of the nearest cameras
+            for r, pid in zip(accept[~normal], ids[~normal]):
+                cand = nn[r, vis[r]]
+                L = min(long_track_len, len(cand))
+                chosen = np.sort(cand[np.linspace(0, len(cand) - 1, L).astype(int)]) if L > track_len else np.sort(cand[:track_len])
+                obs_img_l.append(chosen)
+                obs_pt_l.append(np.full(len(chosen), pid))
+            pts.append(X[accept])
+            done += len(accept)
         stalled = stalled + 1 if done == before else 0
-    X_true = np.array(pts)
-    obs_img = np.array(obs_img, np.int32)
-    obs_pt = np.array(obs_pt, np.int32)
+    X_true = np.concatenate(pts)
+    obs_img = np.concatenate(obs_img_l).astype(np.int32)
+    obs_pt = np.concatenate(obs_pt_l).astype(np.int32)
 
     # move the world frame into image 0's frame -> pose 0 == (0, 0) exactly
     R0, t0 = R_wc[0].copy(), t_wc[0].copy()
