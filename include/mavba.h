@@ -263,6 +263,21 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses,
  * HIP events on the session's stream; *ms_avg = average per launch. */
 int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg);
 
+/* Structure of the session's linear algebra (for roofline accounting in bench.py). */
+typedef struct mavba_session_info {
+  int64_t num_obs_kept;        /* observations in the reduced program                         */
+  int32_t reduced_dim;         /* n = 6*num_images + 9*num_cameras (incl. constant columns)   */
+  int32_t padded_dim;          /* n rounded up to the 64-column tile                           */
+  int64_t schur_terms[3];      /* entry-pair terms of the pose-pose / intr-pose / intr-intr blocks */
+  int64_t schur_blocks;        /* blocks of the reduced camera system that are assembled      */
+  int64_t intr_entries;        /* (point, camera) intrinsics entries                          */
+  int64_t envelope_tiles;      /* 64x64 tiles inside the factorisation's envelope (lower)      */
+  int64_t dense_tiles;         /* nb*(nb+1)/2                                                   */
+  double factor_flops;         /* FP64 flops of one factorisation + solves on the envelope     */
+  double dense_factor_flops;   /* n^3/3 + 2 n^2, the dense-equivalent count of SURVEY.md 8(d)  */
+} mavba_session_info;
+int mavba_session_get_info(mavba_session* s, mavba_session_info* out);
+
 /* Per-kernel event timings accumulated while options.profile_kernels != 0.
  * Returns the number of kernels; fills up to `cap` entries. */
 typedef struct mavba_kernel_stat {

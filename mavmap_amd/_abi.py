@@ -75,6 +75,13 @@ class CResult(C.Structure):
         return d
 
 
+class CSessionInfo(C.Structure):
+    _fields_ = [("num_obs_kept", C.c_int64), ("reduced_dim", C.c_int32), ("padded_dim", C.c_int32),
+                ("schur_terms", C.c_int64 * 3), ("schur_blocks", C.c_int64), ("intr_entries", C.c_int64),
+                ("envelope_tiles", C.c_int64), ("dense_tiles", C.c_int64), ("factor_flops", C.c_double),
+                ("dense_factor_flops", C.c_double)]
+
+
 class CKernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
 

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "mavba_session_result", "mavba_session_get_params", "mavba_session_point_errors",
     "mavba_session_set_allreduce", "mavba_session_eval_jacobian", "mavba_session_reduced_dim",
     "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian",
-    "mavba_session_kernel_stats", "mavba_dense_spd_solve",
+    "mavba_session_kernel_stats", "mavba_session_get_info", "mavba_dense_spd_solve",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -79,6 +79,7 @@ def load():
     L.mavba_session_linear_step.argtypes = [sp, C.c_double, dp, dp, dp, dp]
     L.mavba_session_time_jacobian.argtypes = [sp, C.c_int32, C.POINTER(C.c_float)]
     L.mavba_session_kernel_stats.argtypes = [sp, C.POINTER(A.CKernelStat), C.c_int32]
+    L.mavba_session_get_info.argtypes = [sp, C.POINTER(A.CSessionInfo)]
     L.mavba_dense_spd_solve.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
     for f in EXPORTED_SYMBOLS:
         if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy"):
@@ -289,6 +290,13 @@ class Session:
         ms = C.c_float()
         _check(load().mavba_session_time_jacobian(self._h, int(reps), C.byref(ms)))
         return float(ms.value)
+
+    def info(self):
+        i = A.CSessionInfo()
+        _check(load().mavba_session_get_info(self._h, C.byref(i)))
+        d = {k: getattr(i, k) for k, _ in i._fields_ if k != "schur_terms"}
+        d["schur_terms"] = list(i.schur_terms)
+        return d
 
     def kernel_stats(self):
         buf = (A.CKernelStat * 64)()

@@ -239,11 +239,12 @@ __global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M
 // Panel k: row block k+1+blockIdx.x (the last one is the right-hand-side block) of panel k
 //   A_ik <- A_ik L_kk^-T = A_ik (L_kk^-1)^T
 __global__ void __launch_bounds__(256) k_chol_trsm(const double* __restrict__ M, double* __restrict__ Lout, int ld, int k,
-                                                   const double* __restrict__ inv) {
+                                                   const double* __restrict__ inv, const int* __restrict__ act,
+                                                   int na, int aug) {
   __shared__ __attribute__((aligned(16))) double As[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * GLD];
   const int tid = threadIdx.x;
-  const int i = k + 1 + blockIdx.x;
+  const int i = (int)blockIdx.x < na ? act[blockIdx.x] : aug;  // active row block, or the right-hand side
   const double* Ain = M + (size_t)i * NB * ld + (size_t)k * NB;
   double* A = Lout + (size_t)i * NB * ld + (size_t)k * NB;
   load_tile(Ain, ld, As, tid);
@@ -285,8 +286,10 @@ __device__ __forceinline__ void quadrant_to_lds(double* S, int wr, int wc, int l
 template <bool FUSED>
 __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, double* __restrict__ Lout, int ld, int k,
                                                      double* __restrict__ diag, double* __restrict__ inv,
-                                                     double* __restrict__ fail) {
-  const int j = k + 1 + blockIdx.x, i = k + 1 + blockIdx.y;
+                                                     double* __restrict__ fail, const int* __restrict__ act,
+                                                     int na, int aug) {
+  // only the row blocks whose envelope reaches panel k take part (act[0] is always k + 1)
+  const int j = act[blockIdx.x], i = (int)blockIdx.y < na ? act[blockIdx.y] : aug;
   if (j > i) return;
   __shared__ __attribute__((aligned(16))) double As[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * GLD];
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
 
 // Backward substitution, tile k: y_k = L_kk^-T z_k; then z_j -= L_kj^T y_k for j < k.
 // grid = k + 1: block k stores y_k, block j < k updates z_j (disjoint segments).
-__global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict__ M, int ld, int k,
+__global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict__ M, int ld, int k, int first,
                                                        const double* __restrict__ inv,
                                                        double* __restrict__ z, double* __restrict__ y) {
   __shared__ double zk[NB];
@@ -373,10 +376,10 @@ __global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict_
     acc1 += Li[(m + 1) * NB + lane] * zk[m + 1];
   }
   const double mine = acc0 + acc1;  // (L^-T z)_lane = sum_m Linv[m][lane] z_m
-  if ((int)blockIdx.x == k) { y[k * NB + lane] = mine; return; }
+  const int j = first + blockIdx.x;  // L_kj is structurally zero left of `first`
+  if (j == k) { y[k * NB + lane] = mine; return; }
   yk[lane] = mine;
   __syncthreads();
-  const int j = blockIdx.x;
   const double* L = M + (size_t)k * NB * ld + (size_t)j * NB;
   double a0 = 0.0, a1 = 0.0;
 #pragma unroll 8
@@ -387,32 +390,62 @@ __global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict_
   z[j * NB + lane] -= a0 + a1;
 }
 
+void CholStructure::build_dense(int nb_) {
+  std::vector<int> f(nb_, 0);
+  build(nb_, f, 0);
+}
+void CholStructure::build(int nb_, const std::vector<int>& first_tile, hipStream_t st) {
+  nb = nb_;
+  first = first_tile;
+  off.assign(nb + 1, 0);
+  std::vector<int> rows;
+  for (int k = 0; k < nb; ++k) {
+    off[k] = (int)rows.size();
+    // active at panel k: row blocks i > k whose envelope starts at or before k. Row k + 1 leads the
+    // list unconditionally (its diagonal tile is factorised by the owner of tile (k+1, k+1)).
+    if (k + 1 < nb) rows.push_back(k + 1);
+    for (int i = k + 2; i < nb; ++i) if (first[i] <= k) rows.push_back(i);
+  }
+  off[nb] = (int)rows.size();
+  if (d_rows) (void)hipFree(d_rows);
+  d_rows = nullptr;
+  if (!rows.empty()) {
+    (void)hipMalloc(&d_rows, rows.size() * sizeof(int));
+    (void)hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st);
+    (void)hipStreamSynchronize(st);
+  }
+}
+CholStructure::~CholStructure() { if (d_rows) (void)hipFree(d_rows); }
+
 // diag_ws: 2 * n_pad * 64 doubles (factor tiles, then their inverses); L: second
 // (n_pad + 64) x n_pad matrix receiving the factor's off-diagonal tiles and the
-// forward-substituted right-hand side.
+// forward-substituted right-hand side. `cs` = tile envelope of the matrix: tiles left of
+// first[i] in tile row i are structurally zero (and stay zero in the factor), so panel k only
+// involves the row blocks listed for it.
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
-                            double* diag_ws, double* L) {
+                            double* diag_ws, double* L, const CholStructure& cs) {
   const int nb = n_pad / NB, ld = n_pad;
   double* diag = diag_ws;
   double* inv = diag_ws + (size_t)n_pad * NB;
   hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, diag, inv, fail);
   for (int k = 0; k < nb; ++k) {
-    const int below = nb - 1 - k;  // real row blocks below tile k
-    if (below > kFuseBelow) {
+    const int na = cs.off[k + 1] - cs.off[k];  // active row blocks below tile k
+    const int* act = cs.d_rows + cs.off[k];
+    if (na > kFuseBelow) {
       // large trailing matrix: one panel solve, then a lean update (2 work-groups per CU)
-      hipLaunchKernelGGL(k_chol_trsm, dim3(below + 1), dim3(256), 0, st, M, L, ld, k, inv);
-      hipLaunchKernelGGL((k_chol_update<false>), dim3(below, below + 1), dim3(256), 0, st, M, L, ld, k, diag, inv, fail);
-    } else if (below > 0) {
+      hipLaunchKernelGGL(k_chol_trsm, dim3(na + 1), dim3(256), 0, st, M, L, ld, k, inv, act, na, nb);
+      hipLaunchKernelGGL((k_chol_update<false>), dim3(na, na + 1), dim3(256), 0, st, M, L, ld, k, diag, inv, fail, act, na, nb);
+    } else if (na > 0) {
       // small trailing matrix: latency matters, fold the panel solve into the update launch
-      hipLaunchKernelGGL((k_chol_update<true>), dim3(below, below + 1), dim3(256), 0, st, M, L, ld, k, diag, inv, fail);
+      hipLaunchKernelGGL((k_chol_update<true>), dim3(na, na + 1), dim3(256), 0, st, M, L, ld, k, diag, inv, fail, act, na, nb);
     } else {
       // last tile: only the right-hand-side block is left
-      hipLaunchKernelGGL(k_chol_trsm, dim3(1), dim3(256), 0, st, M, L, ld, k, inv);
+      hipLaunchKernelGGL(k_chol_trsm, dim3(1), dim3(256), 0, st, M, L, ld, k, inv, act, 0, nb);
     }
   }
   double* z = L + (size_t)n_pad * ld;
   for (int k = nb - 1; k >= 0; --k)
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(k + 1), dim3(64), 0, st, L, ld, k, inv, z, y);
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(k - cs.first[k] + 1), dim3(64), 0, st, L, ld, k, cs.first[k], inv, z, y);
 }
 
 }  // namespace mavba

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace mavba {
 
 // Record strides (doubles) of the Schur "entry" arrays.
@@ -152,8 +154,22 @@ void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const doub
 // (device double) is incremented if a pivot is not positive.
 // diag_ws: workspace of 2 * n_pad * 64 doubles (the factor's diagonal tiles and their inverses).
 // L: scratch matrix of the same shape as M (receives the factor).
+// CholStructure: tile envelope (skyline) of the matrix, 64x64 tiles: first[i] = first structurally
+// non-zero tile of tile row i. The factorisation only visits tiles inside the envelope.
+struct CholStructure {
+  int nb = 0;
+  std::vector<int> first;  // [nb]
+  std::vector<int> off;    // [nb + 1] into d_rows: active row blocks of every panel
+  int* d_rows = nullptr;
+  CholStructure() {}
+  CholStructure(const CholStructure&) = delete;
+  CholStructure& operator=(const CholStructure&) = delete;
+  ~CholStructure();
+  void build(int nb, const std::vector<int>& first_tile, hipStream_t st);
+  void build_dense(int nb);
+};
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
-                            double* diag_ws, double* L);
+                            double* diag_ws, double* L, const CholStructure& cs);
 
 }  // namespace mavba
 #endif

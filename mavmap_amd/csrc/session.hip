@@ -120,6 +120,7 @@ struct mavba_session {
   DevBuf<double> d_rnorm, d_perr;
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
+  CholStructure chol_struct;
 
   // ---- LM state (Ceres TrustRegionMinimizer / LevenbergMarquardtStrategy) ----
   bool evaluated = false, scales_ready = false, started = false, assembled = false;
@@ -538,6 +539,20 @@ void mavba_session::finish_structure() {
   enumerate([&](int kind, int r, int c, int x, int y) {
     terms[kind][(size_t)cursor[kind][(size_t)r * ncols[kind] + c]++] = make_int2(x, y);
   });
+  {
+    // Tile envelope of the reduced camera system for the factorisation: first structurally
+    // non-zero 64-column tile of every 64-row tile (rows >= cols; padding rows are diagonal).
+    const int nbt = n_pad / 64;
+    std::vector<int> first_tile(nbt);
+    for (int t = 0; t < nbt; ++t) first_tile[t] = t;
+    for (const SchurBlock& B : blocks) {
+      const int r0 = B.kind == BLK_PP ? 6 * B.row_ent : 6 * NI + 9 * B.row_ent;
+      const int r1 = r0 + (B.kind == BLK_PP ? 5 : 8);
+      const int c0 = B.kind == BLK_II ? 6 * NI + 9 * B.col_ent : 6 * B.col_ent;
+      for (int tr = r0 / 64; tr <= r1 / 64; ++tr) first_tile[tr] = std::min(first_tile[tr], c0 / 64);
+    }
+    chol_struct.build(nbt, first_tile, st);
+  }
   num_blocks = (int)blocks.size();
   d_blocks.upload(blocks, st);
   for (int k = 0; k < 3; ++k) {
@@ -649,7 +664,7 @@ void mavba_session::assemble(double r) {
 
 void mavba_session::solve_linear(double r) {
   assemble(r);
-  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_pad, d_y.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p); });
+  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_pad, d_y.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct); });
   assembled = false;  // the factorisation overwrote S
 }
 
@@ -1014,6 +1029,34 @@ int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   MAVBA_CATCH
 }
 
+int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
+  MAVBA_TRY
+  if (!s || !out) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
+  std::memset(out, 0, sizeof(*out));
+  out->num_obs_kept = s->N;
+  out->reduced_dim = s->n_full; out->padded_dim = s->n_pad;
+  for (int k = 0; k < 3; ++k) out->schur_terms[k] = s->num_terms[k];
+  out->schur_blocks = s->num_blocks; out->intr_entries = s->Q;
+  const CholStructure& cs = s->chol_struct;
+  const long long nb = cs.nb;
+  out->dense_tiles = nb * (nb + 1) / 2;
+  long long tiles = 0;
+  double fl = 0.0;
+  const double t3 = 64.0 * 64.0 * 64.0;
+  for (int k = 0; k < cs.nb; ++k) {
+    tiles += k - cs.first[k] + 1;
+    const double na = cs.off[k + 1] - cs.off[k];
+    // tile factor + inverse (~2/3 t3), panel solves (na + rhs) * 2 t3, trailing update incl. rhs row
+    fl += (2.0 / 3.0) * t3 + (na + 1.0) * 2.0 * t3 + (na * (na + 1.0) / 2.0 + na) * 2.0 * t3;
+  }
+  out->envelope_tiles = tiles;
+  out->factor_flops = fl;
+  const double n = (double)s->n_full;
+  out->dense_factor_flops = n * n * n / 3.0 + 2.0 * n * n;
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
 int mavba_session_kernel_stats(mavba_session* s, mavba_kernel_stat* out, int32_t cap) {
   if (!s) return 0;
   const int n = (int)s->timers.size();
@@ -1093,7 +1136,9 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
   {
     DevBuf<double> dM, dL, dy, dws, dfail;
     dM.upload(M, st); dL.alloc(M.size()); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
-    dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p, dL.p);
+    CholStructure cs;
+    cs.build_dense(n_pad / 64);
+    dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p, dL.p, cs);
     std::vector<double> y(n_pad);
     double fail = 0.0;
     HIP_OK(hipMemcpyAsync(y.data(), dy.p, (size_t)n_pad * 8, hipMemcpyDeviceToHost, st));

@@ -39,7 +39,7 @@ def test_struct_layouts_match_the_header():
 #include <stddef.h>
 #include "mavba.h"
 int main(void) {
-  printf("%zu %zu %zu %zu\n", sizeof(mavba_problem), sizeof(mavba_options), sizeof(mavba_result), sizeof(mavba_kernel_stat));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(mavba_problem), sizeof(mavba_options), sizeof(mavba_result), sizeof(mavba_kernel_stat), sizeof(mavba_session_info));
   printf("%zu %zu %zu %zu\n", offsetof(mavba_problem, obs_uv), offsetof(mavba_problem, rot_prior_weight),
          offsetof(mavba_options, parameter_tolerance), offsetof(mavba_result, termination));
   return 0;
@@ -49,11 +49,11 @@ int main(void) {
         exe = os.path.join(td, "t")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(td, "t.c"), "-o", exe])
         out = subprocess.check_output([exe]).decode().split()
-    sizes = [C.sizeof(A.CProblem), C.sizeof(A.COptions), C.sizeof(A.CResult), C.sizeof(A.CKernelStat)]
+    sizes = [C.sizeof(A.CProblem), C.sizeof(A.COptions), C.sizeof(A.CResult), C.sizeof(A.CKernelStat), C.sizeof(A.CSessionInfo)]
     offs = [A.CProblem.obs_uv.offset, A.CProblem.rot_prior_weight.offset, A.COptions.parameter_tolerance.offset,
             A.CResult.termination.offset]
-    assert [int(x) for x in out[:4]] == sizes
-    assert [int(x) for x in out[4:]] == offs
+    assert [int(x) for x in out[:5]] == sizes
+    assert [int(x) for x in out[5:]] == offs
 
 
 def test_options_defaults_are_the_reference_and_ceres_defaults(mavba):
