@@ -17,8 +17,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mavba.h"
@@ -68,6 +70,17 @@ static inline double now_s() {
 }
 
 struct KernelTimer { std::string name; long long launches = 0; double total_ms = 0.0; };
+
+// Run body(begin, end) over [0, n) on a few host threads (set-up work only).
+template <typename F>
+static void parallel_ranges(long long n, F&& body) {
+  int T = (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+  if (n < 200000) T = 1;
+  if (T == 1) { body(0ll, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back([&, t] { body(n * t / T, n * (t + 1) / T); });
+  for (auto& x : th) x.join();
+}
 
 }  // namespace mavba
 
@@ -243,6 +256,9 @@ void mavba_session::derive_free_flags() {
 
 void mavba_session::build(const mavba_problem* P) {
   const double t0 = now_s();
+  const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
+  double tl = t0;
+  auto lap = [&](const char* what) { if (tt) { const double t = now_s(); std::fprintf(stderr, "[setup] %-28s %8.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
   NI = P->num_images; NC = P->num_cameras; NP = P->num_points; NO_all = P->num_obs;
   if (NI < 0 || NC < 0 || NP < 0 || NO_all < 0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "negative size");
   if (NO_all >= (1ll << 31) - 64) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 observations per session");
@@ -299,6 +315,7 @@ void mavba_session::build(const mavba_problem* P) {
     kept.push_back(o);
     h_img_used[i] = 1; h_cam_used[c] = 1; h_pt_used[p] = 1;
   }
+  lap("validate + fixed blocks");
   N = (int)kept.size();
   Nstride = std::max(32, round_up(N, 32));
   NPs = std::max(32, round_up(NP, 32));
@@ -335,12 +352,15 @@ void mavba_session::build(const mavba_problem* P) {
   std::vector<double2> uv(N);
   std::vector<int> opt_(N);
   h_oimg.assign(N, 0);
-  for (int a = 0; a < N; ++a) {
-    const long long o = perm[a];
-    uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
-    h_oimg[a] = P->obs_image[o]; opt_[a] = P->obs_point[o];
-  }
+  parallel_ranges(N, [&](long long b0, long long b1) {
+    for (long long a = b0; a < b1; ++a) {
+      const long long o = perm[a];
+      uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
+      h_oimg[a] = P->obs_image[o]; opt_[a] = P->obs_point[o];
+    }
+  });
 
+  lap("point-major sort");
   // ---- image-major view for the camera sweep ----
   std::vector<int> img_start(NI + 1, 0);
   for (int a = 0; a < N; ++a) img_start[h_oimg[a] + 1]++;
@@ -380,6 +400,7 @@ void mavba_session::build(const mavba_problem* P) {
   n_full = 6 * NI + 9 * NC;
   n_pad = std::max(64, round_up(n_full, 64));
 
+  lap("image-major view");
   // ---- uploads of the static data ----
   d_uv.upload(uv, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload(opt_, st); d_pt_start.upload(h_pt_start, st);
   d_im_uv.upload(im_uv, st); d_im_pt.upload(im_pt, st);
@@ -413,10 +434,13 @@ void mavba_session::build(const mavba_problem* P) {
   d_scal.alloc(SC_COUNT); d_scal.zero(st);
   d_rnorm.alloc(std::max(N, 1)); d_perr.alloc(nP);
 
+  lap("alloc + upload");
   derive_free_flags();
   finish_structure();
+  lap("finish_structure total");
   reset_state();
   sync();
+  lap("reset + sync");
   setup_seconds = now_s() - t0;
 }
 
@@ -424,6 +448,9 @@ void mavba_session::build(const mavba_problem* P) {
 // intrinsics entries (one per free point x free camera seen by it) and the term / chunk /
 // block lists of the Schur complement.
 void mavba_session::finish_structure() {
+  const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
+  double tl = now_s();
+  auto lap = [&](const char* what) { if (tt) { const double t = now_s(); std::fprintf(stderr, "[setup]   %-26s %8.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
   d_pose_free.upload(h_pose_free, st); d_intr_free.upload(h_intr_free, st); d_pt_free.upload(h_pt_free, st);
   std::vector<unsigned char> img_active(NI, 0), cam_active(NC, 0);
   for (int i = 0; i < NI; ++i) for (int e = 0; e < 6; ++e) img_active[i] |= h_pose_free[(size_t)i * 6 + e];
@@ -451,9 +478,10 @@ void mavba_session::finish_structure() {
   d_Eintr.alloc((size_t)std::max(Q, 1) * kIntrRec);
   d_Wk.alloc((size_t)std::max(Q, 1) * 27);
 
-  // term enumeration: f(kind, row_ent, col_ent, x, y)
-  auto enumerate = [&](auto&& f) {
-    for (int p = 0; p < NP; ++p) {
+  lap("flags + intr entries");
+  // term enumeration over a range of points: f(kind, row_ent, col_ent, x, y)
+  auto enumerate = [&](int p_begin, int p_end, auto&& f) {
+    for (int p = p_begin; p < p_end; ++p) {
       if (!h_pt_free[p]) continue;
       const int a0 = h_pt_start[p], a1 = h_pt_start[p + 1], q0 = q_start[p], q1 = q_start[p + 1];
       for (int a = a0; a < a1; ++a) {
@@ -473,17 +501,49 @@ void mavba_session::finish_structure() {
   };
   const long long ncols[3] = {NI, NI, NC};
   const long long nrows[3] = {NI, NC, NC};
+  size_t nkeys[3], nkeys_tot = 0;
+  for (int k = 0; k < 3; ++k) { nkeys[k] = (size_t)(nrows[k] * ncols[k]); nkeys_tot += nkeys[k]; }
+  // Host threads own contiguous point ranges (balanced by observations). Per-thread counts turn
+  // into per-thread cursors, so the term order inside a block (by point) does not depend on the
+  // number of threads: the device sums stay bit-reproducible.
+  int T = (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+  if (N < 50000) T = 1;
+  while (T > 1 && (size_t)T * nkeys_tot > (size_t)48 << 20) T /= 2;
+  std::vector<int> range(T + 1, NP);
+  range[0] = 0;
+  for (int t = 1; t < T; ++t) {
+    const long long target = (long long)N * t / T;
+    range[t] = (int)(std::upper_bound(h_pt_start.begin(), h_pt_start.end(), (int)target) - h_pt_start.begin()) - 1;
+    range[t] = std::max(range[t - 1], std::min(range[t], NP));
+  }
+  std::vector<std::vector<int>> tcount(T * 3);
+  auto run_threads = [&](auto&& body) {
+    if (T == 1) { body(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(body, t);
+    for (auto& x : th) x.join();
+  };
+  run_threads([&](int t) {
+    for (int k = 0; k < 3; ++k) tcount[t * 3 + k].assign(nkeys[k], 0);
+    enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int, int) { tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++; });
+  });
   std::vector<int> count[3];
   std::vector<unsigned char> mandatory[3];
-  for (int k = 0; k < 3; ++k) { count[k].assign((size_t)(nrows[k] * ncols[k]), 0); mandatory[k].assign(count[k].size(), 0); }
+  long long tot[3] = {0, 0, 0};
+  for (int k = 0; k < 3; ++k) {
+    count[k].assign(nkeys[k], 0);
+    mandatory[k].assign(nkeys[k], 0);
+    for (int t = 0; t < T; ++t)
+      for (size_t key = 0; key < nkeys[k]; ++key) count[k][key] += tcount[t * 3 + k][key];
+    for (size_t key = 0; key < nkeys[k]; ++key) tot[k] += count[k][key];
+  }
   for (int i = 0; i < NI; ++i) {
     if (!img_active[i]) continue;
     mandatory[BLK_PP][(size_t)i * NI + i] = 1;
     if (cam_active[h_img_cam[i]]) mandatory[BLK_IP][(size_t)h_img_cam[i] * NI + i] = 1;
   }
   for (int c = 0; c < NC; ++c) if (cam_active[c]) mandatory[BLK_II][(size_t)c * NC + c] = 1;
-  long long tot[3] = {0, 0, 0};
-  enumerate([&](int kind, int r, int c, int, int) { count[kind][(size_t)r * ncols[kind] + c]++; tot[kind]++; });
+  lap("count terms");
   for (int k = 0; k < 3; ++k)
     if (tot[k] >= (1ll << 31) - 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 Schur terms of one kind");
   // One wave per chunk. A block gets ceil(terms / 1024) chunks but never more than 256, so the
@@ -534,11 +594,21 @@ void mavba_session::finish_structure() {
       off += cnt;
     }
   }
-  std::vector<int2> terms[3];
-  for (int k = 0; k < 3; ++k) terms[k].resize((size_t)tot[k]);
-  enumerate([&](int kind, int r, int c, int x, int y) {
-    terms[kind][(size_t)cursor[kind][(size_t)r * ncols[kind] + c]++] = make_int2(x, y);
+  lap("order blocks + chunks");
+  std::unique_ptr<int2[]> terms[3];  // uninitialised on purpose: first touched by the filling threads
+  for (int k = 0; k < 3; ++k) terms[k].reset(new int2[std::max<size_t>((size_t)tot[k], 1)]);
+  // per-thread cursors: block offset + what the threads owning earlier points put into the block
+  for (int k = 0; k < 3; ++k)
+    for (size_t key = 0; key < nkeys[k]; ++key) {
+      int run = cursor[k][key];
+      for (int t = 0; t < T; ++t) { const int c = tcount[t * 3 + k][key]; tcount[t * 3 + k][key] = run; run += c; }
+    }
+  run_threads([&](int t) {
+    enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int x, int y) {
+      terms[kind][(size_t)tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++] = make_int2(x, y);
+    });
   });
+  lap("fill terms");
   {
     // Tile envelope of the reduced camera system for the factorisation: first structurally
     // non-zero 64-column tile of every 64-row tile (rows >= cols; padding rows are diagonal).
@@ -559,10 +629,12 @@ void mavba_session::finish_structure() {
     num_chunks[k] = (int)chunks[k].size();
     num_terms[k] = tot[k];
     d_chunks[k].upload(chunks[k], st);
-    d_terms[k].upload(terms[k], st);
+    d_terms[k].alloc(std::max<size_t>((size_t)tot[k], 1));
+    if (tot[k]) HIP_OK(hipMemcpyAsync(d_terms[k].p, terms[k].get(), (size_t)tot[k] * sizeof(int2), hipMemcpyHostToDevice, st));
     d_part[k].alloc((size_t)std::max(num_chunks[k], 1) * schur_partial_stride(k));
   }
   sync();
+  lap("upload terms");
 }
 
 void mavba_session::reset_state() {
