@@ -101,7 +101,7 @@ def _camera_grid(num_images, spacing):
 
 def make_scene(num_images, num_points, track_len, models, seed, rot_priors=False,
                long_track_frac=0.0, long_track_len=0, noise_px=0.5, outlier_frac=0.01,
-               perturb=True, spacing=11.0, refine_camera_params=True):
+               perturb=True, spacing=11.0, refine_camera_params=True, image_camera=None):
     """Build one global-BA problem. Returns a BAProblem with `truth` filled."""
     from scipy.spatial import cKDTree
 
@@ -110,7 +110,10 @@ def make_scene(num_images, num_points, track_len, models, seed, rot_priors=False
     centres = centres + rng.normal(0, 0.3, centres.shape)
     NI = num_images
     NC = len(models)
-    image_camera = (np.arange(NI) % NC).astype(np.int32)
+    if image_camera is None:
+        image_camera = np.arange(NI) % NC  # round-robin over the cameras
+    image_camera = np.asarray(image_camera, np.int32)
+    assert image_camera.shape == (NI,) and image_camera.min() >= 0 and image_camera.max() < NC
     camera_model = np.array(models, np.int32)
     intr_true = np.stack([{A.MODEL_PINHOLE: PINHOLE_PARAMS, A.MODEL_OPENCV: OPENCV_PARAMS,
                            A.MODEL_CATA: CATA_PARAMS}[m] for m in models]).copy()
