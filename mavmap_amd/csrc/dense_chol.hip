@@ -34,6 +34,16 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 
+// Same value with one third-order (Halley) correction of the hardware seed instead of two Newton
+// steps: y (1 + h (1/2 + 3/8 h)), h = 1 - d y^2. Seed error e -> ~e^3, two dependent operations shorter.
+__device__ __forceinline__ double rsqrt_finish(double y, double h) {
+  return __builtin_fma(y * h, __builtin_fma(0.375, h, 0.5), y);
+}
+__device__ __forceinline__ double rsqrt_halley(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  return rsqrt_finish(y, __builtin_fma(-(d * y), y, 1.0));
+}
+
 __device__ __forceinline__ double readlane_d(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -56,7 +66,7 @@ __device__ __forceinline__ void potrf_inv16_step(d4& acc, d4& xacc, d4& xfin, in
   constexpr int T4 = J & 3, RR = J >> 2;
   const double piv = readlane_d(acc[RR], 16 * T4 + J);
   ok = ok && (piv > 0.0);  // recorded, not repaired: a bad pivot just propagates NaNs and the solve is rejected
-  const double rs = rsqrt_nr(piv);
+  const double rs = rsqrt_halley(piv);
   const bool in_row = (lane >> 4) == T4;
   const bool live = in_row && (lane & 15) >= J;
   const double u = live ? acc[RR] * rs : 0.0;      // row J of L^T (zero left of the diagonal)
@@ -67,6 +77,9 @@ __device__ __forceinline__ void potrf_inv16_step(d4& acc, d4& xacc, d4& xfin, in
   // The finished inverse row is collected on the side (off the matrix-core dependency chain).
   xfin[RR] = in_row ? xj : xfin[RR];
 }
+// (Tried and measured slower on gfx950, scripts/_dbg/tile_bench.hip: running the scalar pivot recurrence
+// piv_{J+1} = a11 - (a10 rs_J)^2 one step ahead of the matrix instructions so that the rsqrt overlaps the
+// MFMA latency - 4600 instead of 4200 cycles per block, with or without a pinned instruction order.)
 __device__ __forceinline__ bool potrf_inv16(d4& acc, d4& xacc, int lane) {
   bool ok = true;
   const int li = lane & 15, lk = lane >> 4;
@@ -178,6 +191,147 @@ __device__ __forceinline__ bool tile_potrf_inv(double* T, double* Ti, double* sc
   return ok;
 }
 
+// Order LDS traffic inside ONE wave: a block written by some lanes is read back by other lanes of
+// the same wave. The hardware executes a wave's LDS instructions in order; this only stops the
+// compiler from moving the loads above the stores.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Look-ahead variant of tile_potrf_inv: same result in Ti (L^-1, lower; upper zero), two LDS tiles,
+// no extra scratch, 6 work-group barriers instead of 18.
+//
+// The critical chain of a blocked tile factorisation is  potrf(D_c) -> L_{c+1,c} -> D_{c+1} -> potrf.
+// Wave 0 walks exactly that chain; everything else (the rest of panel c, the trailing update by
+// panel c, the off-diagonal blocks of the inverse) is done by waves 1..3 WHILE wave 0 is inside the
+// next 16-pivot factorisation, each wave re-deriving the few panel blocks it needs instead of waiting
+// for their owner (a 16^3 product costs ~4 matrix instructions, a barrier costs the whole potrf).
+//
+// LDS use: T lower blocks = the matrix (column c stays raw, blocks right of it are updated in place
+// by their owner wave); T upper blocks = per-wave scratch; Ti diagonal + lower = the inverse;
+// Ti upper block (c, j) = L_jc while the factorisation runs (zeroed at the end).
+__device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid) {
+  const int wv = tid >> 6, lane = tid & 63;
+  const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
+  auto Tb = [&](int i, int j) { return T + (16 * i) * GLD + 16 * j; };
+  auto Xb = [&](int i, int j) { return Ti + (16 * i) * GLD + 16 * j; };
+  auto Lb = [&](int i, int j) { return Ti + (16 * j) * GLD + 16 * i; };  // L_ij (i > j) parked at Ti block (j, i)
+  // P = B * Dinv^T -> dst
+  auto panel = [&](const double* B, const double* Dinv, double* dst) {
+    d4 a = gemm16(B, GLD, Dinv, GLD, true, 1.0, zero, lane);
+    store_d16(dst, GLD, a, lane);
+  };
+  // C -= Pa * Pb^T (in place)
+  auto downdate = [&](double* C, const double* Pa, const double* Pb) {
+    d4 a = load_d16(C, GLD, lane);
+    a = gemm16(Pa, GLD, Pb, GLD, true, -1.0, a, lane);
+    store_d16(C, GLD, a, lane);
+  };
+  // factor D_c = C - P P^T in registers, park its inverse in Ti(c, c)
+  auto chain = [&](double* C, const double* P, int c) -> bool {
+    d4 a = load_d16(C, GLD, lane), x;
+    if (P) a = gemm16(P, GLD, P, GLD, true, -1.0, a, lane);
+    const bool ok = potrf_inv16(a, x, lane);
+    store_d16(Xb(c, c), GLD, x, lane);
+    return ok;
+  };
+  bool ok = true;
+  // ---- phase 0: D_0
+  if (wv == 0) ok = chain(Tb(0, 0), nullptr, 0);
+  __syncthreads();
+  // ---- phase 1: panel 0; wave 0 goes on to D_1
+  if (wv == 0) {
+    panel(Tb(1, 0), Xb(0, 0), Lb(1, 0));
+    wave_lds_sync();
+    ok = chain(Tb(1, 1), Lb(1, 0), 1) && ok;
+  } else if (wv == 1) {
+    panel(Tb(2, 0), Xb(0, 0), Lb(2, 0));
+    panel(Tb(1, 0), Xb(0, 0), Tb(0, 1));
+    wave_lds_sync();
+    downdate(Tb(2, 1), Lb(2, 0), Tb(0, 1));
+    downdate(Tb(2, 2), Lb(2, 0), Lb(2, 0));
+  } else if (wv == 2) {
+    panel(Tb(3, 0), Xb(0, 0), Lb(3, 0));
+    panel(Tb(1, 0), Xb(0, 0), Tb(0, 2));
+    wave_lds_sync();
+    downdate(Tb(3, 1), Lb(3, 0), Tb(0, 2));
+    downdate(Tb(3, 3), Lb(3, 0), Lb(3, 0));
+  } else {
+    panel(Tb(3, 0), Xb(0, 0), Tb(1, 2));
+    panel(Tb(2, 0), Xb(0, 0), Tb(1, 3));
+    wave_lds_sync();
+    downdate(Tb(3, 2), Tb(1, 2), Tb(1, 3));
+  }
+  __syncthreads();
+  // ---- phase 2: panel 1; wave 0 goes on to D_2; wave 3 starts on the inverse
+  if (wv == 0) {
+    panel(Tb(2, 1), Xb(1, 1), Lb(2, 1));
+    wave_lds_sync();
+    ok = chain(Tb(2, 2), Lb(2, 1), 2) && ok;
+  } else if (wv == 1) {
+    panel(Tb(3, 1), Xb(1, 1), Lb(3, 1));
+    panel(Tb(2, 1), Xb(1, 1), Tb(0, 1));
+    wave_lds_sync();
+    downdate(Tb(3, 2), Lb(3, 1), Tb(0, 1));
+  } else if (wv == 2) {
+    panel(Tb(3, 1), Xb(1, 1), Tb(0, 2));
+    wave_lds_sync();
+    downdate(Tb(3, 3), Tb(0, 2), Tb(0, 2));
+  } else {
+    // X_10 = -Dinv_1 (L_10 Dinv_0)
+    d4 m = gemm16(Lb(1, 0), GLD, Xb(0, 0), GLD, false, 1.0, zero, lane);
+    store_d16(Tb(1, 2), GLD, m, lane);
+    wave_lds_sync();
+    m = gemm16(Xb(1, 1), GLD, Tb(1, 2), GLD, false, -1.0, zero, lane);
+    store_d16(Xb(1, 0), GLD, m, lane);
+  }
+  __syncthreads();
+  // ---- phase 3: panel 2; wave 0 goes on to D_3
+  if (wv == 0) {
+    panel(Tb(3, 2), Xb(2, 2), Lb(3, 2));
+    wave_lds_sync();
+    ok = chain(Tb(3, 3), Lb(3, 2), 3) && ok;
+  } else if (wv == 1) {
+    // X_21 = -Dinv_2 (L_21 Dinv_1)
+    d4 m = gemm16(Lb(2, 1), GLD, Xb(1, 1), GLD, false, 1.0, zero, lane);
+    store_d16(Tb(0, 1), GLD, m, lane);
+    wave_lds_sync();
+    m = gemm16(Xb(2, 2), GLD, Tb(0, 1), GLD, false, -1.0, zero, lane);
+    store_d16(Xb(2, 1), GLD, m, lane);
+  } else if (wv == 2) {
+    // X_20 = -Dinv_2 (L_20 X_00 + L_21 X_10)
+    d4 m = gemm16(Lb(2, 0), GLD, Xb(0, 0), GLD, false, 1.0, zero, lane);
+    m = gemm16(Lb(2, 1), GLD, Xb(1, 0), GLD, false, 1.0, m, lane);
+    store_d16(Tb(0, 2), GLD, m, lane);
+    wave_lds_sync();
+    m = gemm16(Xb(2, 2), GLD, Tb(0, 2), GLD, false, -1.0, zero, lane);
+    store_d16(Xb(2, 0), GLD, m, lane);
+  }
+  __syncthreads();
+  // ---- phase 4: last block row of the inverse, X_3j = -Dinv_3 sum_{k=j}^{2} L_3k X_kj
+  if (wv < 3) {
+    const int j = 2 - wv;  // wave 0: X_32, wave 1: X_31, wave 2: X_30
+    double* scr = wv == 0 ? Tb(1, 2) : (wv == 1 ? Tb(0, 1) : Tb(0, 2));
+    d4 m = zero;
+    for (int k = j; k < 3; ++k) m = gemm16(Lb(3, k), GLD, Xb(k, j), GLD, false, 1.0, m, lane);
+    store_d16(scr, GLD, m, lane);
+    wave_lds_sync();
+    m = gemm16(Xb(3, 3), GLD, scr, GLD, false, -1.0, zero, lane);
+    store_d16(Xb(3, j), GLD, m, lane);
+  }
+  __syncthreads();
+  // ---- the parked factor blocks leave the upper triangle of Ti
+  for (int e = tid; e < 6 * 256; e += 256) {
+    const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+    const int bi = b < 3 ? 0 : (b < 5 ? 1 : 2), bj = b < 3 ? b + 1 : (b < 5 ? b - 1 : 3);
+    Ti[(16 * bi + r) * GLD + 16 * bj + c] = 0.0;
+  }
+  __syncthreads();
+  return ok;
+}
+
 // acc (2x2 MFMA tiles of the wave's 32x32 quadrant) = As(rows wr..) * Bs(rows wc..)^T, K = 64.
 __device__ __forceinline__ void mfma_quadrant_nt(const double* As, const double* Bs, int wr, int wc,
                                                  int lane, d4 acc[2][2]) {
@@ -221,18 +375,14 @@ __device__ __forceinline__ void store_tile(double* __restrict__ G, size_t ld, co
 
 // Factor + invert diagonal tile 0 (one work-group).
 __global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M, int ld,
-                                                    double* __restrict__ diag, double* __restrict__ inv,
-                                                    double* __restrict__ fail) {
+                                                    double* __restrict__ inv, double* __restrict__ fail) {
   __shared__ __attribute__((aligned(16))) double T[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Ti[NB * GLD];
-  __shared__ __attribute__((aligned(16))) double rd[4 * 16 * MLD];
   const int tid = threadIdx.x;
   load_tile(M, ld, T, tid);
-  for (int i = tid; i < NB * GLD; i += 256) Ti[i] = 0.0;
   __syncthreads();
-  const bool ok = tile_potrf_inv(T, Ti, rd, tid);
+  const bool ok = tile_potrf_inv_la(T, Ti, tid);
   if (tid == 0 && !ok) atomicAdd(fail, 1.0);
-  store_tile(diag, NB, T, tid);
   store_tile(inv, NB, Ti, tid);
 }
 
@@ -285,7 +435,7 @@ __device__ __forceinline__ void quadrant_to_lds(double* S, int wr, int wc, int l
 // the owner of tile (k+1, k+1) then factorises + inverts it for the next panel.
 template <bool FUSED>
 __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, double* __restrict__ Lout, int ld, int k,
-                                                     double* __restrict__ diag, double* __restrict__ inv,
+                                                     double* __restrict__ inv,
                                                      double* __restrict__ fail, const int* __restrict__ act,
                                                      int na, int aug) {
   // only the row blocks whose envelope reaches panel k take part (act[0] is always k + 1)
@@ -294,10 +444,19 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
   __shared__ __attribute__((aligned(16))) double As[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Cs[NB * GLD];
-  __shared__ __attribute__((aligned(16))) double rd[4 * 16 * MLD];
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63;
   const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+  const int li = lane & 15, lk = lane >> 4;
+  // the tile being updated: its loads are issued first so that their latency hides behind the products
+  double* C = M + (size_t)i * NB * ld + (size_t)j * NB;
+  d4 cin[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cin[m][n][r] = C[(size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li];
   d4 acc[2][2];
   if constexpr (FUSED) {
     load_tile(M + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
@@ -322,8 +481,6 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
   }
   const double* Pj = (i != j) ? Cs : As;
   mfma_quadrant_nt(As, Pj, wr, wc, lane, acc);
-  const int li = lane & 15, lk = lane >> 4;
-  double* C = M + (size_t)i * NB * ld + (size_t)j * NB;
   const bool next_diag = (blockIdx.x == 0 && blockIdx.y == 0);
   if (!next_diag) {
 #pragma unroll
@@ -331,31 +488,23 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
 #pragma unroll
       for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const size_t off = (size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li;
-          C[off] -= acc[m][n][r];
-        }
+        for (int r = 0; r < 4; ++r)
+          C[(size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li] = cin[m][n][r] - acc[m][n][r];
     return;
   }
   // tile (k+1, k+1): keep the updated tile in LDS, factorise + invert it for the next panel
-  __syncthreads();  // everyone is done reading As
+  __syncthreads();  // everyone is done reading As / Cs
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wr + 16 * m + lk + 4 * r, col = wc + 16 * n + li;
-        Cs[row * GLD + col] = C[(size_t)row * ld + col] - acc[m][n][r];
-      }
-  double* Ti = As;  // the plain variant has no third tile: reuse As (its reads ended at the barrier above)
-  if constexpr (FUSED) Ti = Bs;
-  for (int t = tid; t < NB * GLD; t += 256) Ti[t] = 0.0;
+      for (int r = 0; r < 4; ++r)
+        Cs[(wr + 16 * m + lk + 4 * r) * GLD + wc + 16 * n + li] = cin[m][n][r] - acc[m][n][r];
   __syncthreads();
-  const bool ok = tile_potrf_inv(Cs, Ti, rd, tid);
+  const bool ok = tile_potrf_inv_la(Cs, As, tid);
   if (tid == 0 && !ok) atomicAdd(fail, 1.0);
-  store_tile(diag + (size_t)(k + 1) * NB * NB, NB, Cs, tid);
-  store_tile(inv + (size_t)(k + 1) * NB * NB, NB, Ti, tid);
+  store_tile(inv + (size_t)(k + 1) * NB * NB, NB, As, tid);
 }
 
 // Backward substitution, tile k: y_k = L_kk^-T z_k; then z_j -= L_kj^T y_k for j < k.
@@ -417,7 +566,7 @@ void CholStructure::build(int nb_, const std::vector<int>& first_tile, hipStream
 }
 CholStructure::~CholStructure() { if (d_rows) (void)hipFree(d_rows); }
 
-// diag_ws: 2 * n_pad * 64 doubles (factor tiles, then their inverses); L: second
+// diag_ws: n_pad * 64 doubles (the inverses of the factor's diagonal tiles); L: second
 // (n_pad + 64) x n_pad matrix receiving the factor's off-diagonal tiles and the
 // forward-substituted right-hand side. `cs` = tile envelope of the matrix: tiles left of
 // first[i] in tile row i are structurally zero (and stay zero in the factor), so panel k only
@@ -425,19 +574,18 @@ CholStructure::~CholStructure() { if (d_rows) (void)hipFree(d_rows); }
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws, double* L, const CholStructure& cs) {
   const int nb = n_pad / NB, ld = n_pad;
-  double* diag = diag_ws;
-  double* inv = diag_ws + (size_t)n_pad * NB;
-  hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, diag, inv, fail);
+  double* inv = diag_ws;
+  hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, inv, fail);
   for (int k = 0; k < nb; ++k) {
     const int na = cs.off[k + 1] - cs.off[k];  // active row blocks below tile k
     const int* act = cs.d_rows + cs.off[k];
     if (na > kFuseBelow) {
       // large trailing matrix: one panel solve, then a lean update (2 work-groups per CU)
       hipLaunchKernelGGL(k_chol_trsm, dim3(na + 1), dim3(256), 0, st, M, L, ld, k, inv, act, na, nb);
-      hipLaunchKernelGGL((k_chol_update<false>), dim3(na, na + 1), dim3(256), 0, st, M, L, ld, k, diag, inv, fail, act, na, nb);
+      hipLaunchKernelGGL((k_chol_update<false>), dim3(na, na + 1), dim3(256), 0, st, M, L, ld, k, inv, fail, act, na, nb);
     } else if (na > 0) {
       // small trailing matrix: latency matters, fold the panel solve into the update launch
-      hipLaunchKernelGGL((k_chol_update<true>), dim3(na, na + 1), dim3(256), 0, st, M, L, ld, k, diag, inv, fail, act, na, nb);
+      hipLaunchKernelGGL((k_chol_update<true>), dim3(na, na + 1), dim3(256), 0, st, M, L, ld, k, inv, fail, act, na, nb);
     } else {
       // last tile: only the right-hand-side block is left
       hipLaunchKernelGGL(k_chol_trsm, dim3(1), dim3(256), 0, st, M, L, ld, k, inv, act, 0, nb);

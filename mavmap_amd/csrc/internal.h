@@ -152,7 +152,7 @@ void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const doub
 // SPD matrix (lower triangle is read), row n_pad holds the right-hand side.
 // On return y[0..n_pad) = A^-1 b; M is overwritten by the factor. *fail
 // (device double) is incremented if a pivot is not positive.
-// diag_ws: workspace of 2 * n_pad * 64 doubles (the factor's diagonal tiles and their inverses).
+// diag_ws: workspace of n_pad * 64 doubles (the inverses of the factor's diagonal tiles).
 // L: scratch matrix of the same shape as M (receives the factor).
 // CholStructure: tile envelope (skyline) of the matrix, 64x64 tiles: first[i] = first structurally
 // non-zero tile of tile row i. The factorisation only visits tiles inside the envelope.

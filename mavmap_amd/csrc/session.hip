@@ -428,7 +428,7 @@ void mavba_session::build(const mavba_problem* P) {
   d_prior_res.alloc(std::max(num_priors, 1)); d_prior_jac.alloc((size_t)std::max(num_priors, 1) * 3);
   d_prior_cost.alloc(std::max(num_priors, 1));
   d_Epose.alloc((size_t)std::max(N, 1) * kPoseRec);
-  d_M.alloc((size_t)(n_pad + 64) * n_pad); d_L.alloc((size_t)(n_pad + 64) * n_pad); d_y.alloc(n_pad); d_diag_ws.alloc((size_t)2 * n_pad * 64);
+  d_M.alloc((size_t)(n_pad + 64) * n_pad); d_L.alloc((size_t)(n_pad + 64) * n_pad); d_y.alloc(n_pad); d_diag_ws.alloc((size_t)n_pad * 64);
   d_delta_cam.alloc(n_pad); d_delta_pts.alloc(nP * 3);
   d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + 2) * 3);
   d_scal.alloc(SC_COUNT); d_scal.zero(st);

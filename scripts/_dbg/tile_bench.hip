@@ -1,0 +1,77 @@
+// Cycle counts + correctness of the 64x64 tile factor/inverse variants (debug harness, not product).
+// Build: hipcc --offload-arch=gfx950 -O3 -I mavmap_amd/csrc -I include scripts/_dbg/tile_bench.hip -o scripts/_dbg/tile_bench
+#include "../../mavmap_amd/csrc/dense_chol.hip"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+namespace mavba { namespace {
+__global__ void __launch_bounds__(256) k_bench(const double* A, double* Xout, long long* cyc, int variant, int reps) {
+  __shared__ __attribute__((aligned(16))) double T[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double Ti[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double rd[4 * 16 * MLD];
+  const int tid = threadIdx.x;
+  long long total = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    load_tile(A, NB, T, tid);
+    for (int i = tid; i < NB * GLD; i += 256) Ti[i] = 0.0;
+    __syncthreads();
+    const long long t0 = clock64();
+    if (variant == 0) tile_potrf_inv(T, Ti, rd, tid);
+    else if (variant == 1) tile_potrf_inv_la(T, Ti, tid);
+    else if (variant == 2) {  // 4 x potrf_inv16 alone (timing only)
+      if (tid < 64) for (int cb = 0; cb < 4; ++cb) {
+        d4 a = load_d16(T + 16 * cb * GLD + 16 * cb, GLD, tid), x;
+        potrf_inv16(a, x, tid);
+        store_d16(Ti + 16 * cb * GLD + 16 * cb, GLD, x, tid);
+      }
+    }
+    __syncthreads();
+    total += clock64() - t0;
+  }
+  if (tid == 0) cyc[0] = total / reps;
+  store_tile(Xout, NB, Ti, tid);
+}
+__global__ void k_rsq(const double* d, double* out_nr, double* out_h, double* out_seed, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { out_nr[i] = rsqrt_nr(d[i]); out_h[i] = rsqrt_halley(d[i]); out_seed[i] = __builtin_amdgcn_rsq(d[i]); }
+}
+}}
+int main() {
+  using namespace mavba;
+  const int n = 64;
+  std::vector<double> G(n * n), A(n * n, 0.0);
+  unsigned s = 12345;
+  for (auto& g : G) { s = s * 1664525u + 1013904223u; g = ((s >> 8) & 0xffff) / 65536.0 - 0.5; }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double a = 0; for (int k = 0; k < n; ++k) a += G[i * n + k] * G[j * n + k]; A[i * n + j] = a + (i == j ? 4.0 : 0.0); }
+  // host reference: L, then X = L^-1
+  std::vector<double> L(A), X(n * n, 0.0);
+  for (int j = 0; j < n; ++j) { for (int k = 0; k < j; ++k) for (int i = j; i < n; ++i) L[i * n + j] -= L[i * n + k] * L[j * n + k];
+    const double d = std::sqrt(L[j * n + j]); for (int i = j; i < n; ++i) L[i * n + j] /= d; }
+  for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) L[i * n + j] = 0.0;
+  for (int c = 0; c < n; ++c) for (int i = c; i < n; ++i) { double v = (i == c) ? 1.0 : 0.0; for (int k = c; k < i; ++k) v -= L[i * n + k] * X[k * n + c]; X[i * n + c] = v / L[i * n + i]; }
+  double *dA, *dX; long long* dc;
+  hipMalloc(&dA, n * n * 8); hipMalloc(&dX, n * n * 8); hipMalloc(&dc, 8);
+  hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+  for (int v = 0; v < 3; ++v) {
+    hipLaunchKernelGGL(k_bench, dim3(1), dim3(256), 0, 0, dA, dX, dc, v, 20);
+    hipDeviceSynchronize();
+    std::vector<double> Xd(n * n); long long c;
+    hipMemcpy(Xd.data(), dX, n * n * 8, hipMemcpyDeviceToHost); hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+    double err = 0, mx = 0, up = 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { if (v == 2 && (i / 16 != j / 16)) continue; mx = std::fmax(mx, std::fabs(X[i * n + j])); if (j <= i) err = std::fmax(err, std::fabs(Xd[i * n + j] - X[i * n + j])); else up = std::fmax(up, std::fabs(Xd[i * n + j])); }
+    printf("variant %d: %lld cycles/tile, inverse max err %.2e (scale %.2e), upper max %.2e\n", v, c, err, mx, up);
+  }
+  {
+    const int m = 1 << 20; std::vector<double> d(m), o1(m), o2(m), o3(m);
+    for (int i = 0; i < m; ++i) { s = s * 1664525u + 1013904223u; const double f = 1.0 + (s >> 8) / 16777216.0; s = s * 1664525u + 1013904223u; d[i] = std::ldexp(f, (int)((s >> 8) % 600) - 300); }
+    double *dd, *d1, *d2, *d3; hipMalloc(&dd, m * 8); hipMalloc(&d1, m * 8); hipMalloc(&d2, m * 8); hipMalloc(&d3, m * 8);
+    hipMemcpy(dd, d.data(), m * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_rsq, dim3(m / 256), dim3(256), 0, 0, dd, d1, d2, d3, m); hipDeviceSynchronize();
+    hipMemcpy(o1.data(), d1, m * 8, hipMemcpyDeviceToHost); hipMemcpy(o2.data(), d2, m * 8, hipMemcpyDeviceToHost); hipMemcpy(o3.data(), d3, m * 8, hipMemcpyDeviceToHost);
+    long double e1 = 0, e2 = 0, e3 = 0;
+    for (int i = 0; i < m; ++i) { const long double r = 1.0L / sqrtl((long double)d[i]);
+      e1 = fmaxl(e1, fabsl(o1[i] - r) / r); e2 = fmaxl(e2, fabsl(o2[i] - r) / r); e3 = fmaxl(e3, fabsl(o3[i] - r) / r); }
+    printf("rsqrt max rel err: 2xNewton %.3Le  Halley %.3Le  seed %.3Le (eps %.3e)\n", e1, e2, e3, 2.22e-16);
+  }
+  return 0;
+}
