@@ -134,7 +134,8 @@ __device__ __forceinline__ void store_d16(double* C, int ldc, d4 v, int lane) {
 // All 256 threads must call it (uniform barriers). scr: 4 * 16 * 18 doubles of LDS.
 // Returns false (in thread 0) if a pivot is not positive.
 constexpr int MLD = 18;
-constexpr int kFuseBelow = 12;  // fuse the panel solve into the update when <= this many row blocks remain
+constexpr int kFuseBelow = 12;
+constexpr int kMaxBacksolveGroups = 2048;  // single-launch backward substitution up to this many tile rows  // fuse the panel solve into the update when <= this many row blocks remain
 __device__ __forceinline__ bool tile_potrf_inv(double* T, double* Ti, double* scr, int tid) {
   const int wv = tid >> 6, lane = tid & 63;
   bool ok = true;
@@ -375,10 +376,12 @@ __device__ __forceinline__ void store_tile(double* __restrict__ G, size_t ld, co
 
 // Factor + invert diagonal tile 0 (one work-group).
 __global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M, int ld,
-                                                    double* __restrict__ inv, double* __restrict__ fail) {
+                                                    double* __restrict__ inv, double* __restrict__ fail,
+                                                    unsigned* __restrict__ flags, int nb) {
   __shared__ __attribute__((aligned(16))) double T[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Ti[NB * GLD];
   const int tid = threadIdx.x;
+  for (int t = tid; t < nb; t += 256) flags[t] = 0u;  // the backward substitution's flags, for this solve
   load_tile(M, ld, T, tid);
   __syncthreads();
   const bool ok = tile_potrf_inv_la(T, Ti, tid);
@@ -539,6 +542,80 @@ __global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict_
   z[j * NB + lane] -= a0 + a1;
 }
 
+// Backward substitution L^T x = z in ONE launch: work-group b owns tile row k = nb - 1 - b,
+//   x_k = L_kk^-T (z_k - sum_{i > k} L_ik^T x_i),
+// and consumes the x_i in decreasing i as their owners publish them (flag per tile, release/acquire at
+// agent scope). Owners of later rows have smaller block indices, so they are dispatched first and the
+// wait can never dead-lock. Each of the 4 waves takes 16 of the 64 rows of every tile; the tile values
+// are fetched BEFORE the wait, so a step of the chain is {flag + 64 values of x, 16 FMAs, two LDS
+// reductions}, not a kernel launch.
+__global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __restrict__ L, int ld, int nb,
+                                                            const int* __restrict__ first,
+                                                            const double* __restrict__ inv,
+                                                            const double* __restrict__ z, double* y,
+                                                            unsigned* flags) {
+  const int k = nb - 1 - (int)blockIdx.x;
+  __shared__ double part[4][NB];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  double acc = (wv == 0) ? z[(size_t)k * NB + lane] : 0.0;
+  // this wave's 16 rows of L_kk^-1 (lower, compact 64 x 64)
+  double li[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) li[q] = inv[(size_t)k * NB * NB + (size_t)(16 * wv + q) * NB + lane];
+  int i = nb - 1;
+  while (i > k && first[i] > k) --i;  // tiles left of first[i] are structurally zero
+  double l[16];
+  if (i > k) {
+    const double* Lt = L + (size_t)i * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) l[q] = Lt[(size_t)q * ld];
+  }
+  while (i > k) {
+    int nx = i - 1;
+    while (nx > k && first[nx] > k) --nx;
+    double ln[16];
+    if (nx > k) {
+      const double* Lt = L + (size_t)nx * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ln[q] = Lt[(size_t)q * ld];
+    }
+    while (__hip_atomic_load(&flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+    const double* xi = y + (size_t)i * NB + 16 * wv;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      a0 = __builtin_fma(l[q], xi[q], a0);
+      a1 = __builtin_fma(l[q + 1], xi[q + 1], a1);
+    }
+    acc -= a0 + a1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) l[q] = ln[q];
+    i = nx;
+  }
+  part[wv][lane] = acc;
+  __syncthreads();
+  const double r = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];  // (z_k - sum)_lane
+  __syncthreads();
+  if (wv == 0) part[0][lane] = r;
+  __syncthreads();
+  // x_k[c] = sum_m Linv[m][c] r[m]; this wave's m range
+  double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; q += 2) {
+    b0 = __builtin_fma(li[q], part[0][16 * wv + q], b0);
+    b1 = __builtin_fma(li[q + 1], part[0][16 * wv + q + 1], b1);
+  }
+  __syncthreads();
+  part[wv][lane] = b0 + b1;
+  __syncthreads();
+  if (wv == 0) {
+    y[(size_t)k * NB + lane] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(&flags[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 void CholStructure::build_dense(int nb_) {
   std::vector<int> f(nb_, 0);
   build(nb_, f, 0);
@@ -557,12 +634,15 @@ void CholStructure::build(int nb_, const std::vector<int>& first_tile, hipStream
   }
   off[nb] = (int)rows.size();
   if (d_rows) (void)hipFree(d_rows);
-  d_rows = nullptr;
-  if (!rows.empty()) {
-    (void)hipMalloc(&d_rows, rows.size() * sizeof(int));
-    (void)hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st);
-    (void)hipStreamSynchronize(st);
-  }
+  // one allocation: panel row lists | first[] | flags
+  const size_t nrows = rows.size();
+  rows.insert(rows.end(), first.begin(), first.end());
+  rows.resize(rows.size() + nb, 0);
+  (void)hipMalloc(&d_rows, rows.size() * sizeof(int));
+  (void)hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipStreamSynchronize(st);
+  d_first = d_rows + nrows;
+  d_flags = reinterpret_cast<unsigned*>(d_first + nb);
 }
 CholStructure::~CholStructure() { if (d_rows) (void)hipFree(d_rows); }
 
@@ -575,7 +655,7 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
                             double* diag_ws, double* L, const CholStructure& cs) {
   const int nb = n_pad / NB, ld = n_pad;
   double* inv = diag_ws;
-  hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, inv, fail);
+  hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, inv, fail, cs.d_flags, nb);
   for (int k = 0; k < nb; ++k) {
     const int na = cs.off[k + 1] - cs.off[k];  // active row blocks below tile k
     const int* act = cs.d_rows + cs.off[k];
@@ -592,8 +672,13 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
     }
   }
   double* z = L + (size_t)n_pad * ld;
-  for (int k = nb - 1; k >= 0; --k)
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(k - cs.first[k] + 1), dim3(64), 0, st, L, ld, k, cs.first[k], inv, z, y);
+  if (nb <= kMaxBacksolveGroups) {
+    hipLaunchKernelGGL(k_chol_backsolve_all, dim3(nb), dim3(256), 0, st, L, ld, nb, cs.d_first, inv, z, y, cs.d_flags);
+  } else {
+    // more tile rows than work-groups that are certainly resident: one small launch per tile
+    for (int k = nb - 1; k >= 0; --k)
+      hipLaunchKernelGGL(k_chol_backsolve, dim3(k - cs.first[k] + 1), dim3(64), 0, st, L, ld, k, cs.first[k], inv, z, y);
+  }
 }
 
 }  // namespace mavba

@@ -161,6 +161,8 @@ struct CholStructure {
   std::vector<int> first;  // [nb]
   std::vector<int> off;    // [nb + 1] into d_rows: active row blocks of every panel
   int* d_rows = nullptr;
+  int* d_first = nullptr;        // [nb] copy of first[] (inside the d_rows allocation)
+  unsigned* d_flags = nullptr;   // [nb] per-tile 'solution segment published' flags of the backward substitution
   CholStructure() {}
   CholStructure(const CholStructure&) = delete;
   CholStructure& operator=(const CholStructure&) = delete;
