@@ -621,6 +621,18 @@ void mavba_session::finish_structure() {
       const int c0 = B.kind == BLK_II ? 6 * NI + 9 * B.col_ent : 6 * B.col_ent;
       for (int tr = r0 / 64; tr <= r1 / 64; ++tr) first_tile[tr] = std::min(first_tile[tr], c0 / 64);
     }
+    if (world > 1 && ar_fn) {
+      // The matrix that gets factorised is the SUM over ranks: its envelope is the union of the ranks'
+      // envelopes (min of the first tiles = max of their negatives, the hook has no min).
+      std::vector<double> h(nbt);
+      for (int t = 0; t < nbt; ++t) h[t] = -(double)first_tile[t];
+      DevBuf<double> d;
+      d.upload(h, st);
+      allreduce(d.p, nbt, 1);
+      HIP_OK(hipMemcpyAsync(h.data(), d.p, (size_t)nbt * 8, hipMemcpyDeviceToHost, st));
+      sync();
+      for (int t = 0; t < nbt; ++t) first_tile[t] = (int)(-h[t]);
+    }
     chol_struct.build(nbt, first_tile, st);
   }
   num_blocks = (int)blocks.size();

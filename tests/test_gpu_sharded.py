@@ -113,6 +113,30 @@ def test_rank_without_observations_of_an_image_keeps_it_free(mavba):
     assert rel_err(out[0][1], single.poses) < 1e-8
 
 
+def test_tile_envelope_is_the_union_over_ranks(mavba):
+    """The factorisation skips tiles left of the reduced system's envelope. With shards the all-reduced
+    matrix has the UNION of the ranks' structures: here only the last rank owns the long tracks that
+    couple far-apart images, so a rank using its local envelope would drop their blocks."""
+    full = synth.make_scene(num_images=48, num_points=2400, track_len=3, models=[A.MODEL_PINHOLE], seed=91,
+                            long_track_frac=0.02, long_track_len=40, spacing=6.0)
+    cnt = np.bincount(full.obs_point, minlength=full.num_points)
+    order = np.argsort(cnt, kind="stable")  # long tracks last -> all on the last rank
+    inv = np.empty_like(order); inv[order] = np.arange(len(order))
+    full.points = np.ascontiguousarray(full.points[order]); full.point_const = np.ascontiguousarray(full.point_const[order])
+    full.obs_point = inv[full.obs_point].astype(np.int32)
+    s0, _ = full.shard_by_point(0, 2)
+    with mavba.Session(s0) as a, mavba.Session(full) as b:
+        assert a.info()["envelope_tiles"] < b.info()["envelope_tiles"]  # rank 0 alone sees a narrower band
+    opts = global_opts()
+    single = full.copy()
+    _, r1 = mavba.bundle_adjustment(single, opts)
+    out, _ = solve_sharded(mavba, full, 2, opts)
+    for res, poses, intr, p, owned in out:
+        assert res["termination"] == r1["termination"]
+        assert abs(res["final_cost"] - r1["final_cost"]) <= 1e-9 * r1["final_cost"]
+        assert rel_err(poses, single.poses) < 1e-8
+
+
 def test_torch_zero_copy_view_of_a_device_pointer(mavba):
     """bench.py's RCCL hook wraps the session's raw device pointer as a torch tensor (CUDA array
     interface). Check that the view aliases the memory (no copy) on this GPU."""
