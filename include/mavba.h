@@ -275,6 +275,10 @@ typedef struct mavba_session_info {
   int64_t dense_tiles;         /* nb*(nb+1)/2                                                   */
   double factor_flops;         /* FP64 flops of one factorisation + solves on the envelope     */
   double dense_factor_flops;   /* n^3/3 + 2 n^2, the dense-equivalent count of SURVEY.md 8(d)  */
+  int32_t matrix_dim;          /* columns of the factorised matrix (elimination order, parts padded to tiles) */
+  int32_t nd_parts;            /* uncoupled leading parts factorised concurrently (0 = single chain) */
+  int32_t chain_steps;         /* dependent 64-column panel steps of the factorisation schedule */
+  int32_t reserved0;
 } mavba_session_info;
 int mavba_session_get_info(mavba_session* s, mavba_session_info* out);
 

@@ -15,6 +15,7 @@
 // The right-hand side rides along as an extra row block below the matrix, so the forward
 // substitution is free; the backward substitution is one small launch per tile.
 #include "internal.h"
+#include <algorithm>
 
 namespace mavba {
 
@@ -374,30 +375,37 @@ __device__ __forceinline__ void store_tile(double* __restrict__ G, size_t ld, co
 }
 }  // namespace
 
-// Factor + invert diagonal tile 0 (one work-group).
-__global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M, int ld,
+// Factor + invert the diagonal tiles listed in `tiles` (one work-group each): the first tile of every
+// front. Block 0 also clears the backward substitution's flags for this solve.
+__global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M, int ld, const int* __restrict__ tiles,
                                                     double* __restrict__ inv, double* __restrict__ fail,
-                                                    unsigned* __restrict__ flags, int nb) {
+                                                    unsigned* __restrict__ flags, int nflags) {
   __shared__ __attribute__((aligned(16))) double T[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Ti[NB * GLD];
   const int tid = threadIdx.x;
-  for (int t = tid; t < nb; t += 256) flags[t] = 0u;  // the backward substitution's flags, for this solve
-  load_tile(M, ld, T, tid);
+  const int t = tiles[blockIdx.x];
+  if (blockIdx.x == 0)
+    for (int f = tid; f < nflags; f += 256) flags[f] = 0u;
+  load_tile(M + (size_t)t * NB * ld + (size_t)t * NB, ld, T, tid);
   __syncthreads();
   const bool ok = tile_potrf_inv_la(T, Ti, tid);
   if (tid == 0 && !ok) atomicAdd(fail, 1.0);
-  store_tile(inv, NB, Ti, tid);
+  store_tile(inv + (size_t)t * NB * NB, NB, Ti, tid);
 }
 
-// Panel k: row block k+1+blockIdx.x (the last one is the right-hand-side block) of panel k
-//   A_ik <- A_ik L_kk^-T = A_ik (L_kk^-1)^T
-__global__ void __launch_bounds__(256) k_chol_trsm(const double* __restrict__ M, double* __restrict__ Lout, int ld, int k,
-                                                   const double* __restrict__ inv, const int* __restrict__ act,
-                                                   int na, int aug) {
+// Panel solve, front blockIdx.z: row block blockIdx.x of the front's active list (the last one is the
+// right-hand-side block):   A_ik <- A_ik L_kk^-T = A_ik (L_kk^-1)^T
+__global__ void __launch_bounds__(256) k_chol_trsm(const double* __restrict__ M, double* __restrict__ Lout, int ld,
+                                                   const CholFront* __restrict__ fronts,
+                                                   const double* __restrict__ inv, const int* __restrict__ rows,
+                                                   int aug) {
+  const CholFront F = fronts[blockIdx.z];
+  if ((int)blockIdx.x > F.na) return;
   __shared__ __attribute__((aligned(16))) double As[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * GLD];
   const int tid = threadIdx.x;
-  const int i = (int)blockIdx.x < na ? act[blockIdx.x] : aug;  // active row block, or the right-hand side
+  const int k = F.k;
+  const int i = (int)blockIdx.x < F.na ? rows[F.act_off + blockIdx.x] : aug;  // active row block, or the right-hand side
   const double* Ain = M + (size_t)i * NB * ld + (size_t)k * NB;
   double* A = Lout + (size_t)i * NB * ld + (size_t)k * NB;
   load_tile(Ain, ld, As, tid);
@@ -437,11 +445,16 @@ __device__ __forceinline__ void quadrant_to_lds(double* S, int wr, int wc, int l
 // Column j == k+1 work-groups store P_i (the final L_ik, needed by the backward substitution);
 // the owner of tile (k+1, k+1) then factorises + inverts it for the next panel.
 template <bool FUSED>
-__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, double* __restrict__ Lout, int ld, int k,
-                                                     double* __restrict__ inv,
-                                                     double* __restrict__ fail, const int* __restrict__ act,
-                                                     int na, int aug) {
-  // only the row blocks whose envelope reaches panel k take part (act[0] is always k + 1)
+__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, double* __restrict__ Lout, int ld,
+                                                     const CholFront* __restrict__ fronts,
+                                                     double* __restrict__ inv, double* __restrict__ fail,
+                                                     const int* __restrict__ rows, int aug,
+                                                     double* __restrict__ shadow, int s_begin, size_t shadow_stride) {
+  const CholFront F = fronts[blockIdx.z];
+  const int na = F.na, k = F.k;
+  if ((int)blockIdx.x >= na || (int)blockIdx.y > na) return;
+  // only the row blocks whose envelope reaches panel k take part (act[0] is k + 1 when the front goes on)
+  const int* act = rows + F.act_off;
   const int j = act[blockIdx.x], i = (int)blockIdx.y < na ? act[blockIdx.y] : aug;
   if (j > i) return;
   __shared__ __attribute__((aligned(16))) double As[NB * GLD];
@@ -451,15 +464,21 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
   const int wv = tid >> 6, lane = tid & 63;
   const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
   const int li = lane & 15, lk = lane >> 4;
-  // the tile being updated: its loads are issued first so that their latency hides behind the products
+  // the tile being updated (separator columns of a front with a shadow: that front's shadow block);
+  // its loads are issued first so that their latency hides behind the products
   double* C = M + (size_t)i * NB * ld + (size_t)j * NB;
+  size_t ldc = (size_t)ld;
+  if (F.shadow >= 0 && j >= s_begin) {
+    ldc = (size_t)(aug - s_begin) * NB;
+    C = shadow + (size_t)F.shadow * shadow_stride + (size_t)(i - s_begin) * NB * ldc + (size_t)(j - s_begin) * NB;
+  }
   d4 cin[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cin[m][n][r] = C[(size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li];
+      for (int r = 0; r < 4; ++r) cin[m][n][r] = C[(size_t)(wr + 16 * m + lk + 4 * r) * ldc + wc + 16 * n + li];
   d4 acc[2][2];
   if constexpr (FUSED) {
     load_tile(M + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
@@ -484,7 +503,7 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
   }
   const double* Pj = (i != j) ? Cs : As;
   mfma_quadrant_nt(As, Pj, wr, wc, lane, acc);
-  const bool next_diag = (blockIdx.x == 0 && blockIdx.y == 0);
+  const bool next_diag = (blockIdx.x == 0 && blockIdx.y == 0 && F.factor_next);
   if (!next_diag) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -492,7 +511,7 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          C[(size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li] = cin[m][n][r] - acc[m][n][r];
+          C[(size_t)(wr + 16 * m + lk + 4 * r) * ldc + wc + 16 * n + li] = cin[m][n][r] - acc[m][n][r];
     return;
   }
   // tile (k+1, k+1): keep the updated tile in LDS, factorise + invert it for the next panel
@@ -510,7 +529,28 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
   store_tile(inv + (size_t)(k + 1) * NB * NB, NB, As, tid);
 }
 
-// Backward substitution, tile k: y_k = L_kk^-T z_k; then z_j -= L_kj^T y_k for j < k.
+// Separator block after the fronts are done: M[i][j] += sum of the fronts' shadow blocks (i, j >= s_begin,
+// i may be the right-hand-side row). grid = (ns, ns + 1).
+__global__ void __launch_bounds__(256) k_chol_merge(double* __restrict__ M, int ld, const double* __restrict__ shadow,
+                                                    int num_shadows, int s_begin, int ns, size_t stride) {
+  const int js = blockIdx.x, is = blockIdx.y;
+  if (js > is) return;
+  const size_t lds = (size_t)ns * NB;
+  double* C = M + (size_t)(s_begin + is) * NB * ld + (size_t)(s_begin + js) * NB;
+  const double* Sh = shadow + (size_t)is * NB * lds + (size_t)js * NB;
+  for (int e = threadIdx.x; e < NB * NB / 2; e += 256) {
+    const int row = e >> 5, c2 = (e & 31) * 2;
+    double2 v = *reinterpret_cast<const double2*>(C + (size_t)row * ld + c2);
+    for (int q = 0; q < num_shadows; ++q) {
+      const double2 w = *reinterpret_cast<const double2*>(Sh + (size_t)q * stride + (size_t)row * lds + c2);
+      v.x += w.x; v.y += w.y;
+    }
+    *reinterpret_cast<double2*>(C + (size_t)row * ld + c2) = v;
+  }
+}
+
+// Backward substitution, tile k (fallback for very many tile rows, single segment only):
+// y_k = L_kk^-T z_k; then z_j -= L_kj^T y_k for j < k.
 // grid = k + 1: block k stores y_k, block j < k updates z_j (disjoint segments).
 __global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict__ M, int ld, int k, int first,
                                                        const double* __restrict__ inv,
@@ -541,6 +581,10 @@ __global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict_
   }
   z[j * NB + lane] -= a0 + a1;
 }
+__global__ void k_scatter_y(int n, const int* __restrict__ scatter, const double* __restrict__ y, double* __restrict__ y_nat) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n && scatter[t] >= 0) y_nat[scatter[t]] = y[t];
+}
 
 // Backward substitution L^T x = z in ONE launch: work-group b owns tile row k = nb - 1 - b,
 //   x_k = L_kk^-T (z_k - sum_{i > k} L_ik^T x_i),
@@ -548,13 +592,17 @@ __global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict_
 // agent scope). Owners of later rows have smaller block indices, so they are dispatched first and the
 // wait can never dead-lock. Each of the 4 waves takes 16 of the 64 rows of every tile; the tile values
 // are fetched BEFORE the wait, so a step of the chain is {flag + 64 values of x, 16 FMAs, two LDS
-// reductions}, not a kernel launch.
-__global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __restrict__ L, int ld, int nb,
-                                                            const int* __restrict__ first,
+// reductions}, not a kernel launch. Tile (i, k) takes part iff k is inside row i's envelope for k's
+// segment - uncoupled parts of a nested-dissection ordering therefore never wait for each other.
+__global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __restrict__ L, int ld, int nb, int nseg,
+                                                            const int* __restrict__ seg_of_tile,
+                                                            const int* __restrict__ seg_first,
                                                             const double* __restrict__ inv,
                                                             const double* __restrict__ z, double* y,
-                                                            unsigned* flags) {
+                                                            unsigned* flags, const int* __restrict__ scatter,
+                                                            double* __restrict__ y_nat) {
   const int k = nb - 1 - (int)blockIdx.x;
+  const int sk = seg_of_tile[k];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   double acc = (wv == 0) ? z[(size_t)k * NB + lane] : 0.0;
@@ -563,7 +611,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
 #pragma unroll
   for (int q = 0; q < 16; ++q) li[q] = inv[(size_t)k * NB * NB + (size_t)(16 * wv + q) * NB + lane];
   int i = nb - 1;
-  while (i > k && first[i] > k) --i;  // tiles left of first[i] are structurally zero
+  while (i > k && seg_first[i * nseg + sk] > k) --i;  // tiles outside the envelope are structurally zero
   double l[16];
   if (i > k) {
     const double* Lt = L + (size_t)i * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
@@ -572,7 +620,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
   }
   while (i > k) {
     int nx = i - 1;
-    while (nx > k && first[nx] > k) --nx;
+    while (nx > k && seg_first[nx * nseg + sk] > k) --nx;
     double ln[16];
     if (nx > k) {
       const double* Lt = L + (size_t)nx * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
@@ -609,75 +657,180 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
   part[wv][lane] = b0 + b1;
   __syncthreads();
   if (wv == 0) {
-    y[(size_t)k * NB + lane] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    const double x = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    y[(size_t)k * NB + lane] = x;
+    if (scatter) {
+      const int t = scatter[k * NB + lane];
+      if (t >= 0) y_nat[t] = x;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(&flags[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
+void CholStructure::release() {
+  if (d_ints) (void)hipFree(d_ints);
+  if (d_fronts) (void)hipFree(d_fronts);
+  if (d_shadow) (void)hipFree(d_shadow);
+  d_ints = nullptr; d_fronts = nullptr; d_shadow = nullptr;
+}
+CholStructure::~CholStructure() { release(); }
+
 void CholStructure::build_dense(int nb_) {
-  std::vector<int> f(nb_, 0);
-  build(nb_, f, 0);
+  std::vector<std::pair<int, int>> pairs;
+  for (int i = 0; i < nb_; ++i) pairs.emplace_back(i, 0);  // every row starts at tile 0
+  build(nb_, pairs, {}, 0);
 }
-void CholStructure::build(int nb_, const std::vector<int>& first_tile, hipStream_t st) {
+
+void CholStructure::build(int nb_, const std::vector<std::pair<int, int>>& tile_pairs,
+                          const std::vector<std::pair<int, int>>& parts_in, hipStream_t st) {
+  release();
   nb = nb_;
-  first = first_tile;
-  off.assign(nb + 1, 0);
+  std::vector<std::pair<int, int>> parts = parts_in;
+  if (nb > kMaxBacksolveGroups) parts.clear();  // the per-tile fallback of the backward substitution is single-segment
+  const int never = nb + 1;
+  auto assign_segments = [&]() {
+    const int P = (int)parts.size();
+    nseg = P + 1;
+    s_begin = P ? parts.back().second : 0;
+    seg_of_tile.assign(nb, P);
+    for (int p = 0; p < P; ++p)
+      for (int t = parts[p].first; t < parts[p].second; ++t) seg_of_tile[t] = p;
+    seg_first.assign((size_t)nb * nseg, never);
+    for (int i = 0; i < nb; ++i) seg_first[(size_t)i * nseg + seg_of_tile[i]] = i;
+    bool ok = true;
+    for (const auto& pr : tile_pairs) {
+      const int tr = pr.first, tc = pr.second;
+      const int q = seg_of_tile[tc];
+      if (seg_of_tile[tr] < P && seg_of_tile[tr] != q) ok = false;  // two leading parts are coupled: not a valid dissection
+      int& f = seg_first[(size_t)tr * nseg + q];
+      f = std::min(f, tc);
+    }
+    return ok;
+  };
+  if (!assign_segments()) { parts.clear(); assign_segments(); }
+  const int P = (int)parts.size();
+  if (P)  // the separator block fills in: treat it as dense
+    for (int i = s_begin; i < nb; ++i) seg_first[(size_t)i * nseg + P] = s_begin;
+
   std::vector<int> rows;
-  for (int k = 0; k < nb; ++k) {
-    off[k] = (int)rows.size();
-    // active at panel k: row blocks i > k whose envelope starts at or before k. Row k + 1 leads the
-    // list unconditionally (its diagonal tile is factorised by the owner of tile (k+1, k+1)).
-    if (k + 1 < nb) rows.push_back(k + 1);
-    for (int i = k + 2; i < nb; ++i) if (first[i] <= k) rows.push_back(i);
+  fronts.clear(); steps.clear(); init_tiles.clear();
+  envelope_tiles = 0; factor_flops = 0.0;
+  const double t3 = 64.0 * 64.0 * 64.0;
+  auto add_front = [&](std::vector<CholFront>& cur, int k, int seg, int seg_end, int shadow) {
+    CholFront F;
+    F.k = k; F.act_off = (int)rows.size(); F.shadow = shadow; F.factor_next = (k + 1 < seg_end) ? 1 : 0;
+    // Row k + 1 leads the list whenever the front goes on (its diagonal tile is factorised by the owner of
+    // tile (k+1, k+1)); then the rows of the same segment whose envelope reaches panel k, then - for a
+    // leading part - the separator rows coupled to it.
+    if (F.factor_next) rows.push_back(k + 1);
+    for (int i = k + 2; i < seg_end; ++i) if (seg_first[(size_t)i * nseg + seg] <= k) rows.push_back(i);
+    if (seg < P)
+      for (int i = s_begin; i < nb; ++i) if (seg_first[(size_t)i * nseg + seg] <= k) rows.push_back(i);
+    F.na = (int)rows.size() - F.act_off;
+    envelope_tiles += 1 + F.na;
+    const double na = F.na;
+    // tile factor + inverse (~2/3 t3), panel solves (na + rhs) * 2 t3, trailing update incl. rhs row
+    factor_flops += (2.0 / 3.0) * t3 + (na + 1.0) * 2.0 * t3 + (na * (na + 1.0) / 2.0 + na) * 2.0 * t3;
+    cur.push_back(F);
+  };
+  auto close_step = [&](std::vector<CholFront>& cur) {
+    std::stable_sort(cur.begin(), cur.end(), [](const CholFront& a, const CholFront& b) { return (a.na > 0) > (b.na > 0); });
+    CholStep S;
+    S.front_off = (int)fronts.size(); S.nf = 0; S.nf0 = 0; S.max_na = 0; S.merge = 0;
+    for (const CholFront& F : cur) { if (F.na > 0) ++S.nf; else ++S.nf0; S.max_na = std::max(S.max_na, F.na); }
+    fronts.insert(fronts.end(), cur.begin(), cur.end());
+    steps.push_back(S);
+    cur.clear();
+  };
+  std::vector<CholFront> cur;
+  int lead = 0;
+  if (P) {
+    for (const auto& pr : parts) { lead = std::max(lead, pr.second - pr.first); init_tiles.push_back(pr.first); }
+    for (int s = 0; s < lead; ++s) {
+      for (int p = 0; p < P; ++p)
+        if (parts[p].first + s < parts[p].second) add_front(cur, parts[p].first + s, p, parts[p].second, p - 1);
+      close_step(cur);
+    }
+    CholStep M;
+    M.front_off = 0; M.nf = 0; M.nf0 = 0; M.max_na = 0; M.merge = 1;
+    steps.push_back(M);
+  } else {
+    init_tiles.push_back(0);
   }
-  off[nb] = (int)rows.size();
-  if (d_rows) (void)hipFree(d_rows);
-  // one allocation: panel row lists | first[] | flags
-  const size_t nrows = rows.size();
-  rows.insert(rows.end(), first.begin(), first.end());
-  rows.resize(rows.size() + nb, 0);
-  (void)hipMalloc(&d_rows, rows.size() * sizeof(int));
-  (void)hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  init_tiles.push_back(s_begin);  // last entry: the separator's first tile, factorised after the merge
+  for (int k = s_begin; k < nb; ++k) { add_front(cur, k, P, nb, -1); close_step(cur); }
+  chain_steps = lead + (nb - s_begin);
+  num_shadows = P > 1 ? P - 1 : 0;
+
+  // device copies: rows | seg_of_tile | seg_first | init_tiles | flags
+  std::vector<int> pack(rows);
+  const size_t o_seg = pack.size();
+  pack.insert(pack.end(), seg_of_tile.begin(), seg_of_tile.end());
+  const size_t o_first = pack.size();
+  pack.insert(pack.end(), seg_first.begin(), seg_first.end());
+  const size_t o_init = pack.size();
+  pack.insert(pack.end(), init_tiles.begin(), init_tiles.end());
+  const size_t o_flags = pack.size();
+  pack.resize(pack.size() + nb, 0);
+  (void)hipMalloc(&d_ints, pack.size() * sizeof(int));
+  (void)hipMemcpyAsync(d_ints, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMalloc(&d_fronts, std::max<size_t>(fronts.size(), 1) * sizeof(CholFront));
+  (void)hipMemcpyAsync(d_fronts, fronts.data(), fronts.size() * sizeof(CholFront), hipMemcpyHostToDevice, st);
+  if (num_shadows) (void)hipMalloc(&d_shadow, (size_t)num_shadows * shadow_stride() * sizeof(double));
   (void)hipStreamSynchronize(st);
-  d_first = d_rows + nrows;
-  d_flags = reinterpret_cast<unsigned*>(d_first + nb);
+  d_rows = d_ints;
+  d_seg_of_tile = d_ints + o_seg;
+  d_seg_first = d_ints + o_first;
+  d_init = d_ints + o_init;
+  d_flags = reinterpret_cast<unsigned*>(d_ints + o_flags);
 }
-CholStructure::~CholStructure() { if (d_rows) (void)hipFree(d_rows); }
 
 // diag_ws: n_pad * 64 doubles (the inverses of the factor's diagonal tiles); L: second
 // (n_pad + 64) x n_pad matrix receiving the factor's off-diagonal tiles and the
-// forward-substituted right-hand side. `cs` = tile envelope of the matrix: tiles left of
-// first[i] in tile row i are structurally zero (and stay zero in the factor), so panel k only
-// involves the row blocks listed for it.
+// forward-substituted right-hand side. `cs` = tile structure + launch schedule of the matrix.
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
-                            double* diag_ws, double* L, const CholStructure& cs) {
+                            double* diag_ws, double* L, const CholStructure& cs,
+                            const int* y_scatter, double* y_nat) {
   const int nb = n_pad / NB, ld = n_pad;
   double* inv = diag_ws;
-  hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, inv, fail, cs.d_flags, nb);
-  for (int k = 0; k < nb; ++k) {
-    const int na = cs.off[k + 1] - cs.off[k];  // active row blocks below tile k
-    const int* act = cs.d_rows + cs.off[k];
-    if (na > kFuseBelow) {
-      // large trailing matrix: one panel solve, then a lean update (2 work-groups per CU)
-      hipLaunchKernelGGL(k_chol_trsm, dim3(na + 1), dim3(256), 0, st, M, L, ld, k, inv, act, na, nb);
-      hipLaunchKernelGGL((k_chol_update<false>), dim3(na, na + 1), dim3(256), 0, st, M, L, ld, k, inv, fail, act, na, nb);
-    } else if (na > 0) {
-      // small trailing matrix: latency matters, fold the panel solve into the update launch
-      hipLaunchKernelGGL((k_chol_update<true>), dim3(na, na + 1), dim3(256), 0, st, M, L, ld, k, inv, fail, act, na, nb);
-    } else {
-      // last tile: only the right-hand-side block is left
-      hipLaunchKernelGGL(k_chol_trsm, dim3(1), dim3(256), 0, st, M, L, ld, k, inv, act, 0, nb);
+  const size_t sstride = cs.shadow_stride();
+  if (cs.num_shadows)
+    (void)hipMemsetAsync(cs.d_shadow, 0, (size_t)cs.num_shadows * sstride * sizeof(double), st);
+  const int ninit = (int)cs.init_tiles.size() - 1;
+  hipLaunchKernelGGL(k_chol_diag0, dim3(ninit), dim3(256), 0, st, M, ld, cs.d_init, inv, fail, cs.d_flags, nb);
+  for (const CholStep& S : cs.steps) {
+    if (S.merge) {
+      const int ns = nb - cs.s_begin;
+      if (cs.num_shadows)
+        hipLaunchKernelGGL(k_chol_merge, dim3(ns, ns + 1), dim3(256), 0, st, M, ld, cs.d_shadow, cs.num_shadows, cs.s_begin, ns, sstride);
+      hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, cs.d_init + ninit, inv, fail, cs.d_flags, 0);
+      continue;
     }
+    const CholFront* F = cs.d_fronts + S.front_off;
+    if (S.max_na > kFuseBelow) {
+      // large trailing matrix: one panel solve, then a lean update (2 work-groups per CU)
+      hipLaunchKernelGGL(k_chol_trsm, dim3(S.max_na + 1, 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, cs.d_rows, nb);
+      hipLaunchKernelGGL((k_chol_update<false>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, fail,
+                         cs.d_rows, nb, cs.d_shadow, cs.s_begin, sstride);
+    } else if (S.max_na > 0) {
+      // small trailing matrix: latency matters, fold the panel solve into the update launch
+      hipLaunchKernelGGL((k_chol_update<true>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, fail,
+                         cs.d_rows, nb, cs.d_shadow, cs.s_begin, sstride);
+    }
+    if (S.nf0)  // fronts with nothing below their tile: only the right-hand-side block is left
+      hipLaunchKernelGGL(k_chol_trsm, dim3(1, 1, S.nf0), dim3(256), 0, st, M, L, ld, F + S.nf, inv, cs.d_rows, nb);
   }
   double* z = L + (size_t)n_pad * ld;
   if (nb <= kMaxBacksolveGroups) {
-    hipLaunchKernelGGL(k_chol_backsolve_all, dim3(nb), dim3(256), 0, st, L, ld, nb, cs.d_first, inv, z, y, cs.d_flags);
+    hipLaunchKernelGGL(k_chol_backsolve_all, dim3(nb), dim3(256), 0, st, L, ld, nb, cs.nseg, cs.d_seg_of_tile, cs.d_seg_first,
+                       inv, z, y, cs.d_flags, y_scatter, y_nat);
   } else {
-    // more tile rows than work-groups that are certainly resident: one small launch per tile
+    // more tile rows than work-groups that are certainly resident: one small launch per tile (single segment)
     for (int k = nb - 1; k >= 0; --k)
-      hipLaunchKernelGGL(k_chol_backsolve, dim3(k - cs.first[k] + 1), dim3(64), 0, st, L, ld, k, cs.first[k], inv, z, y);
+      hipLaunchKernelGGL(k_chol_backsolve, dim3(k - cs.seg_first[k] + 1), dim3(64), 0, st, L, ld, k, cs.seg_first[k], inv, z, y);
+    if (y_scatter) hipLaunchKernelGGL(k_scatter_y, dim3((n_pad + 255) / 256), dim3(256), 0, st, n_pad, y_scatter, y, y_nat);
   }
 }
 

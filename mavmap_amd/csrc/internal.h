@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
 #include <vector>
 
 namespace mavba {
@@ -118,12 +119,16 @@ void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurCh
                          const int2* terms, const double* Epose, const double* Eintr,
                          double* partial);
 int schur_partial_stride(int kind);
+// off_img[i] / off_cam[c]: first matrix column of image i's pose block / camera c's intrinsics block
+// (the matrix is assembled in the factorisation's elimination order, the vectors keep the variables' order).
 void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blocks,
                            const double* part_pp, const double* part_ip, const double* part_ii,
                            int NI, int NC, int ld, bool add_base, double radius, double dmin,
                            double dmax, const int* img_cam, const double* img_rec,
-                           const double* cam_rec, const double* scale_cam, double* S, double* v);
-void launch_fix_diag(hipStream_t st, int n_full, int n_pad, int ld, bool add_one,
+                           const double* cam_rec, const double* scale_cam, const int* off_img, const int* off_cam,
+                           double* S, double* v);
+// col_var[t]: variable (index into scale_cam) held by matrix column t, -1 for padding columns.
+void launch_fix_diag(hipStream_t st, int n_mat, int ld, bool add_one, const int* col_var,
                      const double* scale_cam, double* S);
 
 void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radius, double dmin,
@@ -154,24 +159,58 @@ void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const doub
 // (device double) is incremented if a pivot is not positive.
 // diag_ws: workspace of n_pad * 64 doubles (the inverses of the factor's diagonal tiles).
 // L: scratch matrix of the same shape as M (receives the factor).
-// CholStructure: tile envelope (skyline) of the matrix, 64x64 tiles: first[i] = first structurally
-// non-zero tile of tile row i. The factorisation only visits tiles inside the envelope.
+// CholStructure: tile structure of the matrix (64x64 tiles) and the launch schedule derived from it.
+//
+// Envelope: inside a segment of tile columns, tile row i is structurally zero left of seg_first[i][seg];
+// the factorisation only visits tiles inside the envelope (a skyline per segment).
+//
+// Segments: with a nested-dissection ordering [A_1 | ... | A_P | S] the leading parts A_p are mutually
+// uncoupled, so their panels are factorised CONCURRENTLY (one "front" per part in the same launch); each
+// front's Schur contribution to the separator block S x S goes to its own shadow block (front 0 writes
+// the matrix itself), the shadows are merged, then S is factorised as one dense chain. The number of
+// dependent panel steps drops from nb to max|A_p| + |S|. Without parts there is one segment and the
+// schedule is the plain right-looking chain over the envelope.
+struct CholFront {
+  int k;            // panel (tile column) this front eliminates
+  int na;           // active row blocks below tile k (rows + act_off)
+  int act_off;
+  int shadow;       // -1: updates go to the matrix; >= 0: updates of separator columns go to this shadow block
+  int factor_next;  // the owner of tile (k+1, k+1) factorises it for the front's next step
+};
+struct CholStep { int front_off, nf, nf0, max_na, merge; };  // nf fronts with na > 0, then nf0 with na == 0
 struct CholStructure {
-  int nb = 0;
-  std::vector<int> first;  // [nb]
-  std::vector<int> off;    // [nb + 1] into d_rows: active row blocks of every panel
-  int* d_rows = nullptr;
-  int* d_first = nullptr;        // [nb] copy of first[] (inside the d_rows allocation)
-  unsigned* d_flags = nullptr;   // [nb] per-tile 'solution segment published' flags of the backward substitution
+  int nb = 0, nseg = 1, s_begin = 0, num_shadows = 0;
+  std::vector<int> seg_of_tile;   // [nb]
+  std::vector<int> seg_first;     // [nb * nseg]
+  std::vector<CholFront> fronts;
+  std::vector<CholStep> steps;
+  std::vector<int> init_tiles;    // diagonal tiles factorised before the first step
+  int chain_steps = 0;            // dependent panel steps of the schedule
+  long long envelope_tiles = 0;   // lower-triangle tiles visited (incl. diagonal)
+  double factor_flops = 0.0;      // MFMA flops executed by the factorisation
+  int* d_ints = nullptr;          // one allocation: rows | seg_of_tile | seg_first | init_tiles | flags
+  int *d_rows = nullptr, *d_seg_of_tile = nullptr, *d_seg_first = nullptr, *d_init = nullptr;
+  unsigned* d_flags = nullptr;    // [nb] 'solution segment published' flags of the backward substitution
+  CholFront* d_fronts = nullptr;
+  double* d_shadow = nullptr;     // num_shadows blocks of (ns + 1) x ns tiles, ns = nb - s_begin
   CholStructure() {}
   CholStructure(const CholStructure&) = delete;
   CholStructure& operator=(const CholStructure&) = delete;
   ~CholStructure();
-  void build(int nb, const std::vector<int>& first_tile, hipStream_t st);
+  void release();
+  // tile_pairs: (row tile, col tile), row >= col, of every structurally non-zero tile (diagonal tiles are
+  // implied). parts: tile ranges [begin, end) of the leading uncoupled parts, ascending and contiguous from
+  // tile 0; everything after the last part is the separator. Empty parts = single chain.
+  void build(int nb, const std::vector<std::pair<int, int>>& tile_pairs,
+             const std::vector<std::pair<int, int>>& parts, hipStream_t st);
   void build_dense(int nb);
+  size_t shadow_stride() const { const size_t ns = (size_t)(nb - s_begin); return (ns + 1) * ns * 4096; }
 };
+// y_scatter (may be null): y_nat[y_scatter[t]] = y[t] for every t with y_scatter[t] >= 0 (the solution in
+// the caller's variable order when the matrix was assembled in a permuted order).
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
-                            double* diag_ws, double* L, const CholStructure& cs);
+                            double* diag_ws, double* L, const CholStructure& cs,
+                            const int* y_scatter = nullptr, double* y_nat = nullptr);
 
 }  // namespace mavba
 #endif

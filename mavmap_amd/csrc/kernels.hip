@@ -856,7 +856,8 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
     const double* __restrict__ part_ip, const double* __restrict__ part_ii, int NI, int NC, int ld,
     int add_base, double radius, double dmin, double dmax, const int* __restrict__ img_cam,
     const double* __restrict__ img_rec, const double* __restrict__ cam_rec,
-    const double* __restrict__ scale_cam, double* __restrict__ S, double* __restrict__ v) {
+    const double* __restrict__ scale_cam, const int* __restrict__ off_img, const int* __restrict__ off_cam,
+    double* __restrict__ S, double* __restrict__ v) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bid = blockIdx.x * 4 + wv;
   if (bid >= num_blocks) return;
@@ -866,8 +867,12 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
   const bool diag_kind = B.kind != BLK_IP;
   const int PS = NA + (diag_kind ? RX : 0);
   const double* part = B.kind == BLK_PP ? part_pp : B.kind == BLK_IP ? part_ip : part_ii;
+  // row0 / col0: the block in the variables' own order (scales, camera sums); prow0 / pcol0: where it
+  // goes in the matrix, whose columns follow the elimination order chosen for the factorisation
   const int row0 = B.kind == BLK_PP ? 6 * B.row_ent : 6 * NI + 9 * B.row_ent;
   const int col0 = B.kind == BLK_II ? 6 * NI + 9 * B.col_ent : 6 * B.col_ent;
+  const int prow0 = B.kind == BLK_PP ? off_img[B.row_ent] : off_cam[B.row_ent];
+  const int pcol0 = B.kind == BLK_II ? off_cam[B.col_ent] : off_img[B.col_ent];
   const bool is_diag = diag_kind && B.row_ent == B.col_ent;
   auto apply = [&](int idx, double s) {
     if (idx < NA) {
@@ -889,9 +894,9 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
         }
       }
       const double val = base - s;
-      if (!is_diag || gr >= gc) {
-        S[(size_t)gr * ld + gc] = val;
-        S[(size_t)gc * ld + gr] = val;
+      if (!is_diag || r >= c) {
+        S[(size_t)(prow0 + r) * ld + pcol0 + c] = val;
+        S[(size_t)(pcol0 + c) * ld + prow0 + r] = val;
       }
     } else if (is_diag) {
       const int r = idx - NA;
@@ -902,7 +907,7 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
                                           : cam_rec[(size_t)B.row_ent * kCamRec + 45 + r];
         base = scale_cam[gr] * g;
       }
-      v[gr] = base - s;
+      v[prow0 + r] = base - s;
     }
   };
   // one lane per element; the block's chunk partials are added in a fixed order, eight independent
@@ -922,21 +927,23 @@ void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blo
                            const double* part_pp, const double* part_ip, const double* part_ii,
                            int NI, int NC, int ld, bool add_base, double radius, double dmin,
                            double dmax, const int* img_cam, const double* img_rec,
-                           const double* cam_rec, const double* scale_cam, double* S, double* v) {
+                           const double* cam_rec, const double* scale_cam, const int* off_img, const int* off_cam,
+                           double* S, double* v) {
   if (num_blocks <= 0) return;
   hipLaunchKernelGGL(k_schur_finalize, dim3((num_blocks + 3) / 4), dim3(256), 0, st, num_blocks, blocks, part_pp,
                      part_ip, part_ii, NI, NC, ld, add_base ? 1 : 0, radius, dmin, dmax, img_cam, img_rec, cam_rec,
-                     scale_cam, S, v);
+                     scale_cam, off_img, off_cam, S, v);
 }
 // Constant / unused / padding columns: unit diagonal (their rows and columns are zero).
-__global__ void k_fix_diag(int n_full, int n_pad, int ld, int add_one, const double* __restrict__ scale_cam,
-                           double* __restrict__ S) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_pad) return;
-  if (j >= n_full || scale_cam[j] == 0.0) S[(size_t)j * ld + j] = add_one ? 1.0 : 0.0;
+__global__ void k_fix_diag(int n_mat, int ld, int add_one, const int* __restrict__ col_var,
+                           const double* __restrict__ scale_cam, double* __restrict__ S) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_mat) return;
+  const int j = col_var[t];  // the variable in matrix column t, -1 for padding
+  if (j < 0 || scale_cam[j] == 0.0) S[(size_t)t * ld + t] = add_one ? 1.0 : 0.0;
 }
-void launch_fix_diag(hipStream_t st, int n_full, int n_pad, int ld, bool add_one, const double* scale_cam, double* S) {
-  hipLaunchKernelGGL(k_fix_diag, dim3((n_pad + 255) / 256), dim3(256), 0, st, n_full, n_pad, ld, add_one ? 1 : 0, scale_cam, S);
+void launch_fix_diag(hipStream_t st, int n_mat, int ld, bool add_one, const int* col_var, const double* scale_cam, double* S) {
+  hipLaunchKernelGGL(k_fix_diag, dim3((n_mat + 255) / 256), dim3(256), 0, st, n_mat, ld, add_one ? 1 : 0, col_var, scale_cam, S);
 }
 
 // ---------------------------------------------------------------------------

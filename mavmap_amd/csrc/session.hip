@@ -134,6 +134,13 @@ struct mavba_session {
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
+  // The reduced camera matrix is assembled in the factorisation's elimination order: n_mat (multiple of 64)
+  // columns, image i's pose block at h_off_img[i], camera c's intrinsics block at h_off_cam[c]; col_var maps a
+  // matrix column back to the variable (index into the length-n_pad camera vectors), -1 for padding.
+  int n_mat = 64, nd_parts = 0;
+  std::vector<int> h_off_img, h_off_cam, h_col_var;
+  DevBuf<int> d_off, d_col_var;
+  DevBuf<double> d_ymat;
 
   // ---- LM state (Ceres TrustRegionMinimizer / LevenbergMarquardtStrategy) ----
   bool evaluated = false, scales_ready = false, started = false, assembled = false;
@@ -211,6 +218,7 @@ struct mavba_session {
   void build(const mavba_problem* P);
   void derive_free_flags();
   void finish_structure();
+  void choose_elimination_order(const std::vector<SchurBlock>& blocks);
   void reset_state();
   void evaluate();
   void assemble(double r);
@@ -428,7 +436,7 @@ void mavba_session::build(const mavba_problem* P) {
   d_prior_res.alloc(std::max(num_priors, 1)); d_prior_jac.alloc((size_t)std::max(num_priors, 1) * 3);
   d_prior_cost.alloc(std::max(num_priors, 1));
   d_Epose.alloc((size_t)std::max(N, 1) * kPoseRec);
-  d_M.alloc((size_t)(n_pad + 64) * n_pad); d_L.alloc((size_t)(n_pad + 64) * n_pad); d_y.alloc(n_pad); d_diag_ws.alloc((size_t)n_pad * 64);
+  d_y.alloc(n_pad); d_y.zero(st);  // the matrix-sized buffers follow the elimination order chosen in finish_structure
   d_delta_cam.alloc(n_pad); d_delta_pts.alloc(nP * 3);
   d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + 2) * 3);
   d_scal.alloc(SC_COUNT); d_scal.zero(st);
@@ -447,6 +455,146 @@ void mavba_session::build(const mavba_problem* P) {
 // Everything that depends on which parameter blocks are free: flags on the device, the
 // intrinsics entries (one per free point x free camera seen by it) and the term / chunk /
 // block lists of the Schur complement.
+// Elimination order of the reduced camera system + the factorisation's tile structure.
+//
+// The dependent chain of the blocked Cholesky is one 64-column panel after the other, ~20 us each, and
+// at BA sizes that chain - not the flops - is the cost of the solve. Images are connected through the
+// points they share; in acquisition order that graph is banded, so a band partition is a nested
+// dissection: cut the order into P runs, move every image that has a neighbour in an EARLIER run into the
+// separator S, and the remaining parts A_1..A_P are mutually uncoupled. Ordered [A_1 | .. | A_P | S |
+// intrinsics] their panels are factorised concurrently and the chain is max|A_p| + |S| instead of the sum.
+// P (and for P = 2 the cut position) is chosen to minimise that chain, P = 1 (no dissection) included.
+void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& blocks) {
+  const int tiles0 = std::max(1, round_up(n_full, 64) / 64);
+  std::vector<int> seg(NI, 0);   // run of every image; -1 = separator
+  int P = 1;
+  int forced = -1;
+  if (const char* e = std::getenv("MAVBA_ND_PARTS")) forced = std::atoi(e);  // 0/1 = off, n = force n parts
+  const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && (world == 1 || NI <= 4096);
+  if (can_dissect) {
+    // image adjacency (lower: col < row) from the pose-pose blocks; with shards, the union over ranks
+    std::vector<std::vector<int>> lower(NI);
+    if (world > 1 && ar_fn) {
+      std::vector<double> a((size_t)NI * NI, 0.0);
+      for (const SchurBlock& B : blocks)
+        if (B.kind == BLK_PP && B.row_ent != B.col_ent) a[(size_t)std::max(B.row_ent, B.col_ent) * NI + std::min(B.row_ent, B.col_ent)] = 1.0;
+      DevBuf<double> d;
+      d.upload(a, st);
+      allreduce(d.p, (long long)NI * NI, 1);
+      HIP_OK(hipMemcpyAsync(a.data(), d.p, a.size() * 8, hipMemcpyDeviceToHost, st));
+      sync();
+      for (int r = 0; r < NI; ++r)
+        for (int c = 0; c < r; ++c) if (a[(size_t)r * NI + c] != 0.0) lower[r].push_back(c);
+    } else {
+      for (const SchurBlock& B : blocks)
+        if (B.kind == BLK_PP && B.row_ent != B.col_ent) lower[std::max(B.row_ent, B.col_ent)].push_back(std::min(B.row_ent, B.col_ent));
+    }
+    std::vector<int> min_nb(NI);  // smallest neighbour index (an image is in S iff it lies in an earlier run)
+    for (int i = 0; i < NI; ++i) {
+      int m = i;
+      for (int c : lower[i]) m = std::min(m, c);
+      min_nb[i] = m;
+    }
+    const int tail = 9 * NC;
+    // chain length (tiles) of the dissection with run boundaries `cut` (ascending, cut[0] = 0)
+    auto evaluate = [&](const std::vector<int>& cut, std::vector<int>* out_seg) {
+      const int np = (int)cut.size();
+      std::vector<int> size(np, 0);
+      int ns = 0, run = 0;
+      for (int i = 0; i < NI; ++i) {
+        while (run + 1 < np && i >= cut[run + 1]) ++run;
+        const bool sep = min_nb[i] < cut[run];
+        if (sep) ++ns; else ++size[run];
+        if (out_seg) (*out_seg)[i] = sep ? -1 : run;
+      }
+      int lead = 0;
+      for (int q = 0; q < np; ++q) lead = std::max(lead, (6 * size[q] + 63) / 64);
+      return lead + (6 * ns + tail + 63) / 64;
+    };
+    int best = forced > 1 ? (1 << 30) : tiles0;  // a forced part count is taken even when it does not pay
+    std::vector<int> best_cut{0};
+    auto consider = [&](const std::vector<int>& cut) {
+      const int c = evaluate(cut, nullptr);
+      if (c < best) { best = c; best_cut = cut; }
+    };
+    const int pmax = forced > 1 ? forced : 8;
+    for (int np = (forced > 1 ? forced : 2); np <= pmax; ++np) {
+      if (NI / np < 8) break;
+      std::vector<int> cut(np);
+      for (int q = 0; q < np; ++q) cut[q] = (int)((long long)q * NI / np);
+      consider(cut);
+      if (np == 2)  // the separator sits in the second run: scan the cut for the best balance
+        for (int m = NI / 4; m <= 3 * NI / 4; m += std::max(1, NI / 64)) consider({0, m});
+    }
+    const bool worth = forced > 1 ? best_cut.size() > 1 : (best_cut.size() > 1 && best <= tiles0 - std::max(2, tiles0 / 8));
+    if (worth) {
+      P = (int)best_cut.size();
+      evaluate(best_cut, &seg);
+    }
+  }
+  // column offsets: parts (each padded to whole tiles), then separator images, then intrinsics
+  h_off_img.assign(NI, 0); h_off_cam.assign(NC, 0);
+  std::vector<std::pair<int, int>> parts;
+  int col = 0;
+  if (P > 1) {
+    for (int q = 0; q < P; ++q) {
+      const int begin = col;
+      for (int i = 0; i < NI; ++i) if (seg[i] == q) { h_off_img[i] = col; col += 6; }
+      if (col == begin) continue;  // a run that went entirely into the separator
+      col = round_up(col, 64);
+      parts.emplace_back(begin / 64, col / 64);
+    }
+    for (int i = 0; i < NI; ++i) if (seg[i] < 0) { h_off_img[i] = col; col += 6; }
+  } else {
+    for (int i = 0; i < NI; ++i) { h_off_img[i] = col; col += 6; }
+  }
+  for (int c = 0; c < NC; ++c) { h_off_cam[c] = col; col += 9; }
+  if (parts.size() < 2) {  // nothing to run concurrently: plain order
+    parts.clear();
+    col = 0;
+    for (int i = 0; i < NI; ++i) { h_off_img[i] = col; col += 6; }
+    for (int c = 0; c < NC; ++c) { h_off_cam[c] = col; col += 9; }
+  }
+  nd_parts = (int)parts.size();
+  n_mat = std::max(64, round_up(col, 64));
+  h_col_var.assign(n_mat, -1);
+  for (int i = 0; i < NI; ++i) for (int e = 0; e < 6; ++e) h_col_var[h_off_img[i] + e] = 6 * i + e;
+  for (int c = 0; c < NC; ++c) for (int k = 0; k < 9; ++k) h_col_var[h_off_cam[c] + k] = 6 * NI + 9 * c + k;
+  {
+    std::vector<int> off(h_off_img);
+    off.insert(off.end(), h_off_cam.begin(), h_off_cam.end());
+    d_off.upload(off, st);
+    d_col_var.upload(h_col_var, st);
+  }
+  // structurally non-zero tiles (lower) of the permuted matrix
+  const int nbt = n_mat / 64;
+  std::vector<unsigned char> mark((size_t)nbt * nbt, 0);
+  for (const SchurBlock& B : blocks) {
+    const int r0 = B.kind == BLK_PP ? h_off_img[B.row_ent] : h_off_cam[B.row_ent];
+    const int r1 = r0 + (B.kind == BLK_PP ? 5 : 8);
+    const int c0 = B.kind == BLK_II ? h_off_cam[B.col_ent] : h_off_img[B.col_ent];
+    const int c1 = c0 + (B.kind == BLK_II ? 8 : 5);
+    for (int tr = r0 / 64; tr <= r1 / 64; ++tr)
+      for (int tc = c0 / 64; tc <= c1 / 64; ++tc) mark[(size_t)std::max(tr, tc) * nbt + std::min(tr, tc)] = 1;
+  }
+  if (world > 1 && ar_fn) {
+    // The matrix that gets factorised is the SUM over ranks: its structure is the union of the ranks'.
+    std::vector<double> h(mark.begin(), mark.end());
+    DevBuf<double> d;
+    d.upload(h, st);
+    allreduce(d.p, (long long)h.size(), 1);
+    HIP_OK(hipMemcpyAsync(h.data(), d.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+    sync();
+    for (size_t t = 0; t < h.size(); ++t) mark[t] = h[t] != 0.0;
+  }
+  std::vector<std::pair<int, int>> tile_pairs;
+  for (int tr = 0; tr < nbt; ++tr)
+    for (int tc = 0; tc <= tr; ++tc) if (mark[(size_t)tr * nbt + tc]) tile_pairs.emplace_back(tr, tc);
+  chol_struct.build(nbt, tile_pairs, parts, st);
+  d_M.alloc((size_t)(n_mat + 64) * n_mat); d_L.alloc((size_t)(n_mat + 64) * n_mat);
+  d_ymat.alloc(n_mat); d_diag_ws.alloc((size_t)n_mat * 64);
+}
+
 void mavba_session::finish_structure() {
   const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
   double tl = now_s();
@@ -609,32 +757,8 @@ void mavba_session::finish_structure() {
     });
   });
   lap("fill terms");
-  {
-    // Tile envelope of the reduced camera system for the factorisation: first structurally
-    // non-zero 64-column tile of every 64-row tile (rows >= cols; padding rows are diagonal).
-    const int nbt = n_pad / 64;
-    std::vector<int> first_tile(nbt);
-    for (int t = 0; t < nbt; ++t) first_tile[t] = t;
-    for (const SchurBlock& B : blocks) {
-      const int r0 = B.kind == BLK_PP ? 6 * B.row_ent : 6 * NI + 9 * B.row_ent;
-      const int r1 = r0 + (B.kind == BLK_PP ? 5 : 8);
-      const int c0 = B.kind == BLK_II ? 6 * NI + 9 * B.col_ent : 6 * B.col_ent;
-      for (int tr = r0 / 64; tr <= r1 / 64; ++tr) first_tile[tr] = std::min(first_tile[tr], c0 / 64);
-    }
-    if (world > 1 && ar_fn) {
-      // The matrix that gets factorised is the SUM over ranks: its envelope is the union of the ranks'
-      // envelopes (min of the first tiles = max of their negatives, the hook has no min).
-      std::vector<double> h(nbt);
-      for (int t = 0; t < nbt; ++t) h[t] = -(double)first_tile[t];
-      DevBuf<double> d;
-      d.upload(h, st);
-      allreduce(d.p, nbt, 1);
-      HIP_OK(hipMemcpyAsync(h.data(), d.p, (size_t)nbt * 8, hipMemcpyDeviceToHost, st));
-      sync();
-      for (int t = 0; t < nbt; ++t) first_tile[t] = (int)(-h[t]);
-    }
-    chol_struct.build(nbt, first_tile, st);
-  }
+  choose_elimination_order(blocks);
+  lap("elimination order");
   num_blocks = (int)blocks.size();
   d_blocks.upload(blocks, st);
   for (int k = 0; k < 3; ++k) {
@@ -732,23 +856,23 @@ void mavba_session::assemble(double r) {
     launch_entries_intr(st, Q, NI, NPs, d_q_pt.p, d_q_cam.p, d_Wk.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p,
                         d_Eintr.p);
   });
-  timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_pad + 64) * n_pad * sizeof(double), st)); });
+  timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st)); });
   timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
   timed("schur_chunks_ip", [&] { launch_schur_chunks(st, BLK_IP, num_chunks[1], d_chunks[1].p, d_terms[1].p, d_Epose.p, d_Eintr.p, d_part[1].p); });
   timed("schur_chunks_ii", [&] { launch_schur_chunks(st, BLK_II, num_chunks[2], d_chunks[2].p, d_terms[2].p, d_Epose.p, d_Eintr.p, d_part[2].p); });
-  double* v = d_M.p + (size_t)n_pad * n_pad;
+  double* v = d_M.p + (size_t)n_mat * n_mat;
   timed("schur_finalize", [&] {
-    launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, n_pad, rank == 0,
-                          r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_M.p, v);
-    launch_fix_diag(st, n_full, n_pad, n_pad, rank == 0, d_scale_cam.p, d_M.p);
+    launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, n_mat, rank == 0,
+                          r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p, v);
+    launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
   });
-  allreduce(d_M.p, (long long)(n_pad + 1) * n_pad, 0);
+  allreduce(d_M.p, (long long)(n_mat + 1) * n_mat, 0);
   assembled = true;
 }
 
 void mavba_session::solve_linear(double r) {
   assemble(r);
-  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_pad, d_y.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct); });
+  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p); });
   assembled = false;  // the factorisation overwrote S
 }
 
@@ -1065,12 +1189,18 @@ int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, 
   MAVBA_TRY
   if (!s->evaluated) s->evaluate();
   s->assemble(radius);
-  const int n = s->n_full, ld = s->n_pad;
-  if (Sout && n)
-    HIP_OK(hipMemcpy2DAsync(Sout, (size_t)n * 8, s->d_M.p, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, s->st));
-  if (vout && n)
-    HIP_OK(hipMemcpyAsync(vout, s->d_M.p + (size_t)s->n_pad * ld, (size_t)n * 8, hipMemcpyDeviceToHost, s->st));
+  // the device matrix is in elimination order; hand it out in the variables' order
+  const int n = s->n_full, m = s->n_mat;
+  std::vector<double> h((size_t)(m + 1) * m);
+  HIP_OK(hipMemcpyAsync(h.data(), s->d_M.p, h.size() * 8, hipMemcpyDeviceToHost, s->st));
   s->sync();
+  std::vector<int> var_col(n, 0);
+  for (int t = 0; t < m; ++t) if (s->h_col_var[t] >= 0) var_col[s->h_col_var[t]] = t;
+  if (Sout)
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) Sout[(size_t)r * n + c] = h[(size_t)var_col[r] * m + var_col[c]];
+  if (vout)
+    for (int r = 0; r < n; ++r) vout[r] = h[(size_t)m * m + var_col[r]];
   return MAVBA_OK;
   MAVBA_CATCH
 }
@@ -1124,17 +1254,11 @@ int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
   const CholStructure& cs = s->chol_struct;
   const long long nb = cs.nb;
   out->dense_tiles = nb * (nb + 1) / 2;
-  long long tiles = 0;
-  double fl = 0.0;
-  const double t3 = 64.0 * 64.0 * 64.0;
-  for (int k = 0; k < cs.nb; ++k) {
-    tiles += k - cs.first[k] + 1;
-    const double na = cs.off[k + 1] - cs.off[k];
-    // tile factor + inverse (~2/3 t3), panel solves (na + rhs) * 2 t3, trailing update incl. rhs row
-    fl += (2.0 / 3.0) * t3 + (na + 1.0) * 2.0 * t3 + (na * (na + 1.0) / 2.0 + na) * 2.0 * t3;
-  }
-  out->envelope_tiles = tiles;
-  out->factor_flops = fl;
+  out->envelope_tiles = cs.envelope_tiles;
+  out->factor_flops = cs.factor_flops;
+  out->matrix_dim = s->n_mat;
+  out->nd_parts = s->nd_parts;
+  out->chain_steps = cs.chain_steps;
   const double n = (double)s->n_full;
   out->dense_factor_flops = n * n * n / 3.0 + 2.0 * n * n;
   return MAVBA_OK;

@@ -276,3 +276,47 @@ def test_envelope_factorisation_on_a_banded_system(mavba, oracle):
     assert rel_err(st["d_poses"], ref["d_poses"]) < 1e-8
     assert rel_err(st["d_intr"], ref["d_intr"]) < 1e-8
     assert rel_err(st["d_points"], ref["d_points"]) < 1e-8
+
+
+# ---- elimination order / concurrent fronts ------------------------------------------------------------
+
+def _band_scene():
+    return synth.make_scene(num_images=130, num_points=5000, track_len=4, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV],
+                            seed=5, long_track_frac=0.01, long_track_len=12, spacing=6.0)
+
+
+@pytest.mark.parametrize("parts", [0, 2, 3, 5])
+def test_dissection_orders_give_the_oracle_step(mavba, oracle, parts, monkeypatch):
+    """The reduced system is assembled in a nested-dissection order and its leading parts are factorised
+    concurrently (shadow blocks for the separator). Whatever the number of parts, the system handed out in the
+    variables' order and the solved step must be the oracle's."""
+    p = _band_scene()
+    ref = oracle.linear_step(p, 1e4)
+    monkeypatch.setenv("MAVBA_ND_PARTS", str(parts))
+    with mavba.Session(p) as s:
+        info = s.info()
+        S, v = s.reduced_system(1e4)
+        st = s.linear_step(1e4)
+    if parts > 1:
+        assert 2 <= info["nd_parts"] <= parts and info["matrix_dim"] >= info["padded_dim"]
+        if parts < 5:  # (5 parts of this small scene are forced, not profitable)
+            assert info["chain_steps"] < info["padded_dim"] // 64
+    else:
+        assert info["nd_parts"] == 0 and info["chain_steps"] == info["padded_dim"] // 64
+    assert rel_err(S, ref["S"]) < 1e-9 and np.abs(S - S.T).max() == 0.0
+    assert rel_err(v, ref["v"]) < 1e-9
+    for k in ("d_poses", "d_intr", "d_points"):
+        assert rel_err(st[k], ref[k]) < 1e-8, (parts, k)
+    assert abs(st["model_cost_change"] - ref["model_cost_change"]) < 1e-9 * abs(ref["model_cost_change"])
+
+
+def test_dissection_is_chosen_automatically_and_solves_like_the_oracle(mavba, oracle):
+    p = _band_scene()
+    with mavba.Session(p) as s:
+        info = s.info()
+    assert info["nd_parts"] >= 2, info
+    po, ro, eo, pg, rg, eg = _solve_both(mavba, oracle, p, **global_opts())
+    assert rg["termination"] == ro["termination"]
+    assert rg["num_successful_steps"] == ro["num_successful_steps"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+    assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
