@@ -278,7 +278,9 @@ typedef struct mavba_session_info {
   int32_t matrix_dim;          /* columns of the factorised matrix (elimination order, parts padded to tiles) */
   int32_t nd_parts;            /* uncoupled leading parts factorised concurrently (0 = single chain) */
   int32_t chain_steps;         /* dependent 64-column panel steps of the factorisation schedule */
-  int32_t reserved0;
+  int32_t num_clusters;        /* point clusters of the Schur complement (k_schur_clusters)     */
+  int64_t clustered_points;    /* points whose Schur terms are formed inside a cluster          */
+  int64_t cluster_partials;    /* (cluster, block) partials the clusters emit per linear solve  */
 } mavba_session_info;
 int mavba_session_get_info(mavba_session* s, mavba_session_info* out);
 

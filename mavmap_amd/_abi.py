@@ -80,7 +80,8 @@ class CSessionInfo(C.Structure):
                 ("schur_terms", C.c_int64 * 3), ("schur_blocks", C.c_int64), ("intr_entries", C.c_int64),
                 ("envelope_tiles", C.c_int64), ("dense_tiles", C.c_int64), ("factor_flops", C.c_double),
                 ("dense_factor_flops", C.c_double), ("matrix_dim", C.c_int32), ("nd_parts", C.c_int32),
-                ("chain_steps", C.c_int32), ("reserved0", C.c_int32)]
+                ("chain_steps", C.c_int32), ("num_clusters", C.c_int32),
+                ("clustered_points", C.c_int64), ("cluster_partials", C.c_int64)]
 
 
 class CKernelStat(C.Structure):

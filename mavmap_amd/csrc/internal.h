@@ -38,7 +38,21 @@ struct SchurBlock {
   int row_ent, col_ent;
   int chunk_begin, chunk_end;
 };
-struct SchurChunk { int begin; int end; };  // term range
+struct SchurChunk { int begin; int end; int slot; };  // term range; slot = index of the partial it writes
+
+// Point clusters of the Schur complement (k_schur_clusters): a run of consecutive points [p0, p1) whose
+// images fit a local list of kClImages and whose shared cameras fit kClCams. The cluster's contribution to
+// EVERY block among its images / cameras is one symmetric product E E^T of its stacked entry matrix
+//   rows  6*la + r        : U_a (6 x 3) of the observation in local image la      (la < kClImages)
+//   rows  96 + 9*lc + r   : Uk  (9 x 3) of the point's entry for local camera lc  (lc < kClCams)
+//   row   123             : h^T of the point                                       (gives e_a / ek)
+//   cols  3*point + t
+// computed on the FP64 matrix cores from LDS; each block that is present in the cluster then leaves as
+// ONE partial (slot table) instead of one gathered term per (point, pair).
+constexpr int kClImages = 16, kClCams = 3, kClRows = 128, kClHRow = 123;
+constexpr int kClBatch = 16;                     // points per LDS batch -> K = 48 columns
+constexpr int kClTabPP = 0, kClTabIP = 136, kClTabII = 136 + 48, kClTab = 136 + 48 + 6;
+struct SchurCluster { int p0, p1; };
 
 // Scalars exchanged with the host every LM iteration (device array of doubles).
 // [0, SC_NUM_SUMS) are summed over ranks, SC_GRAD_MAX is max-reduced.
@@ -119,6 +133,11 @@ void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurCh
                          const int2* terms, const double* Epose, const double* Eintr,
                          double* partial);
 int schur_partial_stride(int kind);
+void launch_schur_clusters(hipStream_t st, int num_clusters, const SchurCluster* clusters, const int* tab,
+                           const int* pt_start, const int* q_start, const int* obs_pt, const int* q_pt,
+                           const unsigned char* obs_local, const unsigned char* q_local,
+                           const unsigned char* pt_clustered, const double* Epose, const double* Eintr,
+                           const double* h, int NPs, double* part_pp, double* part_ip, double* part_ii);
 // off_img[i] / off_cam[c]: first matrix column of image i's pose block / camera c's intrinsics block
 // (the matrix is assembled in the factorisation's elimination order, the vectors keep the variables' order).
 void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blocks,

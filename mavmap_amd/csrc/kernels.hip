@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(256) k_schur_chunks(int num_chunks, const Schu
       for (int r = 0; r < RX; ++r) ev[r] += px[RX * 3 + r];
     }
   }
-  double* out = partial + (size_t)cid * PS;
+  double* out = partial + (size_t)ch.slot * PS;
 #pragma unroll
   for (int i = 0; i < NA; ++i) { const double v = wave_sum(acc[i]); if (lane == 0) out[i] = v; }
   if (DIAG) {
@@ -835,6 +835,183 @@ __global__ void __launch_bounds__(256) k_schur_chunks(int num_chunks, const Schu
     for (int r = 0; r < RX; ++r) { const double v = wave_sum(ev[r]); if (lane == 0) out[NA + r] = v; }
   }
 }
+
+// ---------------------------------------------------------------------------
+// Schur clusters (layout in internal.h): one work-group per cluster. The stacked entry matrix E of a batch
+// of kClBatch points is built in LDS (128 rows x 96 columns, pitch 100 -> conflict-free operand reads), and
+// S_cl += E E^T runs on v_mfma_f64_16x16x4_f64: the 36 lower 16x16 tiles are dealt round-robin to the 4
+// waves (9 accumulators each); both operands of a tile are rows of E, so a k-step costs 8 LDS reads and 9
+// matrix instructions per wave. 53 KB of LDS -> three work-groups per CU: one fetches its next batch while
+// the others keep the matrix cores busy. Every entry record is read from HBM exactly once per linear solve.
+// ---------------------------------------------------------------------------
+namespace {
+typedef double cl_d4 __attribute__((ext_vector_type(4)));
+constexpr int kClK = 3 * kClBatch, kClPitch = kClK + 4;
+constexpr int kClThreads = 256, kClWaves = kClThreads / 64, kClAcc = (36 + kClWaves - 1) / kClWaves;
+template <int W>
+__device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int lane, cl_d4 (&acc)[kClAcc]) {
+  const int li = lane & 15, lk = lane >> 4;
+  const double* base = E + li * kClPitch + lk;
+#pragma unroll 2
+  for (int kk = 0; kk < kClK; kk += 4) {
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = base[16 * i * kClPitch + kk];
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        if (t % kClWaves == W) acc[t / kClWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], a[j], acc[t / kClWaves], 0, 0, 0);
+        ++t;
+      }
+  }
+}
+// element (R, C), R >= C, of the cluster's product -> partial slot
+__device__ __forceinline__ void cluster_store(int R, int C, double v, const int* __restrict__ tab,
+                                              double* __restrict__ part_pp, double* __restrict__ part_ip,
+                                              double* __restrict__ part_ii) {
+  if (R < 96) {                       // pose x pose
+    const int la = R / 6, r = R - 6 * la, lb = C / 6, c = C - 6 * lb;
+    if (la == lb && r < c) return;    // diagonal blocks: the finalize pass only reads r >= c
+    const int slot = tab[kClTabPP + la * (la + 1) / 2 + lb];
+    if (slot >= 0) part_pp[(size_t)slot * 42 + r * 6 + c] = v;
+  } else if (R < kClHRow) {
+    const int lc = (R - 96) / 9, r = (R - 96) - 9 * lc;
+    if (C < 96) {                     // intrinsics x pose
+      const int la = C / 6, c = C - 6 * la;
+      const int slot = tab[kClTabIP + lc * kClImages + la];
+      if (slot >= 0) part_ip[(size_t)slot * 54 + r * 6 + c] = v;
+    } else {                          // intrinsics x intrinsics
+      const int lc2 = (C - 96) / 9, c = (C - 96) - 9 * lc2;
+      if (lc == lc2 && r < c) return;
+      const int slot = tab[kClTabII + lc * (lc + 1) / 2 + lc2];
+      if (slot >= 0) part_ii[(size_t)slot * 90 + r * 9 + c] = v;
+    }
+  } else if (R == kClHRow) {          // h row: the right-hand-side parts of the diagonal blocks
+    if (C < 96) {
+      const int la = C / 6, r = C - 6 * la;
+      const int slot = tab[kClTabPP + la * (la + 1) / 2 + la];
+      if (slot >= 0) part_pp[(size_t)slot * 42 + 36 + r] = v;
+    } else if (C < kClHRow) {
+      const int lc = (C - 96) / 9, r = (C - 96) - 9 * lc;
+      const int slot = tab[kClTabII + lc * (lc + 1) / 2 + lc];
+      if (slot >= 0) part_ii[(size_t)slot * 90 + 81 + r] = v;
+    }
+  }
+}
+template <int W>
+__device__ __forceinline__ void cluster_emit(int lane, const cl_d4 (&acc)[kClAcc], const int* __restrict__ tab,
+                                             double* __restrict__ part_pp, double* __restrict__ part_ip,
+                                             double* __restrict__ part_ii) {
+  const int li = lane & 15, lk = lane >> 4;
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      if (t % kClWaves == W) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int R = 16 * i + lk + 4 * r, C = 16 * j + li;  // D layout of the matrix instruction
+          if (R >= C) cluster_store(R, C, acc[t / kClWaves][r], tab, part_pp, part_ip, part_ii);
+        }
+      }
+      ++t;
+    }
+}
+}  // namespace
+
+namespace {
+constexpr int kClChunk = 6;  // loads a thread keeps in flight before it scatters them into the LDS matrix
+// Records of one batch, HBM -> LDS matrix. Element e of a record sits at (row e / 3, column e % 3) relative to
+// the record's base (row 6 la or 96 + 9 lc, column 3 * point-in-batch).
+template <int REC, int USED>
+__device__ __forceinline__ void cluster_load(double* __restrict__ E, int tid, int first, int count,
+                                             int b0, int row0, int row_step, const int* __restrict__ rec_pt,
+                                             const unsigned char* __restrict__ rec_local,
+                                             const double* __restrict__ rec) {
+  constexpr int H = REC / 2;
+  // (the range also holds the records of points that are not in the cluster - long tracks between clustered
+  // points - so its length is not bounded by the cluster's capacity)
+  const int ntot = count * H, u_end = (ntot + kClThreads - 1) / kClThreads;
+  for (int uc = 0; uc < u_end; uc += kClChunk) {
+    double2 v[kClChunk];
+    int vb[kClChunk];
+#pragma unroll
+    for (int u = 0; u < kClChunk; ++u) {
+      const int f = (uc + u) * kClThreads + tid;
+      vb[u] = -1;
+      if (uc + u < u_end && f < ntot) {
+        const int oo = f / H, e2 = (f - oo * H) * 2, o = first + oo;
+        const int l = rec_local[o];
+        if (l != 255 && e2 < USED) {
+          v[u] = *reinterpret_cast<const double2*>(rec + (size_t)o * REC + e2);
+          vb[u] = (row0 + row_step * l + e2 / 3) * kClPitch + 3 * (rec_pt[o] - b0) + e2 % 3;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kClChunk; ++u)
+      if (vb[u] >= 0) {
+        const int f = (uc + u) * kClThreads + tid, e2 = (f % H) * 2;
+        E[vb[u]] = v[u].x;
+        if (e2 + 1 < USED) E[vb[u] + ((e2 % 3 == 2) ? kClPitch - 2 : 1)] = v[u].y;
+      }
+  }
+}
+}  // namespace
+
+__global__ void __launch_bounds__(kClThreads, 2) k_schur_clusters(
+    const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ pt_start,
+    const int* __restrict__ q_start, const int* __restrict__ obs_pt, const int* __restrict__ q_pt,
+    const unsigned char* __restrict__ obs_local, const unsigned char* __restrict__ q_local,
+    const unsigned char* __restrict__ pt_clustered, const double* __restrict__ Epose,
+    const double* __restrict__ Eintr, const double* __restrict__ h, int NPs, double* __restrict__ part_pp,
+    double* __restrict__ part_ip, double* __restrict__ part_ii) {
+  __shared__ __attribute__((aligned(16))) double E[kClRows * kClPitch];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const SchurCluster cl = clusters[blockIdx.x];
+  cl_d4 acc[kClAcc];
+#pragma unroll
+  for (int i = 0; i < kClAcc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
+  for (int b0 = cl.p0; b0 < cl.p1; b0 += kClBatch) {
+    const int b1 = min(b0 + kClBatch, cl.p1);
+    for (int i = tid; i < kClRows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
+    __syncthreads();
+    cluster_load<kPoseRec, 18>(E, tid, pt_start[b0], pt_start[b1] - pt_start[b0], b0, 0, 6, obs_pt, obs_local, Epose);
+    cluster_load<kIntrRec, 27>(E, tid, q_start[b0], q_start[b1] - q_start[b0], b0, 96, 9, q_pt, q_local, Eintr);
+    if (tid < (b1 - b0) * 3) {
+      const int pp = tid / 3, t = tid - 3 * pp;
+      if (pt_clustered[b0 + pp]) E[kClHRow * kClPitch + tid] = h[(size_t)t * NPs + b0 + pp];
+    }
+    __syncthreads();
+    switch (wv) {
+      case 0: cluster_mfma<0>(E, lane, acc); break;
+      case 1: cluster_mfma<1>(E, lane, acc); break;
+      case 2: cluster_mfma<2>(E, lane, acc); break;
+      default: cluster_mfma<3>(E, lane, acc); break;
+    }
+    __syncthreads();
+  }
+  const int* tab = tabs + (size_t)blockIdx.x * kClTab;
+  switch (wv) {
+    case 0: cluster_emit<0>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 1: cluster_emit<1>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 2: cluster_emit<2>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    default: cluster_emit<3>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+  }
+}
+void launch_schur_clusters(hipStream_t st, int num_clusters, const SchurCluster* clusters, const int* tab,
+                           const int* pt_start, const int* q_start, const int* obs_pt, const int* q_pt,
+                           const unsigned char* obs_local, const unsigned char* q_local,
+                           const unsigned char* pt_clustered, const double* Epose, const double* Eintr,
+                           const double* h, int NPs, double* part_pp, double* part_ip, double* part_ii) {
+  if (num_clusters <= 0) return;
+  hipLaunchKernelGGL(k_schur_clusters, dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start, q_start, obs_pt, q_pt,
+                     obs_local, q_local, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii);
+}
+
 int schur_partial_stride(int kind) { return kind == BLK_PP ? 42 : kind == BLK_IP ? 54 : 90; }
 void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurChunk* chunks,
                          const int2* terms, const double* Epose, const double* Eintr, double* partial) {

@@ -99,6 +99,9 @@ struct mavba_session {
   std::vector<int> h_cam_model, h_img_cam, h_pt_start, h_oimg;
   std::vector<long long> perm;      // point-major position -> caller observation index
   std::vector<int> h_pt_count_all;  // observations per point in the caller's problem
+  // Points are renumbered at session creation (sorted by their image lists, so that neighbours in the order
+  // see the same images: the Schur-complement clusters rely on it). h_pt_orig[internal] = caller's index.
+  std::vector<int> h_pt_orig;
   std::vector<unsigned char> h_pose_const, h_intr_const_in, h_pt_const_in;
   std::vector<unsigned char> h_img_used, h_cam_used, h_pt_used;
   std::vector<unsigned char> h_pose_free, h_intr_free, h_pt_free;
@@ -118,6 +121,11 @@ struct mavba_session {
   DevBuf<double> d_prior_R0;
   DevBuf<SchurBlock> d_blocks;
   DevBuf<SchurChunk> d_chunks[3];
+  DevBuf<SchurCluster> d_clusters;
+  DevBuf<int> d_cl_tab;
+  DevBuf<unsigned char> d_obs_local, d_q_local, d_pt_clustered;
+  int num_clusters = 0, num_slots[3] = {0, 0, 0};
+  long long clustered_points = 0, cluster_partials = 0;
   DevBuf<int2> d_terms[3];
   int num_blocks = 0, num_chunks[3] = {0, 0, 0};
   long long num_terms[3] = {0, 0, 0};
@@ -227,6 +235,10 @@ struct mavba_session {
   void start();
   int iterate(int max_iters, int* done);
   void point_errors(double* out);
+  void to_caller_points(const double* internal, double* out, int width) const {
+    for (int q = 0; q < NP; ++q)
+      for (int e = 0; e < width; ++e) out[(size_t)h_pt_orig[q] * width + e] = internal[(size_t)q * width + e];
+  }
   void fill_result(mavba_result* r);
 };
 
@@ -348,14 +360,62 @@ void mavba_session::build(const mavba_problem* P) {
   num_residuals = 2 * NO_all + P->num_rot_priors;
   num_residuals_reduced = 2ll * N + num_priors;
 
+  // ---- internal point order: lexicographic by the sorted list of images that see the point ----
+  std::vector<int> pt_new(NP);
+  {
+    std::vector<int> cstart(NP + 1, 0);
+    for (int k = 0; k < N; ++k) cstart[P->obs_point[kept[k]] + 1]++;
+    for (int p = 0; p < NP; ++p) cstart[p + 1] += cstart[p];
+    std::vector<int> simg(std::max(N, 1));
+    {
+      std::vector<int> cur(cstart.begin(), cstart.end() - 1);
+      for (int k = 0; k < N; ++k) simg[cur[P->obs_point[kept[k]]]++] = P->obs_image[kept[k]];
+    }
+    parallel_ranges(NP, [&](long long b0, long long b1) {
+      for (long long p = b0; p < b1; ++p) std::sort(simg.begin() + cstart[p], simg.begin() + cstart[p + 1]);
+    });
+    h_pt_orig.resize(NP);
+    for (int p = 0; p < NP; ++p) h_pt_orig[p] = p;
+    auto before = [&](int a, int b) {
+      const int* xa = simg.data() + cstart[a]; const int* xb = simg.data() + cstart[b];
+      const int na = cstart[a + 1] - cstart[a], nb = cstart[b + 1] - cstart[b];
+      const int n = std::min(na, nb);
+      for (int i = 0; i < n; ++i) if (xa[i] != xb[i]) return xa[i] < xb[i];
+      if (na != nb) return na < nb;
+      return a < b;
+    };
+    // sorted runs on a few threads, then pairwise merges (the comparator is a strict total order)
+    const int T = NP >= 100000 ? (int)std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    std::vector<int> cut(T + 1);
+    for (int t = 0; t <= T; ++t) cut[t] = (int)((long long)NP * t / T);
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] { std::sort(h_pt_orig.begin() + cut[t], h_pt_orig.begin() + cut[t + 1], before); });
+      for (auto& x : th) x.join();
+    }
+    for (int w = 1; w < T; w *= 2)
+      for (int t = 0; t + w < T; t += 2 * w)
+        std::inplace_merge(h_pt_orig.begin() + cut[t], h_pt_orig.begin() + cut[t + w],
+                           h_pt_orig.begin() + cut[std::min(t + 2 * w, T)], before);
+    for (int q = 0; q < NP; ++q) pt_new[h_pt_orig[q]] = q;
+    auto permute = [&](auto& v, int width) {
+      auto old = v;
+      for (int q = 0; q < NP; ++q)
+        for (int e = 0; e < width; ++e) v[(size_t)q * width + e] = old[(size_t)h_pt_orig[q] * width + e];
+    };
+    permute(h_points0, 3); permute(h_pt_const_in, 1); permute(h_pt_count_all, 1); permute(h_pt_used, 1);
+  }
+  lap("point order");
+
   // ---- point-major order (stable counting sort by point) ----
   h_pt_start.assign(NP + 1, 0);
-  for (int k = 0; k < N; ++k) h_pt_start[P->obs_point[kept[k]] + 1]++;
+  for (int k = 0; k < N; ++k) h_pt_start[pt_new[P->obs_point[kept[k]]] + 1]++;
   for (int p = 0; p < NP; ++p) h_pt_start[p + 1] += h_pt_start[p];
   perm.assign(N, 0);
   {
     std::vector<int> cur(h_pt_start.begin(), h_pt_start.end() - 1);
-    for (int k = 0; k < N; ++k) perm[cur[P->obs_point[kept[k]]]++] = kept[k];
+    for (int k = 0; k < N; ++k) perm[cur[pt_new[P->obs_point[kept[k]]]]++] = kept[k];
   }
   std::vector<double2> uv(N);
   std::vector<int> opt_(N);
@@ -364,7 +424,7 @@ void mavba_session::build(const mavba_problem* P) {
     for (long long a = b0; a < b1; ++a) {
       const long long o = perm[a];
       uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
-      h_oimg[a] = P->obs_image[o]; opt_[a] = P->obs_point[o];
+      h_oimg[a] = P->obs_image[o]; opt_[a] = pt_new[P->obs_point[o]];
     }
   });
 
@@ -627,10 +687,96 @@ void mavba_session::finish_structure() {
   d_Wk.alloc((size_t)std::max(Q, 1) * 27);
 
   lap("flags + intr entries");
+  // ---- point clusters (k_schur_clusters): consecutive points whose images / cameras fit one local list ----
+  // pt_mode: 0 = contributes nothing, 1 = clustered, 2 = generic term lists (long tracks, an image seen twice,
+  // more shared cameras than a cluster holds)
+  std::vector<unsigned char> pt_mode(NP, 0), obs_local((size_t)std::max(N, 1), 255), q_local((size_t)std::max(Q, 1), 255);
+  std::vector<SchurCluster> clusters;
+  std::vector<int> cl_imgs, cl_cams;  // [cluster][kClImages] / [cluster][kClCams], ascending, -1 padded
+  {
+    bool use_clusters = true;
+    if (const char* e = std::getenv("MAVBA_CLUSTERS")) use_clusters = std::atoi(e) != 0;
+    int kMaxPoints = 128;
+    if (const char* e = std::getenv("MAVBA_CLUSTER_POINTS")) kMaxPoints = std::max(1, std::atoi(e));
+    std::vector<int> cur_i, cur_c, mi, mc, pi;
+    int cur_p0 = 0, cur_n = 0;
+    auto close = [&](int p_end) {
+      if (cur_n > 0) {
+        clusters.push_back(SchurCluster{cur_p0, p_end});
+        for (int k = 0; k < kClImages; ++k) cl_imgs.push_back(k < (int)cur_i.size() ? cur_i[k] : -1);
+        for (int k = 0; k < kClCams; ++k) cl_cams.push_back(k < (int)cur_c.size() ? cur_c[k] : -1);
+      }
+      cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end;
+    };
+    for (int p = 0; p < NP; ++p) {
+      if (!h_pt_free[p]) continue;
+      pi.clear();
+      for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) if (img_active[h_oimg[a]]) pi.push_back(h_oimg[a]);
+      const int nq = q_start[p + 1] - q_start[p];
+      if (pi.empty() && nq == 0) continue;
+      std::sort(pi.begin(), pi.end());
+      const bool dup = std::adjacent_find(pi.begin(), pi.end()) != pi.end();
+      if (!use_clusters || dup || (int)pi.size() > kClImages || nq > kClCams) { pt_mode[p] = 2; continue; }
+      auto merged_sizes = [&]() {
+        mi.clear(); mc.clear();
+        std::set_union(cur_i.begin(), cur_i.end(), pi.begin(), pi.end(), std::back_inserter(mi));
+        std::set_union(cur_c.begin(), cur_c.end(), q_cam.begin() + q_start[p], q_cam.begin() + q_start[p + 1], std::back_inserter(mc));
+      };
+      merged_sizes();
+      if ((int)mi.size() > kClImages || (int)mc.size() > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= 4 * kMaxPoints) {
+        close(p);
+        merged_sizes();
+      }
+      if (cur_n == 0) cur_p0 = p;
+      cur_i.swap(mi); cur_c.swap(mc);
+      ++cur_n;
+      pt_mode[p] = 1;
+    }
+    close(NP);
+  }
+  num_clusters = (int)clusters.size();
+  // local indices of every clustered observation / intrinsics entry, and which blocks a cluster touches
+  std::vector<unsigned char> cl_present((size_t)std::max(num_clusters, 1) * kClTab, 0);
+  parallel_ranges(num_clusters, [&](long long c0, long long c1) {
+    int loc[kClImages];
+    for (long long cl = c0; cl < c1; ++cl) {
+      const int* imgs = &cl_imgs[(size_t)cl * kClImages];
+      const int* cams = &cl_cams[(size_t)cl * kClCams];
+      int ni = 0, nc = 0;
+      while (ni < kClImages && imgs[ni] >= 0) ++ni;
+      while (nc < kClCams && cams[nc] >= 0) ++nc;
+      unsigned char* pres = &cl_present[(size_t)cl * kClTab];
+      for (int p = clusters[cl].p0; p < clusters[cl].p1; ++p) {
+        if (pt_mode[p] != 1) continue;
+        int n = 0;
+        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
+          if (!img_active[h_oimg[a]]) continue;
+          const int l = (int)(std::lower_bound(imgs, imgs + ni, h_oimg[a]) - imgs);
+          obs_local[a] = (unsigned char)l;
+          loc[n++] = l;
+        }
+        for (int x = 0; x < n; ++x)
+          for (int y = 0; y < n; ++y)
+            if (loc[x] >= loc[y]) pres[kClTabPP + loc[x] * (loc[x] + 1) / 2 + loc[y]] = 1;
+        for (int q = q_start[p]; q < q_start[p + 1]; ++q) {
+          const int lc = (int)(std::lower_bound(cams, cams + nc, q_cam[q]) - cams);
+          q_local[q] = (unsigned char)lc;
+          for (int x = 0; x < n; ++x) pres[kClTabIP + lc * kClImages + loc[x]] = 1;
+          for (int q2 = q_start[p]; q2 <= q; ++q2) {
+            const int lc2 = (int)(std::lower_bound(cams, cams + nc, q_cam[q2]) - cams);
+            pres[kClTabII + lc * (lc + 1) / 2 + lc2] = 1;
+          }
+        }
+      }
+    }
+  });
+  clustered_points = 0;
+  for (int p = 0; p < NP; ++p) clustered_points += pt_mode[p] == 1;
+  lap("point clusters");
   // term enumeration over a range of points: f(kind, row_ent, col_ent, x, y)
   auto enumerate = [&](int p_begin, int p_end, auto&& f) {
     for (int p = p_begin; p < p_end; ++p) {
-      if (!h_pt_free[p]) continue;
+      if (pt_mode[p] != 2) continue;  // clustered points never become terms
       const int a0 = h_pt_start[p], a1 = h_pt_start[p + 1], q0 = q_start[p], q1 = q_start[p + 1];
       for (int a = a0; a < a1; ++a) {
         const int i = h_oimg[a];
@@ -691,6 +837,34 @@ void mavba_session::finish_structure() {
     if (cam_active[h_img_cam[i]]) mandatory[BLK_IP][(size_t)h_img_cam[i] * NI + i] = 1;
   }
   for (int c = 0; c < NC; ++c) if (cam_active[c]) mandatory[BLK_II][(size_t)c * NC + c] = 1;
+  // blocks a cluster touches get one partial slot per cluster
+  std::vector<int> cref[3];
+  for (int k = 0; k < 3; ++k) cref[k].assign(nkeys[k], 0);
+  auto cluster_key = [&](long long cl, int slot, int& kind) -> size_t {
+    const int* imgs = &cl_imgs[(size_t)cl * kClImages];
+    const int* cams = &cl_cams[(size_t)cl * kClCams];
+    if (slot < kClTabIP) {
+      int la = 0;
+      while ((la + 1) * (la + 2) / 2 <= slot) ++la;
+      const int lb = slot - la * (la + 1) / 2;
+      kind = BLK_PP;
+      return (size_t)imgs[la] * NI + imgs[lb];
+    }
+    if (slot < kClTabII) {
+      const int lc = (slot - kClTabIP) / kClImages, la = (slot - kClTabIP) % kClImages;
+      kind = BLK_IP;
+      return (size_t)cams[lc] * NI + imgs[la];
+    }
+    int lc = 0;
+    const int sl = slot - kClTabII;
+    while ((lc + 1) * (lc + 2) / 2 <= sl) ++lc;
+    kind = BLK_II;
+    return (size_t)cams[lc] * NC + cams[sl - lc * (lc + 1) / 2];
+  };
+  cluster_partials = 0;
+  for (long long cl = 0; cl < num_clusters; ++cl)
+    for (int sl = 0; sl < kClTab; ++sl)
+      if (cl_present[(size_t)cl * kClTab + sl]) { int kind; const size_t key = cluster_key(cl, sl, kind); cref[kind][key]++; ++cluster_partials; }
   lap("count terms");
   for (int k = 0; k < 3; ++k)
     if (tot[k] >= (1ll << 31) - 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 Schur terms of one kind");
@@ -714,7 +888,7 @@ void mavba_session::finish_structure() {
     cursor[k].assign(count[k].size(), 0);
     std::vector<size_t> keys;
     for (size_t key = 0; key < count[k].size(); ++key)
-      if (count[k][key] != 0 || mandatory[k][key]) keys.push_back(key);
+      if (count[k][key] != 0 || mandatory[k][key] || cref[k][key] != 0) keys.push_back(key);
     if (k == BLK_PP) {
       const long long nc = ncols[k];
       std::stable_sort(keys.begin(), keys.end(), [&](size_t a, size_t b) {
@@ -727,21 +901,31 @@ void mavba_session::finish_structure() {
       const long long nc = ncols[k];
       std::stable_sort(keys.begin(), keys.end(), [&](size_t a, size_t b) { return a % nc < b % nc; });
     }
-    int off = 0;
+    int off = 0, slot = 0;
     for (size_t key : keys) {
       const int cnt = count[k][key];
       SchurBlock B;
       B.kind = k; B.row_ent = (int)(key / ncols[k]); B.col_ent = (int)(key % ncols[k]);
-      B.chunk_begin = (int)chunks[k].size();
+      // the block's partials: its term-list chunks, then one slot per cluster that touches it
+      B.chunk_begin = slot;
       const int ct = block_chunk_terms(cnt);
       for (int b0 = off; b0 < off + cnt; b0 += ct)
-        chunks[k].push_back(SchurChunk{b0, std::min(b0 + ct, off + cnt)});
-      B.chunk_end = (int)chunks[k].size();
+        chunks[k].push_back(SchurChunk{b0, std::min(b0 + ct, off + cnt), slot++});
+      const int nref = cref[k][key];
+      cref[k][key] = slot;  // from here on: the next free cluster slot of this block
+      slot += nref;
+      B.chunk_end = slot;
       blocks.push_back(B);
       cursor[k][key] = off;
       off += cnt;
     }
+    num_slots[k] = slot;
   }
+  // slot tables of the clusters (clusters in order -> a block's partials are added in a fixed order)
+  std::vector<int> cl_tab((size_t)std::max(num_clusters, 1) * kClTab, -1);
+  for (long long cl = 0; cl < num_clusters; ++cl)
+    for (int sl = 0; sl < kClTab; ++sl)
+      if (cl_present[(size_t)cl * kClTab + sl]) { int kind; const size_t key = cluster_key(cl, sl, kind); cl_tab[(size_t)cl * kClTab + sl] = cref[kind][key]++; }
   lap("order blocks + chunks");
   std::unique_ptr<int2[]> terms[3];  // uninitialised on purpose: first touched by the filling threads
   for (int k = 0; k < 3; ++k) terms[k].reset(new int2[std::max<size_t>((size_t)tot[k], 1)]);
@@ -767,7 +951,13 @@ void mavba_session::finish_structure() {
     d_chunks[k].upload(chunks[k], st);
     d_terms[k].alloc(std::max<size_t>((size_t)tot[k], 1));
     if (tot[k]) HIP_OK(hipMemcpyAsync(d_terms[k].p, terms[k].get(), (size_t)tot[k] * sizeof(int2), hipMemcpyHostToDevice, st));
-    d_part[k].alloc((size_t)std::max(num_chunks[k], 1) * schur_partial_stride(k));
+    d_part[k].alloc((size_t)std::max(num_slots[k], 1) * schur_partial_stride(k));
+  }
+  {
+    std::vector<unsigned char> ptc(std::max(NP, 1), 0);
+    for (int p = 0; p < NP; ++p) ptc[p] = pt_mode[p] == 1;
+    d_clusters.upload(clusters, st); d_cl_tab.upload(cl_tab, st);
+    d_obs_local.upload(obs_local, st); d_q_local.upload(q_local, st); d_pt_clustered.upload(ptc, st);
   }
   sync();
   lap("upload terms");
@@ -857,6 +1047,11 @@ void mavba_session::assemble(double r) {
                         d_Eintr.p);
   });
   timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st)); });
+  timed("schur_clusters", [&] {
+    launch_schur_clusters(st, num_clusters, d_clusters.p, d_cl_tab.p, d_pt_start.p, d_q_start.p, d_obs_pt.p, d_q_pt.p,
+                          d_obs_local.p, d_q_local.p, d_pt_clustered.p, d_Epose.p, d_Eintr.p, d_h.p, NPs, d_part[0].p,
+                          d_part[1].p, d_part[2].p);
+  });
   timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
   timed("schur_chunks_ip", [&] { launch_schur_chunks(st, BLK_IP, num_chunks[1], d_chunks[1].p, d_terms[1].p, d_Epose.p, d_Eintr.p, d_part[1].p); });
   timed("schur_chunks_ii", [&] { launch_schur_chunks(st, BLK_II, num_chunks[2], d_chunks[2].p, d_terms[2].p, d_Epose.p, d_Eintr.p, d_part[2].p); });
@@ -986,7 +1181,7 @@ void mavba_session::point_errors(double* out) {
   // Only points that have observations in the problem are touched (bundle_adjustment.cc:578-581);
   // observations dropped as all-constant blocks still count (they are residual blocks there).
   for (int p = 0; p < NP; ++p)
-    if (h_pt_count_all[p] > 0) out[p] = h[p];
+    if (h_pt_count_all[p] > 0) out[h_pt_orig[p]] = h[p];
 }
 
 void mavba_session::fill_result(mavba_result* r) {
@@ -1101,8 +1296,10 @@ int mavba_session_get_params(mavba_session* s, double* poses, double* intrinsics
   MAVBA_TRY
   if (poses && s->NI) HIP_OK(hipMemcpyAsync(poses, s->d_poses.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
   if (intrinsics && s->NC) HIP_OK(hipMemcpyAsync(intrinsics, s->d_intr.p, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
-  if (points && s->NP) HIP_OK(hipMemcpyAsync(points, s->d_points.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st));
+  std::vector<double> hp;
+  if (points && s->NP) { hp.resize((size_t)s->NP * 3); HIP_OK(hipMemcpyAsync(hp.data(), s->d_points.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st)); }
   s->sync();
+  if (points) s->to_caller_points(hp.data(), points, 3);
   return MAVBA_OK;
   MAVBA_CATCH
 }
@@ -1215,8 +1412,10 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, 
   if (model_cost_change) *model_cost_change = h[SC_MODEL_CHANGE];
   if (d_poses && s->NI) HIP_OK(hipMemcpyAsync(d_poses, s->d_delta_cam.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
   if (d_intr && s->NC) HIP_OK(hipMemcpyAsync(d_intr, s->d_delta_cam.p + 6 * (size_t)s->NI, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
-  if (d_points && s->NP) HIP_OK(hipMemcpyAsync(d_points, s->d_delta_pts.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st));
+  std::vector<double> hdp;
+  if (d_points && s->NP) { hdp.resize((size_t)s->NP * 3); HIP_OK(hipMemcpyAsync(hdp.data(), s->d_delta_pts.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st)); }
   s->sync();
+  if (d_points) s->to_caller_points(hdp.data(), d_points, 3);
   if (h[SC_FAIL] != 0.0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "linear solve failed (matrix not positive definite)");
   return MAVBA_OK;
   MAVBA_CATCH
@@ -1259,6 +1458,9 @@ int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
   out->matrix_dim = s->n_mat;
   out->nd_parts = s->nd_parts;
   out->chain_steps = cs.chain_steps;
+  out->num_clusters = s->num_clusters;
+  out->clustered_points = s->clustered_points;
+  out->cluster_partials = s->cluster_partials;
   const double n = (double)s->n_full;
   out->dense_factor_flops = n * n * n / 3.0 + 2.0 * n * n;
   return MAVBA_OK;
