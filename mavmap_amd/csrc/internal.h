@@ -52,6 +52,7 @@ struct SchurChunk { int begin; int end; int slot; };  // term range; slot = inde
 constexpr int kClImages = 16, kClCams = 3, kClRows = 128, kClHRow = 123;
 constexpr int kClBatch = 16;                     // points per LDS batch -> K = 48 columns
 constexpr int kClTabPP = 0, kClTabIP = 136, kClTabII = 136 + 48, kClTab = 136 + 48 + 6;
+constexpr int kClMaxBatches = 64;                // a cluster spans at most kClMaxBatches * kClBatch consecutive points
 struct SchurCluster { int p0, p1; };
 
 // Scalars exchanged with the host every LM iteration (device array of doubles).
@@ -133,11 +134,13 @@ void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurCh
                          const int2* terms, const double* Epose, const double* Eintr,
                          double* partial);
 int schur_partial_stride(int kind);
+// obs_meta / q_meta: per observation / intrinsics entry, local index << 8 | (point - cluster.p0) % kClBatch,
+// 0xFFFF for records that are not part of a cluster.
 void launch_schur_clusters(hipStream_t st, int num_clusters, const SchurCluster* clusters, const int* tab,
-                           const int* pt_start, const int* q_start, const int* obs_pt, const int* q_pt,
-                           const unsigned char* obs_local, const unsigned char* q_local,
-                           const unsigned char* pt_clustered, const double* Epose, const double* Eintr,
-                           const double* h, int NPs, double* part_pp, double* part_ip, double* part_ii);
+                           const int* pt_start, const int* q_start, const unsigned short* obs_meta,
+                           const unsigned short* q_meta, const unsigned char* pt_clustered, const double* Epose,
+                           const double* Eintr, const double* h, int NPs, double* part_pp, double* part_ip,
+                           double* part_ii);
 // off_img[i] / off_cam[c]: first matrix column of image i's pose block / camera c's intrinsics block
 // (the matrix is assembled in the factorisation's elimination order, the vectors keep the variables' order).
 void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blocks,

@@ -852,11 +852,16 @@ template <int W>
 __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int lane, cl_d4 (&acc)[kClAcc]) {
   const int li = lane & 15, lk = lane >> 4;
   const double* base = E + li * kClPitch + lk;
-#pragma unroll 2
-  for (int kk = 0; kk < kClK; kk += 4) {
-    double a[8];
+  // the operands of k-step kk + 4 are read from LDS while the matrix cores work on k-step kk
+  double a[8], an[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = base[16 * i * kClPitch + kk];
+  for (int i = 0; i < 8; ++i) a[i] = base[16 * i * kClPitch];
+#pragma unroll 1
+  for (int kk = 0; kk < kClK; kk += 4) {
+    if (kk + 4 < kClK) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) an[i] = base[16 * i * kClPitch + kk + 4];
+    }
     int t = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -865,6 +870,8 @@ __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int l
         if (t % kClWaves == W) acc[t / kClWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], a[j], acc[t / kClWaves], 0, 0, 0);
         ++t;
       }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = an[i];
   }
 }
 // element (R, C), R >= C, of the cluster's product -> partial slot
@@ -923,69 +930,109 @@ __device__ __forceinline__ void cluster_emit(int lane, const cl_d4 (&acc)[kClAcc
 }  // namespace
 
 namespace {
-constexpr int kClChunk = 6;  // loads a thread keeps in flight before it scatters them into the LDS matrix
+constexpr int kClChunk = 8, kClQChunk = 4;  // value loads a thread has in flight per batch (pose / intrinsics records)
 // Records of one batch, HBM -> LDS matrix. Element e of a record sits at (row e / 3, column e % 3) relative to
-// the record's base (row 6 la or 96 + 9 lc, column 3 * point-in-batch).
-template <int REC, int USED>
-__device__ __forceinline__ void cluster_load(double* __restrict__ E, int tid, int first, int count,
-                                             int b0, int row0, int row_step, const int* __restrict__ rec_pt,
-                                             const unsigned char* __restrict__ rec_local,
-                                             const double* __restrict__ rec) {
+// the record's base (row 6 la or 96 + 9 lc, column 3 * point-in-batch). Thread tid takes the double2 number
+// f = u * 256 + tid of the batch's contiguous record range. The value loads do not wait for the record's local
+// index (only the scatter does), so a batch costs ONE memory latency - and that one is spent while the matrix
+// cores work on the previous batch.
+template <int REC, int USED, int NU>
+struct ClusterRegs { double2 v[NU]; unsigned short meta[NU]; };  // meta = local index << 8 | point in batch (host-packed), 0xFFFF = not in the cluster
+template <int REC, int USED, int NU>
+__device__ __forceinline__ void cluster_fetch(ClusterRegs<REC, USED, NU>& R, int tid, int u0, int first, int count,
+                                              const unsigned short* __restrict__ rec_meta, const double* __restrict__ rec) {
   constexpr int H = REC / 2;
-  // (the range also holds the records of points that are not in the cluster - long tracks between clustered
-  // points - so its length is not bounded by the cluster's capacity)
-  const int ntot = count * H, u_end = (ntot + kClThreads - 1) / kClThreads;
-  for (int uc = 0; uc < u_end; uc += kClChunk) {
-    double2 v[kClChunk];
-    int vb[kClChunk];
+  const int ntot = count * H;
 #pragma unroll
-    for (int u = 0; u < kClChunk; ++u) {
-      const int f = (uc + u) * kClThreads + tid;
-      vb[u] = -1;
-      if (uc + u < u_end && f < ntot) {
-        const int oo = f / H, e2 = (f - oo * H) * 2, o = first + oo;
-        const int l = rec_local[o];
-        if (l != 255 && e2 < USED) {
-          v[u] = *reinterpret_cast<const double2*>(rec + (size_t)o * REC + e2);
-          vb[u] = (row0 + row_step * l + e2 / 3) * kClPitch + 3 * (rec_pt[o] - b0) + e2 % 3;
-        }
+  for (int u = 0; u < NU; ++u) {
+    const int f = (u0 + u) * kClThreads + tid;
+    R.meta[u] = 0xFFFFu;
+    if (f < ntot) {
+      const int oo = f / H, e2 = (f - oo * H) * 2, o = first + oo;
+      if (e2 < USED) {  // nothing below depends on a loaded value: the loads just go out
+        R.v[u] = *reinterpret_cast<const double2*>(rec + (size_t)o * REC + e2);
+        R.meta[u] = rec_meta[o];
       }
     }
+  }
+}
+template <int REC, int USED, int NU>
+__device__ __forceinline__ void cluster_scatter(const ClusterRegs<REC, USED, NU>& R, double* __restrict__ E, int tid, int u0,
+                                                int row0, int row_step) {
+  constexpr int H = REC / 2;
 #pragma unroll
-    for (int u = 0; u < kClChunk; ++u)
-      if (vb[u] >= 0) {
-        const int f = (uc + u) * kClThreads + tid, e2 = (f % H) * 2;
-        E[vb[u]] = v[u].x;
-        if (e2 + 1 < USED) E[vb[u] + ((e2 % 3 == 2) ? kClPitch - 2 : 1)] = v[u].y;
-      }
+  for (int u = 0; u < NU; ++u)
+    if (R.meta[u] != 0xFFFFu) {
+      const int f = (u0 + u) * kClThreads + tid, e2 = (f % H) * 2;
+      const int at = (row0 + row_step * (R.meta[u] >> 8) + e2 / 3) * kClPitch + 3 * (R.meta[u] & 255) + e2 % 3;
+      E[at] = R.v[u].x;
+      if (e2 + 1 < USED) E[at + ((e2 % 3 == 2) ? kClPitch - 2 : 1)] = R.v[u].y;
+    }
+}
+// what does not fit the prefetch registers (the range also holds the records of points that are not in the
+// cluster - long tracks between clustered points - so its length is not bounded by the cluster's capacity)
+template <int REC, int USED, int NU>
+__device__ __forceinline__ void cluster_overflow(double* __restrict__ E, int tid, int first, int count, int row0,
+                                                 int row_step, const unsigned short* __restrict__ rec_meta,
+                                                 const double* __restrict__ rec) {
+  const int u_end = (count * (REC / 2) + kClThreads - 1) / kClThreads;
+  for (int uc = NU; uc < u_end; uc += NU) {
+    ClusterRegs<REC, USED, NU> R;
+    cluster_fetch(R, tid, uc, first, count, rec_meta, rec);
+    cluster_scatter(R, E, tid, uc, row0, row_step);
   }
 }
 }  // namespace
 
-__global__ void __launch_bounds__(kClThreads, 2) k_schur_clusters(
+__global__ void __launch_bounds__(kClThreads) k_schur_clusters(
     const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ pt_start,
-    const int* __restrict__ q_start, const int* __restrict__ obs_pt, const int* __restrict__ q_pt,
-    const unsigned char* __restrict__ obs_local, const unsigned char* __restrict__ q_local,
-    const unsigned char* __restrict__ pt_clustered, const double* __restrict__ Epose,
-    const double* __restrict__ Eintr, const double* __restrict__ h, int NPs, double* __restrict__ part_pp,
-    double* __restrict__ part_ip, double* __restrict__ part_ii) {
+    const int* __restrict__ q_start, const unsigned short* __restrict__ obs_meta,
+    const unsigned short* __restrict__ q_meta, const unsigned char* __restrict__ pt_clustered,
+    const double* __restrict__ Epose, const double* __restrict__ Eintr, const double* __restrict__ h, int NPs,
+    double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
   __shared__ __attribute__((aligned(16))) double E[kClRows * kClPitch];
+  __shared__ int s_bounds[2][kClMaxBatches + 1];  // first observation / intrinsics entry of every batch
+  __shared__ int s_tab[kClTab];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const SchurCluster cl = clusters[blockIdx.x];
+  const int nbatch = (cl.p1 - cl.p0 + kClBatch - 1) / kClBatch;
+  for (int i = tid; i <= nbatch; i += kClThreads) {
+    const int p = min(cl.p0 + i * kClBatch, cl.p1);
+    s_bounds[0][i] = pt_start[p];
+    s_bounds[1][i] = q_start[p];
+  }
+  for (int i = tid; i < kClTab; i += kClThreads) s_tab[i] = tabs[(size_t)blockIdx.x * kClTab + i];
   cl_d4 acc[kClAcc];
 #pragma unroll
   for (int i = 0; i < kClAcc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
-  for (int b0 = cl.p0; b0 < cl.p1; b0 += kClBatch) {
-    const int b1 = min(b0 + kClBatch, cl.p1);
-    for (int i = tid; i < kClRows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
-    __syncthreads();
-    cluster_load<kPoseRec, 18>(E, tid, pt_start[b0], pt_start[b1] - pt_start[b0], b0, 0, 6, obs_pt, obs_local, Epose);
-    cluster_load<kIntrRec, 27>(E, tid, q_start[b0], q_start[b1] - q_start[b0], b0, 96, 9, q_pt, q_local, Eintr);
+  __syncthreads();
+  ClusterRegs<kPoseRec, 18, kClChunk> RP;
+  ClusterRegs<kIntrRec, 27, kClQChunk> RQ;
+  double hv = 0.0;
+  unsigned char hon = 0;
+  auto fetch = [&](int bi) {
+    const int b0 = cl.p0 + bi * kClBatch, b1 = min(b0 + kClBatch, cl.p1);
+    cluster_fetch(RP, tid, 0, s_bounds[0][bi], s_bounds[0][bi + 1] - s_bounds[0][bi], obs_meta, Epose);
+    cluster_fetch(RQ, tid, 0, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], q_meta, Eintr);
+    hon = 0;
     if (tid < (b1 - b0) * 3) {
       const int pp = tid / 3, t = tid - 3 * pp;
-      if (pt_clustered[b0 + pp]) E[kClHRow * kClPitch + tid] = h[(size_t)t * NPs + b0 + pp];
+      hon = pt_clustered[b0 + pp];
+      hv = h[(size_t)t * NPs + b0 + pp];
     }
+  };
+  fetch(0);
+  for (int bi = 0; bi < nbatch; ++bi) {
+    for (int i = tid; i < kClRows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
     __syncthreads();
+    cluster_scatter(RP, E, tid, 0, 0, 6);
+    cluster_scatter(RQ, E, tid, 0, 96, 9);
+    if (hon) E[kClHRow * kClPitch + tid] = hv;
+    cluster_overflow<kPoseRec, 18, kClChunk>(E, tid, s_bounds[0][bi], s_bounds[0][bi + 1] - s_bounds[0][bi], 0, 6, obs_meta, Epose);
+    cluster_overflow<kIntrRec, 27, kClQChunk>(E, tid, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], 96, 9, q_meta, Eintr);
+    __syncthreads();
+    if (bi + 1 < nbatch) fetch(bi + 1);  // travels while the matrix cores work on this batch
+    __builtin_amdgcn_sched_barrier(0);   // (keep the loads here: the scheduler would sink them to their use)
     switch (wv) {
       case 0: cluster_mfma<0>(E, lane, acc); break;
       case 1: cluster_mfma<1>(E, lane, acc); break;
@@ -994,7 +1041,7 @@ __global__ void __launch_bounds__(kClThreads, 2) k_schur_clusters(
     }
     __syncthreads();
   }
-  const int* tab = tabs + (size_t)blockIdx.x * kClTab;
+  const int* tab = s_tab;
   switch (wv) {
     case 0: cluster_emit<0>(lane, acc, tab, part_pp, part_ip, part_ii); break;
     case 1: cluster_emit<1>(lane, acc, tab, part_pp, part_ip, part_ii); break;
@@ -1003,13 +1050,13 @@ __global__ void __launch_bounds__(kClThreads, 2) k_schur_clusters(
   }
 }
 void launch_schur_clusters(hipStream_t st, int num_clusters, const SchurCluster* clusters, const int* tab,
-                           const int* pt_start, const int* q_start, const int* obs_pt, const int* q_pt,
-                           const unsigned char* obs_local, const unsigned char* q_local,
-                           const unsigned char* pt_clustered, const double* Epose, const double* Eintr,
-                           const double* h, int NPs, double* part_pp, double* part_ip, double* part_ii) {
+                           const int* pt_start, const int* q_start, const unsigned short* obs_meta,
+                           const unsigned short* q_meta, const unsigned char* pt_clustered, const double* Epose,
+                           const double* Eintr, const double* h, int NPs, double* part_pp, double* part_ip,
+                           double* part_ii) {
   if (num_clusters <= 0) return;
-  hipLaunchKernelGGL(k_schur_clusters, dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start, q_start, obs_pt, q_pt,
-                     obs_local, q_local, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii);
+  hipLaunchKernelGGL(k_schur_clusters, dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start, q_start,
+                     obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii);
 }
 
 int schur_partial_stride(int kind) { return kind == BLK_PP ? 42 : kind == BLK_IP ? 54 : 90; }

@@ -123,7 +123,8 @@ struct mavba_session {
   DevBuf<SchurChunk> d_chunks[3];
   DevBuf<SchurCluster> d_clusters;
   DevBuf<int> d_cl_tab;
-  DevBuf<unsigned char> d_obs_local, d_q_local, d_pt_clustered;
+  DevBuf<unsigned short> d_obs_meta, d_q_meta;
+  DevBuf<unsigned char> d_pt_clustered;
   int num_clusters = 0, num_slots[3] = {0, 0, 0};
   long long clustered_points = 0, cluster_partials = 0;
   DevBuf<int2> d_terms[3];
@@ -690,7 +691,8 @@ void mavba_session::finish_structure() {
   // ---- point clusters (k_schur_clusters): consecutive points whose images / cameras fit one local list ----
   // pt_mode: 0 = contributes nothing, 1 = clustered, 2 = generic term lists (long tracks, an image seen twice,
   // more shared cameras than a cluster holds)
-  std::vector<unsigned char> pt_mode(NP, 0), obs_local((size_t)std::max(N, 1), 255), q_local((size_t)std::max(Q, 1), 255);
+  std::vector<unsigned char> pt_mode(NP, 0);
+  std::vector<unsigned short> obs_meta((size_t)std::max(N, 1), 0xFFFFu), q_meta((size_t)std::max(Q, 1), 0xFFFFu);
   std::vector<SchurCluster> clusters;
   std::vector<int> cl_imgs, cl_cams;  // [cluster][kClImages] / [cluster][kClCams], ascending, -1 padded
   {
@@ -723,7 +725,7 @@ void mavba_session::finish_structure() {
         std::set_union(cur_c.begin(), cur_c.end(), q_cam.begin() + q_start[p], q_cam.begin() + q_start[p + 1], std::back_inserter(mc));
       };
       merged_sizes();
-      if ((int)mi.size() > kClImages || (int)mc.size() > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= 4 * kMaxPoints) {
+      if ((int)mi.size() > kClImages || (int)mc.size() > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1) {
         close(p);
         merged_sizes();
       }
@@ -752,7 +754,7 @@ void mavba_session::finish_structure() {
         for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
           if (!img_active[h_oimg[a]]) continue;
           const int l = (int)(std::lower_bound(imgs, imgs + ni, h_oimg[a]) - imgs);
-          obs_local[a] = (unsigned char)l;
+          obs_meta[a] = (unsigned short)(l << 8 | ((p - clusters[cl].p0) % kClBatch));
           loc[n++] = l;
         }
         for (int x = 0; x < n; ++x)
@@ -760,7 +762,7 @@ void mavba_session::finish_structure() {
             if (loc[x] >= loc[y]) pres[kClTabPP + loc[x] * (loc[x] + 1) / 2 + loc[y]] = 1;
         for (int q = q_start[p]; q < q_start[p + 1]; ++q) {
           const int lc = (int)(std::lower_bound(cams, cams + nc, q_cam[q]) - cams);
-          q_local[q] = (unsigned char)lc;
+          q_meta[q] = (unsigned short)(lc << 8 | ((p - clusters[cl].p0) % kClBatch));
           for (int x = 0; x < n; ++x) pres[kClTabIP + lc * kClImages + loc[x]] = 1;
           for (int q2 = q_start[p]; q2 <= q; ++q2) {
             const int lc2 = (int)(std::lower_bound(cams, cams + nc, q_cam[q2]) - cams);
@@ -957,7 +959,7 @@ void mavba_session::finish_structure() {
     std::vector<unsigned char> ptc(std::max(NP, 1), 0);
     for (int p = 0; p < NP; ++p) ptc[p] = pt_mode[p] == 1;
     d_clusters.upload(clusters, st); d_cl_tab.upload(cl_tab, st);
-    d_obs_local.upload(obs_local, st); d_q_local.upload(q_local, st); d_pt_clustered.upload(ptc, st);
+    d_obs_meta.upload(obs_meta, st); d_q_meta.upload(q_meta, st); d_pt_clustered.upload(ptc, st);
   }
   sync();
   lap("upload terms");
@@ -1048,9 +1050,9 @@ void mavba_session::assemble(double r) {
   });
   timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st)); });
   timed("schur_clusters", [&] {
-    launch_schur_clusters(st, num_clusters, d_clusters.p, d_cl_tab.p, d_pt_start.p, d_q_start.p, d_obs_pt.p, d_q_pt.p,
-                          d_obs_local.p, d_q_local.p, d_pt_clustered.p, d_Epose.p, d_Eintr.p, d_h.p, NPs, d_part[0].p,
-                          d_part[1].p, d_part[2].p);
+    launch_schur_clusters(st, num_clusters, d_clusters.p, d_cl_tab.p, d_pt_start.p, d_q_start.p, d_obs_meta.p,
+                          d_q_meta.p, d_pt_clustered.p, d_Epose.p, d_Eintr.p, d_h.p, NPs, d_part[0].p, d_part[1].p,
+                          d_part[2].p);
   });
   timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
   timed("schur_chunks_ip", [&] { launch_schur_chunks(st, BLK_IP, num_chunks[1], d_chunks[1].p, d_terms[1].p, d_Epose.p, d_Eintr.p, d_part[1].p); });
