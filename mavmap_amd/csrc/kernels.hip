@@ -852,26 +852,36 @@ template <int W>
 __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int lane, cl_d4 (&acc)[kClAcc]) {
   const int li = lane & 15, lk = lane >> 4;
   const double* base = E + li * kClPitch + lk;
-  // the operands of k-step kk + 4 are read from LDS while the matrix cores work on k-step kk
-  double a[8], an[8];
+  // Two operand register sets, no copies: the LDS reads of k-step kk + 4 are issued before the matrix
+  // instructions of k-step kk, so their latency hides behind those (copies between the sets made the
+  // compiler wait for the reads at the top of every step).
+  auto load = [&](double (&x)[8], int kk) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = base[16 * i * kClPitch];
-#pragma unroll 1
-  for (int kk = 0; kk < kClK; kk += 4) {
-    if (kk + 4 < kClK) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) an[i] = base[16 * i * kClPitch + kk + 4];
-    }
+    for (int i = 0; i < 8; ++i) x[i] = base[16 * i * kClPitch + kk];
+  };
+  auto mma = [&](const double (&x)[8]) {
     int t = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
-        if (t % kClWaves == W) acc[t / kClWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], a[j], acc[t / kClWaves], 0, 0, 0);
+        if (t % kClWaves == W) acc[t / kClWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], x[j], acc[t / kClWaves], 0, 0, 0);
         ++t;
       }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = an[i];
+  };
+  static_assert(kClK % 8 == 0, "two k-steps per trip");
+  double a[8], b[8];
+  load(a, 0);
+#pragma unroll 1
+  for (int kk = 0; kk < kClK; kk += 8) {
+    load(b, kk + 4);
+    __builtin_amdgcn_sched_barrier(0);  // reads first, then the matrix instructions they hide behind
+    mma(a);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kk + 8 < kClK) load(a, kk + 8);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(b);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // element (R, C), R >= C, of the cluster's product -> partial slot
@@ -930,7 +940,7 @@ __device__ __forceinline__ void cluster_emit(int lane, const cl_d4 (&acc)[kClAcc
 }  // namespace
 
 namespace {
-constexpr int kClChunk = 8, kClQChunk = 4;  // value loads a thread has in flight per batch (pose / intrinsics records)
+constexpr int kClChunk = kClImages * kClBatch * (kPoseRec / 2) / 256 * 2 / 3, kClQChunk = (kClCams * kClBatch * (kIntrRec / 2) + 255) / 256;  // value loads a thread has in flight per batch (pose / intrinsics records)
 // Records of one batch, HBM -> LDS matrix. Element e of a record sits at (row e / 3, column e % 3) relative to
 // the record's base (row 6 la or 96 + 9 lc, column 3 * point-in-batch). Thread tid takes the double2 number
 // f = u * 256 + tid of the batch's contiguous record range. The value loads do not wait for the record's local
