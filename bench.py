@@ -50,7 +50,12 @@ def algorithmic_work(stats_name, prob, sess_info):
     if stats_name == "cost_only":
         return "hbm", 48.0 * n_obs, "B"
     if stats_name in ("point_sums", "point_reduce"):
-        return "hbm", 64.0 * n_obs + 72.0 * n_pts, "B"
+        # r, Jp and the Jk planes (padded to the widest model) in; Cu, gu per point and Wk per (point, camera) out
+        kmax = int(K.max())
+        return "hbm", (64.0 + 16.0 * kmax) * n_obs + 72.0 * n_pts + 216.0 * sess_info["intr_entries"], "B"
+    if stats_name == "schur_clusters":
+        # E E^T on the matrix cores, structural zeros of the stacked entry matrix included
+        return "mfma", sess_info["cluster_flops"], "FLOP"
     if stats_name == "camera_sweep":
         return "hbm", 44.0 * n_obs, "B"
     if stats_name == "entries_pose":
@@ -72,7 +77,7 @@ PMC_KERNEL = {  # bench timer name -> rocprofv3 kernel-name prefix in profiles/*
     "jacobian_sweep": "k_jacobian_sweep", "cost_only": "k_cost_only", "point_reduce": "k_point_reduce",
     "camera_sweep": "k_camera_sweep", "entries_pose": "k_entries_pose", "entries_intr": "k_entries_intr",
     "backsub_points": "k_backsub_points", "schur_chunks_pp": "k_schur_chunks<6, 6", "schur_chunks_ip": "k_schur_chunks<9, 6",
-    "schur_chunks_ii": "k_schur_chunks<9, 9", "schur_finalize": "k_schur_finalize", "point_factor": "k_point_factor",
+    "schur_chunks_ii": "k_schur_chunks<9, 9", "schur_clusters": "k_schur_clusters", "schur_finalize": "k_schur_finalize", "point_factor": "k_point_factor",
 }
 
 
@@ -261,7 +266,9 @@ def main():
                         "launch from rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes in profiles/"},
             "reduced_system": {"n": info["reduced_dim"], "envelope_tiles": info["envelope_tiles"],
                                "dense_tiles": info["dense_tiles"], "matrix_dim": info["matrix_dim"], "nd_parts": info["nd_parts"],
-                               "chain_steps": info["chain_steps"], "factor_gflop_envelope": round(info["factor_flops"] / 1e9, 3),
+                               "chain_steps": info["chain_steps"], "schur_clusters": info["num_clusters"],
+                               "clustered_points": info["clustered_points"], "cluster_partials": info["cluster_partials"],
+                               "factor_gflop_envelope": round(info["factor_flops"] / 1e9, 3),
                                "factor_gflop_dense_equivalent": round(info["dense_factor_flops"] / 1e9, 3)},
             "cpu_baseline": cpu_baseline,
             "kernels": table,

@@ -281,6 +281,7 @@ typedef struct mavba_session_info {
   int32_t num_clusters;        /* point clusters of the Schur complement (k_schur_clusters)     */
   int64_t clustered_points;    /* points whose Schur terms are formed inside a cluster          */
   int64_t cluster_partials;    /* (cluster, block) partials the clusters emit per linear solve  */
+  double cluster_flops;        /* FP64 MFMA flops k_schur_clusters executes per linear solve (E E^T incl. structural zeros) */
 } mavba_session_info;
 int mavba_session_get_info(mavba_session* s, mavba_session_info* out);
 

@@ -81,7 +81,8 @@ class CSessionInfo(C.Structure):
                 ("envelope_tiles", C.c_int64), ("dense_tiles", C.c_int64), ("factor_flops", C.c_double),
                 ("dense_factor_flops", C.c_double), ("matrix_dim", C.c_int32), ("nd_parts", C.c_int32),
                 ("chain_steps", C.c_int32), ("num_clusters", C.c_int32),
-                ("clustered_points", C.c_int64), ("cluster_partials", C.c_int64)]
+                ("clustered_points", C.c_int64), ("cluster_partials", C.c_int64),
+                ("cluster_flops", C.c_double)]
 
 
 class CKernelStat(C.Structure):

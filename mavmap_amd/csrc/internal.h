@@ -38,7 +38,11 @@ struct SchurBlock {
   int row_ent, col_ent;
   int chunk_begin, chunk_end;
 };
-struct SchurChunk { int begin; int end; int slot; };  // term range; slot = index of the partial it writes
+struct SchurChunk { int begin; int end; int slot; };
+// Pre-reduction of a long run of partials of one block: partial[dst] = sum partial[src_begin..src_end) (fixed order)
+struct PartialReduce { int kind, src_begin, src_end, dst; };
+void launch_partial_reduce(hipStream_t st, int num_tasks, const PartialReduce* tasks, double* part_pp, double* part_ip,
+                           double* part_ii);  // term range; slot = index of the partial it writes
 
 // Point clusters of the Schur complement (k_schur_clusters): a run of consecutive points [p0, p1) whose
 // images fit a local list of kClImages and whose shared cameras fit kClCams. The cluster's contribution to

@@ -1082,6 +1082,33 @@ void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurCh
     hipLaunchKernelGGL((k_schur_chunks<9, 9, kIntrRec, kIntrRec, true>), g, b, 0, st, num_chunks, chunks, terms, Eintr, Eintr, partial);
 }
 
+// Blocks that many clusters touch (every cluster touches the intrinsics blocks) would make one finalize group add
+// thousands of partials one after the other: runs of 32 are summed here first, one wave per run, same fixed order.
+__global__ void __launch_bounds__(256) k_partial_reduce(int num_tasks, const PartialReduce* __restrict__ tasks,
+                                                        double* __restrict__ part_pp, double* __restrict__ part_ip,
+                                                        double* __restrict__ part_ii) {
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (task >= num_tasks) return;
+  const PartialReduce T = tasks[task];
+  double* part = T.kind == BLK_PP ? part_pp : T.kind == BLK_IP ? part_ip : part_ii;
+  const int PS = T.kind == BLK_PP ? 42 : T.kind == BLK_IP ? 54 : 90;
+  for (int idx = lane; idx < PS; idx += 64) {
+    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int c = T.src_begin;
+    for (; c + 8 <= T.src_end; c += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s8[u] += part[(size_t)(c + u) * PS + idx];
+    }
+    for (; c < T.src_end; ++c) s8[0] += part[(size_t)c * PS + idx];
+    part[(size_t)T.dst * PS + idx] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  }
+}
+void launch_partial_reduce(hipStream_t st, int num_tasks, const PartialReduce* tasks, double* part_pp, double* part_ip,
+                           double* part_ii) {
+  if (num_tasks <= 0) return;
+  hipLaunchKernelGGL(k_partial_reduce, dim3((num_tasks + 3) / 4), dim3(256), 0, st, num_tasks, tasks, part_pp, part_ip, part_ii);
+}
+
 // Finalize: one 64-lane group per block of S.
 //   S_blk = base - sum_chunks partial,   v_rows = base_g - sum_chunks e   (diagonal kinds)
 // base (only when add_base, i.e. on one rank): scaled F^T F + D^2 from the camera sums.

@@ -122,11 +122,14 @@ struct mavba_session {
   DevBuf<SchurBlock> d_blocks;
   DevBuf<SchurChunk> d_chunks[3];
   DevBuf<SchurCluster> d_clusters;
+  DevBuf<PartialReduce> d_reduce_tasks;
+  int num_reduce_tasks = 0;
   DevBuf<int> d_cl_tab;
   DevBuf<unsigned short> d_obs_meta, d_q_meta;
   DevBuf<unsigned char> d_pt_clustered;
   int num_clusters = 0, num_slots[3] = {0, 0, 0};
   long long clustered_points = 0, cluster_partials = 0;
+  double cluster_flops = 0.0;
   DevBuf<int2> d_terms[3];
   int num_blocks = 0, num_chunks[3] = {0, 0, 0};
   long long num_terms[3] = {0, 0, 0};
@@ -737,6 +740,9 @@ void mavba_session::finish_structure() {
     close(NP);
   }
   num_clusters = (int)clusters.size();
+  cluster_flops = 0.0;
+  for (const SchurCluster& c : clusters)  // batches x k-steps x 36 lower tiles x 2*16*16*4
+    cluster_flops += (double)((c.p1 - c.p0 + kClBatch - 1) / kClBatch) * (3 * kClBatch / 4) * 36.0 * 2048.0;
   // local indices of every clustered observation / intrinsics entry, and which blocks a cluster touches
   std::vector<unsigned char> cl_present((size_t)std::max(num_clusters, 1) * kClTab, 0);
   parallel_ranges(num_clusters, [&](long long c0, long long c1) {
@@ -923,6 +929,18 @@ void mavba_session::finish_structure() {
     }
     num_slots[k] = slot;
   }
+  // long partial runs are pre-reduced in groups of 32 into extra slots; the block then points at those
+  std::vector<PartialReduce> reduce_tasks;
+  for (SchurBlock& B : blocks) {
+    const int n = B.chunk_end - B.chunk_begin;
+    if (n <= 64) continue;
+    const int first = num_slots[B.kind];
+    for (int b0 = B.chunk_begin; b0 < B.chunk_end; b0 += 32)
+      reduce_tasks.push_back(PartialReduce{B.kind, b0, std::min(b0 + 32, B.chunk_end), num_slots[B.kind]++});
+    B.chunk_begin = first; B.chunk_end = num_slots[B.kind];
+  }
+  num_reduce_tasks = (int)reduce_tasks.size();
+  d_reduce_tasks.upload(reduce_tasks, st);
   // slot tables of the clusters (clusters in order -> a block's partials are added in a fixed order)
   std::vector<int> cl_tab((size_t)std::max(num_clusters, 1) * kClTab, -1);
   for (long long cl = 0; cl < num_clusters; ++cl)
@@ -1054,11 +1072,12 @@ void mavba_session::assemble(double r) {
                           d_q_meta.p, d_pt_clustered.p, d_Epose.p, d_Eintr.p, d_h.p, NPs, d_part[0].p, d_part[1].p,
                           d_part[2].p);
   });
-  timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
-  timed("schur_chunks_ip", [&] { launch_schur_chunks(st, BLK_IP, num_chunks[1], d_chunks[1].p, d_terms[1].p, d_Epose.p, d_Eintr.p, d_part[1].p); });
-  timed("schur_chunks_ii", [&] { launch_schur_chunks(st, BLK_II, num_chunks[2], d_chunks[2].p, d_terms[2].p, d_Epose.p, d_Eintr.p, d_part[2].p); });
+  if (num_chunks[0] > 0) timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
+  if (num_chunks[1] > 0) timed("schur_chunks_ip", [&] { launch_schur_chunks(st, BLK_IP, num_chunks[1], d_chunks[1].p, d_terms[1].p, d_Epose.p, d_Eintr.p, d_part[1].p); });
+  if (num_chunks[2] > 0) timed("schur_chunks_ii", [&] { launch_schur_chunks(st, BLK_II, num_chunks[2], d_chunks[2].p, d_terms[2].p, d_Epose.p, d_Eintr.p, d_part[2].p); });
   double* v = d_M.p + (size_t)n_mat * n_mat;
   timed("schur_finalize", [&] {
+    launch_partial_reduce(st, num_reduce_tasks, d_reduce_tasks.p, d_part[0].p, d_part[1].p, d_part[2].p);
     launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, n_mat, rank == 0,
                           r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p, v);
     launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
@@ -1463,6 +1482,7 @@ int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
   out->num_clusters = s->num_clusters;
   out->clustered_points = s->clustered_points;
   out->cluster_partials = s->cluster_partials;
+  out->cluster_flops = s->cluster_flops;
   const double n = (double)s->n_full;
   out->dense_factor_flops = n * n * n / 3.0 + 2.0 * n * n;
   return MAVBA_OK;
