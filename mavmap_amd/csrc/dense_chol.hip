@@ -16,6 +16,7 @@
 // substitution is free; the backward substitution is one small launch per tile.
 #include "internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace mavba {
 
@@ -135,7 +136,7 @@ __device__ __forceinline__ void store_d16(double* C, int ldc, d4 v, int lane) {
 // All 256 threads must call it (uniform barriers). scr: 4 * 16 * 18 doubles of LDS.
 // Returns false (in thread 0) if a pivot is not positive.
 constexpr int MLD = 18;
-constexpr int kFuseBelow = 12;
+constexpr int kFuseBelow = 24;
 constexpr int kMaxBacksolveGroups = 2048;  // single-launch backward substitution up to this many tile rows  // fuse the panel solve into the update when <= this many row blocks remain
 __device__ __forceinline__ bool tile_potrf_inv(double* T, double* Ti, double* scr, int tid) {
   const int wv = tid >> 6, lane = tid & 63;
@@ -799,6 +800,7 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
   if (cs.num_shadows)
     (void)hipMemsetAsync(cs.d_shadow, 0, (size_t)cs.num_shadows * sstride * sizeof(double), st);
   const int ninit = (int)cs.init_tiles.size() - 1;
+  static const int fuse_below = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE"); return e ? std::atoi(e) : kFuseBelow; }();  // tuning knob
   hipLaunchKernelGGL(k_chol_diag0, dim3(ninit), dim3(256), 0, st, M, ld, cs.d_init, inv, fail, cs.d_flags, nb);
   for (const CholStep& S : cs.steps) {
     if (S.merge) {
@@ -809,7 +811,7 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
       continue;
     }
     const CholFront* F = cs.d_fronts + S.front_off;
-    if (S.max_na > kFuseBelow) {
+    if (S.max_na > fuse_below) {
       // large trailing matrix: one panel solve, then a lean update (2 work-groups per CU)
       hipLaunchKernelGGL(k_chol_trsm, dim3(S.max_na + 1, 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, cs.d_rows, nb);
       hipLaunchKernelGGL((k_chol_update<false>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, fail,

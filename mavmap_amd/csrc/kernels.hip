@@ -303,16 +303,18 @@ __global__ void __launch_bounds__(256) k_point_reduce(
     c[3] += jp[1] * jp[1] + jp[4] * jp[4]; c[4] += jp[1] * jp[2] + jp[4] * jp[5]; c[5] += jp[2] * jp[2] + jp[5] * jp[5];
     gg[0] += jp[0] * r0 + jp[3] * r1; gg[1] += jp[1] * r0 + jp[4] * r1; gg[2] += jp[2] * r0 + jp[5] * r1;
     if (nq > 0) {
+      // the Jk loads go out together with the image -> camera lookup (they do not wait for it)
+      double jk[2 * KMAX];
+#pragma unroll
+      for (int k = 0; k < 2 * KMAX; ++k) jk[k] = Jk[k * S + o];
       const int cam = img_cam[obs_img[o]];
       const double s0 = cam == cam0 ? 1.0 : 0.0, s1 = cam == cam1 ? 1.0 : 0.0;
-      if (cam == cam0 || cam == cam1) {
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-          const double j0 = Jk[k * S + o], j1 = Jk[(KMAX + k) * S + o];
-          const double w0 = j0 * jp[0] + j1 * jp[3], w1 = j0 * jp[1] + j1 * jp[4], w2 = j0 * jp[2] + j1 * jp[5];
-          W0[3 * k] += s0 * w0; W0[3 * k + 1] += s0 * w1; W0[3 * k + 2] += s0 * w2;
-          W1[3 * k] += s1 * w0; W1[3 * k + 1] += s1 * w1; W1[3 * k + 2] += s1 * w2;
-        }
+      for (int k = 0; k < KMAX; ++k) {
+        const double j0 = jk[k], j1 = jk[KMAX + k];
+        const double w0 = j0 * jp[0] + j1 * jp[3], w1 = j0 * jp[1] + j1 * jp[4], w2 = j0 * jp[2] + j1 * jp[5];
+        W0[3 * k] += s0 * w0; W0[3 * k + 1] += s0 * w1; W0[3 * k + 2] += s0 * w2;
+        W1[3 * k] += s1 * w0; W1[3 * k + 1] += s1 * w1; W1[3 * k + 2] += s1 * w2;
       }
     }
   }
