@@ -153,6 +153,7 @@ void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blo
                            double dmax, const int* img_cam, const double* img_rec,
                            const double* cam_rec, const double* scale_cam, const int* off_img, const int* off_cam,
                            double* S, double* v);
+void launch_tiles_copy(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, double* buf, bool to_buf);
 // col_var[t]: variable (index into scale_cam) held by matrix column t, -1 for padding columns.
 void launch_fix_diag(hipStream_t st, int n_mat, int ld, bool add_one, const int* col_var,
                      const double* scale_cam, double* S);

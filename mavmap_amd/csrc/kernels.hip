@@ -1197,6 +1197,27 @@ void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blo
                      part_ip, part_ii, NI, NC, ld, add_base ? 1 : 0, radius, dmin, dmax, img_cam, img_rec, cam_rec,
                      scale_cam, off_img, off_cam, S, v);
 }
+// Multi-rank exchange of the reduced system: only the structurally non-zero lower 64x64 tiles (and the
+// right-hand-side row) travel. pack: tile t of the list -> buf[t * 4096 ...]; unpack: the reverse.
+__global__ void __launch_bounds__(256) k_tiles_copy(int num_tiles, const int2* __restrict__ tiles, double* __restrict__ M,
+                                                    int ld, double* __restrict__ buf, int to_buf) {
+  const int t = blockIdx.x;
+  if (t >= num_tiles) return;
+  const int2 rc = tiles[t];
+  double* tile = M + (size_t)rc.x * 64 * ld + (size_t)rc.y * 64;
+  double* lin = buf + (size_t)t * 4096;
+  for (int e = threadIdx.x; e < 2048; e += 256) {
+    const int row = e >> 5, c2 = (e & 31) * 2;
+    double2* a = reinterpret_cast<double2*>(tile + (size_t)row * ld + c2);
+    double2* b = reinterpret_cast<double2*>(lin + row * 64 + c2);
+    if (to_buf) *b = *a; else *a = *b;
+  }
+}
+void launch_tiles_copy(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, double* buf, bool to_buf) {
+  if (num_tiles <= 0) return;
+  hipLaunchKernelGGL(k_tiles_copy, dim3(num_tiles), dim3(256), 0, st, num_tiles, tiles, M, ld, buf, to_buf ? 1 : 0);
+}
+
 // Constant / unused / padding columns: unit diagonal (their rows and columns are zero).
 __global__ void k_fix_diag(int n_mat, int ld, int add_one, const int* __restrict__ col_var,
                            const double* __restrict__ scale_cam, double* __restrict__ S) {

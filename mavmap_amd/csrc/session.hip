@@ -153,6 +153,10 @@ struct mavba_session {
   std::vector<int> h_off_img, h_off_cam, h_col_var;
   DevBuf<int> d_off, d_col_var;
   DevBuf<double> d_ymat;
+  // multi-rank: the structurally non-zero lower tiles of the matrix, packed for the all-reduce
+  DevBuf<int2> d_ar_tiles;
+  DevBuf<double> d_ar_buf;
+  int num_ar_tiles = 0;
 
   // ---- LM state (Ceres TrustRegionMinimizer / LevenbergMarquardtStrategy) ----
   bool evaluated = false, scales_ready = false, started = false, assembled = false;
@@ -655,6 +659,16 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   for (int tr = 0; tr < nbt; ++tr)
     for (int tc = 0; tc <= tr; ++tc) if (mark[(size_t)tr * nbt + tc]) tile_pairs.emplace_back(tr, tc);
   chol_struct.build(nbt, tile_pairs, parts, st);
+  if (world > 1) {
+    std::vector<int2> tl;
+    std::vector<unsigned char> have((size_t)nbt * nbt, 0);
+    for (int t = 0; t < nbt; ++t) { tl.push_back(make_int2(t, t)); have[(size_t)t * nbt + t] = 1; }
+    for (const auto& pr : tile_pairs)
+      if (!have[(size_t)pr.first * nbt + pr.second]) { have[(size_t)pr.first * nbt + pr.second] = 1; tl.push_back(make_int2(pr.first, pr.second)); }
+    num_ar_tiles = (int)tl.size();
+    d_ar_tiles.upload(tl, st);
+    d_ar_buf.alloc((size_t)num_ar_tiles * 4096 + n_mat);
+  }
   d_M.alloc((size_t)(n_mat + 64) * n_mat); d_L.alloc((size_t)(n_mat + 64) * n_mat);
   d_ymat.alloc(n_mat); d_diag_ws.alloc((size_t)n_mat * 64);
 }
@@ -1082,7 +1096,15 @@ void mavba_session::assemble(double r) {
                           r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p, v);
     launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
   });
-  allreduce(d_M.p, (long long)(n_mat + 1) * n_mat, 0);
+  if (world > 1 && ar_fn) {
+    // only the tiles the factorisation reads (lower, inside the structure) and the right-hand side travel
+    double* rhs = d_ar_buf.p + (size_t)num_ar_tiles * 4096;
+    launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, d_M.p, n_mat, d_ar_buf.p, true);
+    HIP_OK(hipMemcpyAsync(rhs, v, (size_t)n_mat * 8, hipMemcpyDeviceToDevice, st));
+    allreduce(d_ar_buf.p, (long long)num_ar_tiles * 4096 + n_mat, 0);
+    launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, d_M.p, n_mat, d_ar_buf.p, false);
+    HIP_OK(hipMemcpyAsync(v, rhs, (size_t)n_mat * 8, hipMemcpyDeviceToDevice, st));
+  }
   assembled = true;
 }
 
@@ -1416,7 +1438,10 @@ int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, 
   for (int t = 0; t < m; ++t) if (s->h_col_var[t] >= 0) var_col[s->h_col_var[t]] = t;
   if (Sout)
     for (int r = 0; r < n; ++r)
-      for (int c = 0; c < n; ++c) Sout[(size_t)r * n + c] = h[(size_t)var_col[r] * m + var_col[c]];
+      for (int c = 0; c < n; ++c) {  // the lower triangle is the one that is factorised (and, with shards, all-reduced)
+        const int a = std::max(var_col[r], var_col[c]), b = std::min(var_col[r], var_col[c]);
+        Sout[(size_t)r * n + c] = h[(size_t)a * m + b];
+      }
   if (vout)
     for (int r = 0; r < n; ++r) vout[r] = h[(size_t)m * m + var_col[r]];
   return MAVBA_OK;
