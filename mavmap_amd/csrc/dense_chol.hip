@@ -671,9 +671,9 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
 }
 
 void CholStructure::release() {
-  if (d_ints) (void)hipFree(d_ints);
-  if (d_fronts) (void)hipFree(d_fronts);
-  if (d_shadow) (void)hipFree(d_shadow);
+  if (d_ints) device_free(d_ints);
+  if (d_fronts) device_free(d_fronts);
+  if (d_shadow) device_free(d_shadow);
   d_ints = nullptr; d_fronts = nullptr; d_shadow = nullptr;
 }
 CholStructure::~CholStructure() { release(); }
@@ -775,11 +775,11 @@ void CholStructure::build(int nb_, const std::vector<std::pair<int, int>>& tile_
   pack.insert(pack.end(), init_tiles.begin(), init_tiles.end());
   const size_t o_flags = pack.size();
   pack.resize(pack.size() + nb, 0);
-  (void)hipMalloc(&d_ints, pack.size() * sizeof(int));
+  (void)device_alloc(reinterpret_cast<void**>(&d_ints), pack.size() * sizeof(int));
   (void)hipMemcpyAsync(d_ints, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, st);
-  (void)hipMalloc(&d_fronts, std::max<size_t>(fronts.size(), 1) * sizeof(CholFront));
+  (void)device_alloc(reinterpret_cast<void**>(&d_fronts), std::max<size_t>(fronts.size(), 1) * sizeof(CholFront));
   (void)hipMemcpyAsync(d_fronts, fronts.data(), fronts.size() * sizeof(CholFront), hipMemcpyHostToDevice, st);
-  if (num_shadows) (void)hipMalloc(&d_shadow, (size_t)num_shadows * shadow_stride() * sizeof(double));
+  if (num_shadows) (void)device_alloc(reinterpret_cast<void**>(&d_shadow), (size_t)num_shadows * shadow_stride() * sizeof(double));
   (void)hipStreamSynchronize(st);
   d_rows = d_ints;
   d_seg_of_tile = d_ints + o_seg;

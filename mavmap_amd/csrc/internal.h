@@ -179,6 +179,13 @@ void launch_reduce_cols(hipStream_t st, const double* partial, int rows, int col
 void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,
                          const int* pt_count, double* perr);
 
+// ---- device memory (session.hip) ---------------------------------------------
+// Process-wide caching allocator: local BA creates and destroys a session per call (hundreds per run) and
+// ~60 hipMalloc/hipFree pairs cost more than the solve of a small window. Blocks are cached per (device, size
+// class) and handed out again; contents are NOT cleared. MAVBA_POOL_MB caps the cache (default 16384, 0 = off).
+hipError_t device_alloc(void** p, size_t bytes);
+void device_free(void* p);
+
 // ---- dense SPD solve (dense_chol.hip) --------------------------------------
 // M: (n_pad + 64) x n_pad row-major, n_pad % 64 == 0. Rows [0, n_pad) hold the
 // SPD matrix (lower triangle is read), row n_pad holds the right-hand side.

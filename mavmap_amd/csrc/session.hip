@@ -17,10 +17,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mavba.h"
@@ -50,11 +53,11 @@ struct DevBuf {
   DevBuf() {}
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) device_free(p); }
   void alloc(size_t count) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { device_free(p); p = nullptr; }
     n = count;
-    if (count) HIP_OK(hipMalloc(&p, count * sizeof(T)));
+    if (count) HIP_OK(device_alloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
   }
   void upload(const std::vector<T>& h, hipStream_t st) {
     alloc(std::max<size_t>(h.size(), 1));
@@ -62,6 +65,108 @@ struct DevBuf {
   }
   void zero(hipStream_t st) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
 };
+
+// ---- caching device allocator (declared in internal.h) ----------------------------------------------------
+namespace {
+struct DevicePool {
+  std::mutex m;
+  std::multimap<std::pair<int, size_t>, void*> free_blocks;      // (device, class size) -> block
+  std::unordered_map<void*, std::pair<int, size_t>> live;        // every block handed out by device_alloc
+  std::multimap<int, hipStream_t> streams;                        // idle streams per device
+  size_t cached = 0, cap = 0;
+  DevicePool() {
+    const char* e = std::getenv("MAVBA_POOL_MB");
+    cap = (size_t)(e ? std::atoll(e) : 16384) << 20;
+  }
+  ~DevicePool() {}  // blocks are left to the driver at process exit (the HIP runtime may already be gone)
+  // size classes 1, 1.25, 1.5, 1.75 x 2^k (>= 256 B): at most 25 % slack, few distinct sizes
+  static size_t size_class(size_t bytes) {
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    if (c >= 1024) {
+      const size_t q = c >> 3;
+      for (int k = 5; k <= 7; ++k) if (bytes <= (size_t)k * q) return (size_t)k * q;
+    }
+    return c;
+  }
+};
+DevicePool& pool() { static DevicePool* p = new DevicePool; return *p; }
+}  // namespace
+
+hipError_t device_alloc(void** out, size_t bytes) {
+  DevicePool& P = pool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t cls = DevicePool::size_class(bytes);
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.free_blocks.find({dev, cls});
+    if (it != P.free_blocks.end()) {
+      *out = it->second;
+      P.free_blocks.erase(it);
+      P.cached -= cls;
+      P.live[*out] = {dev, cls};
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, cls);
+  if (e != hipSuccess) {
+    // out of memory: give the cache back and try once more
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> g(P.m);
+      for (auto& kv : P.free_blocks) drop.push_back(kv.second);
+      P.free_blocks.clear();
+      P.cached = 0;
+    }
+    for (void* q : drop) (void)hipFree(q);
+    (void)hipGetLastError();
+    e = hipMalloc(out, cls);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> g(P.m);
+  P.live[*out] = {dev, cls};
+  return hipSuccess;
+}
+
+void device_free(void* p) {
+  if (!p) return;
+  DevicePool& P = pool();
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.live.find(p);
+    if (it != P.live.end()) {
+      const auto key = it->second;
+      P.live.erase(it);
+      if (P.cached + key.second <= P.cap) {
+        P.free_blocks.insert({key, p});
+        P.cached += key.second;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+
+// Streams are cached too (hipStreamCreate + hipStreamDestroy cost ~2 ms per session, more than a local-BA solve).
+hipError_t stream_acquire(hipStream_t* st) {
+  DevicePool& P = pool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.streams.find(dev);
+    if (it != P.streams.end()) { *st = it->second; P.streams.erase(it); return hipSuccess; }
+  }
+  return hipStreamCreate(st);
+}
+void stream_release(hipStream_t st, int dev) {  // the caller has synchronised it
+  if (!st) return;
+  DevicePool& P = pool();
+  std::lock_guard<std::mutex> g(P.m);
+  if (P.streams.count(dev) < 8) { P.streams.insert({dev, st}); return; }
+  (void)hipStreamDestroy(st);
+}
 
 static inline int model_k(int m) { return m == MAVBA_MODEL_PINHOLE ? 4 : m == MAVBA_MODEL_OPENCV ? 8 : 9; }
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -177,9 +282,11 @@ struct mavba_session {
   std::vector<hipEvent_t> ev_pool;
 
   ~mavba_session() {
+    // the buffers go back to the process-wide pool: nothing may still be running on them
+    if (st) (void)hipStreamSynchronize(st);
     for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& e : ev_pool) (void)hipEventDestroy(e);
-    if (st) (void)hipStreamDestroy(st);
+    if (st) stream_release(st, device);
   }
 
   int timer_index(const char* name) {
@@ -1298,7 +1405,7 @@ int mavba_session_create(const mavba_problem* problem, const mavba_options* opti
   s->opt = *options;
   if (options->device >= 0) HIP_OK(hipSetDevice(options->device));
   HIP_OK(hipGetDevice(&s->device));
-  HIP_OK(hipStreamCreate(&s->st));
+  HIP_OK(stream_acquire(&s->st));
   s->build(problem);
   *out = s;
   return MAVBA_OK;
