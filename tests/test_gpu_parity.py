@@ -320,3 +320,58 @@ def test_dissection_is_chosen_automatically_and_solves_like_the_oracle(mavba, or
     assert rg["num_successful_steps"] == ro["num_successful_steps"]
     assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
     assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+
+
+def test_dissection_with_constant_blocks_and_unused_images(mavba, oracle):
+    """Dissection order + point clusters when some pose blocks are constant, some images have no observation
+    and one camera's intrinsics are fixed: the unit-diagonal columns sit inside parts and separator."""
+    p = _band_scene()
+    rng = np.random.default_rng(3)
+    p.pose_const = p.pose_const.copy()
+    for i in rng.choice(np.arange(2, p.num_images), 12, replace=False):
+        p.pose_const[i] = int(rng.choice([A.CONST_POSE, A.CONST_RVEC, A.CONST_TX | A.CONST_TZ]))
+    drop = rng.choice(np.arange(2, p.num_images), 3, replace=False)
+    keep = ~np.isin(p.obs_image, drop)
+    p.obs_uv, p.obs_image, p.obs_point = p.obs_uv[keep], p.obs_image[keep], p.obs_point[keep]
+    p.intr_const = np.array([0, 1], np.uint8)
+    ref = oracle.linear_step(p, 300.0)
+    with mavba.Session(p) as s:
+        assert s.info()["nd_parts"] >= 2 and s.info()["num_clusters"] > 0
+        st = s.linear_step(300.0)
+    for k in ("d_poses", "d_intr", "d_points"):
+        assert rel_err(st[k], ref[k]) < 1e-8, k
+    assert not st["d_poses"][drop].any() and not st["d_intr"][1].any()
+
+
+def test_point_seen_twice_by_one_image_and_long_tracks_mix_with_clusters(mavba, oracle):
+    """Points the clusters cannot take (an image observing the point twice; more images than a cluster's local
+    list) go through the generic term lists; both paths add into the same blocks."""
+    p = synth.make_scene(num_images=30, num_points=900, track_len=5, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=23,
+                         long_track_frac=0.05, long_track_len=24, spacing=5.0)
+    rng = np.random.default_rng(5)
+    dup = rng.choice(p.num_obs, 40, replace=False)  # a second, slightly different observation of the same (image, point)
+    p.obs_uv = np.concatenate([p.obs_uv, p.obs_uv[dup] + rng.normal(0, 0.3, (len(dup), 2))])
+    p.obs_image = np.concatenate([p.obs_image, p.obs_image[dup]]).astype(np.int32)
+    p.obs_point = np.concatenate([p.obs_point, p.obs_point[dup]]).astype(np.int32)
+    for radius in (1e4, 10.0):
+        ref = oracle.linear_step(p, radius)
+        with mavba.Session(p) as s:
+            info = s.info()
+            S, v = s.reduced_system(radius)
+            st = s.linear_step(radius)
+        assert info["num_clusters"] > 0 and 0 < info["clustered_points"] < p.num_points and sum(info["schur_terms"]) > 0
+        assert rel_err(S, ref["S"]) < 1e-9 and rel_err(v, ref["v"]) < 1e-9
+        for k in ("d_poses", "d_intr", "d_points"):
+            assert rel_err(st[k], ref[k]) < 1e-8, (radius, k)
+
+
+def test_clusters_off_gives_the_same_system(mavba, monkeypatch):
+    p = _scene("mixed")
+    with mavba.Session(p) as s:
+        S1, v1 = s.reduced_system(1e4)
+        assert s.info()["num_clusters"] > 0
+    monkeypatch.setenv("MAVBA_CLUSTERS", "0")
+    with mavba.Session(p) as s:
+        S0, v0 = s.reduced_system(1e4)
+        assert s.info()["num_clusters"] == 0 and sum(s.info()["schur_terms"]) > 0
+    assert rel_err(S1, S0) < 1e-12 and rel_err(v1, v0) < 1e-12

@@ -137,6 +137,27 @@ def test_tile_envelope_is_the_union_over_ranks(mavba):
         assert rel_err(poses, single.poses) < 1e-8
 
 
+def test_sharded_dissection_order_is_the_same_on_every_rank(mavba):
+    """A problem large enough for the nested-dissection order: the image graph is max-reduced, so both ranks
+    pick the same parts even though each sees only its own points; only the structure's lower tiles travel."""
+    full = synth.make_scene(num_images=130, num_points=5000, track_len=4, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV],
+                            seed=5, long_track_frac=0.01, long_track_len=12, spacing=6.0)
+    opts = global_opts()
+    single = full.copy()
+    _, r1 = mavba.bundle_adjustment(single, opts)
+    out, _ = solve_sharded(mavba, full, 2, opts)
+    pts = np.zeros_like(full.points)
+    for res, poses, intr, p, owned in out:
+        assert res["termination"] == r1["termination"]
+        assert res["num_successful_steps"] == r1["num_successful_steps"]
+        assert abs(res["final_cost"] - r1["final_cost"]) <= 1e-9 * r1["final_cost"]
+        assert np.array_equal(poses, out[0][1])
+        # (different summation order than the single-rank run over a 40-iteration path of a 130-image problem)
+        assert rel_err(poses, single.poses) < 1e-7 and rel_err(intr, single.intrinsics) < 1e-7
+        pts[owned] = p
+    assert rel_err(pts, single.points) < 1e-7
+
+
 def test_torch_zero_copy_view_of_a_device_pointer(mavba):
     """bench.py's RCCL hook wraps the session's raw device pointer as a torch tensor (CUDA array
     interface). Check that the view aliases the memory (no copy) on this GPU."""
