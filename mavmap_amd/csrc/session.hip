@@ -178,9 +178,10 @@ struct KernelTimer { std::string name; long long launches = 0; double total_ms =
 
 // Run body(begin, end) over [0, n) on a few host threads (set-up work only).
 template <typename F>
-static void parallel_ranges(long long n, F&& body) {
+static void parallel_ranges(long long n, F&& body, long long min_parallel = 200000) {
   int T = (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
-  if (n < 200000) T = 1;
+  T = (int)std::min<long long>(T, std::max<long long>(n, 1));
+  if (n < min_parallel) T = 1;
   if (T == 1) { body(0ll, n); return; }
   std::vector<std::thread> th;
   for (int t = 0; t < T; ++t) th.emplace_back([&, t] { body(n * t / T, n * (t + 1) / T); });
@@ -476,15 +477,18 @@ void mavba_session::build(const mavba_problem* P) {
   num_residuals_reduced = 2ll * N + num_priors;
 
   // ---- internal point order: lexicographic by the sorted list of images that see the point ----
+  // One stable counting sort of the kept observations by (caller's) point gives every point's bucket; the
+  // point-major order is the buckets concatenated in the new point order.
   std::vector<int> pt_new(NP);
+  std::vector<int> cstart(NP + 1, 0);
+  std::vector<long long> bucket(std::max(N, 1));  // kept observation ids, grouped by caller's point, input order inside
   {
-    std::vector<int> cstart(NP + 1, 0);
     for (int k = 0; k < N; ++k) cstart[P->obs_point[kept[k]] + 1]++;
     for (int p = 0; p < NP; ++p) cstart[p + 1] += cstart[p];
     std::vector<int> simg(std::max(N, 1));
     {
       std::vector<int> cur(cstart.begin(), cstart.end() - 1);
-      for (int k = 0; k < N; ++k) simg[cur[P->obs_point[kept[k]]]++] = P->obs_image[kept[k]];
+      for (int k = 0; k < N; ++k) { const int at = cur[P->obs_point[kept[k]]]++; bucket[at] = kept[k]; simg[at] = P->obs_image[kept[k]]; }
     }
     parallel_ranges(NP, [&](long long b0, long long b1) {
       for (long long p = b0; p < b1; ++p) std::sort(simg.begin() + cstart[p], simg.begin() + cstart[p + 1]);
@@ -500,7 +504,7 @@ void mavba_session::build(const mavba_problem* P) {
       return a < b;
     };
     // sorted runs on a few threads, then pairwise merges (the comparator is a strict total order)
-    const int T = NP >= 100000 ? (int)std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    const int T = NP >= 100000 ? (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
     std::vector<int> cut(T + 1);
     for (int t = 0; t <= T; ++t) cut[t] = (int)((long long)NP * t / T);
     {
@@ -509,50 +513,76 @@ void mavba_session::build(const mavba_problem* P) {
         th.emplace_back([&, t] { std::sort(h_pt_orig.begin() + cut[t], h_pt_orig.begin() + cut[t + 1], before); });
       for (auto& x : th) x.join();
     }
-    for (int w = 1; w < T; w *= 2)
+    for (int w = 1; w < T; w *= 2) {
+      std::vector<std::thread> th;
       for (int t = 0; t + w < T; t += 2 * w)
-        std::inplace_merge(h_pt_orig.begin() + cut[t], h_pt_orig.begin() + cut[t + w],
-                           h_pt_orig.begin() + cut[std::min(t + 2 * w, T)], before);
+        th.emplace_back([&, t, w] {
+          std::inplace_merge(h_pt_orig.begin() + cut[t], h_pt_orig.begin() + cut[t + w],
+                             h_pt_orig.begin() + cut[std::min(t + 2 * w, T)], before);
+        });
+      for (auto& x : th) x.join();
+    }
     for (int q = 0; q < NP; ++q) pt_new[h_pt_orig[q]] = q;
     auto permute = [&](auto& v, int width) {
       auto old = v;
-      for (int q = 0; q < NP; ++q)
-        for (int e = 0; e < width; ++e) v[(size_t)q * width + e] = old[(size_t)h_pt_orig[q] * width + e];
+      parallel_ranges(NP, [&](long long b0, long long b1) {
+        for (long long q = b0; q < b1; ++q)
+          for (int e = 0; e < width; ++e) v[(size_t)q * width + e] = old[(size_t)h_pt_orig[q] * width + e];
+      });
     };
     permute(h_points0, 3); permute(h_pt_const_in, 1); permute(h_pt_count_all, 1); permute(h_pt_used, 1);
   }
   lap("point order");
 
-  // ---- point-major order (stable counting sort by point) ----
+  // ---- point-major order: the buckets in the new point order ----
   h_pt_start.assign(NP + 1, 0);
-  for (int k = 0; k < N; ++k) h_pt_start[pt_new[P->obs_point[kept[k]]] + 1]++;
-  for (int p = 0; p < NP; ++p) h_pt_start[p + 1] += h_pt_start[p];
+  for (int q = 0; q < NP; ++q) h_pt_start[q + 1] = h_pt_start[q] + (cstart[h_pt_orig[q] + 1] - cstart[h_pt_orig[q]]);
   perm.assign(N, 0);
-  {
-    std::vector<int> cur(h_pt_start.begin(), h_pt_start.end() - 1);
-    for (int k = 0; k < N; ++k) perm[cur[pt_new[P->obs_point[kept[k]]]]++] = kept[k];
-  }
   std::vector<double2> uv(N);
   std::vector<int> opt_(N);
   h_oimg.assign(N, 0);
-  parallel_ranges(N, [&](long long b0, long long b1) {
-    for (long long a = b0; a < b1; ++a) {
-      const long long o = perm[a];
-      uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
-      h_oimg[a] = P->obs_image[o]; opt_[a] = pt_new[P->obs_point[o]];
+  parallel_ranges(NP, [&](long long q0, long long q1) {
+    for (long long q = q0; q < q1; ++q) {
+      const int src = cstart[h_pt_orig[q]], cnt = h_pt_start[q + 1] - h_pt_start[q];
+      for (int j = 0; j < cnt; ++j) {
+        const long long o = bucket[src + j];
+        const int a = h_pt_start[q] + j;
+        perm[a] = o;
+        uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
+        h_oimg[a] = P->obs_image[o]; opt_[a] = (int)q;
+      }
     }
   });
 
   lap("point-major sort");
   // ---- image-major view for the camera sweep ----
   std::vector<int> img_start(NI + 1, 0);
-  for (int a = 0; a < N; ++a) img_start[h_oimg[a] + 1]++;
-  for (int i = 0; i < NI; ++i) img_start[i + 1] += img_start[i];
   std::vector<double2> im_uv(N);
   std::vector<int> im_pt(N);
   {
-    std::vector<int> cur(img_start.begin(), img_start.end() - 1);
-    for (int a = 0; a < N; ++a) { const int t = cur[h_oimg[a]]++; im_uv[t] = uv[a]; im_pt[t] = opt_[a]; }
+    // stable counting sort by image on T threads: per-thread histograms -> per-thread cursors
+    const int T = N >= 200000 ? (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    std::vector<std::vector<int>> hist(T, std::vector<int>(NI, 0));
+    auto run = [&](auto&& body) {
+      if (T == 1) { body(0); return; }
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t) th.emplace_back(body, t);
+      for (auto& x : th) x.join();
+    };
+    run([&](int t) {
+      const int a0 = (int)((long long)N * t / T), a1 = (int)((long long)N * (t + 1) / T);
+      for (int a = a0; a < a1; ++a) hist[t][h_oimg[a]]++;
+    });
+    int runpos = 0;
+    for (int i = 0; i < NI; ++i) {
+      img_start[i] = runpos;
+      for (int t = 0; t < T; ++t) { const int c = hist[t][i]; hist[t][i] = runpos; runpos += c; }
+    }
+    img_start[NI] = runpos;
+    run([&](int t) {
+      const int a0 = (int)((long long)N * t / T), a1 = (int)((long long)N * (t + 1) / T);
+      for (int a = a0; a < a1; ++a) { const int at = hist[t][h_oimg[a]]++; im_uv[at] = uv[a]; im_pt[at] = opt_[a]; }
+    });
   }
   const int kSweepChunk = 2048;
   std::vector<SweepChunk> sweep_chunks;
@@ -824,41 +854,57 @@ void mavba_session::finish_structure() {
     if (const char* e = std::getenv("MAVBA_CLUSTERS")) use_clusters = std::atoi(e) != 0;
     int kMaxPoints = 128;
     if (const char* e = std::getenv("MAVBA_CLUSTER_POINTS")) kMaxPoints = std::max(1, std::atoi(e));
-    std::vector<int> cur_i, cur_c, mi, mc, pi;
-    int cur_p0 = 0, cur_n = 0;
-    auto close = [&](int p_end) {
-      if (cur_n > 0) {
-        clusters.push_back(SchurCluster{cur_p0, p_end});
-        for (int k = 0; k < kClImages; ++k) cl_imgs.push_back(k < (int)cur_i.size() ? cur_i[k] : -1);
-        for (int k = 0; k < kClCams; ++k) cl_cams.push_back(k < (int)cur_c.size() ? cur_c[k] : -1);
-      }
-      cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end;
-    };
-    for (int p = 0; p < NP; ++p) {
-      if (!h_pt_free[p]) continue;
-      pi.clear();
-      for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) if (img_active[h_oimg[a]]) pi.push_back(h_oimg[a]);
-      const int nq = q_start[p + 1] - q_start[p];
-      if (pi.empty() && nq == 0) continue;
-      std::sort(pi.begin(), pi.end());
-      const bool dup = std::adjacent_find(pi.begin(), pi.end()) != pi.end();
-      if (!use_clusters || dup || (int)pi.size() > kClImages || nq > kClCams) { pt_mode[p] = 2; continue; }
-      auto merged_sizes = [&]() {
-        mi.clear(); mc.clear();
-        std::set_union(cur_i.begin(), cur_i.end(), pi.begin(), pi.end(), std::back_inserter(mi));
-        std::set_union(cur_c.begin(), cur_c.end(), q_cam.begin() + q_start[p], q_cam.begin() + q_start[p + 1], std::back_inserter(mc));
+    // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
+    // thread": the clusters - and with them the order in which partials are added - must not depend on the
+    // machine's core count).
+    const int kRange = 16384;
+    const int nranges = (NP + kRange - 1) / kRange;
+    std::vector<std::vector<SchurCluster>> r_clusters(nranges);
+    std::vector<std::vector<int>> r_imgs(nranges), r_cams(nranges);
+    auto do_range = [&](int rg) {
+      const int r0 = rg * kRange, r1 = std::min(NP, r0 + kRange);
+      std::vector<int> cur_i, cur_c, mi, mc, pi;
+      int cur_p0 = r0, cur_n = 0;
+      auto close = [&](int p_end) {
+        if (cur_n > 0) {
+          r_clusters[rg].push_back(SchurCluster{cur_p0, p_end});
+          for (int k = 0; k < kClImages; ++k) r_imgs[rg].push_back(k < (int)cur_i.size() ? cur_i[k] : -1);
+          for (int k = 0; k < kClCams; ++k) r_cams[rg].push_back(k < (int)cur_c.size() ? cur_c[k] : -1);
+        }
+        cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end;
       };
-      merged_sizes();
-      if ((int)mi.size() > kClImages || (int)mc.size() > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1) {
-        close(p);
+      for (int p = r0; p < r1; ++p) {
+        if (!h_pt_free[p]) continue;
+        pi.clear();
+        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) if (img_active[h_oimg[a]]) pi.push_back(h_oimg[a]);
+        const int nq = q_start[p + 1] - q_start[p];
+        if (pi.empty() && nq == 0) continue;
+        std::sort(pi.begin(), pi.end());
+        const bool dup = std::adjacent_find(pi.begin(), pi.end()) != pi.end();
+        if (!use_clusters || dup || (int)pi.size() > kClImages || nq > kClCams) { pt_mode[p] = 2; continue; }
+        auto merged_sizes = [&]() {
+          mi.clear(); mc.clear();
+          std::set_union(cur_i.begin(), cur_i.end(), pi.begin(), pi.end(), std::back_inserter(mi));
+          std::set_union(cur_c.begin(), cur_c.end(), q_cam.begin() + q_start[p], q_cam.begin() + q_start[p + 1], std::back_inserter(mc));
+        };
         merged_sizes();
+        if ((int)mi.size() > kClImages || (int)mc.size() > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1) {
+          close(p);
+          merged_sizes();
+        }
+        if (cur_n == 0) cur_p0 = p;
+        cur_i.swap(mi); cur_c.swap(mc);
+        ++cur_n;
+        pt_mode[p] = 1;
       }
-      if (cur_n == 0) cur_p0 = p;
-      cur_i.swap(mi); cur_c.swap(mc);
-      ++cur_n;
-      pt_mode[p] = 1;
+      close(r1);
+    };
+    parallel_ranges(nranges, [&](long long g0, long long g1) { for (long long g = g0; g < g1; ++g) do_range((int)g); }, 2);
+    for (int rg = 0; rg < nranges; ++rg) {
+      clusters.insert(clusters.end(), r_clusters[rg].begin(), r_clusters[rg].end());
+      cl_imgs.insert(cl_imgs.end(), r_imgs[rg].begin(), r_imgs[rg].end());
+      cl_cams.insert(cl_cams.end(), r_cams[rg].begin(), r_cams[rg].end());
     }
-    close(NP);
   }
   num_clusters = (int)clusters.size();
   cluster_flops = 0.0;
