@@ -54,7 +54,7 @@ void launch_partial_reduce(hipStream_t st, int num_tasks, const PartialReduce* t
 // computed on the FP64 matrix cores from LDS; each block that is present in the cluster then leaves as
 // ONE partial (slot table) instead of one gathered term per (point, pair).
 constexpr int kClImages = 16, kClCams = 3, kClRows = 128, kClHRow = 123;
-constexpr int kClBatch = 32;                     // points per LDS batch -> K = 96 columns
+constexpr int kClBatch = 32;                     // points per LDS batch -> K = 96 columns (16 -> two work-groups per CU, measured slower)
 constexpr int kClTabPP = 0, kClTabIP = 136, kClTabII = 136 + 48, kClTab = 136 + 48 + 6;
 constexpr int kClMaxBatches = 64;                // a cluster spans at most kClMaxBatches * kClBatch consecutive points
 struct SchurCluster { int p0, p1; };

@@ -858,6 +858,9 @@ namespace {
 typedef double cl_d4 __attribute__((ext_vector_type(4)));
 constexpr int kClK = 3 * kClBatch, kClPitch = kClK + 4;
 constexpr int kClThreads = 256, kClWaves = kClThreads / 64, kClAcc = (36 + kClWaves - 1) / kClWaves;
+// false: small batches, two work-groups per CU that hide each other's latencies; true: one work-group per CU that
+// prefetches its next batch and double-buffers the operand reads itself
+constexpr bool kClPipelined = kClBatch >= 32;
 template <int W>
 __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int lane, cl_d4 (&acc)[kClAcc]) {
   const int li = lane & 15, lk = lane >> 4;
@@ -879,19 +882,26 @@ __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int l
         ++t;
       }
   };
-  static_assert(kClK % 8 == 0, "two k-steps per trip");
-  double a[8], b[8];
-  load(a, 0);
+  if constexpr (!kClPipelined) {
+    // two work-groups share the CU: the other one's matrix instructions cover this wave's LDS reads
+    double a[8];
 #pragma unroll 1
-  for (int kk = 0; kk < kClK; kk += 8) {
-    load(b, kk + 4);
-    __builtin_amdgcn_sched_barrier(0);  // reads first, then the matrix instructions they hide behind
-    mma(a);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kk + 8 < kClK) load(a, kk + 8);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(b);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int kk = 0; kk < kClK; kk += 4) { load(a, kk); mma(a); }
+  } else {
+    static_assert(kClK % 8 == 0, "two k-steps per trip");
+    double a[8], b[8];
+    load(a, 0);
+#pragma unroll 1
+    for (int kk = 0; kk < kClK; kk += 8) {
+      load(b, kk + 4);
+      __builtin_amdgcn_sched_barrier(0);  // reads first, then the matrix instructions they hide behind
+      mma(a);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 8 < kClK) load(a, kk + 8);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 // element (R, C), R >= C, of the cluster's product -> partial slot
@@ -1004,7 +1014,7 @@ __device__ __forceinline__ void cluster_overflow(double* __restrict__ E, int tid
 }
 }  // namespace
 
-__global__ void __launch_bounds__(kClThreads) k_schur_clusters(
+__global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clusters(
     const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ pt_start,
     const int* __restrict__ q_start, const unsigned short* __restrict__ obs_meta,
     const unsigned short* __restrict__ q_meta, const unsigned char* __restrict__ pt_clustered,
@@ -1041,8 +1051,9 @@ __global__ void __launch_bounds__(kClThreads) k_schur_clusters(
       hv = h[(size_t)t * NPs + b0 + pp];
     }
   };
-  fetch(0);
+  if constexpr (kClPipelined) fetch(0);
   for (int bi = 0; bi < nbatch; ++bi) {
+    if constexpr (!kClPipelined) fetch(bi);  // all loads of the batch are in flight while E is cleared
     for (int i = tid; i < kClRows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
     __syncthreads();
     cluster_scatter(RP, E, tid, 0, 0, 6);
@@ -1051,8 +1062,10 @@ __global__ void __launch_bounds__(kClThreads) k_schur_clusters(
     cluster_overflow<kPoseRec, 18, kClChunk>(E, tid, s_bounds[0][bi], s_bounds[0][bi + 1] - s_bounds[0][bi], 0, 6, obs_meta, Epose);
     cluster_overflow<kIntrRec, 27, kClQChunk>(E, tid, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], 96, 9, q_meta, Eintr);
     __syncthreads();
-    if (bi + 1 < nbatch) fetch(bi + 1);  // travels while the matrix cores work on this batch
-    __builtin_amdgcn_sched_barrier(0);   // (keep the loads here: the scheduler would sink them to their use)
+    if constexpr (kClPipelined) {
+      if (bi + 1 < nbatch) fetch(bi + 1);  // travels while the matrix cores work on this batch
+      __builtin_amdgcn_sched_barrier(0);   // (keep the loads here: the scheduler would sink them to their use)
+    }
     switch (wv) {
       case 0: cluster_mfma<0>(E, lane, acc); break;
       case 1: cluster_mfma<1>(E, lane, acc); break;
