@@ -96,3 +96,33 @@ def test_random_structure_step_and_solve(mavba, oracle, seed):
         assert rel_err(pg.intrinsics, po.intrinsics) < 1e-6
     else:
         assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-2 * ro["final_cost"]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_structure_at_dissection_size(mavba, oracle, seed):
+    """The same random structure at a size where the elimination order is dissected and most points are
+    clustered (100-160 images): the LM step must still be the oracle's."""
+    rng = np.random.default_rng(7000 + seed)
+    ni = int(rng.integers(100, 161))
+    ncam = int(rng.integers(1, 5))          # up to 4 shared cameras: more than a cluster's 3 -> some generic points
+    models = [int(m) for m in rng.choice([1, 2, 3], size=ncam)]
+    p = synth.make_scene(num_images=ni, num_points=int(rng.integers(3000, 6000)), track_len=int(rng.integers(3, 7)),
+                         models=models, seed=int(rng.integers(1 << 30)), rot_priors=bool(rng.random() < 0.5),
+                         long_track_frac=float(rng.choice([0.0, 0.02])), long_track_len=20, spacing=6.0,
+                         image_camera=rng.integers(0, ncam, ni))
+    masks = [0, 0, 0, 0, A.CONST_POSE, A.CONST_TX, A.CONST_RVEC, A.CONST_TY | A.CONST_TZ]
+    p.pose_const = np.array([A.CONST_POSE, A.CONST_TX] + [int(rng.choice(masks)) for _ in range(ni - 2)], np.uint8)
+    p.intr_const = (rng.random(ncam) < 0.3).astype(np.uint8)
+    p.point_const = (rng.random(p.num_points) < 0.03).astype(np.uint8)
+    opts = dict(loss_scale_factor=float(rng.choice([1.0, 2.0])))
+    radius = float(10 ** rng.uniform(1, 4))
+    ref = oracle.linear_step(p, radius, oracle.options(**opts))
+    with mavba.Session(p, opts) as s:
+        info = s.info()
+        st = s.linear_step(radius)
+    assert info["num_clusters"] > 0
+    for k in ("d_poses", "d_intr", "d_points"):
+        assert rel_err(st[k], ref[k]) < 1e-7, (seed, k, info["nd_parts"])
+    assert abs(st["model_cost_change"] - ref["model_cost_change"]) < 1e-8 * abs(ref["model_cost_change"])
+    assert not st["d_points"][p.point_const.astype(bool)].any()
+    assert not st["d_intr"][p.intr_const.astype(bool)].any()
