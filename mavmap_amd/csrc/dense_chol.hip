@@ -678,14 +678,14 @@ void CholStructure::release() {
 }
 CholStructure::~CholStructure() { release(); }
 
-void CholStructure::build_dense(int nb_) {
+hipError_t CholStructure::build_dense(int nb_) {
   std::vector<std::pair<int, int>> pairs;
   for (int i = 0; i < nb_; ++i) pairs.emplace_back(i, 0);  // every row starts at tile 0
-  build(nb_, pairs, {}, 0);
+  return build(nb_, pairs, {}, 0);
 }
 
-void CholStructure::build(int nb_, const std::vector<std::pair<int, int>>& tile_pairs,
-                          const std::vector<std::pair<int, int>>& parts_in, hipStream_t st) {
+hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>& tile_pairs,
+                                const std::vector<std::pair<int, int>>& parts_in, hipStream_t st) {
   release();
   nb = nb_;
   std::vector<std::pair<int, int>> parts = parts_in;
@@ -775,17 +775,21 @@ void CholStructure::build(int nb_, const std::vector<std::pair<int, int>>& tile_
   pack.insert(pack.end(), init_tiles.begin(), init_tiles.end());
   const size_t o_flags = pack.size();
   pack.resize(pack.size() + nb, 0);
-  (void)device_alloc(reinterpret_cast<void**>(&d_ints), pack.size() * sizeof(int));
-  (void)hipMemcpyAsync(d_ints, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, st);
-  (void)device_alloc(reinterpret_cast<void**>(&d_fronts), std::max<size_t>(fronts.size(), 1) * sizeof(CholFront));
-  (void)hipMemcpyAsync(d_fronts, fronts.data(), fronts.size() * sizeof(CholFront), hipMemcpyHostToDevice, st);
-  if (num_shadows) (void)device_alloc(reinterpret_cast<void**>(&d_shadow), (size_t)num_shadows * shadow_stride() * sizeof(double));
-  (void)hipStreamSynchronize(st);
+  hipError_t e = device_alloc(reinterpret_cast<void**>(&d_ints), pack.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ints, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_fronts), std::max<size_t>(fronts.size(), 1) * sizeof(CholFront));
+  if (e == hipSuccess && !fronts.empty())
+    e = hipMemcpyAsync(d_fronts, fronts.data(), fronts.size() * sizeof(CholFront), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && num_shadows)
+    e = device_alloc(reinterpret_cast<void**>(&d_shadow), (size_t)num_shadows * shadow_stride() * sizeof(double));
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging vectors go out of scope
+  if (e != hipSuccess) { release(); return e; }
   d_rows = d_ints;
   d_seg_of_tile = d_ints + o_seg;
   d_seg_first = d_ints + o_first;
   d_init = d_ints + o_init;
   d_flags = reinterpret_cast<unsigned*>(d_ints + o_flags);
+  return hipSuccess;
 }
 
 // diag_ws: n_pad * 64 doubles (the inverses of the factor's diagonal tiles); L: second

@@ -235,9 +235,9 @@ struct CholStructure {
   // tile_pairs: (row tile, col tile), row >= col, of every structurally non-zero tile (diagonal tiles are
   // implied). parts: tile ranges [begin, end) of the leading uncoupled parts, ascending and contiguous from
   // tile 0; everything after the last part is the separator. Empty parts = single chain.
-  void build(int nb, const std::vector<std::pair<int, int>>& tile_pairs,
-             const std::vector<std::pair<int, int>>& parts, hipStream_t st);
-  void build_dense(int nb);
+  hipError_t build(int nb, const std::vector<std::pair<int, int>>& tile_pairs,
+                   const std::vector<std::pair<int, int>>& parts, hipStream_t st);
+  hipError_t build_dense(int nb);
   size_t shadow_stride() const { const size_t ns = (size_t)(nb - s_begin); return (ns + 1) * ns * 4096; }
 };
 // y_scatter (may be null): y_nat[y_scatter[t]] = y[t] for every t with y_scatter[t] >= 0 (the solution in

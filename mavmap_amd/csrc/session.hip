@@ -795,7 +795,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   std::vector<std::pair<int, int>> tile_pairs;
   for (int tr = 0; tr < nbt; ++tr)
     for (int tc = 0; tc <= tr; ++tc) if (mark[(size_t)tr * nbt + tc]) tile_pairs.emplace_back(tr, tc);
-  chol_struct.build(nbt, tile_pairs, parts, st);
+  HIP_OK(chol_struct.build(nbt, tile_pairs, parts, st));
   if (world > 1) {
     std::vector<int2> tl;
     std::vector<unsigned char> have((size_t)nbt * nbt, 0);
@@ -1747,7 +1747,7 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
     DevBuf<double> dM, dL, dy, dws, dfail;
     dM.upload(M, st); dL.alloc(M.size()); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
     CholStructure cs;
-    cs.build_dense(n_pad / 64);
+    HIP_OK(cs.build_dense(n_pad / 64));
     dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p, dL.p, cs);
     std::vector<double> y(n_pad);
     double fail = 0.0;
