@@ -63,6 +63,10 @@ struct DevBuf {
     alloc(std::max<size_t>(h.size(), 1));
     if (!h.empty()) HIP_OK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
   }
+  void upload(const T* h, size_t count, hipStream_t st) {
+    alloc(std::max<size_t>(count, 1));
+    if (count) HIP_OK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));
+  }
   void zero(hipStream_t st) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
 };
 
@@ -166,6 +170,48 @@ void stream_release(hipStream_t st, int dev) {  // the caller has synchronised i
   std::lock_guard<std::mutex> g(P.m);
   if (P.streams.count(dev) < 8) { P.streams.insert({dev, st}); return; }
   (void)hipStreamDestroy(st);
+}
+
+// Host scratch array WITHOUT value-initialisation (std::vector<T>(n) clears the memory first: ~1 ms per 10 MB,
+// and the set-up shuffles ~100 MB of such arrays that are fully overwritten anyway).
+template <typename T>
+struct HostBuf {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  explicit HostBuf(size_t count) : p(new T[std::max<size_t>(count, 1)]), n(count) {}
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* data() { return p.get(); }
+};
+
+// Stable counting sort of items 0..n-1 by key(i) in [0, nkeys) on a few threads (per-thread histograms turned
+// into per-thread cursors): start[k] = first position of key k, emit(i, position) is called once per item.
+// The result does not depend on the number of threads.
+template <typename KeyFn, typename EmitFn>
+static void counting_sort_parallel(long long n, int nkeys, KeyFn key, std::vector<int>& start, EmitFn emit) {
+  int T = n >= 200000 ? (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  while (T > 1 && (size_t)T * nkeys > ((size_t)64 << 20)) T /= 2;
+  std::vector<std::vector<int>> hist(T);
+  auto run = [&](auto&& body) {
+    if (T == 1) { body(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(body, t);
+    for (auto& x : th) x.join();
+  };
+  run([&](int t) {
+    hist[t].assign((size_t)nkeys, 0);
+    for (long long i = n * t / T; i < n * (t + 1) / T; ++i) hist[t][key(i)]++;
+  });
+  start.assign((size_t)nkeys + 1, 0);
+  int pos = 0;
+  for (int k = 0; k < nkeys; ++k) {
+    start[k] = pos;
+    for (int t = 0; t < T; ++t) { const int c = hist[t][k]; hist[t][k] = pos; pos += c; }
+  }
+  start[nkeys] = pos;
+  run([&](int t) {
+    for (long long i = n * t / T; i < n * (t + 1) / T; ++i) emit(i, hist[t][key(i)]++);
+  });
 }
 
 static inline int model_k(int m) { return m == MAVBA_MODEL_PINHOLE ? 4 : m == MAVBA_MODEL_OPENCV ? 8 : 9; }
@@ -414,9 +460,16 @@ void mavba_session::build(const mavba_problem* P) {
   KMAX = kmax;  // 4, 8 or 9: number of intrinsics columns the Jacobian planes carry
   for (int i = 0; i < NI; ++i)
     if (h_img_cam[i] < 0 || h_img_cam[i] >= NC) throw Failure(MAVBA_ERR_BAD_INDEX, "image_camera out of range");
-  for (long long o = 0; o < NO_all; ++o)
-    if (P->obs_image[o] < 0 || P->obs_image[o] >= NI || P->obs_point[o] < 0 || P->obs_point[o] >= NP)
-      throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
+  {
+    int bad = 0;
+    parallel_ranges(NO_all, [&](long long b0, long long b1) {
+      int local = 0;
+      for (long long o = b0; o < b1; ++o)
+        local |= (P->obs_image[o] < 0) | (P->obs_image[o] >= NI) | (P->obs_point[o] < 0) | (P->obs_point[o] >= NP);
+      if (local) __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+    });
+    if (bad) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
+  }
   for (int q = 0; q < P->num_rot_priors; ++q)
     if (P->rot_prior_image[q] < 0 || P->rot_prior_image[q] >= NI) throw Failure(MAVBA_ERR_BAD_INDEX, "rot_prior_image out of range");
 
@@ -436,20 +489,33 @@ void mavba_session::build(const mavba_problem* P) {
   fixed_cost = 0.0;
   const double b = opt.loss_scale_factor * opt.loss_scale_factor;
   h_img_used.assign(NI, 0); h_cam_used.assign(NC, 0); h_pt_used.assign(NP, 0);
-  for (long long o = 0; o < NO_all; ++o) {
-    const int i = P->obs_image[o], p = P->obs_point[o], c = h_img_cam[i];
-    h_pt_count_all[p]++;
-    if ((h_pose_const[i] & 15u) == 15u && h_intr_const_in[c] && h_pt_const_in[p]) {
-      double rec[9], r[2], w, hr;
-      cam_prepare(&h_poses0[(size_t)i * 6], rec);
-      obs_residual(h_cam_model[c], rec, &h_intr0[(size_t)c * 9], &h_points0[(size_t)p * 3], P->obs_uv[2 * o],
-                   P->obs_uv[2 * o + 1], r);
-      cauchy_weight(r[0] * r[0] + r[1] * r[1], b, 1.0 / b, w, hr);
-      fixed_cost += hr;
-      continue;
+  // Only an observation whose image is entirely constant (pose AND its camera's intrinsics) on a constant point
+  // can leave the program. Without such a combination (the normal case: global BA has no constant points, local
+  // BA windows only a few) every observation is kept and the pass is a parallel histogram.
+  bool any_const_img = false, any_const_pt = false;
+  for (int i = 0; i < NI; ++i) any_const_img |= (h_pose_const[i] & 15u) == 15u && h_intr_const_in[h_img_cam[i]];
+  for (int p = 0; p < NP; ++p) any_const_pt |= h_pt_const_in[p] != 0;
+  const bool all_kept = !(any_const_img && any_const_pt);
+  if (all_kept) {
+    // (the per-point counts and the used flags then fall out of the counting sorts below)
+    kept.resize((size_t)NO_all);
+    parallel_ranges(NO_all, [&](long long b0, long long b1) { for (long long o = b0; o < b1; ++o) kept[o] = o; });
+  } else {
+    for (long long o = 0; o < NO_all; ++o) {
+      const int i = P->obs_image[o], p = P->obs_point[o], c = h_img_cam[i];
+      h_pt_count_all[p]++;
+      if ((h_pose_const[i] & 15u) == 15u && h_intr_const_in[c] && h_pt_const_in[p]) {
+        double rec[9], r[2], w, hr;
+        cam_prepare(&h_poses0[(size_t)i * 6], rec);
+        obs_residual(h_cam_model[c], rec, &h_intr0[(size_t)c * 9], &h_points0[(size_t)p * 3], P->obs_uv[2 * o],
+                     P->obs_uv[2 * o + 1], r);
+        cauchy_weight(r[0] * r[0] + r[1] * r[1], b, 1.0 / b, w, hr);
+        fixed_cost += hr;
+        continue;
+      }
+      kept.push_back(o);
+      h_img_used[i] = 1; h_cam_used[c] = 1; h_pt_used[p] = 1;
     }
-    kept.push_back(o);
-    h_img_used[i] = 1; h_cam_used[c] = 1; h_pt_used[p] = 1;
   }
   lap("validate + fixed blocks");
   N = (int)kept.size();
@@ -480,22 +546,21 @@ void mavba_session::build(const mavba_problem* P) {
   // One stable counting sort of the kept observations by (caller's) point gives every point's bucket; the
   // point-major order is the buckets concatenated in the new point order.
   std::vector<int> pt_new(NP);
-  std::vector<int> cstart(NP + 1, 0);
-  std::vector<long long> bucket(std::max(N, 1));  // kept observation ids, grouped by caller's point, input order inside
+  std::vector<int> cstart;
+  HostBuf<long long> bucket(N);  // kept observation ids, grouped by caller's point, input order inside
   {
-    for (int k = 0; k < N; ++k) cstart[P->obs_point[kept[k]] + 1]++;
-    for (int p = 0; p < NP; ++p) cstart[p + 1] += cstart[p];
-    std::vector<int> simg(std::max(N, 1));
-    {
-      std::vector<int> cur(cstart.begin(), cstart.end() - 1);
-      for (int k = 0; k < N; ++k) { const int at = cur[P->obs_point[kept[k]]]++; bucket[at] = kept[k]; simg[at] = P->obs_image[kept[k]]; }
-    }
+    HostBuf<int> simg(N);
+    counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept[k]]; }, cstart,
+                           [&](long long k, int at) { bucket[at] = kept[k]; simg[at] = P->obs_image[kept[k]]; });
+    if (all_kept)
+      for (int p = 0; p < NP; ++p) { h_pt_count_all[p] = cstart[p + 1] - cstart[p]; h_pt_used[p] = h_pt_count_all[p] > 0; }
     parallel_ranges(NP, [&](long long b0, long long b1) {
-      for (long long p = b0; p < b1; ++p) std::sort(simg.begin() + cstart[p], simg.begin() + cstart[p + 1]);
+      for (long long p = b0; p < b1; ++p) std::sort(simg.data() + cstart[p], simg.data() + cstart[p + 1]);
     });
-    h_pt_orig.resize(NP);
-    for (int p = 0; p < NP; ++p) h_pt_orig[p] = p;
-    auto before = [&](int a, int b) {
+    // Order: by the first four images packed into one 64-bit key (cache-friendly sort of (key, point) pairs),
+    // ties by the full list, then by point id - a strict total order, so the result does not depend on the
+    // number of threads.
+    auto before_full = [&](int a, int b) {
       const int* xa = simg.data() + cstart[a]; const int* xb = simg.data() + cstart[b];
       const int na = cstart[a + 1] - cstart[a], nb = cstart[b + 1] - cstart[b];
       const int n = std::min(na, nb);
@@ -503,25 +568,41 @@ void mavba_session::build(const mavba_problem* P) {
       if (na != nb) return na < nb;
       return a < b;
     };
-    // sorted runs on a few threads, then pairwise merges (the comparator is a strict total order)
+    typedef std::pair<unsigned long long, int> KeyId;
+    HostBuf<KeyId> keyed(NP);
+    const bool packable = NI < 65535;
+    parallel_ranges(NP, [&](long long b0, long long b1) {
+      for (long long p = b0; p < b1; ++p) {
+        unsigned long long key = 0;
+        const int n = cstart[p + 1] - cstart[p];
+        for (int i = 0; i < 4; ++i) key = key << 16 | (unsigned long long)(packable && i < n ? simg[cstart[p] + i] : 0xFFFF);
+        keyed[p] = KeyId(packable ? key : 0ull, (int)p);
+      }
+    });
+    auto before = [&](const KeyId& a, const KeyId& b) {
+      if (a.first != b.first) return a.first < b.first;
+      return before_full(a.second, b.second);
+    };
+    // sorted runs on a few threads, then pairwise merges
     const int T = NP >= 100000 ? (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
     std::vector<int> cut(T + 1);
     for (int t = 0; t <= T; ++t) cut[t] = (int)((long long)NP * t / T);
     {
       std::vector<std::thread> th;
       for (int t = 0; t < T; ++t)
-        th.emplace_back([&, t] { std::sort(h_pt_orig.begin() + cut[t], h_pt_orig.begin() + cut[t + 1], before); });
+        th.emplace_back([&, t] { std::sort(keyed.data() + cut[t], keyed.data() + cut[t + 1], before); });
       for (auto& x : th) x.join();
     }
     for (int w = 1; w < T; w *= 2) {
       std::vector<std::thread> th;
       for (int t = 0; t + w < T; t += 2 * w)
         th.emplace_back([&, t, w] {
-          std::inplace_merge(h_pt_orig.begin() + cut[t], h_pt_orig.begin() + cut[t + w],
-                             h_pt_orig.begin() + cut[std::min(t + 2 * w, T)], before);
+          std::inplace_merge(keyed.data() + cut[t], keyed.data() + cut[t + w], keyed.data() + cut[std::min(t + 2 * w, T)], before);
         });
       for (auto& x : th) x.join();
     }
+    h_pt_orig.resize(NP);
+    for (int q = 0; q < NP; ++q) h_pt_orig[q] = keyed[q].second;
     for (int q = 0; q < NP; ++q) pt_new[h_pt_orig[q]] = q;
     auto permute = [&](auto& v, int width) {
       auto old = v;
@@ -538,8 +619,8 @@ void mavba_session::build(const mavba_problem* P) {
   h_pt_start.assign(NP + 1, 0);
   for (int q = 0; q < NP; ++q) h_pt_start[q + 1] = h_pt_start[q] + (cstart[h_pt_orig[q] + 1] - cstart[h_pt_orig[q]]);
   perm.assign(N, 0);
-  std::vector<double2> uv(N);
-  std::vector<int> opt_(N);
+  HostBuf<double2> uv(N);
+  HostBuf<int> opt_(N);
   h_oimg.assign(N, 0);
   parallel_ranges(NP, [&](long long q0, long long q1) {
     for (long long q = q0; q < q1; ++q) {
@@ -556,34 +637,14 @@ void mavba_session::build(const mavba_problem* P) {
 
   lap("point-major sort");
   // ---- image-major view for the camera sweep ----
-  std::vector<int> img_start(NI + 1, 0);
-  std::vector<double2> im_uv(N);
-  std::vector<int> im_pt(N);
-  {
-    // stable counting sort by image on T threads: per-thread histograms -> per-thread cursors
-    const int T = N >= 200000 ? (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
-    std::vector<std::vector<int>> hist(T, std::vector<int>(NI, 0));
-    auto run = [&](auto&& body) {
-      if (T == 1) { body(0); return; }
-      std::vector<std::thread> th;
-      for (int t = 0; t < T; ++t) th.emplace_back(body, t);
-      for (auto& x : th) x.join();
-    };
-    run([&](int t) {
-      const int a0 = (int)((long long)N * t / T), a1 = (int)((long long)N * (t + 1) / T);
-      for (int a = a0; a < a1; ++a) hist[t][h_oimg[a]]++;
-    });
-    int runpos = 0;
-    for (int i = 0; i < NI; ++i) {
-      img_start[i] = runpos;
-      for (int t = 0; t < T; ++t) { const int c = hist[t][i]; hist[t][i] = runpos; runpos += c; }
-    }
-    img_start[NI] = runpos;
-    run([&](int t) {
-      const int a0 = (int)((long long)N * t / T), a1 = (int)((long long)N * (t + 1) / T);
-      for (int a = a0; a < a1; ++a) { const int at = hist[t][h_oimg[a]]++; im_uv[at] = uv[a]; im_pt[at] = opt_[a]; }
-    });
-  }
+  std::vector<int> img_start;
+  HostBuf<double2> im_uv(N);
+  HostBuf<int> im_pt(N);
+  counting_sort_parallel(N, NI, [&](long long a) { return h_oimg[a]; }, img_start,
+                         [&](long long a, int at) { im_uv[at] = uv[a]; im_pt[at] = opt_[a]; });
+  if (all_kept)
+    for (int i = 0; i < NI; ++i)
+      if (img_start[i + 1] > img_start[i]) { h_img_used[i] = 1; h_cam_used[h_img_cam[i]] = 1; }
   const int kSweepChunk = 2048;
   std::vector<SweepChunk> sweep_chunks;
   std::vector<int> img_chunk_start(NI + 1, 0);
@@ -615,8 +676,8 @@ void mavba_session::build(const mavba_problem* P) {
 
   lap("image-major view");
   // ---- uploads of the static data ----
-  d_uv.upload(uv, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload(opt_, st); d_pt_start.upload(h_pt_start, st);
-  d_im_uv.upload(im_uv, st); d_im_pt.upload(im_pt, st);
+  d_uv.upload(uv.data(), (size_t)N, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload(opt_.data(), (size_t)N, st); d_pt_start.upload(h_pt_start, st);
+  d_im_uv.upload(im_uv.data(), (size_t)N, st); d_im_pt.upload(im_pt.data(), (size_t)N, st);
   d_img_cam.upload(h_img_cam, st); d_cam_model.upload(h_cam_model, st);
   d_sweep_chunks.upload(sweep_chunks, st); d_img_chunk_start.upload(img_chunk_start, st);
   d_cam_img_start.upload(cam_img_start, st); d_cam_imgs.upload(cam_imgs, st);
@@ -857,7 +918,7 @@ void mavba_session::finish_structure() {
     // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
     // thread": the clusters - and with them the order in which partials are added - must not depend on the
     // machine's core count).
-    const int kRange = 16384;
+    const int kRange = 4096;
     const int nranges = (NP + kRange - 1) / kRange;
     std::vector<std::vector<SchurCluster>> r_clusters(nranges);
     std::vector<std::vector<int>> r_imgs(nranges), r_cams(nranges);
@@ -944,7 +1005,7 @@ void mavba_session::finish_structure() {
         }
       }
     }
-  });
+  }, 64);
   clustered_points = 0;
   for (int p = 0; p < NP; ++p) clustered_points += pt_mode[p] == 1;
   lap("point clusters");
