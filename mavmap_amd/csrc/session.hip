@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <limits>
 #include <map>
 #include <memory>
@@ -172,6 +174,57 @@ void stream_release(hipStream_t st, int dev) {  // the caller has synchronised i
   (void)hipStreamDestroy(st);
 }
 
+// Persistent host worker threads for the set-up passes: creating and joining 16 threads costs ~0.5-1 ms on a
+// 256-thread host and build() has ~20 parallel passes. host_run(T, body) runs body(0..T-1) on the workers and
+// returns when all are done; calls are serialised (sessions may be created from several user threads).
+class HostWorkers {
+  std::vector<std::thread> workers;
+  std::mutex m, run_m;
+  std::condition_variable cv_start, cv_done;
+  const std::function<void(int)>* job = nullptr;
+  int job_T = 0, remaining = 0;
+  unsigned long long generation = 0;
+
+  void loop(int id) {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_start.wait(lk, [&] { return generation != seen; });
+      seen = generation;
+      if (id < job_T) {
+        const std::function<void(int)>* j = job;
+        lk.unlock();
+        (*j)(id);
+        lk.lock();
+        if (--remaining == 0) cv_done.notify_one();
+      }
+    }
+  }
+
+ public:
+  explicit HostWorkers(int n) {
+    for (int i = 0; i < n; ++i) { workers.emplace_back([this, i] { loop(i); }); workers.back().detach(); }
+  }
+  int size() const { return (int)workers.size(); }
+  void run(int T, const std::function<void(int)>& body) {
+    std::lock_guard<std::mutex> one(run_m);
+    std::unique_lock<std::mutex> lk(m);
+    job = &body; job_T = T; remaining = T; ++generation;
+    cv_start.notify_all();
+    cv_done.wait(lk, [&] { return remaining == 0; });
+    job = nullptr;
+  }
+};
+static int host_threads() {
+  static const int n = (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+  return n;
+}
+static void host_run(int T, const std::function<void(int)>& body) {
+  if (T <= 1) { body(0); return; }
+  static HostWorkers* W = new HostWorkers(host_threads());  // never destroyed: the workers outlive static destruction
+  W->run(std::min(T, W->size()), body);
+}
+
 // Host scratch array WITHOUT value-initialisation (std::vector<T>(n) clears the memory first: ~1 ms per 10 MB,
 // and the set-up shuffles ~100 MB of such arrays that are fully overwritten anyway).
 template <typename T>
@@ -189,15 +242,10 @@ struct HostBuf {
 // The result does not depend on the number of threads.
 template <typename KeyFn, typename EmitFn>
 static void counting_sort_parallel(long long n, int nkeys, KeyFn key, std::vector<int>& start, EmitFn emit) {
-  int T = n >= 200000 ? (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  int T = n >= 200000 ? host_threads() : 1;
   while (T > 1 && (size_t)T * nkeys > ((size_t)64 << 20)) T /= 2;
   std::vector<std::vector<int>> hist(T);
-  auto run = [&](auto&& body) {
-    if (T == 1) { body(0); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) th.emplace_back(body, t);
-    for (auto& x : th) x.join();
-  };
+  auto run = [&](const std::function<void(int)>& body) { host_run(T, body); };
   run([&](int t) {
     hist[t].assign((size_t)nkeys, 0);
     for (long long i = n * t / T; i < n * (t + 1) / T; ++i) hist[t][key(i)]++;
@@ -225,13 +273,10 @@ struct KernelTimer { std::string name; long long launches = 0; double total_ms =
 // Run body(begin, end) over [0, n) on a few host threads (set-up work only).
 template <typename F>
 static void parallel_ranges(long long n, F&& body, long long min_parallel = 200000) {
-  int T = (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
-  T = (int)std::min<long long>(T, std::max<long long>(n, 1));
+  int T = (int)std::min<long long>(host_threads(), std::max<long long>(n, 1));
   if (n < min_parallel) T = 1;
   if (T == 1) { body(0ll, n); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < T; ++t) th.emplace_back([&, t] { body(n * t / T, n * (t + 1) / T); });
-  for (auto& x : th) x.join();
+  host_run(T, [&](int t) { body(n * t / T, n * (t + 1) / T); });
 }
 
 }  // namespace mavba
@@ -552,6 +597,7 @@ void mavba_session::build(const mavba_problem* P) {
     HostBuf<int> simg(N);
     counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept[k]]; }, cstart,
                            [&](long long k, int at) { bucket[at] = kept[k]; simg[at] = P->obs_image[kept[k]]; });
+    lap("  buckets by point");
     if (all_kept)
       for (int p = 0; p < NP; ++p) { h_pt_count_all[p] = cstart[p + 1] - cstart[p]; h_pt_used[p] = h_pt_count_all[p] > 0; }
     parallel_ranges(NP, [&](long long b0, long long b1) {
@@ -568,6 +614,7 @@ void mavba_session::build(const mavba_problem* P) {
       if (na != nb) return na < nb;
       return a < b;
     };
+    lap("  per-point image lists");
     typedef std::pair<unsigned long long, int> KeyId;
     HostBuf<KeyId> keyed(NP);
     const bool packable = NI < 65535;
@@ -584,23 +631,19 @@ void mavba_session::build(const mavba_problem* P) {
       return before_full(a.second, b.second);
     };
     // sorted runs on a few threads, then pairwise merges
-    const int T = NP >= 100000 ? (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    const int T = NP >= 100000 ? host_threads() : 1;
     std::vector<int> cut(T + 1);
     for (int t = 0; t <= T; ++t) cut[t] = (int)((long long)NP * t / T);
-    {
-      std::vector<std::thread> th;
-      for (int t = 0; t < T; ++t)
-        th.emplace_back([&, t] { std::sort(keyed.data() + cut[t], keyed.data() + cut[t + 1], before); });
-      for (auto& x : th) x.join();
-    }
+    host_run(T, [&](int t) { std::sort(keyed.data() + cut[t], keyed.data() + cut[t + 1], before); });
     for (int w = 1; w < T; w *= 2) {
-      std::vector<std::thread> th;
-      for (int t = 0; t + w < T; t += 2 * w)
-        th.emplace_back([&, t, w] {
+      const int pairs = (T + 2 * w - 1) / (2 * w);
+      host_run(pairs, [&](int q) {
+        const int t = q * 2 * w;
+        if (t + w < T)
           std::inplace_merge(keyed.data() + cut[t], keyed.data() + cut[t + w], keyed.data() + cut[std::min(t + 2 * w, T)], before);
-        });
-      for (auto& x : th) x.join();
+      });
     }
+    lap("  sort points");
     h_pt_orig.resize(NP);
     for (int q = 0; q < NP; ++q) h_pt_orig[q] = keyed[q].second;
     for (int q = 0; q < NP; ++q) pt_new[h_pt_orig[q]] = q;
@@ -1036,7 +1079,7 @@ void mavba_session::finish_structure() {
   // Host threads own contiguous point ranges (balanced by observations). Per-thread counts turn
   // into per-thread cursors, so the term order inside a block (by point) does not depend on the
   // number of threads: the device sums stay bit-reproducible.
-  int T = (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+  int T = host_threads();
   if (N < 50000) T = 1;
   while (T > 1 && (size_t)T * nkeys_tot > (size_t)48 << 20) T /= 2;
   std::vector<int> range(T + 1, NP);
@@ -1047,12 +1090,7 @@ void mavba_session::finish_structure() {
     range[t] = std::max(range[t - 1], std::min(range[t], NP));
   }
   std::vector<std::vector<int>> tcount(T * 3);
-  auto run_threads = [&](auto&& body) {
-    if (T == 1) { body(0); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) th.emplace_back(body, t);
-    for (auto& x : th) x.join();
-  };
+  auto run_threads = [&](const std::function<void(int)>& body) { host_run(T, body); };
   run_threads([&](int t) {
     for (int k = 0; k < 3; ++k) tcount[t * 3 + k].assign(nkeys[k], 0);
     enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int, int) { tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++; });
