@@ -53,9 +53,20 @@ void launch_partial_reduce(hipStream_t st, int num_tasks, const PartialReduce* t
 //   cols  3*point + t
 // computed on the FP64 matrix cores from LDS; each block that is present in the cluster then leaves as
 // ONE partial (slot table) instead of one gathered term per (point, pair).
-constexpr int kClImages = 16, kClCams = 3, kClRows = 128, kClHRow = 123;
+// Two shapes: 16 images x 3 cameras (128 rows, 36 lower 16x16 tiles) and 12 images x 2 cameras (96 rows, 21 tiles:
+// 42 % fewer matrix instructions when the tracks are short and at most two cameras are refined).
+struct ClusterShape {
+  int images, cams;
+  int cam_row0() const { return 6 * images; }
+  int hrow() const { return 6 * images + 9 * cams; }
+  int rows() const { return (hrow() + 1 + 15) / 16 * 16; }
+  int tab_pp() const { return 0; }
+  int tab_ip() const { return images * (images + 1) / 2; }
+  int tab_ii() const { return tab_ip() + cams * images; }
+  int tab() const { return tab_ii() + cams * (cams + 1) / 2; }
+};
+constexpr int kClImagesMax = 16, kClCamsMax = 3;
 constexpr int kClBatch = 32;                     // points per LDS batch -> K = 96 columns (16 -> two work-groups per CU, measured slower)
-constexpr int kClTabPP = 0, kClTabIP = 136, kClTabII = 136 + 48, kClTab = 136 + 48 + 6;
 constexpr int kClMaxBatches = 64;                // a cluster spans at most kClMaxBatches * kClBatch consecutive points
 struct SchurCluster { int p0, p1; };
 
@@ -140,7 +151,7 @@ void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurCh
 int schur_partial_stride(int kind);
 // obs_meta / q_meta: per observation / intrinsics entry, local index << 8 | (point - cluster.p0) % kClBatch,
 // 0xFFFF for records that are not part of a cluster.
-void launch_schur_clusters(hipStream_t st, int num_clusters, const SchurCluster* clusters, const int* tab,
+void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters, const SchurCluster* clusters, const int* tab,
                            const int* pt_start, const int* q_start, const unsigned short* obs_meta,
                            const unsigned short* q_meta, const unsigned char* pt_clustered, const double* Epose,
                            const double* Eintr, const double* h, int NPs, double* part_pp, double* part_ip,

@@ -848,34 +848,41 @@ __global__ void __launch_bounds__(256) k_schur_chunks(int num_chunks, const Schu
 
 // ---------------------------------------------------------------------------
 // Schur clusters (layout in internal.h): one work-group per cluster. The stacked entry matrix E of a batch
-// of kClBatch points is built in LDS (128 rows x 96 columns, pitch 100 -> conflict-free operand reads), and
-// S_cl += E E^T runs on v_mfma_f64_16x16x4_f64: the 36 lower 16x16 tiles are dealt round-robin to the 4
-// waves (9 accumulators each); both operands of a tile are rows of E, so a k-step costs 8 LDS reads and 9
+// of kClBatch points is built in LDS (rows x 96 columns, pitch 100 -> conflict-free operand reads), and
+// S_cl += E E^T runs on v_mfma_f64_16x16x4_f64: the lower 16x16 tiles (36 for 128 rows, 21 for 96) are dealt
+// round-robin to the 4 waves; both operands of a tile are rows of E, so a k-step costs NT LDS reads and <= 9
 // matrix instructions per wave. 53 KB of LDS -> three work-groups per CU: one fetches its next batch while
 // the others keep the matrix cores busy. Every entry record is read from HBM exactly once per linear solve.
 // ---------------------------------------------------------------------------
 namespace {
 typedef double cl_d4 __attribute__((ext_vector_type(4)));
 constexpr int kClK = 3 * kClBatch, kClPitch = kClK + 4;
-constexpr int kClThreads = 256, kClWaves = kClThreads / 64, kClAcc = (36 + kClWaves - 1) / kClWaves;
+constexpr int kClThreads = 256, kClWaves = kClThreads / 64;
+template <int I, int C>
+struct ClShape {
+  static constexpr int images = I, cams = C, cam_row0 = 6 * I, hrow = 6 * I + 9 * C, rows = (hrow + 16) / 16 * 16;
+  static constexpr int NT = rows / 16, tiles = NT * (NT + 1) / 2, acc = (tiles + kClWaves - 1) / kClWaves;
+  static constexpr int tab_ip = I * (I + 1) / 2, tab_ii = tab_ip + C * I, tab = tab_ii + C * (C + 1) / 2;
+};
 // false: small batches, two work-groups per CU that hide each other's latencies; true: one work-group per CU that
 // prefetches its next batch and double-buffers the operand reads itself
 constexpr bool kClPipelined = kClBatch >= 32;
-template <int W>
-__device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int lane, cl_d4 (&acc)[kClAcc]) {
+template <class SH, int W>
+__device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int lane, cl_d4 (&acc)[SH::acc]) {
+  constexpr int NT = SH::NT;
   const int li = lane & 15, lk = lane >> 4;
   const double* base = E + li * kClPitch + lk;
   // Two operand register sets, no copies: the LDS reads of k-step kk + 4 are issued before the matrix
   // instructions of k-step kk, so their latency hides behind those (copies between the sets made the
   // compiler wait for the reads at the top of every step).
-  auto load = [&](double (&x)[8], int kk) {
+  auto load = [&](double (&x)[NT], int kk) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = base[16 * i * kClPitch + kk];
+    for (int i = 0; i < NT; ++i) x[i] = base[16 * i * kClPitch + kk];
   };
-  auto mma = [&](const double (&x)[8]) {
+  auto mma = [&](const double (&x)[NT]) {
     int t = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
         if (t % kClWaves == W) acc[t / kClWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], x[j], acc[t / kClWaves], 0, 0, 0);
@@ -884,12 +891,12 @@ __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int l
   };
   if constexpr (!kClPipelined) {
     // two work-groups share the CU: the other one's matrix instructions cover this wave's LDS reads
-    double a[8];
+    double a[NT];
 #pragma unroll 1
     for (int kk = 0; kk < kClK; kk += 4) { load(a, kk); mma(a); }
   } else {
     static_assert(kClK % 8 == 0, "two k-steps per trip");
-    double a[8], b[8];
+    double a[NT], b[NT];
     load(a, 0);
 #pragma unroll 1
     for (int kk = 0; kk < kClK; kk += 8) {
@@ -905,53 +912,55 @@ __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int l
   }
 }
 // element (R, C), R >= C, of the cluster's product -> partial slot
+template <class SH>
 __device__ __forceinline__ void cluster_store(int R, int C, double v, const int* __restrict__ tab,
                                               double* __restrict__ part_pp, double* __restrict__ part_ip,
                                               double* __restrict__ part_ii) {
-  if (R < 96) {                       // pose x pose
+  constexpr int P0 = SH::cam_row0, H = SH::hrow;
+  if (R < P0) {                       // pose x pose
     const int la = R / 6, r = R - 6 * la, lb = C / 6, c = C - 6 * lb;
     if (la == lb && r < c) return;    // diagonal blocks: the finalize pass only reads r >= c
-    const int slot = tab[kClTabPP + la * (la + 1) / 2 + lb];
+    const int slot = tab[la * (la + 1) / 2 + lb];
     if (slot >= 0) part_pp[(size_t)slot * 42 + r * 6 + c] = v;
-  } else if (R < kClHRow) {
-    const int lc = (R - 96) / 9, r = (R - 96) - 9 * lc;
-    if (C < 96) {                     // intrinsics x pose
+  } else if (R < H) {
+    const int lc = (R - P0) / 9, r = (R - P0) - 9 * lc;
+    if (C < P0) {                     // intrinsics x pose
       const int la = C / 6, c = C - 6 * la;
-      const int slot = tab[kClTabIP + lc * kClImages + la];
+      const int slot = tab[SH::tab_ip + lc * SH::images + la];
       if (slot >= 0) part_ip[(size_t)slot * 54 + r * 6 + c] = v;
     } else {                          // intrinsics x intrinsics
-      const int lc2 = (C - 96) / 9, c = (C - 96) - 9 * lc2;
+      const int lc2 = (C - P0) / 9, c = (C - P0) - 9 * lc2;
       if (lc == lc2 && r < c) return;
-      const int slot = tab[kClTabII + lc * (lc + 1) / 2 + lc2];
+      const int slot = tab[SH::tab_ii + lc * (lc + 1) / 2 + lc2];
       if (slot >= 0) part_ii[(size_t)slot * 90 + r * 9 + c] = v;
     }
-  } else if (R == kClHRow) {          // h row: the right-hand-side parts of the diagonal blocks
-    if (C < 96) {
+  } else if (R == H) {                // h row: the right-hand-side parts of the diagonal blocks
+    if (C < P0) {
       const int la = C / 6, r = C - 6 * la;
-      const int slot = tab[kClTabPP + la * (la + 1) / 2 + la];
+      const int slot = tab[la * (la + 1) / 2 + la];
       if (slot >= 0) part_pp[(size_t)slot * 42 + 36 + r] = v;
-    } else if (C < kClHRow) {
-      const int lc = (C - 96) / 9, r = (C - 96) - 9 * lc;
-      const int slot = tab[kClTabII + lc * (lc + 1) / 2 + lc];
+    } else if (C < H) {
+      const int lc = (C - P0) / 9, r = (C - P0) - 9 * lc;
+      const int slot = tab[SH::tab_ii + lc * (lc + 1) / 2 + lc];
       if (slot >= 0) part_ii[(size_t)slot * 90 + 81 + r] = v;
     }
   }
 }
-template <int W>
-__device__ __forceinline__ void cluster_emit(int lane, const cl_d4 (&acc)[kClAcc], const int* __restrict__ tab,
+template <class SH, int W>
+__device__ __forceinline__ void cluster_emit(int lane, const cl_d4 (&acc)[SH::acc], const int* __restrict__ tab,
                                              double* __restrict__ part_pp, double* __restrict__ part_ip,
                                              double* __restrict__ part_ii) {
   const int li = lane & 15, lk = lane >> 4;
   int t = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < SH::NT; ++i)
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
       if (t % kClWaves == W) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int R = 16 * i + lk + 4 * r, C = 16 * j + li;  // D layout of the matrix instruction
-          if (R >= C) cluster_store(R, C, acc[t / kClWaves][r], tab, part_pp, part_ip, part_ii);
+          if (R >= C) cluster_store<SH>(R, C, acc[t / kClWaves][r], tab, part_pp, part_ip, part_ii);
         }
       }
       ++t;
@@ -960,7 +969,7 @@ __device__ __forceinline__ void cluster_emit(int lane, const cl_d4 (&acc)[kClAcc
 }  // namespace
 
 namespace {
-constexpr int kClChunk = kClImages * kClBatch * (kPoseRec / 2) / 256 * 2 / 3, kClQChunk = (kClCams * kClBatch * (kIntrRec / 2) + 255) / 256;  // value loads a thread has in flight per batch (pose / intrinsics records)
+constexpr int kClChunk = kClImagesMax * kClBatch * (kPoseRec / 2) / 256 * 2 / 3, kClQChunk = (2 * kClBatch * (kIntrRec / 2) + 255) / 256;  // value loads a thread has in flight per batch (pose / intrinsics records)
 // Records of one batch, HBM -> LDS matrix. Element e of a record sits at (row e / 3, column e % 3) relative to
 // the record's base (row 6 la or 96 + 9 lc, column 3 * point-in-batch). Thread tid takes the double2 number
 // f = u * 256 + tid of the batch's contiguous record range. The value loads do not wait for the record's local
@@ -1014,15 +1023,16 @@ __device__ __forceinline__ void cluster_overflow(double* __restrict__ E, int tid
 }
 }  // namespace
 
+template <class SH>
 __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clusters(
     const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ pt_start,
     const int* __restrict__ q_start, const unsigned short* __restrict__ obs_meta,
     const unsigned short* __restrict__ q_meta, const unsigned char* __restrict__ pt_clustered,
     const double* __restrict__ Epose, const double* __restrict__ Eintr, const double* __restrict__ h, int NPs,
     double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
-  __shared__ __attribute__((aligned(16))) double E[kClRows * kClPitch];
+  __shared__ __attribute__((aligned(16))) double E[SH::rows * kClPitch];
   __shared__ int s_bounds[2][kClMaxBatches + 1];  // first observation / intrinsics entry of every batch
-  __shared__ int s_tab[kClTab];
+  __shared__ int s_tab[SH::tab];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const SchurCluster cl = clusters[blockIdx.x];
   const int nbatch = (cl.p1 - cl.p0 + kClBatch - 1) / kClBatch;
@@ -1031,10 +1041,10 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
     s_bounds[0][i] = pt_start[p];
     s_bounds[1][i] = q_start[p];
   }
-  for (int i = tid; i < kClTab; i += kClThreads) s_tab[i] = tabs[(size_t)blockIdx.x * kClTab + i];
-  cl_d4 acc[kClAcc];
+  for (int i = tid; i < SH::tab; i += kClThreads) s_tab[i] = tabs[(size_t)blockIdx.x * SH::tab + i];
+  cl_d4 acc[SH::acc];
 #pragma unroll
-  for (int i = 0; i < kClAcc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < SH::acc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
   __syncthreads();
   ClusterRegs<kPoseRec, 18, kClChunk> RP;
   ClusterRegs<kIntrRec, 27, kClQChunk> RQ;
@@ -1054,42 +1064,46 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
   if constexpr (kClPipelined) fetch(0);
   for (int bi = 0; bi < nbatch; ++bi) {
     if constexpr (!kClPipelined) fetch(bi);  // all loads of the batch are in flight while E is cleared
-    for (int i = tid; i < kClRows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
+    for (int i = tid; i < SH::rows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
     __syncthreads();
     cluster_scatter(RP, E, tid, 0, 0, 6);
-    cluster_scatter(RQ, E, tid, 0, 96, 9);
-    if (hon) E[kClHRow * kClPitch + tid] = hv;
+    cluster_scatter(RQ, E, tid, 0, SH::cam_row0, 9);
+    if (hon) E[SH::hrow * kClPitch + tid] = hv;
     cluster_overflow<kPoseRec, 18, kClChunk>(E, tid, s_bounds[0][bi], s_bounds[0][bi + 1] - s_bounds[0][bi], 0, 6, obs_meta, Epose);
-    cluster_overflow<kIntrRec, 27, kClQChunk>(E, tid, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], 96, 9, q_meta, Eintr);
+    cluster_overflow<kIntrRec, 27, kClQChunk>(E, tid, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], SH::cam_row0, 9, q_meta, Eintr);
     __syncthreads();
     if constexpr (kClPipelined) {
       if (bi + 1 < nbatch) fetch(bi + 1);  // travels while the matrix cores work on this batch
       __builtin_amdgcn_sched_barrier(0);   // (keep the loads here: the scheduler would sink them to their use)
     }
     switch (wv) {
-      case 0: cluster_mfma<0>(E, lane, acc); break;
-      case 1: cluster_mfma<1>(E, lane, acc); break;
-      case 2: cluster_mfma<2>(E, lane, acc); break;
-      default: cluster_mfma<3>(E, lane, acc); break;
+      case 0: cluster_mfma<SH, 0>(E, lane, acc); break;
+      case 1: cluster_mfma<SH, 1>(E, lane, acc); break;
+      case 2: cluster_mfma<SH, 2>(E, lane, acc); break;
+      default: cluster_mfma<SH, 3>(E, lane, acc); break;
     }
     __syncthreads();
   }
   const int* tab = s_tab;
   switch (wv) {
-    case 0: cluster_emit<0>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    case 1: cluster_emit<1>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    case 2: cluster_emit<2>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    default: cluster_emit<3>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 0: cluster_emit<SH, 0>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 1: cluster_emit<SH, 1>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 2: cluster_emit<SH, 2>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    default: cluster_emit<SH, 3>(lane, acc, tab, part_pp, part_ip, part_ii); break;
   }
 }
-void launch_schur_clusters(hipStream_t st, int num_clusters, const SchurCluster* clusters, const int* tab,
+void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters, const SchurCluster* clusters, const int* tab,
                            const int* pt_start, const int* q_start, const unsigned short* obs_meta,
                            const unsigned short* q_meta, const unsigned char* pt_clustered, const double* Epose,
                            const double* Eintr, const double* h, int NPs, double* part_pp, double* part_ip,
                            double* part_ii) {
   if (num_clusters <= 0) return;
-  hipLaunchKernelGGL(k_schur_clusters, dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start, q_start,
-                     obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii);
+  if (shape.images == 12)
+    hipLaunchKernelGGL((k_schur_clusters<ClShape<12, 2>>), dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start,
+                       q_start, obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii);
+  else
+    hipLaunchKernelGGL((k_schur_clusters<ClShape<16, 3>>), dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start,
+                       q_start, obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii);
 }
 
 int schur_partial_stride(int kind) { return kind == BLK_PP ? 42 : kind == BLK_IP ? 54 : 90; }

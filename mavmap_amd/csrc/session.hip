@@ -325,6 +325,7 @@ struct mavba_session {
   DevBuf<unsigned short> d_obs_meta, d_q_meta;
   DevBuf<unsigned char> d_pt_clustered;
   int num_clusters = 0, num_slots[3] = {0, 0, 0};
+  ClusterShape cl_shape{16, 3};
   long long clustered_points = 0, cluster_partials = 0;
   double cluster_flops = 0.0;
   DevBuf<int2> d_terms[3];
@@ -952,7 +953,17 @@ void mavba_session::finish_structure() {
   std::vector<unsigned char> pt_mode(NP, 0);
   std::vector<unsigned short> obs_meta((size_t)std::max(N, 1), 0xFFFFu), q_meta((size_t)std::max(Q, 1), 0xFFFFu);
   std::vector<SchurCluster> clusters;
-  std::vector<int> cl_imgs, cl_cams;  // [cluster][kClImages] / [cluster][kClCams], ascending, -1 padded
+  std::vector<int> cl_imgs, cl_cams;  // [cluster][sh.images] / [cluster][sh.cams], ascending, -1 padded
+  {
+    // Cluster shape: 16 images x 3 cameras (128 rows, 36 tiles). MAVBA_CLUSTER_SHAPE=12 selects 12 x 2 (96 rows,
+    // 21 tiles): 42 % fewer matrix instructions per batch, but the smaller image list closes clusters earlier (C3:
+    // 2851 clusters of ~70 points instead of 1799 of ~110) and the per-cluster costs eat the gain - same 0.37 ms.
+    cl_shape = ClusterShape{16, 3};
+    if (const char* e = std::getenv("MAVBA_CLUSTER_SHAPE")) cl_shape = std::atoi(e) == 12 ? ClusterShape{12, 2} : ClusterShape{16, 3};
+  }
+  const ClusterShape sh = cl_shape;
+  const int kClTab = sh.tab(), kClTabPP = sh.tab_pp(), kClTabIP = sh.tab_ip(), kClTabII = sh.tab_ii();
+  const int kClImages = sh.images, kClCams = sh.cams;
   {
     bool use_clusters = true;
     if (const char* e = std::getenv("MAVBA_CLUSTERS")) use_clusters = std::atoi(e) != 0;
@@ -1013,11 +1024,11 @@ void mavba_session::finish_structure() {
   num_clusters = (int)clusters.size();
   cluster_flops = 0.0;
   for (const SchurCluster& c : clusters)  // batches x k-steps x 36 lower tiles x 2*16*16*4
-    cluster_flops += (double)((c.p1 - c.p0 + kClBatch - 1) / kClBatch) * (3 * kClBatch / 4) * 36.0 * 2048.0;
+    cluster_flops += (double)((c.p1 - c.p0 + kClBatch - 1) / kClBatch) * (3 * kClBatch / 4) * (double)((sh.rows() / 16) * (sh.rows() / 16 + 1) / 2) * 2048.0;
   // local indices of every clustered observation / intrinsics entry, and which blocks a cluster touches
   std::vector<unsigned char> cl_present((size_t)std::max(num_clusters, 1) * kClTab, 0);
   parallel_ranges(num_clusters, [&](long long c0, long long c1) {
-    int loc[kClImages];
+    int loc[kClImagesMax];
     for (long long cl = c0; cl < c1; ++cl) {
       const int* imgs = &cl_imgs[(size_t)cl * kClImages];
       const int* cams = &cl_cams[(size_t)cl * kClCams];
@@ -1334,7 +1345,7 @@ void mavba_session::assemble(double r) {
   });
   timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st)); });
   timed("schur_clusters", [&] {
-    launch_schur_clusters(st, num_clusters, d_clusters.p, d_cl_tab.p, d_pt_start.p, d_q_start.p, d_obs_meta.p,
+    launch_schur_clusters(st, cl_shape, num_clusters, d_clusters.p, d_cl_tab.p, d_pt_start.p, d_q_start.p, d_obs_meta.p,
                           d_q_meta.p, d_pt_clustered.p, d_Epose.p, d_Eintr.p, d_h.p, NPs, d_part[0].p, d_part[1].p,
                           d_part[2].p);
   });
