@@ -1,19 +1,22 @@
-// dense_chol.hip — dense SPD solve of the reduced camera system on gfx950.
+// dense_chol.hip — structured SPD solve of the reduced camera system on gfx950.
 //
 // Replaces what the reference gets from Ceres' SPARSE_SCHUR back end (CHOLMOD
 // factorisation of the reduced camera matrix, reference
-// src/base3d/bundle_adjustment.cc:555). Right-looking blocked Cholesky, NB = 64:
+// src/base3d/bundle_adjustment.cc:555). Right-looking blocked Cholesky, NB = 64, every product on
+// v_mfma_f64_16x16x4_f64:
 //
-//   diag    a 64x64 diagonal tile is factorised AND inverted by one wave with its row held
-//           in registers (fully unrolled, the other row broadcast from LDS);
-//   trsm    A_ik <- A_ik L_kk^-T is then a 64x64x64 product on the FP64 matrix cores
-//           (v_mfma_f64_16x16x4_f64) against the explicit inverse;
-//   update  trailing tiles C_ij -= A_ik A_jk^T, also FP64 MFMA; the work-group that owns
-//           tile (k+1, k+1) goes on to factorise + invert it, so the latency-bound tile
-//           factorisation of the NEXT panel overlaps the rest of this panel's update.
+//   diag    a 64x64 diagonal tile is factorised AND inverted (tile_potrf_inv_la: 16x16 blocks whose 16
+//           pivot steps are one rank-1 matrix instruction each, 4x4 blocks scheduled with look-ahead);
+//   trsm    A_ik <- A_ik L_kk^-T is then a 64x64x64 product against the explicit inverse;
+//   update  trailing tiles C_ij -= A_ik A_jk^T; the work-group that owns tile (k+1, k+1) goes on to
+//           factorise + invert it, so a panel step is ONE launch (two for large trailing matrices);
+//   fronts  with a nested-dissection order the uncoupled leading parts are factorised concurrently
+//           (blockIdx.z = front); their contributions to the separator go to shadow blocks that are merged
+//           before the separator's own (dense) chain;
+//   solve   the right-hand side rides along as an extra row block (forward substitution is free); the
+//           backward substitution is one launch of flag-synchronised work-groups, one per tile row.
 //
-// The right-hand side rides along as an extra row block below the matrix, so the forward
-// substitution is free; the backward substitution is one small launch per tile.
+// At BA sizes the cost is the chain of dependent panel steps, not the flops (DESIGN.md sections 4 and 6).
 #include "internal.h"
 #include <algorithm>
 #include <cstdlib>
