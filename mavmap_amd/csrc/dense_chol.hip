@@ -130,72 +130,8 @@ __device__ __forceinline__ void store_d16(double* C, int ldc, d4 v, int lane) {
   for (int r = 0; r < 4; ++r) C[(lk + 4 * r) * ldc + li] = v[r];
 }
 
-// Factorise the SPD tile in T (LDS, pitch GLD) and invert the factor, blocked 4 x 4 in 16x16:
-//   T  <- L below the diagonal blocks (the diagonal blocks themselves are consumed),
-//   Ti <- L^-1 (lower; Ti must come in zeroed).
-// Per 16-column block: the diagonal block is factored + inverted in registers by 16 lanes
-// (potrf_inv16, one wave); the panel below it, the trailing update inside the tile and the assembly of
-// the off-diagonal blocks of L^-1 are 16x16x16 FP64-MFMA products spread over the 4 waves.
-// All 256 threads must call it (uniform barriers). scr: 4 * 16 * 18 doubles of LDS.
-// Returns false (in thread 0) if a pivot is not positive.
-constexpr int MLD = 18;
-constexpr int kFuseBelow = 24;
-constexpr int kMaxBacksolveGroups = 2048;  // single-launch backward substitution up to this many tile rows  // fuse the panel solve into the update when <= this many row blocks remain
-__device__ __forceinline__ bool tile_potrf_inv(double* T, double* Ti, double* scr, int tid) {
-  const int wv = tid >> 6, lane = tid & 63;
-  bool ok = true;
-  for (int cb = 0; cb < 4; ++cb) {
-    double* D = T + (16 * cb) * GLD + 16 * cb;
-    double* Di = Ti + (16 * cb) * GLD + 16 * cb;
-    if (wv == 0) {
-      d4 acc = load_d16(D, GLD, lane), xacc;
-      ok = potrf_inv16(acc, xacc, lane) && ok;
-      store_d16(Di, GLD, xacc, lane);  // the diagonal block of L itself is not needed again
-    }
-    __syncthreads();
-    const int nt = 3 - cb;  // 16-row blocks below the diagonal block
-    if (wv < nt) {          // panel: P = T[rt, cb] * Dinv^T
-      double* P = T + (16 * (cb + 1 + wv)) * GLD + 16 * cb;
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-      acc = gemm16(P, GLD, Di, GLD, true, 1.0, acc, lane);
-      store_d16(P, GLD, acc, lane);
-    }
-    __syncthreads();
-    // trailing update inside the tile: T[i, j] -= P_i P_j^T for cb < j <= i <= 3
-    const int npairs = nt * (nt + 1) / 2;
-    for (int p = wv; p < npairs; p += 4) {
-      int i = 0, q = p;
-      while (q > i) { q -= i + 1; ++i; }   // p -> (i, q) with q <= i
-      const int bi = cb + 1 + i, bj = cb + 1 + q;
-      double* C = T + (16 * bi) * GLD + 16 * bj;
-      d4 acc = load_d16(C, GLD, lane);
-      acc = gemm16(T + (16 * bi) * GLD + 16 * cb, GLD, T + (16 * bj) * GLD + 16 * cb, GLD, true, -1.0, acc, lane);
-      store_d16(C, GLD, acc, lane);
-    }
-    __syncthreads();
-  }
-  // off-diagonal blocks of X = L^-1:  X_ij = -Dinv_i * sum_{k=j}^{i-1} L_ik X_kj,  by distance d = i - j
-  double* Ms = scr + wv * 16 * MLD;
-  for (int d = 1; d < 4; ++d) {
-    const bool mine = wv < 4 - d;
-    const int i = d + wv, j = wv;
-    if (mine) {
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int k = j; k < i; ++k)
-        acc = gemm16(T + (16 * i) * GLD + 16 * k, GLD, Ti + (16 * k) * GLD + 16 * j, GLD, false, 1.0, acc, lane);
-      store_d16(Ms, MLD, acc, lane);
-    }
-    __syncthreads();
-    if (mine) {
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-      acc = gemm16(Ti + (16 * i) * GLD + 16 * i, GLD, Ms, MLD, false, -1.0, acc, lane);
-      store_d16(Ti + (16 * i) * GLD + 16 * j, GLD, acc, lane);
-    }
-    __syncthreads();
-  }
-  // thread 0 is in wave 0 lanes < 16: it carries the pivot verdict
-  return ok;
-}
+constexpr int kFuseBelow = 24;  // fuse the panel solve into the update when <= this many row blocks remain
+constexpr int kMaxBacksolveGroups = 2048;  // single-launch backward substitution up to this many tile rows
 
 // Order LDS traffic inside ONE wave: a block written by some lanes is read back by other lanes of
 // the same wave. The hardware executes a wave's LDS instructions in order; this only stops the
