@@ -4,7 +4,10 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
-namespace mavba { namespace {
+namespace mavba {
+hipError_t device_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }  // (the product's pool lives in session.hip)
+void device_free(void* p) { (void)hipFree(p); }
+namespace {
 // (the first blocked variant, kept here for comparison: 18 barriers, per-wave scratch)
 // Factorise the SPD tile in T (LDS, pitch GLD) and invert the factor, blocked 4 x 4 in 16x16:
 //   T  <- L below the diagonal blocks (the diagonal blocks themselves are consumed),
