@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
                                                      const CholFront* __restrict__ fronts,
                                                      double* __restrict__ inv, double* __restrict__ fail,
                                                      const int* __restrict__ rows, int aug,
-                                                     double* __restrict__ shadow, int s_begin, size_t shadow_stride) {
+                                                     double* __restrict__ shadow) {
   const CholFront F = fronts[blockIdx.z];
   const int na = F.na, k = F.k;
   if ((int)blockIdx.x >= na || (int)blockIdx.y > na) return;
@@ -404,13 +404,13 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
   const int wv = tid >> 6, lane = tid & 63;
   const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
   const int li = lane & 15, lk = lane >> 4;
-  // the tile being updated (separator columns of a front with a shadow: that front's shadow block);
+  // the tile being updated (ancestor columns of a front with a shadow: that front's shadow block);
   // its loads are issued first so that their latency hides behind the products
   double* C = M + (size_t)i * NB * ld + (size_t)j * NB;
   size_t ldc = (size_t)ld;
-  if (F.shadow >= 0 && j >= s_begin) {
-    ldc = (size_t)(aug - s_begin) * NB;
-    C = shadow + (size_t)F.shadow * shadow_stride + (size_t)(i - s_begin) * NB * ldc + (size_t)(j - s_begin) * NB;
+  if (F.sh_off >= 0 && j >= F.sh_begin) {
+    ldc = (size_t)(aug - F.sh_begin) * NB;
+    C = shadow + F.sh_off + (size_t)(i - F.sh_begin) * NB * ldc + (size_t)(j - F.sh_begin) * NB;
   }
   d4 cin[2][2];
 #pragma unroll
@@ -469,20 +469,23 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
   store_tile(inv + (size_t)(k + 1) * NB * NB, NB, As, tid);
 }
 
-// Separator block after the fronts are done: M[i][j] += sum of the fronts' shadow blocks (i, j >= s_begin,
-// i may be the right-hand-side row). grid = (ns, ns + 1).
+// End of a tree level: M[i][j] += sum of the level's shadow blocks that cover tile (i, j) (i may be the
+// right-hand-side row). A shadow with origin o covers tiles i, j >= o. grid = (nb - begin, nb - begin + 1).
 __global__ void __launch_bounds__(256) k_chol_merge(double* __restrict__ M, int ld, const double* __restrict__ shadow,
-                                                    int num_shadows, int s_begin, int ns, size_t stride) {
-  const int js = blockIdx.x, is = blockIdx.y;
-  if (js > is) return;
-  const size_t lds = (size_t)ns * NB;
-  double* C = M + (size_t)(s_begin + is) * NB * ld + (size_t)(s_begin + js) * NB;
-  const double* Sh = shadow + (size_t)is * NB * lds + (size_t)js * NB;
+                                                    const CholMerge* __restrict__ merges, int num_merges, int begin,
+                                                    int aug) {
+  const int j = begin + blockIdx.x, i = begin + blockIdx.y;
+  if (j > i) return;
+  double* C = M + (size_t)i * NB * ld + (size_t)j * NB;
   for (int e = threadIdx.x; e < NB * NB / 2; e += 256) {
     const int row = e >> 5, c2 = (e & 31) * 2;
     double2 v = *reinterpret_cast<const double2*>(C + (size_t)row * ld + c2);
-    for (int q = 0; q < num_shadows; ++q) {
-      const double2 w = *reinterpret_cast<const double2*>(Sh + (size_t)q * stride + (size_t)row * lds + c2);
+    for (int q = 0; q < num_merges; ++q) {
+      const int o = merges[q].sh_begin;
+      if (j < o) continue;  // (i >= j >= o)
+      const size_t lds = (size_t)(aug - o) * NB;
+      const double* Sh = shadow + merges[q].sh_off + (size_t)(i - o) * NB * lds + (size_t)(j - o) * NB;
+      const double2 w = *reinterpret_cast<const double2*>(Sh + (size_t)row * lds + c2);
       v.x += w.x; v.y += w.y;
     }
     *reinterpret_cast<double2*>(C + (size_t)row * ld + c2) = v;
@@ -613,7 +616,8 @@ void CholStructure::release() {
   if (d_ints) device_free(d_ints);
   if (d_fronts) device_free(d_fronts);
   if (d_shadow) device_free(d_shadow);
-  d_ints = nullptr; d_fronts = nullptr; d_shadow = nullptr;
+  if (d_merges) device_free(d_merges);
+  d_ints = nullptr; d_fronts = nullptr; d_shadow = nullptr; d_merges = nullptr;
 }
 CholStructure::~CholStructure() { release(); }
 
@@ -624,50 +628,98 @@ hipError_t CholStructure::build_dense(int nb_) {
 }
 
 hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>& tile_pairs,
-                                const std::vector<std::pair<int, int>>& parts_in, hipStream_t st) {
+                                const std::vector<CholNode>& tree_in, hipStream_t st) {
   release();
   nb = nb_;
-  std::vector<std::pair<int, int>> parts = parts_in;
-  if (nb > kMaxBacksolveGroups) parts.clear();  // the per-tile fallback of the backward substitution is single-segment
   const int never = nb + 1;
+  nodes = tree_in;
+  // valid tree: contiguous ascending cover of [0, nb), parents after children, exactly one root (the last node)
+  auto tree_ok = [&]() {
+    if (nodes.empty() || nb > kMaxBacksolveGroups) return false;  // (the per-tile backward fallback is single-segment)
+    int at = 0;
+    for (size_t n = 0; n < nodes.size(); ++n) {
+      if (nodes[n].begin != at || nodes[n].end <= nodes[n].begin) return false;
+      at = nodes[n].end;
+      const bool last = n + 1 == nodes.size();
+      if (last ? nodes[n].parent != -1 : (nodes[n].parent <= (int)n || nodes[n].parent >= (int)nodes.size())) return false;
+    }
+    return at == nb;
+  };
+  std::vector<int> height;
+  auto is_ancestor = [&](int a, int d) {  // a == d or a above d
+    while (d != -1 && d != a) d = nodes[d].parent;
+    return d == a;
+  };
   auto assign_segments = [&]() {
-    const int P = (int)parts.size();
-    nseg = P + 1;
-    s_begin = P ? parts.back().second : 0;
-    seg_of_tile.assign(nb, P);
-    for (int p = 0; p < P; ++p)
-      for (int t = parts[p].first; t < parts[p].second; ++t) seg_of_tile[t] = p;
+    nseg = (int)nodes.size();
+    seg_of_tile.assign(nb, 0);
+    for (int n = 0; n < nseg; ++n)
+      for (int t = nodes[n].begin; t < nodes[n].end; ++t) seg_of_tile[t] = n;
     seg_first.assign((size_t)nb * nseg, never);
     for (int i = 0; i < nb; ++i) seg_first[(size_t)i * nseg + seg_of_tile[i]] = i;
-    bool ok = true;
     for (const auto& pr : tile_pairs) {
       const int tr = pr.first, tc = pr.second;
       const int q = seg_of_tile[tc];
-      if (seg_of_tile[tr] < P && seg_of_tile[tr] != q) ok = false;  // two leading parts are coupled: not a valid dissection
+      if (!is_ancestor(seg_of_tile[tr], q)) return false;  // coupling across two branches: not a valid dissection
       int& f = seg_first[(size_t)tr * nseg + q];
       f = std::min(f, tc);
     }
-    return ok;
+    return true;
   };
-  if (!assign_segments()) { parts.clear(); assign_segments(); }
-  const int P = (int)parts.size();
-  if (P)  // the separator block fills in: treat it as dense
-    for (int i = s_begin; i < nb; ++i) seg_first[(size_t)i * nseg + P] = s_begin;
+  if (!tree_ok() || !assign_segments()) {
+    nodes.assign(1, CholNode{0, nb, -1});
+    assign_segments();
+  }
+  height.assign(nseg, 0);
+  std::vector<char> is_leaf(nseg, 1);
+  for (int n = 0; n < nseg; ++n)
+    if (nodes[n].parent >= 0) { is_leaf[nodes[n].parent] = 0; height[nodes[n].parent] = std::max(height[nodes[n].parent], height[n] + 1); }
+  // Separators fill in: dense inside, and an ancestor row that couples to any descendant of a separator couples
+  // to the whole separator (children precede parents, so their entries are final when the parent is visited).
+  if (nseg > 1)
+    for (int n = 0; n < nseg; ++n) {
+      if (is_leaf[n]) continue;
+      for (int i = nodes[n].begin; i < nodes[n].end; ++i) seg_first[(size_t)i * nseg + n] = nodes[n].begin;
+      for (int i = nodes[n].end; i < nb; ++i) {
+        bool coupled = seg_first[(size_t)i * nseg + n] != never;
+        for (int d = 0; d < n && !coupled; ++d)
+          coupled = is_ancestor(n, d) && seg_first[(size_t)i * nseg + d] != never;
+        if (coupled) seg_first[(size_t)i * nseg + n] = nodes[n].begin;
+      }
+    }
+
+  // shadow blocks: every non-root node except the first of its level writes its ancestor updates to its own
+  // block, origin = its parent's first tile, (nb - origin + 1) x (nb - origin) tiles
+  const int H = *std::max_element(height.begin(), height.end());
+  std::vector<long long> sh_off(nseg, -1);
+  std::vector<int> sh_begin(nseg, 0);
+  shadow_doubles = 0;
+  for (int hgt = 0; hgt < H; ++hgt) {
+    bool first = true;
+    for (int n = 0; n < nseg; ++n) {
+      if (height[n] != hgt || nodes[n].parent < 0) continue;
+      sh_begin[n] = nodes[nodes[n].parent].begin;
+      if (first) { first = false; continue; }
+      const size_t ns = (size_t)(nb - sh_begin[n]);
+      sh_off[n] = (long long)shadow_doubles;
+      shadow_doubles += (ns + 1) * ns * 4096;
+    }
+  }
 
   std::vector<int> rows;
-  fronts.clear(); steps.clear(); init_tiles.clear();
-  envelope_tiles = 0; factor_flops = 0.0;
+  fronts.clear(); steps.clear(); init_tiles.clear(); merges.clear();
+  envelope_tiles = 0; factor_flops = 0.0; chain_steps = 0; num_fronts_max = 1;
   const double t3 = 64.0 * 64.0 * 64.0;
-  auto add_front = [&](std::vector<CholFront>& cur, int k, int seg, int seg_end, int shadow) {
+  auto add_front = [&](std::vector<CholFront>& cur, int k, int n) {
     CholFront F;
-    F.k = k; F.act_off = (int)rows.size(); F.shadow = shadow; F.factor_next = (k + 1 < seg_end) ? 1 : 0;
+    F.k = k; F.act_off = (int)rows.size(); F.factor_next = (k + 1 < nodes[n].end) ? 1 : 0;
+    F.sh_begin = sh_begin[n]; F.sh_off = sh_off[n];
     // Row k + 1 leads the list whenever the front goes on (its diagonal tile is factorised by the owner of
-    // tile (k+1, k+1)); then the rows of the same segment whose envelope reaches panel k, then - for a
-    // leading part - the separator rows coupled to it.
+    // tile (k+1, k+1)); then the rows of the same node whose envelope reaches panel k, then the rows of its
+    // ancestors that couple to it (rows of other branches never do).
     if (F.factor_next) rows.push_back(k + 1);
-    for (int i = k + 2; i < seg_end; ++i) if (seg_first[(size_t)i * nseg + seg] <= k) rows.push_back(i);
-    if (seg < P)
-      for (int i = s_begin; i < nb; ++i) if (seg_first[(size_t)i * nseg + seg] <= k) rows.push_back(i);
+    for (int i = k + 2; i < nodes[n].end; ++i) if (seg_first[(size_t)i * nseg + n] <= k) rows.push_back(i);
+    for (int i = nodes[n].end; i < nb; ++i) if (seg_first[(size_t)i * nseg + n] <= k) rows.push_back(i);
     F.na = (int)rows.size() - F.act_off;
     envelope_tiles += 1 + F.na;
     const double na = F.na;
@@ -677,32 +729,35 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   };
   auto close_step = [&](std::vector<CholFront>& cur) {
     std::stable_sort(cur.begin(), cur.end(), [](const CholFront& a, const CholFront& b) { return (a.na > 0) > (b.na > 0); });
-    CholStep S;
-    S.front_off = (int)fronts.size(); S.nf = 0; S.nf0 = 0; S.max_na = 0; S.merge = 0;
+    CholStep S{};
+    S.kind = 0; S.front_off = (int)fronts.size();
     for (const CholFront& F : cur) { if (F.na > 0) ++S.nf; else ++S.nf0; S.max_na = std::max(S.max_na, F.na); }
     fronts.insert(fronts.end(), cur.begin(), cur.end());
     steps.push_back(S);
     cur.clear();
   };
   std::vector<CholFront> cur;
-  int lead = 0;
-  if (P) {
-    for (const auto& pr : parts) { lead = std::max(lead, pr.second - pr.first); init_tiles.push_back(pr.first); }
+  for (int n = 0; n < nseg; ++n) if (height[n] == 0) init_tiles.push_back(nodes[n].begin);
+  num_leaf_init = (int)init_tiles.size();
+  for (int hgt = 0; hgt <= H; ++hgt) {
+    int lead = 0, width = 0;
+    for (int n = 0; n < nseg; ++n) if (height[n] == hgt) { lead = std::max(lead, nodes[n].end - nodes[n].begin); ++width; }
+    num_fronts_max = std::max(num_fronts_max, width);
     for (int s = 0; s < lead; ++s) {
-      for (int p = 0; p < P; ++p)
-        if (parts[p].first + s < parts[p].second) add_front(cur, parts[p].first + s, p, parts[p].second, p - 1);
+      for (int n = 0; n < nseg; ++n)
+        if (height[n] == hgt && nodes[n].begin + s < nodes[n].end) add_front(cur, nodes[n].begin + s, n);
       close_step(cur);
     }
-    CholStep M;
-    M.front_off = 0; M.nf = 0; M.nf0 = 0; M.max_na = 0; M.merge = 1;
-    steps.push_back(M);
-  } else {
-    init_tiles.push_back(0);
+    chain_steps += lead;
+    if (hgt == H) break;
+    // end of the level: merge its shadows, then start the next level's nodes
+    CholStep Mg{};
+    Mg.kind = 1; Mg.front_off = (int)merges.size(); Mg.merge_begin = nb; Mg.init_off = (int)init_tiles.size();
+    for (int n = 0; n < nseg; ++n)
+      if (height[n] == hgt && sh_off[n] >= 0) { merges.push_back(CholMerge{sh_begin[n], sh_off[n]}); ++Mg.nf; Mg.merge_begin = std::min(Mg.merge_begin, sh_begin[n]); }
+    for (int n = 0; n < nseg; ++n) if (height[n] == hgt + 1) { init_tiles.push_back(nodes[n].begin); ++Mg.nf0; }
+    steps.push_back(Mg);
   }
-  init_tiles.push_back(s_begin);  // last entry: the separator's first tile, factorised after the merge
-  for (int k = s_begin; k < nb; ++k) { add_front(cur, k, P, nb, -1); close_step(cur); }
-  chain_steps = lead + (nb - s_begin);
-  num_shadows = P > 1 ? P - 1 : 0;
 
   // device copies: rows | seg_of_tile | seg_first | init_tiles | flags
   std::vector<int> pack(rows);
@@ -719,8 +774,11 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_fronts), std::max<size_t>(fronts.size(), 1) * sizeof(CholFront));
   if (e == hipSuccess && !fronts.empty())
     e = hipMemcpyAsync(d_fronts, fronts.data(), fronts.size() * sizeof(CholFront), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess && num_shadows)
-    e = device_alloc(reinterpret_cast<void**>(&d_shadow), (size_t)num_shadows * shadow_stride() * sizeof(double));
+  if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_merges), std::max<size_t>(merges.size(), 1) * sizeof(CholMerge));
+  if (e == hipSuccess && !merges.empty())
+    e = hipMemcpyAsync(d_merges, merges.data(), merges.size() * sizeof(CholMerge), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && shadow_doubles)
+    e = device_alloc(reinterpret_cast<void**>(&d_shadow), shadow_doubles * sizeof(double));
   if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging vectors go out of scope
   if (e != hipSuccess) { release(); return e; }
   d_rows = d_ints;
@@ -739,18 +797,16 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
                             const int* y_scatter, double* y_nat) {
   const int nb = n_pad / NB, ld = n_pad;
   double* inv = diag_ws;
-  const size_t sstride = cs.shadow_stride();
-  if (cs.num_shadows)
-    (void)hipMemsetAsync(cs.d_shadow, 0, (size_t)cs.num_shadows * sstride * sizeof(double), st);
-  const int ninit = (int)cs.init_tiles.size() - 1;
+  if (cs.shadow_doubles) (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);
   static const int fuse_below = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE"); return e ? std::atoi(e) : kFuseBelow; }();  // tuning knob
-  hipLaunchKernelGGL(k_chol_diag0, dim3(ninit), dim3(256), 0, st, M, ld, cs.d_init, inv, fail, cs.d_flags, nb);
+  hipLaunchKernelGGL(k_chol_diag0, dim3(cs.num_leaf_init), dim3(256), 0, st, M, ld, cs.d_init, inv, fail, cs.d_flags, nb);
   for (const CholStep& S : cs.steps) {
-    if (S.merge) {
-      const int ns = nb - cs.s_begin;
-      if (cs.num_shadows)
-        hipLaunchKernelGGL(k_chol_merge, dim3(ns, ns + 1), dim3(256), 0, st, M, ld, cs.d_shadow, cs.num_shadows, cs.s_begin, ns, sstride);
-      hipLaunchKernelGGL(k_chol_diag0, dim3(1), dim3(256), 0, st, M, ld, cs.d_init + ninit, inv, fail, cs.d_flags, 0);
+    if (S.kind == 1) {
+      const int nt = nb - S.merge_begin;
+      if (S.nf > 0)
+        hipLaunchKernelGGL(k_chol_merge, dim3(nt, nt + 1), dim3(256), 0, st, M, ld, cs.d_shadow, cs.d_merges + S.front_off, S.nf,
+                           S.merge_begin, nb);
+      hipLaunchKernelGGL(k_chol_diag0, dim3(S.nf0), dim3(256), 0, st, M, ld, cs.d_init + S.init_off, inv, fail, cs.d_flags, 0);
       continue;
     }
     const CholFront* F = cs.d_fronts + S.front_off;
@@ -758,11 +814,11 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
       // large trailing matrix: one panel solve, then a lean update (2 work-groups per CU)
       hipLaunchKernelGGL(k_chol_trsm, dim3(S.max_na + 1, 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, cs.d_rows, nb);
       hipLaunchKernelGGL((k_chol_update<false>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, fail,
-                         cs.d_rows, nb, cs.d_shadow, cs.s_begin, sstride);
+                         cs.d_rows, nb, cs.d_shadow);
     } else if (S.max_na > 0) {
       // small trailing matrix: latency matters, fold the panel solve into the update launch
       hipLaunchKernelGGL((k_chol_update<true>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, fail,
-                         cs.d_rows, nb, cs.d_shadow, cs.s_begin, sstride);
+                         cs.d_rows, nb, cs.d_shadow);
     }
     if (S.nf0)  // fronts with nothing below their tile: only the right-hand-side block is left
       hipLaunchKernelGGL(k_chol_trsm, dim3(1, 1, S.nf0), dim3(256), 0, st, M, L, ld, F + S.nf, inv, cs.d_rows, nb);

@@ -209,47 +209,61 @@ void device_free(void* p);
 // Envelope: inside a segment of tile columns, tile row i is structurally zero left of seg_first[i][seg];
 // the factorisation only visits tiles inside the envelope (a skyline per segment).
 //
-// Segments: with a nested-dissection ordering [A_1 | ... | A_P | S] the leading parts A_p are mutually
-// uncoupled, so their panels are factorised CONCURRENTLY (one "front" per part in the same launch); each
-// front's Schur contribution to the separator block S x S goes to its own shadow block (front 0 writes
-// the matrix itself), the shadows are merged, then S is factorised as one dense chain. The number of
-// dependent panel steps drops from nb to max|A_p| + |S|. Without parts there is one segment and the
-// schedule is the plain right-looking chain over the envelope.
+// Segments = nodes of an elimination tree (nested dissection, children before parents): nodes of the same
+// level are mutually uncoupled, so their panels are factorised CONCURRENTLY (one "front" per node in the
+// same launch); a front's Schur contribution to its ancestors goes to its own shadow block (the first node of
+// a level writes the matrix itself), the level's shadows are merged, then the next level runs. The number
+// of dependent panel steps drops from nb to the sum over levels of the longest node. Without a tree there is
+// one segment and the schedule is the plain right-looking chain over the envelope.
 struct CholFront {
-  int k;            // panel (tile column) this front eliminates
-  int na;           // active row blocks below tile k (rows + act_off)
+  int k;             // panel (tile column) this front eliminates
+  int na;            // active row blocks below tile k (rows + act_off)
   int act_off;
-  int shadow;       // -1: updates go to the matrix; >= 0: updates of separator columns go to this shadow block
-  int factor_next;  // the owner of tile (k+1, k+1) factorises it for the front's next step
+  int factor_next;   // the owner of tile (k+1, k+1) factorises it for the front's next step
+  int sh_begin;      // updates of tiles in columns >= sh_begin go to the front's shadow block (if it has one)
+  long long sh_off;  // offset (doubles) of that shadow block, -1: everything goes to the matrix
 };
-struct CholStep { int front_off, nf, nf0, max_na, merge; };  // nf fronts with na > 0, then nf0 with na == 0
+// One launch group of the schedule. kind 0: panel step of `nf` concurrent fronts with na > 0 followed by nf0 with
+// na == 0 (fronts + front_off). kind 1: end of a tree level - merge the level's shadow blocks (merges +
+// front_off .. + nf) into the matrix over tiles >= merge_begin, then factorise the diagonal tiles listed at
+// init + init_off .. + nf0 (the first tiles of the next level's nodes).
+struct CholStep { int kind, front_off, nf, nf0, max_na, merge_begin, init_off; };
+struct CholMerge { int sh_begin; long long sh_off; };
+// Node of the elimination tree: tile columns [begin, end); parent = index of the separator it hangs under
+// (-1: root). Nodes are listed in column order, children before parents.
+struct CholNode { int begin, end, parent; };
 struct CholStructure {
-  int nb = 0, nseg = 1, s_begin = 0, num_shadows = 0;
+  int nb = 0, nseg = 1;
+  std::vector<CholNode> nodes;
   std::vector<int> seg_of_tile;   // [nb]
   std::vector<int> seg_first;     // [nb * nseg]
   std::vector<CholFront> fronts;
+  std::vector<CholMerge> merges;
   std::vector<CholStep> steps;
-  std::vector<int> init_tiles;    // diagonal tiles factorised before the first step
+  std::vector<int> init_tiles;    // diagonal tiles factorised before the first step / after the merges
+  int num_leaf_init = 0;          // the first num_leaf_init entries of init_tiles start the schedule
   int chain_steps = 0;            // dependent panel steps of the schedule
+  int num_fronts_max = 0;         // widest level
   long long envelope_tiles = 0;   // lower-triangle tiles visited (incl. diagonal)
   double factor_flops = 0.0;      // MFMA flops executed by the factorisation
+  size_t shadow_doubles = 0;      // total size of the shadow blocks
   int* d_ints = nullptr;          // one allocation: rows | seg_of_tile | seg_first | init_tiles | flags
   int *d_rows = nullptr, *d_seg_of_tile = nullptr, *d_seg_first = nullptr, *d_init = nullptr;
   unsigned* d_flags = nullptr;    // [nb] 'solution segment published' flags of the backward substitution
   CholFront* d_fronts = nullptr;
-  double* d_shadow = nullptr;     // num_shadows blocks of (ns + 1) x ns tiles, ns = nb - s_begin
+  CholMerge* d_merges = nullptr;
+  double* d_shadow = nullptr;
   CholStructure() {}
   CholStructure(const CholStructure&) = delete;
   CholStructure& operator=(const CholStructure&) = delete;
   ~CholStructure();
   void release();
   // tile_pairs: (row tile, col tile), row >= col, of every structurally non-zero tile (diagonal tiles are
-  // implied). parts: tile ranges [begin, end) of the leading uncoupled parts, ascending and contiguous from
-  // tile 0; everything after the last part is the separator. Empty parts = single chain.
-  hipError_t build(int nb, const std::vector<std::pair<int, int>>& tile_pairs,
-                   const std::vector<std::pair<int, int>>& parts, hipStream_t st);
+  // implied). tree: elimination tree over contiguous tile ranges covering [0, nb) (empty = one node = plain
+  // chain over the envelope). Leaves keep a skyline envelope; separators are treated as dense.
+  hipError_t build(int nb, const std::vector<std::pair<int, int>>& tile_pairs, const std::vector<CholNode>& tree,
+                   hipStream_t st);
   hipError_t build_dense(int nb);
-  size_t shadow_stride() const { const size_t ns = (size_t)(nb - s_begin); return (ns + 1) * ns * 4096; }
 };
 // y_scatter (may be null): y_nat[y_scatter[t]] = y[t] for every t with y_scatter[t] >= 0 (the solution in
 // the caller's variable order when the matrix was assembled in a permuted order).

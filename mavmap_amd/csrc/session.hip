@@ -900,7 +900,12 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   std::vector<std::pair<int, int>> tile_pairs;
   for (int tr = 0; tr < nbt; ++tr)
     for (int tc = 0; tc <= tr; ++tc) if (mark[(size_t)tr * nbt + tc]) tile_pairs.emplace_back(tr, tc);
-  HIP_OK(chol_struct.build(nbt, tile_pairs, parts, st));
+  std::vector<CholNode> tree;
+  if (!parts.empty()) {
+    for (const auto& pr : parts) tree.push_back(CholNode{pr.first, pr.second, (int)parts.size()});
+    tree.push_back(CholNode{parts.back().second, nbt, -1});
+  }
+  HIP_OK(chol_struct.build(nbt, tile_pairs, tree, st));
   if (world > 1) {
     std::vector<int2> tl;
     std::vector<unsigned char> have((size_t)nbt * nbt, 0);
