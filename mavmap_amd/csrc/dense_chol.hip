@@ -130,7 +130,8 @@ __device__ __forceinline__ void store_d16(double* C, int ldc, d4 v, int lane) {
   for (int r = 0; r < 4; ++r) C[(lk + 4 * r) * ldc + li] = v[r];
 }
 
-constexpr int kFuseBelow = 24;  // fuse the panel solve into the update when <= this many row blocks remain
+constexpr int kFuseBelow = 24;  // fuse the panel solve into the update when <= this many row blocks remain ...
+constexpr int kFuseTasks = 256;  // ... and the step (all fronts) has at most this many tile updates
 constexpr int kMaxBacksolveGroups = 2048;  // single-launch backward substitution up to this many tile rows
 
 // Order LDS traffic inside ONE wave: a block written by some lanes is read back by other lanes of
@@ -731,7 +732,7 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
     std::stable_sort(cur.begin(), cur.end(), [](const CholFront& a, const CholFront& b) { return (a.na > 0) > (b.na > 0); });
     CholStep S{};
     S.kind = 0; S.front_off = (int)fronts.size();
-    for (const CholFront& F : cur) { if (F.na > 0) ++S.nf; else ++S.nf0; S.max_na = std::max(S.max_na, F.na); }
+    for (const CholFront& F : cur) { if (F.na > 0) ++S.nf; else ++S.nf0; S.max_na = std::max(S.max_na, F.na); S.tasks += F.na * (F.na + 1) / 2 + F.na; }
     fronts.insert(fronts.end(), cur.begin(), cur.end());
     steps.push_back(S);
     cur.clear();
@@ -798,7 +799,8 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
   const int nb = n_pad / NB, ld = n_pad;
   double* inv = diag_ws;
   if (cs.shadow_doubles) (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);
-  static const int fuse_below = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE"); return e ? std::atoi(e) : kFuseBelow; }();  // tuning knob
+  static const int fuse_below = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE"); return e ? std::atoi(e) : kFuseBelow; }();  // tuning knobs
+  static const int fuse_tasks = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE_TASKS"); return e ? std::atoi(e) : kFuseTasks; }();
   hipLaunchKernelGGL(k_chol_diag0, dim3(cs.num_leaf_init), dim3(256), 0, st, M, ld, cs.d_init, inv, fail, cs.d_flags, nb);
   for (const CholStep& S : cs.steps) {
     if (S.kind == 1) {
@@ -810,8 +812,9 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
       continue;
     }
     const CholFront* F = cs.d_fronts + S.front_off;
-    if (S.max_na > fuse_below) {
-      // large trailing matrix: one panel solve, then a lean update (2 work-groups per CU)
+    if (S.max_na > fuse_below || S.tasks > fuse_tasks) {
+      // much trailing work (more tile updates than one round of the CUs absorbs): one panel solve, then a lean
+      // update (one product per work-group, 2 work-groups per CU)
       hipLaunchKernelGGL(k_chol_trsm, dim3(S.max_na + 1, 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, cs.d_rows, nb);
       hipLaunchKernelGGL((k_chol_update<false>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, fail,
                          cs.d_rows, nb, cs.d_shadow);

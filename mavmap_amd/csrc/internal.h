@@ -227,7 +227,7 @@ struct CholFront {
 // na == 0 (fronts + front_off). kind 1: end of a tree level - merge the level's shadow blocks (merges +
 // front_off .. + nf) into the matrix over tiles >= merge_begin, then factorise the diagonal tiles listed at
 // init + init_off .. + nf0 (the first tiles of the next level's nodes).
-struct CholStep { int kind, front_off, nf, nf0, max_na, merge_begin, init_off; };
+struct CholStep { int kind, front_off, nf, nf0, max_na, merge_begin, init_off, tasks; };  // tasks = tile updates of the step, all fronts
 struct CholMerge { int sh_begin; long long sh_off; };
 // Node of the elimination tree: tile columns [begin, end); parent = index of the separator it hangs under
 // (-1: root). Nodes are listed in column order, children before parents.

@@ -776,11 +776,14 @@ void mavba_session::build(const mavba_problem* P) {
 // P (and for P = 2 the cut position) is chosen to minimise that chain, P = 1 (no dissection) included.
 void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& blocks) {
   const int tiles0 = std::max(1, round_up(n_full, 64) / 64);
-  std::vector<int> seg(NI, 0);   // run of every image; -1 = separator
-  int P = 1;
-  int forced = -1;
-  if (const char* e = std::getenv("MAVBA_ND_PARTS")) forced = std::atoi(e);  // 0/1 = off, n = force n parts
-  const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && (world == 1 || NI <= 4096);
+  // Tree of image sets in elimination order (children before parents, root last); the root also carries the
+  // intrinsics blocks. One node = no dissection.
+  struct TNode { std::vector<int> imgs; int parent; };
+  std::vector<TNode> tn;
+  int forced = -1, max_depth = 2;
+  if (const char* e = std::getenv("MAVBA_ND_PARTS")) forced = std::atoi(e);  // 0/1 = off, n = force n flat parts
+  if (const char* e = std::getenv("MAVBA_ND_DEPTH")) max_depth = std::atoi(e);  // recursion depth of the automatic choice
+  const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && max_depth > 0 && (world == 1 || NI <= 4096);
   if (can_dissect) {
     // image adjacency (lower: col < row) from the pose-pose blocks; with shards, the union over ranks
     std::vector<std::vector<int>> lower(NI);
@@ -799,73 +802,88 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
       for (const SchurBlock& B : blocks)
         if (B.kind == BLK_PP && B.row_ent != B.col_ent) lower[std::max(B.row_ent, B.col_ent)].push_back(std::min(B.row_ent, B.col_ent));
     }
-    std::vector<int> min_nb(NI);  // smallest neighbour index (an image is in S iff it lies in an earlier run)
-    for (int i = 0; i < NI; ++i) {
-      int m = i;
-      for (int c : lower[i]) m = std::min(m, c);
-      min_nb[i] = m;
-    }
     const int tail = 9 * NC;
-    // chain length (tiles) of the dissection with run boundaries `cut` (ascending, cut[0] = 0)
-    auto evaluate = [&](const std::vector<int>& cut, std::vector<int>* out_seg) {
-      const int np = (int)cut.size();
-      std::vector<int> size(np, 0);
-      int ns = 0, run = 0;
+    auto tiles_of = [](int cols) { return (cols + 63) / 64; };
+    if (forced > 1) {
+      // flat dissection into `forced` runs of the natural order (kept for tests and experiments)
+      std::vector<int> cut(forced);
+      for (int q = 0; q < forced; ++q) cut[q] = (int)((long long)q * NI / forced);
+      std::vector<std::vector<int>> part(forced);
+      std::vector<int> sep;
+      int run = 0;
       for (int i = 0; i < NI; ++i) {
-        while (run + 1 < np && i >= cut[run + 1]) ++run;
-        const bool sep = min_nb[i] < cut[run];
-        if (sep) ++ns; else ++size[run];
-        if (out_seg) (*out_seg)[i] = sep ? -1 : run;
+        while (run + 1 < forced && i >= cut[run + 1]) ++run;
+        int m = i;
+        for (int c : lower[i]) m = std::min(m, c);
+        if (m < cut[run]) sep.push_back(i); else part[run].push_back(i);
       }
-      int lead = 0;
-      for (int q = 0; q < np; ++q) lead = std::max(lead, (6 * size[q] + 63) / 64);
-      return lead + (6 * ns + tail + 63) / 64;
-    };
-    int best = forced > 1 ? (1 << 30) : tiles0;  // a forced part count is taken even when it does not pay
-    std::vector<int> best_cut{0};
-    auto consider = [&](const std::vector<int>& cut) {
-      const int c = evaluate(cut, nullptr);
-      if (c < best) { best = c; best_cut = cut; }
-    };
-    const int pmax = forced > 1 ? forced : 8;
-    for (int np = (forced > 1 ? forced : 2); np <= pmax; ++np) {
-      if (NI / np < 8) break;
-      std::vector<int> cut(np);
-      for (int q = 0; q < np; ++q) cut[q] = (int)((long long)q * NI / np);
-      consider(cut);
-      if (np == 2)  // the separator sits in the second run: scan the cut for the best balance
-        for (int m = NI / 4; m <= 3 * NI / 4; m += std::max(1, NI / 64)) consider({0, m});
-    }
-    const bool worth = forced > 1 ? best_cut.size() > 1 : (best_cut.size() > 1 && best <= tiles0 - std::max(2, tiles0 / 8));
-    if (worth) {
-      P = (int)best_cut.size();
-      evaluate(best_cut, &seg);
+      int np = 0;
+      for (auto& pr : part) if (!pr.empty()) { tn.push_back(TNode{std::move(pr), -1}); ++np; }
+      if (np >= 2) {
+        for (auto& t : tn) t.parent = np;
+        tn.push_back(TNode{std::move(sep), -1});
+      } else {
+        tn.clear();
+      }
+    } else {
+      // recursive bisection: M (ascending) -> [A | B | S], S = the members of the second run that have a neighbour
+      // in the first; the cut is scanned for the shortest chain max(A, B) + S, and a split must pay
+      std::vector<int> pos(NI, -1);
+      std::function<std::pair<int, int>(std::vector<int>&&, int, int)> rec = [&](std::vector<int>&& M, int depth, int tl) {
+        const int n = (int)M.size();
+        const int leaf_tiles = tiles_of(6 * n + tl);
+        auto make_leaf = [&]() { tn.push_back(TNode{std::move(M), -1}); return std::make_pair((int)tn.size() - 1, leaf_tiles); };
+        if (depth >= max_depth || n < 32 || leaf_tiles < 6) return make_leaf();
+        for (int t = 0; t < n; ++t) pos[M[t]] = t;
+        std::vector<int> mnp(n);
+        for (int t = 0; t < n; ++t) {
+          int m = t;
+          for (int c : lower[M[t]]) if (pos[c] >= 0) m = std::min(m, pos[c]);
+          mnp[t] = m;
+        }
+        for (int t = 0; t < n; ++t) pos[M[t]] = -1;
+        int best = leaf_tiles, best_c = -1;
+        for (int c = n / 4; c <= 3 * n / 4; c += std::max(1, n / 64)) {
+          int ns = 0;
+          for (int t = c; t < n; ++t) ns += mnp[t] < c;
+          if (ns == 0 && tl == 0) continue;  // (a separator node needs at least one column)
+          const int est = std::max(tiles_of(6 * c), tiles_of(6 * (n - c - ns))) + tiles_of(6 * ns + tl);
+          if (est < best) { best = est; best_c = c; }
+        }
+        if (best_c < 0 || best > leaf_tiles - std::max(2, leaf_tiles / 8)) return make_leaf();
+        std::vector<int> A(M.begin(), M.begin() + best_c), B, S;
+        for (int t = best_c; t < n; ++t) (mnp[t] < best_c ? S : B).push_back(M[t]);
+        if (A.size() < 8 || B.size() < 8) return make_leaf();
+        const auto ra = rec(std::move(A), depth + 1, 0);
+        const auto rb = rec(std::move(B), depth + 1, 0);
+        const int sep_tiles = tiles_of(6 * (int)S.size() + tl);
+        tn.push_back(TNode{std::move(S), -1});
+        const int me = (int)tn.size() - 1;
+        tn[ra.first].parent = me; tn[rb.first].parent = me;
+        return std::make_pair(me, std::max(ra.second, rb.second) + sep_tiles);
+      };
+      std::vector<int> all(NI);
+      for (int i = 0; i < NI; ++i) all[i] = i;
+      rec(std::move(all), 0, tail);
+      if (tn.size() < 3) tn.clear();
     }
   }
-  // column offsets: parts (each padded to whole tiles), then separator images, then intrinsics
+  // column offsets in tree order (every node padded to whole tiles), intrinsics at the end of the root
   h_off_img.assign(NI, 0); h_off_cam.assign(NC, 0);
-  std::vector<std::pair<int, int>> parts;
+  std::vector<CholNode> tree;
   int col = 0;
-  if (P > 1) {
-    for (int q = 0; q < P; ++q) {
+  if (tn.size() >= 3) {
+    for (size_t t = 0; t < tn.size(); ++t) {
       const int begin = col;
-      for (int i = 0; i < NI; ++i) if (seg[i] == q) { h_off_img[i] = col; col += 6; }
-      if (col == begin) continue;  // a run that went entirely into the separator
-      col = round_up(col, 64);
-      parts.emplace_back(begin / 64, col / 64);
+      for (int i : tn[t].imgs) { h_off_img[i] = col; col += 6; }
+      if (t + 1 == tn.size()) for (int c = 0; c < NC; ++c) { h_off_cam[c] = col; col += 9; }
+      col = std::max(round_up(col, 64), begin + 64);
+      tree.push_back(CholNode{begin / 64, col / 64, tn[t].parent});
     }
-    for (int i = 0; i < NI; ++i) if (seg[i] < 0) { h_off_img[i] = col; col += 6; }
   } else {
-    for (int i = 0; i < NI; ++i) { h_off_img[i] = col; col += 6; }
-  }
-  for (int c = 0; c < NC; ++c) { h_off_cam[c] = col; col += 9; }
-  if (parts.size() < 2) {  // nothing to run concurrently: plain order
-    parts.clear();
-    col = 0;
     for (int i = 0; i < NI; ++i) { h_off_img[i] = col; col += 6; }
     for (int c = 0; c < NC; ++c) { h_off_cam[c] = col; col += 9; }
   }
-  nd_parts = (int)parts.size();
   n_mat = std::max(64, round_up(col, 64));
   h_col_var.assign(n_mat, -1);
   for (int i = 0; i < NI; ++i) for (int e = 0; e < 6; ++e) h_col_var[h_off_img[i] + e] = 6 * i + e;
@@ -900,12 +918,8 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   std::vector<std::pair<int, int>> tile_pairs;
   for (int tr = 0; tr < nbt; ++tr)
     for (int tc = 0; tc <= tr; ++tc) if (mark[(size_t)tr * nbt + tc]) tile_pairs.emplace_back(tr, tc);
-  std::vector<CholNode> tree;
-  if (!parts.empty()) {
-    for (const auto& pr : parts) tree.push_back(CholNode{pr.first, pr.second, (int)parts.size()});
-    tree.push_back(CholNode{parts.back().second, nbt, -1});
-  }
   HIP_OK(chol_struct.build(nbt, tile_pairs, tree, st));
+  nd_parts = chol_struct.nseg > 1 ? chol_struct.num_fronts_max : 0;
   if (world > 1) {
     std::vector<int2> tl;
     std::vector<unsigned char> have((size_t)nbt * nbt, 0);
