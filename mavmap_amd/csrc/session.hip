@@ -986,7 +986,11 @@ void mavba_session::finish_structure() {
   {
     bool use_clusters = true;
     if (const char* e = std::getenv("MAVBA_CLUSTERS")) use_clusters = std::atoi(e) != 0;
-    int kMaxPoints = 128;
+    // 128 points per cluster amortise the per-cluster costs; small problems get smaller clusters so that there
+    // are at least ~2 per CU (a cluster is one work-group; C2: 235 clusters of 128 would leave CUs idle)
+    long long nfree = 0;
+    for (int p = 0; p < NP; ++p) nfree += h_pt_free[p] != 0;
+    int kMaxPoints = (int)std::min<long long>(128, std::max<long long>(kClBatch, round_up((int)(nfree / 512), kClBatch)));
     if (const char* e = std::getenv("MAVBA_CLUSTER_POINTS")) kMaxPoints = std::max(1, std::atoi(e));
     // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
     // thread": the clusters - and with them the order in which partials are added - must not depend on the
