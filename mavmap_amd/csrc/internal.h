@@ -187,6 +187,10 @@ void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double
 void launch_reduce_cols(hipStream_t st, const double* partial, int rows, int cols, int stride,
                         unsigned max_mask, double* out, bool accumulate);
 
+struct ReduceTask { const double* src; int rows, stride, is_max; const double* src2; int rows2; double* out; };
+struct ReduceTasks { ReduceTask t[6]; };
+void launch_reduce_tasks(hipStream_t st, const ReduceTasks& tasks, int n);
+
 void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,
                          const int* pt_count, double* perr);
 

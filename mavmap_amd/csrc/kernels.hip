@@ -1432,6 +1432,29 @@ void launch_reduce_cols(hipStream_t st, const double* partial, int rows, int col
   hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(256), 0, st, partial, rows, cols, stride, max_mask, out, accumulate ? 1 : 0);
 }
 
+// Several independent single-block reductions in ONE launch (the scalars of an LM phase): block b handles task b,
+//   out = op(src[r * stride], r < rows)  (+ sum of src2[r], r < rows2, for the cost = observations + priors).
+__global__ void __launch_bounds__(256) k_reduce_tasks(ReduceTasks T) {
+  __shared__ double s_red[4];
+  const ReduceTask t = T.t[blockIdx.x];
+  double v = 0.0;
+  for (int r = threadIdx.x; r < t.rows; r += 256) {
+    const double x = t.src[(size_t)r * t.stride];
+    v = t.is_max ? fmax(v, x) : v + x;
+  }
+  double total = t.is_max ? block_max_256(v, s_red) : block_sum_256(v, s_red);
+  if (t.rows2 > 0) {
+    __syncthreads();
+    double w = 0.0;
+    for (int r = threadIdx.x; r < t.rows2; r += 256) w += t.src2[r];
+    total += block_sum_256(w, s_red);
+  }
+  if (threadIdx.x == 0) *t.out = total;
+}
+void launch_reduce_tasks(hipStream_t st, const ReduceTasks& T, int n) {
+  if (n > 0) hipLaunchKernelGGL(k_reduce_tasks, dim3(n), dim3(256), 0, st, T);
+}
+
 // point3D_errors: sum |r_raw| / count over a point's observations (bundle_adjustment.cc:590-596)
 __global__ void k_point_errors(int NP, const int* __restrict__ pt_start, const double* __restrict__ rnorm,
                                const int* __restrict__ pt_count, double* __restrict__ perr) {

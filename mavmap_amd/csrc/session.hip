@@ -1337,10 +1337,12 @@ void mavba_session::evaluate() {
                        d_intr.p, d_points.p, d_img_rec, d_cam_rec, d_gu.p, d_norm_partial.p, &rows);
   });
   timed("reduce", [&] {
-    launch_reduce_cols(st, d_norm_partial.p, rows, 1, 2, 1u, d_scal.p + SC_GRAD_MAX, false);
-    launch_reduce_cols(st, d_norm_partial.p + 1, rows, 1, 2, 0u, d_scal.p + SC_XNORM2, false);
-    launch_reduce_cols(st, d_sweep_partial.p, N > 0 ? jacobian_sweep_grid(N) : 0, 1, 1, 0u, d_scal.p + SC_COST, false);
-    if (num_priors > 0) launch_reduce_cols(st, d_prior_cost.p, num_priors, 1, 1, 0u, d_scal.p + SC_COST, true);
+    const int nsweep = N > 0 ? jacobian_sweep_grid(N) : 0;
+    ReduceTasks T;
+    T.t[0] = ReduceTask{d_norm_partial.p, rows, 2, 1, nullptr, 0, d_scal.p + SC_GRAD_MAX};
+    T.t[1] = ReduceTask{d_norm_partial.p + 1, rows, 2, 0, nullptr, 0, d_scal.p + SC_XNORM2};
+    T.t[2] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
+    launch_reduce_tasks(st, T, 3);
   });
   if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS + 1, 2);  // sums, then max|g| in the last slot
   double h[SC_COUNT];
@@ -1422,11 +1424,13 @@ void mavba_session::candidate(double r, double* h) {
                        d_prior_jac.p, d_prior_cost.p);
     });
   timed("reduce", [&] {
-    launch_reduce_cols(st, d_step_partial.p, rows + 1, 1, 3, 0u, d_scal.p + SC_STEP_NORM2, false);
-    launch_reduce_cols(st, d_step_partial.p + 1, rows + 1, 1, 3, 0u, d_scal.p + SC_MODEL_CHANGE, false);
-    launch_reduce_cols(st, d_step_partial.p + 2, rows + 1, 1, 3, 0u, d_scal.p + SC_CAND_XNORM2, false);
-    launch_reduce_cols(st, d_sweep_partial.p, N > 0 ? jacobian_sweep_grid(N) : 0, 1, 1, 0u, d_scal.p + SC_NEW_COST, false);
-    if (num_priors > 0) launch_reduce_cols(st, d_prior_cost.p, num_priors, 1, 1, 0u, d_scal.p + SC_NEW_COST, true);
+    const int nsweep = N > 0 ? jacobian_sweep_grid(N) : 0;
+    ReduceTasks T;
+    T.t[0] = ReduceTask{d_step_partial.p, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_STEP_NORM2};
+    T.t[1] = ReduceTask{d_step_partial.p + 1, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_MODEL_CHANGE};
+    T.t[2] = ReduceTask{d_step_partial.p + 2, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_CAND_XNORM2};
+    T.t[3] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_NEW_COST};
+    launch_reduce_tasks(st, T, 4);
   });
   if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS, 0);
   read_scalars(h);
