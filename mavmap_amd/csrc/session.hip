@@ -437,6 +437,8 @@ struct mavba_session {
   void choose_elimination_order(const std::vector<SchurBlock>& blocks);
   void reset_state();
   void evaluate();
+  void evaluate_enqueue();  // the launches of evaluate() without reading the scalars back
+  void take_evaluation(const double* h) { cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]); }
   void assemble(double r);
   void solve_linear(double r);
   void candidate(double r, double* h_scal);
@@ -1299,7 +1301,7 @@ void mavba_session::reset_state() {
 // Evaluation at the current x: residuals, Jacobian, cost, gradient norm (ceres
 // Evaluator::Evaluate with jacobian != NULL).
 // ===========================================================================
-void mavba_session::evaluate() {
+void mavba_session::evaluate_enqueue() {
   timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
   SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
   timed("jacobian_sweep", [&] { launch_jacobian_sweep(st, a); });
@@ -1345,10 +1347,13 @@ void mavba_session::evaluate() {
     launch_reduce_tasks(st, T, 3);
   });
   if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS + 1, 2);  // sums, then max|g| in the last slot
+  evaluated = true; assembled = false;
+}
+void mavba_session::evaluate() {
+  evaluate_enqueue();
   double h[SC_COUNT];
   read_scalars(h);
-  cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]);
-  evaluated = true; assembled = false;
+  take_evaluation(h);
 }
 
 // Schur complement for the current Jacobian at trust-region radius r:
@@ -1455,12 +1460,27 @@ int mavba_session::iterate(int max_iters, int* done) {
   const double t0 = now_s();
   int n = 0;
   if (!started) start();
+  // Single process: the scalars of the evaluation at an accepted point are read back together with those of
+  // the NEXT candidate (one host synchronisation per iteration instead of two): the next linear solve is
+  // enqueued right behind the evaluation, and the tests that follow an evaluation in Ceres' loop (gradient
+  // tolerance) are applied when its scalars arrive - before anything of the speculative iteration counts.
+  const bool defer = world == 1 && !opt.print_progress;
+  bool pending_eval = false;
   while (termination == MAVBA_TERM_RUNNING && n < max_iters) {
     if (iteration >= opt.max_num_iterations) { termination = MAVBA_TERM_NO_CONVERGENCE; break; }
     ++iteration; ++n;
     solve_linear(radius);
     double h[SC_COUNT];
     candidate(radius, h);
+    if (pending_eval) {
+      pending_eval = false;
+      take_evaluation(h);
+      if (grad_max <= abs_gtol) {  // the previous iteration ended the solve: this one never happened
+        termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+        --iteration; --n;
+        break;
+      }
+    }
     const double mcc = h[SC_MODEL_CHANGE];
     const bool solved = h[SC_FAIL] == 0.0 && std::isfinite(mcc) && std::isfinite(h[SC_STEP_NORM2]);
     const bool valid = solved && !(mcc < 0.0);
@@ -1484,8 +1504,13 @@ int mavba_session::iterate(int max_iters, int* done) {
       radius = std::min(opt.max_trust_region_radius, radius);
       decrease_factor = 2.0;
       std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
-      evaluate();
-      if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+      if (defer) {
+        evaluate_enqueue();
+        pending_eval = true;
+      } else {
+        evaluate();
+        if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+      }
     } else {
       ++n_fail;
       radius = radius / decrease_factor;
@@ -1495,6 +1520,13 @@ int mavba_session::iterate(int max_iters, int* done) {
       std::printf("%4d %14.6e %12.2e %10.2e %10.2e %10.2e %10.2e\n", iteration, cost + fixed_cost, successful ? cost_change : 0.0,
                   grad_max, step_norm, rel, radius);
     if (termination == MAVBA_TERM_RUNNING && radius < opt.min_trust_region_radius) termination = MAVBA_TERM_PARAMETER_TOLERANCE;
+  }
+  if (pending_eval) {
+    // the evaluation's own test comes before whatever ended the loop after it was enqueued
+    double h[SC_COUNT];
+    read_scalars(h);
+    take_evaluation(h);
+    if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
   }
   if (termination == MAVBA_TERM_RUNNING && iteration >= opt.max_num_iterations) termination = MAVBA_TERM_NO_CONVERGENCE;
   if (done) *done = n;
