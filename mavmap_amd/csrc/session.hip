@@ -334,6 +334,7 @@ struct mavba_session {
   // ---- device: parameters (current x, candidate, initial) ----
   DevBuf<double> d_poses, d_intr, d_points, d_cposes, d_cintr, d_cpoints, d_poses0, d_intr0, d_points0;
   DevBuf<double> d_camrec, d_ccamrec;
+  bool camrec_current = false;  // d_camrec holds the records of d_poses (an accepted step swaps in the candidate's)
   // ---- device: linearisation ----
   DevBuf<double> d_R, d_Jp, d_Jc, d_Jk, d_Cu, d_gu, d_Gi, d_h, d_scale_cam, d_scale_pt;
   DevBuf<double> d_sweep_partial, d_camsum /* img_rec | cam_rec */, d_img_intr_tmp, d_cam_partial;
@@ -1290,6 +1291,7 @@ void mavba_session::reset_state() {
   HIP_OK(hipMemcpyAsync(d_intr.p, d_intr0.p, (size_t)NC * 9 * 8, hipMemcpyDeviceToDevice, st));
   HIP_OK(hipMemcpyAsync(d_points.p, d_points0.p, (size_t)NP * 3 * 8, hipMemcpyDeviceToDevice, st));
   evaluated = scales_ready = started = assembled = false;
+  camrec_current = false;
   radius = opt.initial_trust_region_radius; decrease_factor = 2.0;
   cost = x_norm = grad_max = abs_gtol = initial_cost = 0.0;
   iteration = invalid_steps = n_success = n_fail = 0;
@@ -1302,7 +1304,8 @@ void mavba_session::reset_state() {
 // Evaluator::Evaluate with jacobian != NULL).
 // ===========================================================================
 void mavba_session::evaluate_enqueue() {
-  timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
+  if (!camrec_current) timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
+  camrec_current = true;
   SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
   timed("jacobian_sweep", [&] { launch_jacobian_sweep(st, a); });
   timed("point_reduce", [&] {
@@ -1504,6 +1507,7 @@ int mavba_session::iterate(int max_iters, int* done) {
       radius = std::min(opt.max_trust_region_radius, radius);
       decrease_factor = 2.0;
       std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
+      std::swap(d_camrec.p, d_ccamrec.p);  // the candidate's camera records are the new point's (camrec_current stays true)
       if (defer) {
         evaluate_enqueue();
         pending_eval = true;
