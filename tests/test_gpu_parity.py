@@ -375,3 +375,43 @@ def test_clusters_off_gives_the_same_system(mavba, monkeypatch):
         S0, v0 = s.reduced_system(1e4)
         assert s.info()["num_clusters"] == 0 and sum(s.info()["schur_terms"]) > 0
     assert rel_err(S1, S0) < 1e-12 and rel_err(v1, v0) < 1e-12
+
+
+# ---- LM control flow around the deferred read-back of the evaluation ------------------------------------
+
+@pytest.mark.parametrize("optkw", [dict(gradient_tolerance=1e-3), dict(gradient_tolerance=1e-2, function_tolerance=1e-12),
+                                   dict(max_num_iterations=3), dict(max_num_iterations=1), dict(parameter_tolerance=1e-3)])
+def test_termination_kinds_match_oracle(mavba, oracle, optkw):
+    """Gradient tolerance (tested when an evaluation's scalars arrive, one host sync later than Ceres does it), the
+    iteration limit and the parameter tolerance must end the solve at the same iteration as the oracle."""
+    p = synth.make_scene(num_images=8, num_points=400, track_len=4, models=[A.MODEL_PINHOLE], seed=31, noise_px=0.05,
+                         outlier_frac=0.0)
+    kw = dict(global_opts(), **optkw)
+    po, ro, eo, pg, rg, eg = _solve_both(mavba, oracle, p, **kw)
+    assert rg["termination"] == ro["termination"], (rg["termination_name"], ro["termination_name"])
+    assert rg["num_successful_steps"] == ro["num_successful_steps"]
+    assert rg["num_unsuccessful_steps"] == ro["num_unsuccessful_steps"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"] + 1e-18
+    assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+
+
+def test_stepwise_iteration_equals_one_call(mavba):
+    """mavba_session_iterate(1) repeated must walk the same path as one call (the deferred evaluation is completed
+    at the end of every call)."""
+    p = _scene("mixed")
+    with mavba.Session(p, global_opts()) as s:
+        ra = s.solve()
+        pa = s.get_params()
+    with mavba.Session(p, global_opts()) as s:
+        steps = 0
+        while True:
+            done, term = s.iterate(1)
+            steps += done
+            if term != A.TERM_RUNNING or steps > 500:
+                break
+        rb = s.result()
+        pb = s.get_params()
+    assert rb["termination"] == ra["termination"] and rb["num_successful_steps"] == ra["num_successful_steps"]
+    assert rb["num_unsuccessful_steps"] == ra["num_unsuccessful_steps"] and rb["final_cost"] == ra["final_cost"]
+    for x, y in zip(pa, pb):
+        assert np.array_equal(x, y)
