@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--config", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
+    ap.add_argument("--problem", default=None, help="replay file (BAProblem.save / the shim's MAVBA_DUMP_DIR) instead of a synthetic config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
     args = ap.parse_args()
@@ -139,7 +140,14 @@ def main():
     mavmap_amd.load()
 
     t0 = time.time()
-    full = synth.make_config(args.config, scale=args.scale)
+    if args.problem:
+        from mavmap_amd.problem import BAProblem
+        full, _ = BAProblem.load(args.problem)
+        args.config = "replay"
+        WORKLOADS["replay"] = (f"replay of {os.path.basename(args.problem)}: {full.num_images} images / {full.num_points} points / "
+                               f"{full.num_obs} obs")
+    else:
+        full = synth.make_config(args.config, scale=args.scale)
     prob, _ = full.shard_by_point(rank, world)
     log(f"[rank {rank}] scene {args.config}: {full.num_images} images / {full.num_points} points / "
         f"{full.num_obs} obs (this rank: {prob.num_points} points / {prob.num_obs} obs), generated in {time.time() - t0:.1f}s")
@@ -263,7 +271,7 @@ def main():
             "metric": "global-BA LM iterations/sec", "value": round(value, 3), "unit": "iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.problem else "replay file",
             "config": {"workload": WORKLOADS[args.config] + ("" if args.scale == 1.0 else f" (scaled x{args.scale})"),
                        "images": full.num_images, "points": full.num_points, "observations": full.num_obs,
                        "parallelism": "single GPU" if world == 1 else f"points sharded over {world} ranks, "

@@ -79,6 +79,48 @@ class BAProblem:
         return p
 
     # -- sharding by 3-D point ------------------------------
+    # ---- replay files (same layout as the shim's MAVBA_DUMP_DIR dumps, shim/base3d/bundle_adjustment.cc) ----
+    MAGIC = b"MAVBA1\0\0"
+
+    def save(self, path, options=None):
+        """Write the problem as a replay file; `options` = dict with max_num_iterations, function_tolerance,
+        gradient_tolerance, loss_scale_factor (stored for information, defaults = reference global BA)."""
+        o = dict(max_num_iterations=200, function_tolerance=1e-6, gradient_tolerance=1e-10, loss_scale_factor=1.0)
+        o.update(options or {})
+        with open(path, "wb") as f:
+            f.write(self.MAGIC)
+            np.array([self.num_images, self.num_cameras, self.num_points, len(self.rot_prior_image)], "<i4").tofile(f)
+            np.array([self.num_obs], "<i8").tofile(f)
+            np.array([self.rot_prior_weight, o["max_num_iterations"], o["function_tolerance"], o["gradient_tolerance"],
+                      o["loss_scale_factor"]], "<f8").tofile(f)
+            for a, t in ((self.poses, "<f8"), (self.pose_const, "u1"), (self.image_camera, "<i4"), (self.intrinsics, "<f8"),
+                         (self.camera_model, "<i4"), (self.intr_const, "u1"), (self.points, "<f8"), (self.point_const, "u1"),
+                         (self.obs_uv, "<f8"), (self.obs_image, "<i4"), (self.obs_point, "<i4"), (self.rot_prior_image, "<i4"),
+                         (self.rot_prior_rvec, "<f8")):
+                np.ascontiguousarray(a, dtype=t).tofile(f)
+
+    @classmethod
+    def load(cls, path):
+        """(problem, options dict) from a replay file."""
+        with open(path, "rb") as f:
+            if f.read(8) != cls.MAGIC:
+                raise ValueError(f"{path}: not a mavba replay file")
+            ni, nc, npt, npri = (int(x) for x in np.fromfile(f, "<i4", 4))
+            no = int(np.fromfile(f, "<i8", 1)[0])
+            w, it, ftol, gtol, loss = (float(x) for x in np.fromfile(f, "<f8", 5))
+
+            def rd(t, n, shape=None):
+                a = np.fromfile(f, t, n)
+                if len(a) != n:
+                    raise ValueError(f"{path}: truncated")
+                return a.reshape(shape) if shape else a
+            p = cls(poses=rd("<f8", ni * 6, (ni, 6)), pose_const=rd("u1", ni), image_camera=rd("<i4", ni),
+                    intrinsics=rd("<f8", nc * 9, (nc, 9)), camera_model=rd("<i4", nc), intr_const=rd("u1", nc),
+                    points=rd("<f8", npt * 3, (npt, 3)), point_const=rd("u1", npt), obs_uv=rd("<f8", no * 2, (no, 2)),
+                    obs_image=rd("<i4", no), obs_point=rd("<i4", no), rot_prior_image=rd("<i4", npri),
+                    rot_prior_rvec=rd("<f8", npri * 3, (npri, 3)), rot_prior_weight=w)
+        return p, dict(max_num_iterations=int(it), function_tolerance=ftol, gradient_tolerance=gtol, loss_scale_factor=loss)
+
     def shard_by_point(self, rank, world_size):
         """Points (and all their observations) owned by `rank`; cameras replicated.
 

@@ -16,6 +16,8 @@
 #include "base3d/bundle_adjustment.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <iomanip>
 #include <iostream>
 #include <limits>
@@ -143,6 +145,34 @@ double pose_refinement(Eigen::Vector3d& rvec, Eigen::Vector3d& tvec, std::vector
     print_report(res);
   }
   return std::sqrt(res.final_cost / res.num_residuals);
+}
+
+// Optional replay file of the flattened problem (set MAVBA_DUMP_DIR): lets a maintainer benchmark the backend on the
+// problems a real MAVMAP run produces (`python bench.py --problem <file>`), without the rest of the pipeline.
+// Layout (little endian): "MAVBA1\0\0", int32 NI NC NP NPRI, int64 NO, double prior_weight, double opts[4]
+// {max_num_iterations, function_tolerance, gradient_tolerance, loss_scale_factor}, then the arrays of
+// mavba_problem in declaration order.
+static void dump_problem(const mavba_problem& P, const mavba_options& mo) {
+  const char* dir = std::getenv("MAVBA_DUMP_DIR");
+  if (!dir || !*dir) return;
+  static int counter = 0;
+  char path[1024];
+  std::snprintf(path, sizeof(path), "%s/mavba_problem_%05d_%dimg.bin", dir, counter++, (int)P.num_images);
+  std::FILE* f = std::fopen(path, "wb");
+  if (!f) return;
+  const char magic[8] = {'M', 'A', 'V', 'B', 'A', '1', 0, 0};
+  const int32_t dims[4] = {P.num_images, P.num_cameras, P.num_points, P.num_rot_priors};
+  const int64_t no = P.num_obs;
+  const double opts[4] = {(double)mo.max_num_iterations, mo.function_tolerance, mo.gradient_tolerance, mo.loss_scale_factor};
+  std::fwrite(magic, 1, 8, f); std::fwrite(dims, 4, 4, f); std::fwrite(&no, 8, 1, f);
+  std::fwrite(&P.rot_prior_weight, 8, 1, f); std::fwrite(opts, 8, 4, f);
+  const size_t NI = (size_t)P.num_images, NC = (size_t)P.num_cameras, NP = (size_t)P.num_points, NO = (size_t)P.num_obs, NR = (size_t)P.num_rot_priors;
+  std::fwrite(P.poses, 8, NI * 6, f); std::fwrite(P.pose_const, 1, NI, f); std::fwrite(P.image_camera, 4, NI, f);
+  std::fwrite(P.intrinsics, 8, NC * MAVBA_MAX_INTR, f); std::fwrite(P.camera_model, 4, NC, f); std::fwrite(P.intr_const, 1, NC, f);
+  std::fwrite(P.points, 8, NP * 3, f); std::fwrite(P.point_const, 1, NP, f);
+  std::fwrite(P.obs_uv, 8, NO * 2, f); std::fwrite(P.obs_image, 4, NO, f); std::fwrite(P.obs_point, 4, NO, f);
+  std::fwrite(P.rot_prior_image, 4, NR, f); std::fwrite(P.rot_prior_rvec, 8, NR * 3, f);
+  std::fclose(f);
 }
 
 double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_image_ids,
@@ -322,6 +352,7 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
   fill_options(options, &mo);
   std::vector<double> perr(point_ids.size(), 0.0);
   mavba_result res;
+  dump_problem(P, mo);
   const int rc = mavba_solve(&P, &mo, &res, options.update_point3D_errors ? perr.data() : nullptr);
   if (rc != MAVBA_OK) raise(rc);
 

@@ -110,3 +110,23 @@ def test_chol3_and_cauchy(host):
             host.hm_cauchy(C.c_double(s), C.c_double(a), C.byref(w), C.byref(hr))
             assert abs(hr.value - 0.5 * a * a * np.log1p(s / a / a)) < 1e-14 * max(1, hr.value)
             assert abs(w.value - 1 / np.sqrt(1 + s / a / a)) < 1e-15
+
+
+def test_problem_replay_file_round_trip(tmp_path):
+    """BAProblem.save / load (the layout the shim writes with MAVBA_DUMP_DIR) is lossless."""
+    from mavmap_amd import synth
+    from mavmap_amd.problem import BAProblem
+    p = synth.make_scene(num_images=6, num_points=80, track_len=3, models=[1, 3], seed=3, rot_priors=True)
+    p.point_const[::9] = 1
+    path = str(tmp_path / "p.bin")
+    p.save(path, dict(max_num_iterations=33, loss_scale_factor=2.5))
+    q, o = BAProblem.load(path)
+    for name in ("poses", "pose_const", "image_camera", "intrinsics", "camera_model", "intr_const", "points", "point_const",
+                 "obs_uv", "obs_image", "obs_point", "rot_prior_image", "rot_prior_rvec"):
+        a, b = getattr(p, name), getattr(q, name)
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), name
+    assert q.rot_prior_weight == p.rot_prior_weight and o["max_num_iterations"] == 33 and o["loss_scale_factor"] == 2.5
+    with open(path, "r+b") as f:
+        f.write(b"XX")
+    with pytest.raises(ValueError):
+        BAProblem.load(path)

@@ -191,6 +191,30 @@ def test_global_ba_flattening_order_and_constancy(mock):
         assert np.array_equal(poses, sc.poses) and np.array_equal(points, sc.points) and np.array_equal(cam, sc.cam)
 
 
+def test_shim_dumps_a_replay_file_of_what_it_hands_over(mock, tmp_path, monkeypatch):
+    """With MAVBA_DUMP_DIR set the shim writes the flattened problem of every call; BAProblem.load reads back exactly
+    what the C ABI received (so `bench.py --problem` replays real MAVMAP problems)."""
+    import glob
+    from mavmap_amd.problem import BAProblem
+    monkeypatch.setenv("MAVBA_DUMP_DIR", str(tmp_path))
+    p = small_scene(seed=4)
+    sc = Scene(p, extra_unmatched=5)
+    rc, *_ = run(mock, sc, [2, 3, 4, 5], [0], [1], refine_camera_params=1, max_num_iterations=77,
+                 function_tolerance=1e-5, gradient_tolerance=1e-9, loss_scale_factor=1.5)
+    assert rc == 0
+    r = recorded(mock)
+    files = sorted(glob.glob(str(tmp_path / "mavba_problem_*.bin")))
+    assert len(files) == 1 and files[0].endswith("_6img.bin")
+    q, o = BAProblem.load(files[0])
+    assert (q.num_images, q.num_cameras, q.num_points, q.num_obs) == (r["ni"], r["nc"], r["np"], r["no"])
+    assert np.array_equal(q.poses, r["poses"]) and np.array_equal(q.intrinsics, r["intr"]) and np.array_equal(q.points, r["points"])
+    assert np.array_equal(q.obs_uv, r["uv"]) and list(q.obs_image) == list(r["obs_image"]) and list(q.obs_point) == list(r["obs_point"])
+    assert list(q.pose_const) == list(r["pose_const"]) and list(q.intr_const) == list(r["intr_const"])
+    assert list(q.point_const) == list(r["point_const"]) and list(q.image_camera) == list(r["image_camera"])
+    assert list(q.camera_model) == list(r["camera_model"])
+    assert o == dict(max_num_iterations=77, function_tolerance=1e-5, gradient_tolerance=1e-9, loss_scale_factor=1.5)
+
+
 def test_local_window_min_track_len_counts_inside_the_selected_images(mock):
     p = small_scene(seed=2)
     sc = Scene(p)
