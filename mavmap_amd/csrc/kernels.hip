@@ -438,10 +438,24 @@ __global__ void __launch_bounds__(256) k_camera_sweep(CamSweepArgs a) {
 #pragma unroll
   for (int i = 0; i < KK; ++i) aIg[i] = 0.0;
 
-  for (int o = ch.begin + threadIdx.x; o < ch.end; o += 256) {
-    const double2 m = a.im_uv[o];
+  // The kernel holds ~120 accumulators per lane (one wave per SIMD), so nothing hides the dependent loads
+  // observation -> point index -> point: they are issued two / one trips ahead by hand.
+  int o = ch.begin + threadIdx.x;
+  double2 m = make_double2(0.0, 0.0), m_n = m;
+  int pt_n = 0;
+  double X[3] = {0.0, 0.0, 1.0};
+  if (o < ch.end) {
+    m = a.im_uv[o];
     const int pt = a.im_pt[o];
-    double X[3] = {a.points[3 * (long long)pt], a.points[3 * (long long)pt + 1], a.points[3 * (long long)pt + 2]};
+    X[0] = a.points[3 * (long long)pt]; X[1] = a.points[3 * (long long)pt + 1]; X[2] = a.points[3 * (long long)pt + 2];
+  }
+  if (o + 256 < ch.end) { m_n = a.im_uv[o + 256]; pt_n = a.im_pt[o + 256]; }
+  for (; o < ch.end; o += 256) {
+    double Xn[3] = {0.0, 0.0, 1.0};
+    double2 m_nn = make_double2(0.0, 0.0);
+    int pt_nn = 0;
+    if (o + 256 < ch.end) { Xn[0] = a.points[3 * (long long)pt_n]; Xn[1] = a.points[3 * (long long)pt_n + 1]; Xn[2] = a.points[3 * (long long)pt_n + 2]; }
+    if (o + 512 < ch.end) { m_nn = a.im_uv[o + 512]; pt_nn = a.im_pt[o + 512]; }
     double r[2], Jc[12], Jp[6], Jk[18];
     obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
     double w, half_rho;
@@ -466,6 +480,8 @@ __global__ void __launch_bounds__(256) k_camera_sweep(CamSweepArgs a) {
         aIg[k] += w2 * (Jk[k] * r[0] + Jk[9 + k] * r[1]);
       }
     }
+    X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
+    m = m_n; m_n = m_nn; pt_n = pt_nn;
   }
   // block reduction into the fixed 135-slot layout
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
