@@ -1,0 +1,375 @@
+// api.hip - the C ABI of include/mavba.h over the session object (no exception crosses it).
+#include "session.h"
+
+namespace mavba { thread_local std::string g_last_error; }
+
+using namespace mavba;
+
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+#define MAVBA_TRY try {
+#define MAVBA_CATCH                                                              \
+  }                                                                              \
+  catch (const Failure& f) { g_last_error = f.what(); return f.code; }           \
+  catch (const std::bad_alloc&) { g_last_error = "host out of memory"; return MAVBA_ERR_OUT_OF_MEMORY; } \
+  catch (const std::exception& e) { g_last_error = e.what(); return MAVBA_ERR_HIP; }
+
+extern "C" {
+
+void mavba_options_init(mavba_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 100;       // bundle_adjustment.h:40
+  o->function_tolerance = 1e-4;      // :41
+  o->gradient_tolerance = 1e-8;      // :42
+  o->loss_scale_factor = 1.0;        // :45
+  o->update_point_errors = 0;        // :43
+  o->print_progress = 0;             // :49
+  o->parameter_tolerance = 1e-8;     // Ceres 1.8 Solver::Options defaults below
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 10;  // bundle_adjustment.cc:559
+  o->jacobi_scaling = 1;
+  o->device = -1;
+  o->profile_kernels = 0;
+}
+
+const char* mavba_last_error(void) { return g_last_error.c_str(); }
+
+int mavba_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int mavba_session_create(const mavba_problem* problem, const mavba_options* options, mavba_session** out) {
+  if (!problem || !options || !out) { g_last_error = "null argument"; return MAVBA_ERR_INVALID_ARGUMENT; }
+  *out = nullptr;
+  if (mavba_device_count() <= 0) {
+    g_last_error = "no HIP device: the mavba backend has no CPU path";
+    return MAVBA_ERR_NO_DEVICE;
+  }
+  mavba_session* s = nullptr;
+  MAVBA_TRY
+  s = new mavba_session();
+  s->opt = *options;
+  if (options->device >= 0) HIP_OK(hipSetDevice(options->device));
+  HIP_OK(hipGetDevice(&s->device));
+  HIP_OK(stream_acquire(&s->st));
+  s->build(problem);
+  *out = s;
+  return MAVBA_OK;
+  }
+  catch (const Failure& f) { g_last_error = f.what(); delete s; return f.code; }
+  catch (const std::bad_alloc&) { g_last_error = "host out of memory"; delete s; return MAVBA_ERR_OUT_OF_MEMORY; }
+  catch (const std::exception& e) { g_last_error = e.what(); delete s; return MAVBA_ERR_HIP; }
+}
+
+void mavba_session_destroy(mavba_session* s) { delete s; }
+
+int mavba_session_reset(mavba_session* s) {
+  MAVBA_TRY
+  s->reset_state();
+  s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_iterate(mavba_session* s, int32_t max_iters, int32_t* iters_done, int32_t* termination) {
+  MAVBA_TRY
+  int done = 0;
+  s->iterate(max_iters, &done);
+  if (iters_done) *iters_done = done;
+  if (termination) *termination = s->termination;
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_result(mavba_session* s, mavba_result* result) {
+  MAVBA_TRY
+  s->fill_result(result);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_get_params(mavba_session* s, double* poses, double* intrinsics, double* points) {
+  MAVBA_TRY
+  if (poses && s->NI) HIP_OK(hipMemcpyAsync(poses, s->d_poses.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
+  if (intrinsics && s->NC) HIP_OK(hipMemcpyAsync(intrinsics, s->d_intr.p, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
+  std::vector<double> hp;
+  if (points && s->NP) { hp.resize((size_t)s->NP * 3); HIP_OK(hipMemcpyAsync(hp.data(), s->d_points.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st)); }
+  s->sync();
+  if (points) s->to_caller_points(hp.data(), points, 3);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_point_errors(mavba_session* s, double* point_error) {
+  MAVBA_TRY
+  if (!point_error) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null point_error");
+  s->point_errors(point_error);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_set_allreduce(mavba_session* s, mavba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world_size) {
+  MAVBA_TRY
+  if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_allreduce must precede the first iteration");
+  s->ar_fn = fn; s->ar_ctx = ctx; s->rank = rank; s->world = world_size;
+  if (fn && world_size > 1) {
+    // A camera block is in the problem if ANY rank has a residual block on it; the counts
+    // reported in mavba_result become global.
+    const size_t n = (size_t)s->NI + s->NC + 4;
+    std::vector<double> h(n, 0.0);
+    for (int i = 0; i < s->NI; ++i) h[i] = s->h_img_used[i];
+    for (int c = 0; c < s->NC; ++c) h[s->NI + c] = s->h_cam_used[c];
+    DevBuf<double> d;
+    d.upload(h, s->st);
+    s->allreduce(d.p, (long long)s->NI + s->NC, 1);
+    std::vector<double> g(4, 0.0);
+    long long free_pts = 0;
+    for (unsigned char f : s->h_pt_free) free_pts += f;
+    g[0] = s->fixed_cost; g[1] = (double)s->num_residuals; g[2] = (double)s->num_residuals_reduced; g[3] = (double)free_pts;
+    HIP_OK(hipMemcpyAsync(d.p + s->NI + s->NC, g.data(), 32, hipMemcpyHostToDevice, s->st));
+    s->allreduce(d.p + s->NI + s->NC, 4, 0);
+    HIP_OK(hipMemcpyAsync(h.data(), d.p, n * 8, hipMemcpyDeviceToHost, s->st));
+    s->sync();
+    for (int i = 0; i < s->NI; ++i) s->h_img_used[i] = h[i] != 0.0;
+    for (int c = 0; c < s->NC; ++c) s->h_cam_used[c] = h[s->NI + c] != 0.0;
+    s->derive_free_flags();
+    long long cam_params = 0;
+    for (unsigned char f : s->h_pose_free) cam_params += f;
+    for (unsigned char f : s->h_intr_free) cam_params += f;
+    s->fixed_cost = h[s->NI + s->NC];
+    s->num_residuals = (long long)h[s->NI + s->NC + 1];
+    s->num_residuals_reduced = (long long)h[s->NI + s->NC + 2];
+    s->num_parameters_reduced = cam_params + 3 * (long long)h[s->NI + s->NC + 3];
+    s->finish_structure();
+  }
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, double* Jc, double* Jp, double* Jk) {
+  MAVBA_TRY
+  s->evaluate();
+  if (cost) *cost = s->cost + s->fixed_cost;
+  const size_t S = s->Nstride, N = s->N;
+  auto pull = [&](const double* dev, int planes, std::vector<double>& h) {
+    h.resize((size_t)planes * S);
+    HIP_OK(hipMemcpyAsync(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost, s->st));
+  };
+  std::vector<double> hR, hJp, hJc, hJk;
+  pull(s->d_R.p, 2, hR); pull(s->d_Jp.p, 6, hJp); pull(s->d_Jc.p, 12, hJc); pull(s->d_Jk.p, 2 * s->KMAX, hJk);
+  s->sync();
+  const size_t NO = (size_t)s->NO_all;
+  if (r) std::memset(r, 0, NO * 2 * 8);
+  if (Jc) std::memset(Jc, 0, NO * 12 * 8);
+  if (Jp) std::memset(Jp, 0, NO * 6 * 8);
+  if (Jk) std::memset(Jk, 0, NO * 18 * 8);
+  for (size_t a = 0; a < N; ++a) {
+    const size_t o = (size_t)s->perm[a];
+    if (r) for (int e = 0; e < 2; ++e) r[o * 2 + e] = hR[e * S + a];
+    if (Jp) for (int e = 0; e < 6; ++e) Jp[o * 6 + e] = hJp[e * S + a];
+    if (Jc) for (int e = 0; e < 12; ++e) Jc[o * 12 + e] = hJc[e * S + a];
+    if (Jk)
+      for (int row = 0; row < 2; ++row)
+        for (int k = 0; k < s->KMAX; ++k) Jk[o * 18 + row * 9 + k] = hJk[(size_t)(row * s->KMAX + k) * S + a];
+  }
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_reduced_dim(mavba_session* s) { return s ? s->n_full : 0; }
+
+int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, double* vout) {
+  MAVBA_TRY
+  if (!s->evaluated) s->evaluate();
+  s->assemble(radius);
+  // the device matrix is in elimination order; hand it out in the variables' order
+  const int n = s->n_full, m = s->n_mat;
+  std::vector<double> h((size_t)(m + 1) * m);
+  HIP_OK(hipMemcpyAsync(h.data(), s->d_M.p, h.size() * 8, hipMemcpyDeviceToHost, s->st));
+  s->sync();
+  std::vector<int> var_col(n, 0);
+  for (int t = 0; t < m; ++t) if (s->h_col_var[t] >= 0) var_col[s->h_col_var[t]] = t;
+  if (Sout)
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) {  // the lower triangle is the one that is factorised (and, with shards, all-reduced)
+        const int a = std::max(var_col[r], var_col[c]), b = std::min(var_col[r], var_col[c]);
+        Sout[(size_t)r * n + c] = h[(size_t)a * m + b];
+      }
+  if (vout)
+    for (int r = 0; r < n; ++r) vout[r] = h[(size_t)m * m + var_col[r]];
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, double* d_intr, double* d_points,
+                              double* model_cost_change) {
+  MAVBA_TRY
+  if (!s->evaluated) s->evaluate();
+  s->solve_linear(radius);
+  double h[SC_COUNT];
+  s->candidate(radius, h);
+  if (model_cost_change) *model_cost_change = h[SC_MODEL_CHANGE];
+  if (d_poses && s->NI) HIP_OK(hipMemcpyAsync(d_poses, s->d_delta_cam.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
+  if (d_intr && s->NC) HIP_OK(hipMemcpyAsync(d_intr, s->d_delta_cam.p + 6 * (size_t)s->NI, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
+  std::vector<double> hdp;
+  if (d_points && s->NP) { hdp.resize((size_t)s->NP * 3); HIP_OK(hipMemcpyAsync(hdp.data(), s->d_delta_pts.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st)); }
+  s->sync();
+  if (d_points) s->to_caller_points(hdp.data(), d_points, 3);
+  if (h[SC_FAIL] != 0.0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "linear solve failed (matrix not positive definite)");
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
+  MAVBA_TRY
+  if (reps < 1) reps = 1;
+  launch_cam_prepare(s->st, s->NI, s->d_poses.p, s->d_camrec.p);
+  SweepArgs a = s->sweep_args(s->d_camrec.p, s->d_intr.p, s->d_points.p);
+  launch_jacobian_sweep(s->st, a);  // warm-up
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, s->st));
+  for (int i = 0; i < reps; ++i) launch_jacobian_sweep(s->st, a);
+  HIP_OK(hipEventRecord(e1, s->st));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms_avg) *ms_avg = ms / reps;
+  s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
+  MAVBA_TRY
+  if (!s || !out) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
+  std::memset(out, 0, sizeof(*out));
+  out->num_obs_kept = s->N;
+  out->reduced_dim = s->n_full; out->padded_dim = s->n_pad;
+  for (int k = 0; k < 3; ++k) out->schur_terms[k] = s->num_terms[k];
+  out->schur_blocks = s->num_blocks; out->intr_entries = s->Q;
+  const CholStructure& cs = s->chol_struct;
+  const long long nb = cs.nb;
+  out->dense_tiles = nb * (nb + 1) / 2;
+  out->envelope_tiles = cs.envelope_tiles;
+  out->factor_flops = cs.factor_flops;
+  out->matrix_dim = s->n_mat;
+  out->nd_parts = s->nd_parts;
+  out->chain_steps = cs.chain_steps;
+  out->num_clusters = s->num_clusters;
+  out->clustered_points = s->clustered_points;
+  out->cluster_partials = s->cluster_partials;
+  out->cluster_flops = s->cluster_flops;
+  const double n = (double)s->n_full;
+  out->dense_factor_flops = n * n * n / 3.0 + 2.0 * n * n;
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_kernel_stats(mavba_session* s, mavba_kernel_stat* out, int32_t cap) {
+  if (!s) return 0;
+  const int n = (int)s->timers.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    std::memset(&out[i], 0, sizeof(out[i]));
+    std::strncpy(out[i].name, s->timers[i].name.c_str(), sizeof(out[i].name) - 1);
+    out[i].launches = s->timers[i].launches;
+    out[i].total_ms = s->timers[i].total_ms;
+  }
+  return n;
+}
+
+int mavba_solve(const mavba_problem* problem, const mavba_options* options, mavba_result* result, double* point_error) {
+  mavba_session* s = nullptr;
+  int rc = mavba_session_create(problem, options, &s);
+  if (rc != MAVBA_OK) return rc;
+  int done = 0, term = 0;
+  rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &term);
+  if (rc == MAVBA_OK && result) rc = mavba_session_result(s, result);
+  // ceres leaves the user's parameter blocks untouched after NUMERICAL_FAILURE
+  if (rc == MAVBA_OK && term != MAVBA_TERM_NUMERICAL_FAILURE)
+    rc = mavba_session_get_params(s, problem->poses, problem->intrinsics, problem->points);
+  if (rc == MAVBA_OK && point_error && options->update_point_errors) rc = mavba_session_point_errors(s, point_error);
+  mavba_session_destroy(s);
+  return rc;
+}
+
+int mavba_pose_refine(double rvec[3], double tvec[3], const double* intrinsics, int32_t camera_model,
+                      const double* uv, const double* xyz, const uint8_t* inlier_mask, int64_t n,
+                      const mavba_options* options, mavba_result* result) {
+  if (!rvec || !tvec || !intrinsics || !options || n < 0 || (n > 0 && (!uv || !xyz))) {
+    g_last_error = "null argument"; return MAVBA_ERR_INVALID_ARGUMENT;
+  }
+  if (camera_model < 1 || camera_model > 3) { g_last_error = "bad camera model"; return MAVBA_ERR_BAD_MODEL; }
+  // One image, one (constant) camera, every inlier a constant point: pose_refinement(),
+  // bundle_adjustment.cc:160-193.
+  std::vector<double> pose = {rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]};
+  std::vector<double> intr(9, 0.0), pts, obs;
+  for (int k = 0; k < model_k(camera_model); ++k) intr[k] = intrinsics[k];
+  std::vector<int32_t> oi, op;
+  for (int64_t i = 0; i < n; ++i) {
+    if (inlier_mask && !inlier_mask[i]) continue;
+    op.push_back((int32_t)(pts.size() / 3)); oi.push_back(0);
+    pts.insert(pts.end(), xyz + 3 * i, xyz + 3 * i + 3);
+    obs.insert(obs.end(), uv + 2 * i, uv + 2 * i + 2);
+  }
+  const int32_t np = (int32_t)(pts.size() / 3);
+  std::vector<uint8_t> pconst(std::max(np, 1), 1);
+  uint8_t pose_const = 0, intr_const = 1;
+  int32_t img_cam = 0, model = camera_model;
+  mavba_problem P;
+  std::memset(&P, 0, sizeof(P));
+  P.num_images = 1; P.num_cameras = 1; P.num_points = np; P.num_obs = np;
+  P.poses = pose.data(); P.pose_const = &pose_const; P.image_camera = &img_cam;
+  P.intrinsics = intr.data(); P.camera_model = &model; P.intr_const = &intr_const;
+  P.points = pts.data(); P.point_const = pconst.data();
+  P.obs_uv = obs.data(); P.obs_image = oi.data(); P.obs_point = op.data();
+  mavba_result local;
+  const int rc = mavba_solve(&P, options, result ? result : &local, nullptr);
+  if (rc == MAVBA_OK) { for (int k = 0; k < 3; ++k) { rvec[k] = pose[k]; tvec[k] = pose[3 + k]; } }
+  return rc;
+}
+
+int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x, int32_t device) {
+  if (n <= 0 || !A || !b || !x) { g_last_error = "bad argument"; return MAVBA_ERR_INVALID_ARGUMENT; }
+  if (mavba_device_count() <= 0) { g_last_error = "no HIP device: the mavba backend has no CPU path"; return MAVBA_ERR_NO_DEVICE; }
+  MAVBA_TRY
+  if (device >= 0) HIP_OK(hipSetDevice(device));
+  hipStream_t st;
+  HIP_OK(hipStreamCreate(&st));
+  const int n_pad = std::max(64, round_up(n, 64));
+  std::vector<double> M((size_t)(n_pad + 64) * n_pad, 0.0);
+  for (int i = 0; i < n_pad; ++i) M[(size_t)i * n_pad + i] = 1.0;
+  for (int i = 0; i < n; ++i) std::memcpy(&M[(size_t)i * n_pad], &A[(size_t)i * n], (size_t)n * 8);
+  std::memcpy(&M[(size_t)n_pad * n_pad], b, (size_t)n * 8);
+  int rc = MAVBA_OK;
+  {
+    DevBuf<double> dM, dL, dy, dws, dfail;
+    dM.upload(M, st); dL.alloc(M.size()); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
+    CholStructure cs;
+    HIP_OK(cs.build_dense(n_pad / 64));
+    dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p, dL.p, cs);
+    std::vector<double> y(n_pad);
+    double fail = 0.0;
+    HIP_OK(hipMemcpyAsync(y.data(), dy.p, (size_t)n_pad * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&fail, dfail.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::memcpy(x, y.data(), (size_t)n * 8);
+    if (fail != 0.0) { g_last_error = "matrix is not positive definite"; rc = MAVBA_ERR_INVALID_ARGUMENT; }
+  }
+  (void)hipStreamDestroy(st);
+  return rc;
+  MAVBA_CATCH
+}
+
+}  // extern "C"
+

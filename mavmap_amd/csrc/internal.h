@@ -194,7 +194,7 @@ void launch_reduce_tasks(hipStream_t st, const ReduceTasks& tasks, int n);
 void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,
                          const int* pt_count, double* perr);
 
-// ---- device memory (session.hip) ---------------------------------------------
+// ---- device memory (host_util.hip) ---------------------------------------------
 // Process-wide caching allocator: local BA creates and destroys a session per call (hundreds per run) and
 // ~60 hipMalloc/hipFree pairs cost more than the solve of a small window. Blocks are cached per (device, size
 // class) and handed out again; contents are NOT cleared. MAVBA_POOL_MB caps the cache (default 16384, 0 = off).

@@ -1,0 +1,302 @@
+// session.h - shared by the session_*.hip / api.hip translation units: host-side helpers and the session object.
+// (Split of the former session.hip: set-up in session_build.hip, the LM loop in session_lm.hip, the C ABI in api.hip,
+// the process-wide device pool / stream cache / host worker threads in host_util.hip.)
+#ifndef MAVBA_SESSION_H_
+#define MAVBA_SESSION_H_
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mavba.h"
+#include "ba_math.h"
+#include "internal.h"
+
+namespace mavba {
+
+extern thread_local std::string g_last_error;  // api.hip
+
+struct Failure : std::runtime_error {
+  int code;
+  Failure(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+#define HIP_OK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      throw Failure(e_ == hipErrorOutOfMemory ? MAVBA_ERR_OUT_OF_MEMORY : MAVBA_ERR_HIP, \
+                    std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) device_free(p); }
+  void alloc(size_t count) {
+    if (p) { device_free(p); p = nullptr; }
+    n = count;
+    if (count) HIP_OK(device_alloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+  }
+  void upload(const std::vector<T>& h, hipStream_t st) {
+    alloc(std::max<size_t>(h.size(), 1));
+    if (!h.empty()) HIP_OK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+  void upload(const T* h, size_t count, hipStream_t st) {
+    alloc(std::max<size_t>(count, 1));
+    if (count) HIP_OK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+  void zero(hipStream_t st) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
+};
+
+// host_util.hip
+hipError_t stream_acquire(hipStream_t* st);
+void stream_release(hipStream_t st, int dev);
+int host_threads();
+void host_run(int T, const std::function<void(int)>& body);
+
+// Host scratch array WITHOUT value-initialisation (std::vector<T>(n) clears the memory first: ~1 ms per 10 MB,
+// and the set-up shuffles ~100 MB of such arrays that are fully overwritten anyway).
+template <typename T>
+struct HostBuf {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  explicit HostBuf(size_t count) : p(new T[std::max<size_t>(count, 1)]), n(count) {}
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* data() { return p.get(); }
+};
+
+// Stable counting sort of items 0..n-1 by key(i) in [0, nkeys) on a few threads (per-thread histograms turned
+// into per-thread cursors): start[k] = first position of key k, emit(i, position) is called once per item.
+// The result does not depend on the number of threads.
+template <typename KeyFn, typename EmitFn>
+static void counting_sort_parallel(long long n, int nkeys, KeyFn key, std::vector<int>& start, EmitFn emit) {
+  int T = n >= 200000 ? host_threads() : 1;
+  while (T > 1 && (size_t)T * nkeys > ((size_t)64 << 20)) T /= 2;
+  std::vector<std::vector<int>> hist(T);
+  auto run = [&](const std::function<void(int)>& body) { host_run(T, body); };
+  run([&](int t) {
+    hist[t].assign((size_t)nkeys, 0);
+    for (long long i = n * t / T; i < n * (t + 1) / T; ++i) hist[t][key(i)]++;
+  });
+  start.assign((size_t)nkeys + 1, 0);
+  int pos = 0;
+  for (int k = 0; k < nkeys; ++k) {
+    start[k] = pos;
+    for (int t = 0; t < T; ++t) { const int c = hist[t][k]; hist[t][k] = pos; pos += c; }
+  }
+  start[nkeys] = pos;
+  run([&](int t) {
+    for (long long i = n * t / T; i < n * (t + 1) / T; ++i) emit(i, hist[t][key(i)]++);
+  });
+}
+
+static inline int model_k(int m) { return m == MAVBA_MODEL_PINHOLE ? 4 : m == MAVBA_MODEL_OPENCV ? 8 : 9; }
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct KernelTimer { std::string name; long long launches = 0; double total_ms = 0.0; };
+
+// Run body(begin, end) over [0, n) on a few host threads (set-up work only).
+template <typename F>
+static void parallel_ranges(long long n, F&& body, long long min_parallel = 200000) {
+  int T = (int)std::min<long long>(host_threads(), std::max<long long>(n, 1));
+  if (n < min_parallel) T = 1;
+  if (T == 1) { body(0ll, n); return; }
+  host_run(T, [&](int t) { body(n * t / T, n * (t + 1) / T); });
+}
+
+}  // namespace mavba
+
+// (internal header: mavba_session is the global C-ABI handle type, assembled from mavba:: pieces)
+using namespace mavba;
+
+struct mavba_session {
+  mavba_options opt;
+  int device = 0;
+  hipStream_t st = nullptr;
+  // sizes
+  int NI = 0, NC = 0, NP = 0, N = 0, Nstride = 32, NPs = 32, KMAX = 4, n_full = 0, n_pad = 64, Q = 0;
+  long long NO_all = 0;
+  bool any_intr_free = false;
+  // host-side copies
+  std::vector<double> h_poses0, h_intr0, h_points0;
+  std::vector<int> h_cam_model, h_img_cam, h_pt_start, h_oimg;
+  std::vector<long long> perm;      // point-major position -> caller observation index
+  std::vector<int> h_pt_count_all;  // observations per point in the caller's problem
+  // Points are renumbered at session creation (sorted by their image lists, so that neighbours in the order
+  // see the same images: the Schur-complement clusters rely on it). h_pt_orig[internal] = caller's index.
+  std::vector<int> h_pt_orig;
+  std::vector<unsigned char> h_pose_const, h_intr_const_in, h_pt_const_in;
+  std::vector<unsigned char> h_img_used, h_cam_used, h_pt_used;
+  std::vector<unsigned char> h_pose_free, h_intr_free, h_pt_free;
+  double fixed_cost = 0.0;
+  long long num_residuals = 0, num_residuals_reduced = 0, num_parameters_reduced = 0;
+  int num_priors = 0;
+  double prior_weight = 0.0;
+  double setup_seconds = 0.0, solve_seconds = 0.0;
+
+  // ---- device: static problem data ----
+  DevBuf<double2> d_uv, d_im_uv;
+  DevBuf<int> d_obs_img, d_obs_pt, d_pt_start, d_im_pt, d_img_cam, d_cam_model, d_img_chunk_start,
+      d_cam_img_start, d_cam_imgs, d_prior_img, d_prior_start, d_q_pt, d_q_cam, d_q_start, d_pt_count;
+  DevBuf<SweepChunk> d_sweep_chunks;
+  int num_sweep_chunks = 0;
+  DevBuf<unsigned char> d_pose_free, d_intr_free, d_pt_free;
+  DevBuf<double> d_prior_R0;
+  DevBuf<SchurBlock> d_blocks;
+  DevBuf<SchurChunk> d_chunks[3];
+  DevBuf<SchurCluster> d_clusters;
+  DevBuf<PartialReduce> d_reduce_tasks;
+  int num_reduce_tasks = 0;
+  DevBuf<int> d_cl_tab;
+  DevBuf<unsigned short> d_obs_meta, d_q_meta;
+  DevBuf<unsigned char> d_pt_clustered;
+  int num_clusters = 0, num_slots[3] = {0, 0, 0};
+  ClusterShape cl_shape{16, 3};
+  long long clustered_points = 0, cluster_partials = 0;
+  double cluster_flops = 0.0;
+  DevBuf<int2> d_terms[3];
+  int num_blocks = 0, num_chunks[3] = {0, 0, 0};
+  long long num_terms[3] = {0, 0, 0};
+  // ---- device: parameters (current x, candidate, initial) ----
+  DevBuf<double> d_poses, d_intr, d_points, d_cposes, d_cintr, d_cpoints, d_poses0, d_intr0, d_points0;
+  DevBuf<double> d_camrec, d_ccamrec;
+  bool camrec_current = false;  // d_camrec holds the records of d_poses (an accepted step swaps in the candidate's)
+  // ---- device: linearisation ----
+  DevBuf<double> d_R, d_Jp, d_Jc, d_Jk, d_Cu, d_gu, d_Gi, d_h, d_scale_cam, d_scale_pt;
+  DevBuf<double> d_sweep_partial, d_camsum /* img_rec | cam_rec */, d_img_intr_tmp, d_cam_partial;
+  DevBuf<double> d_prior_res, d_prior_jac, d_prior_cost;
+  DevBuf<double> d_Epose, d_Eintr, d_Wk, d_part[3];
+  DevBuf<double> d_M, d_L, d_y, d_diag_ws, d_delta_cam, d_delta_pts, d_norm_partial, d_step_partial, d_scal;
+  DevBuf<double> d_rnorm, d_perr;
+  double* d_img_rec = nullptr;
+  double* d_cam_rec = nullptr;
+  CholStructure chol_struct;
+  // The reduced camera matrix is assembled in the factorisation's elimination order: n_mat (multiple of 64)
+  // columns, image i's pose block at h_off_img[i], camera c's intrinsics block at h_off_cam[c]; col_var maps a
+  // matrix column back to the variable (index into the length-n_pad camera vectors), -1 for padding.
+  int n_mat = 64, nd_parts = 0;
+  std::vector<int> h_off_img, h_off_cam, h_col_var;
+  DevBuf<int> d_off, d_col_var;
+  DevBuf<double> d_ymat;
+  // multi-rank: the structurally non-zero lower tiles of the matrix, packed for the all-reduce
+  DevBuf<int2> d_ar_tiles;
+  DevBuf<double> d_ar_buf;
+  int num_ar_tiles = 0;
+
+  // ---- LM state (Ceres TrustRegionMinimizer / LevenbergMarquardtStrategy) ----
+  bool evaluated = false, scales_ready = false, started = false, assembled = false;
+  double radius = 1e4, decrease_factor = 2.0;
+  double cost = 0.0, x_norm = 0.0, grad_max = 0.0, abs_gtol = 0.0, initial_cost = 0.0;
+  int iteration = 0, invalid_steps = 0, n_success = 0, n_fail = 0;
+  int termination = MAVBA_TERM_RUNNING;
+
+  // ---- multi-GPU ----
+  mavba_allreduce_fn ar_fn = nullptr;
+  void* ar_ctx = nullptr;
+  int rank = 0, world = 1;
+
+  // ---- profiling ----
+  std::vector<KernelTimer> timers;
+  struct Pending { int idx; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+
+  ~mavba_session() {
+    // the buffers go back to the process-wide pool: nothing may still be running on them
+    if (st) (void)hipStreamSynchronize(st);
+    for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& e : ev_pool) (void)hipEventDestroy(e);
+    if (st) stream_release(st, device);
+  }
+
+  int timer_index(const char* name) {
+    for (size_t i = 0; i < timers.size(); ++i) if (timers[i].name == name) return (int)i;
+    timers.push_back(KernelTimer{name, 0, 0.0});
+    return (int)timers.size() - 1;
+  }
+  hipEvent_t get_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e; HIP_OK(hipEventCreate(&e)); return e;
+  }
+  template <typename F>
+  void timed(const char* name, F&& f) {
+    if (!opt.profile_kernels) { f(); return; }
+    Pending p; p.idx = timer_index(name); p.a = get_event(); p.b = get_event();
+    HIP_OK(hipEventRecord(p.a, st));
+    f();
+    HIP_OK(hipEventRecord(p.b, st));
+    pending.push_back(p);
+  }
+  void flush_timers() {  // only after a stream synchronisation
+    for (auto& p : pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { timers[p.idx].launches++; timers[p.idx].total_ms += ms; }
+      ev_pool.push_back(p.a); ev_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+  void sync() { HIP_OK(hipStreamSynchronize(st)); HIP_OK(hipGetLastError()); flush_timers(); }
+
+  void allreduce(double* dptr, long long count, int op) {
+    if (!ar_fn || world <= 1) return;
+    sync();
+    if (ar_fn(ar_ctx, dptr, count, op) != 0) throw Failure(MAVBA_ERR_HIP, "all-reduce hook failed");
+  }
+
+  SweepArgs sweep_args(const double* camrec, const double* intr, const double* points) {
+    SweepArgs a;
+    a.N = N; a.Nstride = Nstride; a.NI = NI; a.NC = NC; a.KMAX = KMAX;
+    a.uv = d_uv.p; a.obs_img = d_obs_img.p; a.obs_pt = d_obs_pt.p;
+    a.camrec = camrec; a.intr = intr; a.img_cam = d_img_cam.p; a.cam_model = d_cam_model.p;
+    a.points = points;
+    a.loss_b = opt.loss_scale_factor * opt.loss_scale_factor; a.loss_inv_b = 1.0 / a.loss_b;
+    a.R = d_R.p; a.Jp = d_Jp.p; a.Jc = d_Jc.p; a.Jk = d_Jk.p; a.cost_partial = d_sweep_partial.p;
+    return a;
+  }
+  void read_scalars(double* h) {
+    HIP_OK(hipMemcpyAsync(h, d_scal.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+    sync();
+  }
+
+  void build(const mavba_problem* P);
+  void derive_free_flags();
+  void finish_structure();
+  void choose_elimination_order(const std::vector<SchurBlock>& blocks);
+  void reset_state();
+  void evaluate();
+  void evaluate_enqueue();  // the launches of evaluate() without reading the scalars back
+  void take_evaluation(const double* h) { cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]); }
+  void assemble(double r);
+  void solve_linear(double r);
+  void candidate(double r, double* h_scal);
+  void start();
+  int iterate(int max_iters, int* done);
+  void point_errors(double* out);
+  void to_caller_points(const double* internal, double* out, int width) const {
+    for (int q = 0; q < NP; ++q)
+      for (int e = 0; e < width; ++e) out[(size_t)h_pt_orig[q] * width + e] = internal[(size_t)q * width + e];
+  }
+  void fill_result(mavba_result* r);
+};
+#endif  // MAVBA_SESSION_H_

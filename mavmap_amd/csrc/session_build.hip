@@ -1,0 +1,853 @@
+// session_build.hip - session set-up: validation, internal point / observation order, point clusters, Schur block
+// structure, elimination order of the reduced system (reference semantics: src/base3d/bundle_adjustment.cc:228-549
+// for what the caller's flat problem means; everything here is indexing for the device kernels).
+#include "session.h"
+
+using namespace mavba;
+
+
+// ===========================================================================
+// Problem indexing (host) — the device-side counterpart of
+// _bundle_adjustment_extract_data / _fill_problem (bundle_adjustment.cc:228-387): the shim
+// has already selected images and observations; here they are re-ordered point-major and
+// the block structure of the reduced camera system is enumerated.
+// ===========================================================================
+void mavba_session::derive_free_flags() {
+  h_pose_free.assign((size_t)NI * 6, 0);
+  h_intr_free.assign((size_t)NC * 9, 0);
+  h_pt_free.assign(NP, 0);
+  for (int i = 0; i < NI; ++i) {
+    if (!h_img_used[i]) continue;
+    const unsigned m = h_pose_const[i];
+    for (int e = 0; e < 6; ++e) {
+      const bool c = e < 3 ? (m & MAVBA_CONST_RVEC) != 0 : (m & (MAVBA_CONST_TX << (e - 3))) != 0;
+      h_pose_free[(size_t)i * 6 + e] = c ? 0 : 1;
+    }
+  }
+  any_intr_free = false;
+  for (int c = 0; c < NC; ++c) {
+    if (!h_cam_used[c] || h_intr_const_in[c]) continue;
+    for (int k = 0; k < model_k(h_cam_model[c]); ++k) h_intr_free[(size_t)c * 9 + k] = 1;
+    any_intr_free = true;
+  }
+  for (int p = 0; p < NP; ++p) h_pt_free[p] = (h_pt_used[p] && !h_pt_const_in[p]) ? 1 : 0;
+  long long np = 0;
+  for (unsigned char f : h_pose_free) np += f;
+  for (unsigned char f : h_intr_free) np += f;
+  for (unsigned char f : h_pt_free) np += 3 * f;
+  num_parameters_reduced = np;
+}
+
+void mavba_session::build(const mavba_problem* P) {
+  const double t0 = now_s();
+  const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
+  double tl = t0;
+  auto lap = [&](const char* what) { if (tt) { const double t = now_s(); std::fprintf(stderr, "[setup] %-28s %8.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
+  NI = P->num_images; NC = P->num_cameras; NP = P->num_points; NO_all = P->num_obs;
+  if (NI < 0 || NC < 0 || NP < 0 || NO_all < 0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "negative size");
+  if (NO_all >= (1ll << 31) - 64) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 observations per session");
+  if (NI > 16000) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 16000 images per session (dense block index)");
+  if (!(opt.loss_scale_factor > 0.0)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "loss_scale_factor must be > 0");
+  if (NI > 0 && (!P->poses || !P->image_camera)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null pose arrays");
+  if (NC > 0 && (!P->intrinsics || !P->camera_model)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null camera arrays");
+  if (NP > 0 && !P->points) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null point array");
+  if (NO_all > 0 && (!P->obs_uv || !P->obs_image || !P->obs_point)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null observation arrays");
+  h_cam_model.assign(P->camera_model, P->camera_model + NC);
+  h_img_cam.assign(P->image_camera, P->image_camera + NI);
+  int kmax = 4;
+  for (int c = 0; c < NC; ++c) {
+    if (h_cam_model[c] < 1 || h_cam_model[c] > 3) throw Failure(MAVBA_ERR_BAD_MODEL, "camera model code not in {1,2,3}");
+    kmax = std::max(kmax, model_k(h_cam_model[c]));
+  }
+  KMAX = kmax;  // 4, 8 or 9: number of intrinsics columns the Jacobian planes carry
+  for (int i = 0; i < NI; ++i)
+    if (h_img_cam[i] < 0 || h_img_cam[i] >= NC) throw Failure(MAVBA_ERR_BAD_INDEX, "image_camera out of range");
+  {
+    int bad = 0;
+    parallel_ranges(NO_all, [&](long long b0, long long b1) {
+      int local = 0;
+      for (long long o = b0; o < b1; ++o)
+        local |= (P->obs_image[o] < 0) | (P->obs_image[o] >= NI) | (P->obs_point[o] < 0) | (P->obs_point[o] >= NP);
+      if (local) __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+    });
+    if (bad) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
+  }
+  for (int q = 0; q < P->num_rot_priors; ++q)
+    if (P->rot_prior_image[q] < 0 || P->rot_prior_image[q] >= NI) throw Failure(MAVBA_ERR_BAD_INDEX, "rot_prior_image out of range");
+
+  h_poses0.assign(P->poses, P->poses + (size_t)NI * 6);
+  h_intr0.assign(P->intrinsics, P->intrinsics + (size_t)NC * 9);
+  h_points0.assign(P->points, P->points + (size_t)NP * 3);
+  h_pose_const.assign(NI, 0); h_intr_const_in.assign(NC, 0); h_pt_const_in.assign(NP, 0);
+  if (P->pose_const) h_pose_const.assign(P->pose_const, P->pose_const + NI);
+  if (P->intr_const) h_intr_const_in.assign(P->intr_const, P->intr_const + NC);
+  if (P->point_const) h_pt_const_in.assign(P->point_const, P->point_const + NP);
+
+  // Residual blocks without a free parameter block leave the program (ceres
+  // RemoveFixedBlocksFromProgram); their cost is the fixed cost.
+  h_pt_count_all.assign(NP, 0);
+  std::vector<long long> kept;
+  kept.reserve((size_t)NO_all);
+  fixed_cost = 0.0;
+  const double b = opt.loss_scale_factor * opt.loss_scale_factor;
+  h_img_used.assign(NI, 0); h_cam_used.assign(NC, 0); h_pt_used.assign(NP, 0);
+  // Only an observation whose image is entirely constant (pose AND its camera's intrinsics) on a constant point
+  // can leave the program. Without such a combination (the normal case: global BA has no constant points, local
+  // BA windows only a few) every observation is kept and the pass is a parallel histogram.
+  bool any_const_img = false, any_const_pt = false;
+  for (int i = 0; i < NI; ++i) any_const_img |= (h_pose_const[i] & 15u) == 15u && h_intr_const_in[h_img_cam[i]];
+  for (int p = 0; p < NP; ++p) any_const_pt |= h_pt_const_in[p] != 0;
+  const bool all_kept = !(any_const_img && any_const_pt);
+  if (all_kept) {
+    // (the per-point counts and the used flags then fall out of the counting sorts below)
+    kept.resize((size_t)NO_all);
+    parallel_ranges(NO_all, [&](long long b0, long long b1) { for (long long o = b0; o < b1; ++o) kept[o] = o; });
+  } else {
+    for (long long o = 0; o < NO_all; ++o) {
+      const int i = P->obs_image[o], p = P->obs_point[o], c = h_img_cam[i];
+      h_pt_count_all[p]++;
+      if ((h_pose_const[i] & 15u) == 15u && h_intr_const_in[c] && h_pt_const_in[p]) {
+        double rec[9], r[2], w, hr;
+        cam_prepare(&h_poses0[(size_t)i * 6], rec);
+        obs_residual(h_cam_model[c], rec, &h_intr0[(size_t)c * 9], &h_points0[(size_t)p * 3], P->obs_uv[2 * o],
+                     P->obs_uv[2 * o + 1], r);
+        cauchy_weight(r[0] * r[0] + r[1] * r[1], b, 1.0 / b, w, hr);
+        fixed_cost += hr;
+        continue;
+      }
+      kept.push_back(o);
+      h_img_used[i] = 1; h_cam_used[c] = 1; h_pt_used[p] = 1;
+    }
+  }
+  lap("validate + fixed blocks");
+  N = (int)kept.size();
+  Nstride = std::max(32, round_up(N, 32));
+  NPs = std::max(32, round_up(NP, 32));
+
+  // rotation priors: kept when the image's rvec block is free, sorted by image
+  std::vector<std::pair<int, int>> pri;  // (image, index)
+  for (int q = 0; q < P->num_rot_priors; ++q) {
+    const int i = P->rot_prior_image[q];
+    if (h_pose_const[i] & MAVBA_CONST_RVEC) {
+      double R0[9], r, j[3];
+      rot_matrix_colmajor(&P->rot_prior_rvec[3 * q], R0);
+      rot_prior_eval(&h_poses0[(size_t)i * 6], R0, P->rot_prior_weight, r, j);
+      fixed_cost += 0.5 * r * r;
+      continue;
+    }
+    pri.push_back({i, q});
+    h_img_used[i] = 1;
+  }
+  std::stable_sort(pri.begin(), pri.end());
+  num_priors = (int)pri.size();
+  prior_weight = P->rot_prior_weight;
+  num_residuals = 2 * NO_all + P->num_rot_priors;
+  num_residuals_reduced = 2ll * N + num_priors;
+
+  // ---- internal point order: lexicographic by the sorted list of images that see the point ----
+  // One stable counting sort of the kept observations by (caller's) point gives every point's bucket; the
+  // point-major order is the buckets concatenated in the new point order.
+  std::vector<int> pt_new(NP);
+  std::vector<int> cstart;
+  HostBuf<long long> bucket(N);  // kept observation ids, grouped by caller's point, input order inside
+  {
+    HostBuf<int> simg(N);
+    counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept[k]]; }, cstart,
+                           [&](long long k, int at) { bucket[at] = kept[k]; simg[at] = P->obs_image[kept[k]]; });
+    lap("  buckets by point");
+    if (all_kept)
+      for (int p = 0; p < NP; ++p) { h_pt_count_all[p] = cstart[p + 1] - cstart[p]; h_pt_used[p] = h_pt_count_all[p] > 0; }
+    parallel_ranges(NP, [&](long long b0, long long b1) {
+      for (long long p = b0; p < b1; ++p) std::sort(simg.data() + cstart[p], simg.data() + cstart[p + 1]);
+    });
+    // Order: by the first four images packed into one 64-bit key (cache-friendly sort of (key, point) pairs),
+    // ties by the full list, then by point id - a strict total order, so the result does not depend on the
+    // number of threads.
+    auto before_full = [&](int a, int b) {
+      const int* xa = simg.data() + cstart[a]; const int* xb = simg.data() + cstart[b];
+      const int na = cstart[a + 1] - cstart[a], nb = cstart[b + 1] - cstart[b];
+      const int n = std::min(na, nb);
+      for (int i = 0; i < n; ++i) if (xa[i] != xb[i]) return xa[i] < xb[i];
+      if (na != nb) return na < nb;
+      return a < b;
+    };
+    lap("  per-point image lists");
+    typedef std::pair<unsigned long long, int> KeyId;
+    HostBuf<KeyId> keyed(NP);
+    const bool packable = NI < 65535;
+    parallel_ranges(NP, [&](long long b0, long long b1) {
+      for (long long p = b0; p < b1; ++p) {
+        unsigned long long key = 0;
+        const int n = cstart[p + 1] - cstart[p];
+        for (int i = 0; i < 4; ++i) key = key << 16 | (unsigned long long)(packable && i < n ? simg[cstart[p] + i] : 0xFFFF);
+        keyed[p] = KeyId(packable ? key : 0ull, (int)p);
+      }
+    });
+    auto before = [&](const KeyId& a, const KeyId& b) {
+      if (a.first != b.first) return a.first < b.first;
+      return before_full(a.second, b.second);
+    };
+    // sorted runs on a few threads, then pairwise merges
+    const int T = NP >= 100000 ? host_threads() : 1;
+    std::vector<int> cut(T + 1);
+    for (int t = 0; t <= T; ++t) cut[t] = (int)((long long)NP * t / T);
+    host_run(T, [&](int t) { std::sort(keyed.data() + cut[t], keyed.data() + cut[t + 1], before); });
+    for (int w = 1; w < T; w *= 2) {
+      const int pairs = (T + 2 * w - 1) / (2 * w);
+      host_run(pairs, [&](int q) {
+        const int t = q * 2 * w;
+        if (t + w < T)
+          std::inplace_merge(keyed.data() + cut[t], keyed.data() + cut[t + w], keyed.data() + cut[std::min(t + 2 * w, T)], before);
+      });
+    }
+    lap("  sort points");
+    h_pt_orig.resize(NP);
+    for (int q = 0; q < NP; ++q) h_pt_orig[q] = keyed[q].second;
+    for (int q = 0; q < NP; ++q) pt_new[h_pt_orig[q]] = q;
+    auto permute = [&](auto& v, int width) {
+      auto old = v;
+      parallel_ranges(NP, [&](long long b0, long long b1) {
+        for (long long q = b0; q < b1; ++q)
+          for (int e = 0; e < width; ++e) v[(size_t)q * width + e] = old[(size_t)h_pt_orig[q] * width + e];
+      });
+    };
+    permute(h_points0, 3); permute(h_pt_const_in, 1); permute(h_pt_count_all, 1); permute(h_pt_used, 1);
+  }
+  lap("point order");
+
+  // ---- point-major order: the buckets in the new point order ----
+  h_pt_start.assign(NP + 1, 0);
+  for (int q = 0; q < NP; ++q) h_pt_start[q + 1] = h_pt_start[q] + (cstart[h_pt_orig[q] + 1] - cstart[h_pt_orig[q]]);
+  perm.assign(N, 0);
+  HostBuf<double2> uv(N);
+  HostBuf<int> opt_(N);
+  h_oimg.assign(N, 0);
+  parallel_ranges(NP, [&](long long q0, long long q1) {
+    for (long long q = q0; q < q1; ++q) {
+      const int src = cstart[h_pt_orig[q]], cnt = h_pt_start[q + 1] - h_pt_start[q];
+      for (int j = 0; j < cnt; ++j) {
+        const long long o = bucket[src + j];
+        const int a = h_pt_start[q] + j;
+        perm[a] = o;
+        uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
+        h_oimg[a] = P->obs_image[o]; opt_[a] = (int)q;
+      }
+    }
+  });
+
+  lap("point-major sort");
+  // ---- image-major view for the camera sweep ----
+  std::vector<int> img_start;
+  HostBuf<double2> im_uv(N);
+  HostBuf<int> im_pt(N);
+  counting_sort_parallel(N, NI, [&](long long a) { return h_oimg[a]; }, img_start,
+                         [&](long long a, int at) { im_uv[at] = uv[a]; im_pt[at] = opt_[a]; });
+  if (all_kept)
+    for (int i = 0; i < NI; ++i)
+      if (img_start[i + 1] > img_start[i]) { h_img_used[i] = 1; h_cam_used[h_img_cam[i]] = 1; }
+  const int kSweepChunk = 2048;
+  std::vector<SweepChunk> sweep_chunks;
+  std::vector<int> img_chunk_start(NI + 1, 0);
+  for (int i = 0; i < NI; ++i) {
+    img_chunk_start[i] = (int)sweep_chunks.size();
+    for (int b0 = img_start[i]; b0 < img_start[i + 1]; b0 += kSweepChunk)
+      sweep_chunks.push_back(SweepChunk{i, b0, std::min(b0 + kSweepChunk, img_start[i + 1])});
+  }
+  img_chunk_start[NI] = (int)sweep_chunks.size();
+  num_sweep_chunks = (int)sweep_chunks.size();
+  std::vector<int> cam_img_start(NC + 1, 0), cam_imgs(std::max(NI, 1));
+  for (int i = 0; i < NI; ++i) cam_img_start[h_img_cam[i] + 1]++;
+  for (int c = 0; c < NC; ++c) cam_img_start[c + 1] += cam_img_start[c];
+  {
+    std::vector<int> cur(cam_img_start.begin(), cam_img_start.end() - 1);
+    for (int i = 0; i < NI; ++i) cam_imgs[cur[h_img_cam[i]]++] = i;
+  }
+  std::vector<int> prior_img(num_priors), prior_start(NI + 1, 0);
+  std::vector<double> prior_R0((size_t)num_priors * 9);
+  for (int k = 0; k < num_priors; ++k) {
+    prior_img[k] = pri[k].first;
+    prior_start[pri[k].first + 1]++;
+    rot_matrix_colmajor(&P->rot_prior_rvec[3 * pri[k].second], &prior_R0[(size_t)k * 9]);
+  }
+  for (int i = 0; i < NI; ++i) prior_start[i + 1] += prior_start[i];
+
+  n_full = 6 * NI + 9 * NC;
+  n_pad = std::max(64, round_up(n_full, 64));
+
+  lap("image-major view");
+  // ---- uploads of the static data ----
+  d_uv.upload(uv.data(), (size_t)N, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload(opt_.data(), (size_t)N, st); d_pt_start.upload(h_pt_start, st);
+  d_im_uv.upload(im_uv.data(), (size_t)N, st); d_im_pt.upload(im_pt.data(), (size_t)N, st);
+  d_img_cam.upload(h_img_cam, st); d_cam_model.upload(h_cam_model, st);
+  d_sweep_chunks.upload(sweep_chunks, st); d_img_chunk_start.upload(img_chunk_start, st);
+  d_cam_img_start.upload(cam_img_start, st); d_cam_imgs.upload(cam_imgs, st);
+  d_prior_img.upload(prior_img, st); d_prior_start.upload(prior_start, st); d_prior_R0.upload(prior_R0, st);
+  d_pt_count.upload(h_pt_count_all, st);
+  d_poses0.upload(h_poses0, st); d_intr0.upload(h_intr0, st); d_points0.upload(h_points0, st);
+  const size_t nI = std::max(NI, 1), nC = std::max(NC, 1), nP = std::max(NP, 1);
+  d_poses.alloc(nI * 6); d_intr.alloc(nC * 9); d_points.alloc(nP * 3);
+  d_cposes.alloc(nI * 6); d_cintr.alloc(nC * 9); d_cpoints.alloc(nP * 3);
+  d_camrec.alloc(nI * 9); d_ccamrec.alloc(nI * 9);
+  d_R.alloc((size_t)2 * Nstride); d_Jp.alloc((size_t)6 * Nstride); d_Jc.alloc((size_t)12 * Nstride);
+  d_Jk.alloc((size_t)2 * KMAX * Nstride);
+  d_Cu.alloc((size_t)6 * NPs); d_gu.alloc((size_t)3 * NPs); d_Gi.alloc((size_t)6 * NPs); d_h.alloc((size_t)3 * NPs);
+  d_scale_cam.alloc((size_t)n_pad); d_scale_pt.alloc((size_t)3 * NPs);
+  d_scale_cam.zero(st); d_scale_pt.zero(st);
+  d_sweep_partial.alloc((size_t)jacobian_sweep_grid(std::max(N, 1)) + 8);
+  d_camsum.alloc(nI * kImgRec + nC * kCamRec);
+  d_camsum.zero(st);
+  d_img_rec = d_camsum.p; d_cam_rec = d_camsum.p + (size_t)NI * kImgRec;
+  d_img_intr_tmp.alloc(nI * kCamRec);
+  d_cam_partial.alloc((size_t)std::max(num_sweep_chunks, 1) * kSweepAcc);
+  d_prior_res.alloc(std::max(num_priors, 1)); d_prior_jac.alloc((size_t)std::max(num_priors, 1) * 3);
+  d_prior_cost.alloc(std::max(num_priors, 1));
+  d_Epose.alloc((size_t)std::max(N, 1) * kPoseRec);
+  d_y.alloc(n_pad); d_y.zero(st);  // the matrix-sized buffers follow the elimination order chosen in finish_structure
+  d_delta_cam.alloc(n_pad); d_delta_pts.alloc(nP * 3);
+  d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + 2) * 3);
+  d_scal.alloc(SC_COUNT); d_scal.zero(st);
+  d_rnorm.alloc(std::max(N, 1)); d_perr.alloc(nP);
+
+  lap("alloc + upload");
+  derive_free_flags();
+  finish_structure();
+  lap("finish_structure total");
+  reset_state();
+  sync();
+  lap("reset + sync");
+  setup_seconds = now_s() - t0;
+}
+
+// Everything that depends on which parameter blocks are free: flags on the device, the
+// intrinsics entries (one per free point x free camera seen by it) and the term / chunk /
+// block lists of the Schur complement.
+// Elimination order of the reduced camera system + the factorisation's tile structure.
+//
+// The dependent chain of the blocked Cholesky is one 64-column panel after the other, ~20 us each, and
+// at BA sizes that chain - not the flops - is the cost of the solve. Images are connected through the
+// points they share; in acquisition order that graph is banded, so a band partition is a nested
+// dissection: cut the order into P runs, move every image that has a neighbour in an EARLIER run into the
+// separator S, and the remaining parts A_1..A_P are mutually uncoupled. Ordered [A_1 | .. | A_P | S |
+// intrinsics] their panels are factorised concurrently and the chain is max|A_p| + |S| instead of the sum.
+// P (and for P = 2 the cut position) is chosen to minimise that chain, P = 1 (no dissection) included.
+void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& blocks) {
+  const int tiles0 = std::max(1, round_up(n_full, 64) / 64);
+  // Tree of image sets in elimination order (children before parents, root last); the root also carries the
+  // intrinsics blocks. One node = no dissection.
+  struct TNode { std::vector<int> imgs; int parent; };
+  std::vector<TNode> tn;
+  int forced = -1, max_depth = 2;
+  if (const char* e = std::getenv("MAVBA_ND_PARTS")) forced = std::atoi(e);  // 0/1 = off, n = force n flat parts
+  if (const char* e = std::getenv("MAVBA_ND_DEPTH")) max_depth = std::atoi(e);  // recursion depth of the automatic choice
+  const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && max_depth > 0 && (world == 1 || NI <= 4096);
+  if (can_dissect) {
+    // image adjacency (lower: col < row) from the pose-pose blocks; with shards, the union over ranks
+    std::vector<std::vector<int>> lower(NI);
+    if (world > 1 && ar_fn) {
+      std::vector<double> a((size_t)NI * NI, 0.0);
+      for (const SchurBlock& B : blocks)
+        if (B.kind == BLK_PP && B.row_ent != B.col_ent) a[(size_t)std::max(B.row_ent, B.col_ent) * NI + std::min(B.row_ent, B.col_ent)] = 1.0;
+      DevBuf<double> d;
+      d.upload(a, st);
+      allreduce(d.p, (long long)NI * NI, 1);
+      HIP_OK(hipMemcpyAsync(a.data(), d.p, a.size() * 8, hipMemcpyDeviceToHost, st));
+      sync();
+      for (int r = 0; r < NI; ++r)
+        for (int c = 0; c < r; ++c) if (a[(size_t)r * NI + c] != 0.0) lower[r].push_back(c);
+    } else {
+      for (const SchurBlock& B : blocks)
+        if (B.kind == BLK_PP && B.row_ent != B.col_ent) lower[std::max(B.row_ent, B.col_ent)].push_back(std::min(B.row_ent, B.col_ent));
+    }
+    const int tail = 9 * NC;
+    auto tiles_of = [](int cols) { return (cols + 63) / 64; };
+    if (forced > 1) {
+      // flat dissection into `forced` runs of the natural order (kept for tests and experiments)
+      std::vector<int> cut(forced);
+      for (int q = 0; q < forced; ++q) cut[q] = (int)((long long)q * NI / forced);
+      std::vector<std::vector<int>> part(forced);
+      std::vector<int> sep;
+      int run = 0;
+      for (int i = 0; i < NI; ++i) {
+        while (run + 1 < forced && i >= cut[run + 1]) ++run;
+        int m = i;
+        for (int c : lower[i]) m = std::min(m, c);
+        if (m < cut[run]) sep.push_back(i); else part[run].push_back(i);
+      }
+      int np = 0;
+      for (auto& pr : part) if (!pr.empty()) { tn.push_back(TNode{std::move(pr), -1}); ++np; }
+      if (np >= 2) {
+        for (auto& t : tn) t.parent = np;
+        tn.push_back(TNode{std::move(sep), -1});
+      } else {
+        tn.clear();
+      }
+    } else {
+      // recursive bisection: M (ascending) -> [A | B | S], S = the members of the second run that have a neighbour
+      // in the first; the cut is scanned for the shortest chain max(A, B) + S, and a split must pay
+      std::vector<int> pos(NI, -1);
+      std::function<std::pair<int, int>(std::vector<int>&&, int, int)> rec = [&](std::vector<int>&& M, int depth, int tl) {
+        const int n = (int)M.size();
+        const int leaf_tiles = tiles_of(6 * n + tl);
+        auto make_leaf = [&]() { tn.push_back(TNode{std::move(M), -1}); return std::make_pair((int)tn.size() - 1, leaf_tiles); };
+        if (depth >= max_depth || n < 32 || leaf_tiles < 6) return make_leaf();
+        for (int t = 0; t < n; ++t) pos[M[t]] = t;
+        std::vector<int> mnp(n);
+        for (int t = 0; t < n; ++t) {
+          int m = t;
+          for (int c : lower[M[t]]) if (pos[c] >= 0) m = std::min(m, pos[c]);
+          mnp[t] = m;
+        }
+        for (int t = 0; t < n; ++t) pos[M[t]] = -1;
+        int best = leaf_tiles, best_c = -1;
+        for (int c = n / 4; c <= 3 * n / 4; c += std::max(1, n / 64)) {
+          int ns = 0;
+          for (int t = c; t < n; ++t) ns += mnp[t] < c;
+          if (ns == 0 && tl == 0) continue;  // (a separator node needs at least one column)
+          const int est = std::max(tiles_of(6 * c), tiles_of(6 * (n - c - ns))) + tiles_of(6 * ns + tl);
+          if (est < best) { best = est; best_c = c; }
+        }
+        if (best_c < 0 || best > leaf_tiles - std::max(2, leaf_tiles / 8)) return make_leaf();
+        std::vector<int> A(M.begin(), M.begin() + best_c), B, S;
+        for (int t = best_c; t < n; ++t) (mnp[t] < best_c ? S : B).push_back(M[t]);
+        if (A.size() < 8 || B.size() < 8) return make_leaf();
+        const auto ra = rec(std::move(A), depth + 1, 0);
+        const auto rb = rec(std::move(B), depth + 1, 0);
+        const int sep_tiles = tiles_of(6 * (int)S.size() + tl);
+        tn.push_back(TNode{std::move(S), -1});
+        const int me = (int)tn.size() - 1;
+        tn[ra.first].parent = me; tn[rb.first].parent = me;
+        return std::make_pair(me, std::max(ra.second, rb.second) + sep_tiles);
+      };
+      std::vector<int> all(NI);
+      for (int i = 0; i < NI; ++i) all[i] = i;
+      rec(std::move(all), 0, tail);
+      if (tn.size() < 3) tn.clear();
+    }
+  }
+  // column offsets in tree order (every node padded to whole tiles), intrinsics at the end of the root
+  h_off_img.assign(NI, 0); h_off_cam.assign(NC, 0);
+  std::vector<CholNode> tree;
+  int col = 0;
+  if (tn.size() >= 3) {
+    for (size_t t = 0; t < tn.size(); ++t) {
+      const int begin = col;
+      for (int i : tn[t].imgs) { h_off_img[i] = col; col += 6; }
+      if (t + 1 == tn.size()) for (int c = 0; c < NC; ++c) { h_off_cam[c] = col; col += 9; }
+      col = std::max(round_up(col, 64), begin + 64);
+      tree.push_back(CholNode{begin / 64, col / 64, tn[t].parent});
+    }
+  } else {
+    for (int i = 0; i < NI; ++i) { h_off_img[i] = col; col += 6; }
+    for (int c = 0; c < NC; ++c) { h_off_cam[c] = col; col += 9; }
+  }
+  n_mat = std::max(64, round_up(col, 64));
+  h_col_var.assign(n_mat, -1);
+  for (int i = 0; i < NI; ++i) for (int e = 0; e < 6; ++e) h_col_var[h_off_img[i] + e] = 6 * i + e;
+  for (int c = 0; c < NC; ++c) for (int k = 0; k < 9; ++k) h_col_var[h_off_cam[c] + k] = 6 * NI + 9 * c + k;
+  {
+    std::vector<int> off(h_off_img);
+    off.insert(off.end(), h_off_cam.begin(), h_off_cam.end());
+    d_off.upload(off, st);
+    d_col_var.upload(h_col_var, st);
+  }
+  // structurally non-zero tiles (lower) of the permuted matrix
+  const int nbt = n_mat / 64;
+  std::vector<unsigned char> mark((size_t)nbt * nbt, 0);
+  for (const SchurBlock& B : blocks) {
+    const int r0 = B.kind == BLK_PP ? h_off_img[B.row_ent] : h_off_cam[B.row_ent];
+    const int r1 = r0 + (B.kind == BLK_PP ? 5 : 8);
+    const int c0 = B.kind == BLK_II ? h_off_cam[B.col_ent] : h_off_img[B.col_ent];
+    const int c1 = c0 + (B.kind == BLK_II ? 8 : 5);
+    for (int tr = r0 / 64; tr <= r1 / 64; ++tr)
+      for (int tc = c0 / 64; tc <= c1 / 64; ++tc) mark[(size_t)std::max(tr, tc) * nbt + std::min(tr, tc)] = 1;
+  }
+  if (world > 1 && ar_fn) {
+    // The matrix that gets factorised is the SUM over ranks: its structure is the union of the ranks'.
+    std::vector<double> h(mark.begin(), mark.end());
+    DevBuf<double> d;
+    d.upload(h, st);
+    allreduce(d.p, (long long)h.size(), 1);
+    HIP_OK(hipMemcpyAsync(h.data(), d.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+    sync();
+    for (size_t t = 0; t < h.size(); ++t) mark[t] = h[t] != 0.0;
+  }
+  std::vector<std::pair<int, int>> tile_pairs;
+  for (int tr = 0; tr < nbt; ++tr)
+    for (int tc = 0; tc <= tr; ++tc) if (mark[(size_t)tr * nbt + tc]) tile_pairs.emplace_back(tr, tc);
+  HIP_OK(chol_struct.build(nbt, tile_pairs, tree, st));
+  nd_parts = chol_struct.nseg > 1 ? chol_struct.num_fronts_max : 0;
+  if (world > 1) {
+    std::vector<int2> tl;
+    std::vector<unsigned char> have((size_t)nbt * nbt, 0);
+    for (int t = 0; t < nbt; ++t) { tl.push_back(make_int2(t, t)); have[(size_t)t * nbt + t] = 1; }
+    for (const auto& pr : tile_pairs)
+      if (!have[(size_t)pr.first * nbt + pr.second]) { have[(size_t)pr.first * nbt + pr.second] = 1; tl.push_back(make_int2(pr.first, pr.second)); }
+    num_ar_tiles = (int)tl.size();
+    d_ar_tiles.upload(tl, st);
+    d_ar_buf.alloc((size_t)num_ar_tiles * 4096 + n_mat);
+  }
+  d_M.alloc((size_t)(n_mat + 64) * n_mat); d_L.alloc((size_t)(n_mat + 64) * n_mat);
+  d_ymat.alloc(n_mat); d_diag_ws.alloc((size_t)n_mat * 64);
+}
+
+void mavba_session::finish_structure() {
+  const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
+  double tl = now_s();
+  auto lap = [&](const char* what) { if (tt) { const double t = now_s(); std::fprintf(stderr, "[setup]   %-26s %8.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
+  d_pose_free.upload(h_pose_free, st); d_intr_free.upload(h_intr_free, st); d_pt_free.upload(h_pt_free, st);
+  std::vector<unsigned char> img_active(NI, 0), cam_active(NC, 0);
+  for (int i = 0; i < NI; ++i) for (int e = 0; e < 6; ++e) img_active[i] |= h_pose_free[(size_t)i * 6 + e];
+  for (int c = 0; c < NC; ++c) for (int k = 0; k < 9; ++k) cam_active[c] |= h_intr_free[(size_t)c * 9 + k];
+
+  // intrinsics entries
+  std::vector<int> q_start(NP + 1, 0), q_pt, q_cam;
+  {
+    std::vector<int> seen;
+    for (int p = 0; p < NP; ++p) {
+      q_start[p] = (int)q_pt.size();
+      if (!h_pt_free[p]) continue;
+      seen.clear();
+      for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
+        const int c = h_img_cam[h_oimg[a]];
+        if (cam_active[c] && std::find(seen.begin(), seen.end(), c) == seen.end()) seen.push_back(c);
+      }
+      std::sort(seen.begin(), seen.end());
+      for (int c : seen) { q_pt.push_back(p); q_cam.push_back(c); }
+    }
+    q_start[NP] = (int)q_pt.size();
+  }
+  Q = (int)q_pt.size();
+  d_q_start.upload(q_start, st); d_q_pt.upload(q_pt, st); d_q_cam.upload(q_cam, st);
+  d_Eintr.alloc((size_t)std::max(Q, 1) * kIntrRec);
+  d_Wk.alloc((size_t)std::max(Q, 1) * 27);
+
+  lap("flags + intr entries");
+  // ---- point clusters (k_schur_clusters): consecutive points whose images / cameras fit one local list ----
+  // pt_mode: 0 = contributes nothing, 1 = clustered, 2 = generic term lists (long tracks, an image seen twice,
+  // more shared cameras than a cluster holds)
+  std::vector<unsigned char> pt_mode(NP, 0);
+  std::vector<unsigned short> obs_meta((size_t)std::max(N, 1), 0xFFFFu), q_meta((size_t)std::max(Q, 1), 0xFFFFu);
+  std::vector<SchurCluster> clusters;
+  std::vector<int> cl_imgs, cl_cams;  // [cluster][sh.images] / [cluster][sh.cams], ascending, -1 padded
+  {
+    // Cluster shape: 16 images x 3 cameras (128 rows, 36 tiles). MAVBA_CLUSTER_SHAPE=12 selects 12 x 2 (96 rows,
+    // 21 tiles): 42 % fewer matrix instructions per batch, but the smaller image list closes clusters earlier (C3:
+    // 2851 clusters of ~70 points instead of 1799 of ~110) and the per-cluster costs eat the gain - same 0.37 ms.
+    cl_shape = ClusterShape{16, 3};
+    if (const char* e = std::getenv("MAVBA_CLUSTER_SHAPE")) cl_shape = std::atoi(e) == 12 ? ClusterShape{12, 2} : ClusterShape{16, 3};
+  }
+  const ClusterShape sh = cl_shape;
+  const int kClTab = sh.tab(), kClTabPP = sh.tab_pp(), kClTabIP = sh.tab_ip(), kClTabII = sh.tab_ii();
+  const int kClImages = sh.images, kClCams = sh.cams;
+  {
+    bool use_clusters = true;
+    if (const char* e = std::getenv("MAVBA_CLUSTERS")) use_clusters = std::atoi(e) != 0;
+    // 128 points per cluster amortise the per-cluster costs; small problems get smaller clusters so that there
+    // are at least ~2 per CU (a cluster is one work-group; C2: 235 clusters of 128 would leave CUs idle)
+    long long nfree = 0;
+    for (int p = 0; p < NP; ++p) nfree += h_pt_free[p] != 0;
+    int kMaxPoints = (int)std::min<long long>(128, std::max<long long>(kClBatch, round_up((int)(nfree / 512), kClBatch)));
+    if (const char* e = std::getenv("MAVBA_CLUSTER_POINTS")) kMaxPoints = std::max(1, std::atoi(e));
+    // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
+    // thread": the clusters - and with them the order in which partials are added - must not depend on the
+    // machine's core count).
+    const int kRange = 4096;
+    const int nranges = (NP + kRange - 1) / kRange;
+    std::vector<std::vector<SchurCluster>> r_clusters(nranges);
+    std::vector<std::vector<int>> r_imgs(nranges), r_cams(nranges);
+    auto do_range = [&](int rg) {
+      const int r0 = rg * kRange, r1 = std::min(NP, r0 + kRange);
+      std::vector<int> cur_i, cur_c, mi, mc, pi;
+      int cur_p0 = r0, cur_n = 0;
+      auto close = [&](int p_end) {
+        if (cur_n > 0) {
+          r_clusters[rg].push_back(SchurCluster{cur_p0, p_end});
+          for (int k = 0; k < kClImages; ++k) r_imgs[rg].push_back(k < (int)cur_i.size() ? cur_i[k] : -1);
+          for (int k = 0; k < kClCams; ++k) r_cams[rg].push_back(k < (int)cur_c.size() ? cur_c[k] : -1);
+        }
+        cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end;
+      };
+      for (int p = r0; p < r1; ++p) {
+        if (!h_pt_free[p]) continue;
+        pi.clear();
+        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) if (img_active[h_oimg[a]]) pi.push_back(h_oimg[a]);
+        const int nq = q_start[p + 1] - q_start[p];
+        if (pi.empty() && nq == 0) continue;
+        std::sort(pi.begin(), pi.end());
+        const bool dup = std::adjacent_find(pi.begin(), pi.end()) != pi.end();
+        if (!use_clusters || dup || (int)pi.size() > kClImages || nq > kClCams) { pt_mode[p] = 2; continue; }
+        auto merged_sizes = [&]() {
+          mi.clear(); mc.clear();
+          std::set_union(cur_i.begin(), cur_i.end(), pi.begin(), pi.end(), std::back_inserter(mi));
+          std::set_union(cur_c.begin(), cur_c.end(), q_cam.begin() + q_start[p], q_cam.begin() + q_start[p + 1], std::back_inserter(mc));
+        };
+        merged_sizes();
+        if ((int)mi.size() > kClImages || (int)mc.size() > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1) {
+          close(p);
+          merged_sizes();
+        }
+        if (cur_n == 0) cur_p0 = p;
+        cur_i.swap(mi); cur_c.swap(mc);
+        ++cur_n;
+        pt_mode[p] = 1;
+      }
+      close(r1);
+    };
+    parallel_ranges(nranges, [&](long long g0, long long g1) { for (long long g = g0; g < g1; ++g) do_range((int)g); }, 2);
+    for (int rg = 0; rg < nranges; ++rg) {
+      clusters.insert(clusters.end(), r_clusters[rg].begin(), r_clusters[rg].end());
+      cl_imgs.insert(cl_imgs.end(), r_imgs[rg].begin(), r_imgs[rg].end());
+      cl_cams.insert(cl_cams.end(), r_cams[rg].begin(), r_cams[rg].end());
+    }
+  }
+  num_clusters = (int)clusters.size();
+  cluster_flops = 0.0;
+  for (const SchurCluster& c : clusters)  // batches x k-steps x 36 lower tiles x 2*16*16*4
+    cluster_flops += (double)((c.p1 - c.p0 + kClBatch - 1) / kClBatch) * (3 * kClBatch / 4) * (double)((sh.rows() / 16) * (sh.rows() / 16 + 1) / 2) * 2048.0;
+  // local indices of every clustered observation / intrinsics entry, and which blocks a cluster touches
+  std::vector<unsigned char> cl_present((size_t)std::max(num_clusters, 1) * kClTab, 0);
+  parallel_ranges(num_clusters, [&](long long c0, long long c1) {
+    int loc[kClImagesMax];
+    for (long long cl = c0; cl < c1; ++cl) {
+      const int* imgs = &cl_imgs[(size_t)cl * kClImages];
+      const int* cams = &cl_cams[(size_t)cl * kClCams];
+      int ni = 0, nc = 0;
+      while (ni < kClImages && imgs[ni] >= 0) ++ni;
+      while (nc < kClCams && cams[nc] >= 0) ++nc;
+      unsigned char* pres = &cl_present[(size_t)cl * kClTab];
+      for (int p = clusters[cl].p0; p < clusters[cl].p1; ++p) {
+        if (pt_mode[p] != 1) continue;
+        int n = 0;
+        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
+          if (!img_active[h_oimg[a]]) continue;
+          const int l = (int)(std::lower_bound(imgs, imgs + ni, h_oimg[a]) - imgs);
+          obs_meta[a] = (unsigned short)(l << 8 | ((p - clusters[cl].p0) % kClBatch));
+          loc[n++] = l;
+        }
+        for (int x = 0; x < n; ++x)
+          for (int y = 0; y < n; ++y)
+            if (loc[x] >= loc[y]) pres[kClTabPP + loc[x] * (loc[x] + 1) / 2 + loc[y]] = 1;
+        for (int q = q_start[p]; q < q_start[p + 1]; ++q) {
+          const int lc = (int)(std::lower_bound(cams, cams + nc, q_cam[q]) - cams);
+          q_meta[q] = (unsigned short)(lc << 8 | ((p - clusters[cl].p0) % kClBatch));
+          for (int x = 0; x < n; ++x) pres[kClTabIP + lc * kClImages + loc[x]] = 1;
+          for (int q2 = q_start[p]; q2 <= q; ++q2) {
+            const int lc2 = (int)(std::lower_bound(cams, cams + nc, q_cam[q2]) - cams);
+            pres[kClTabII + lc * (lc + 1) / 2 + lc2] = 1;
+          }
+        }
+      }
+    }
+  }, 64);
+  clustered_points = 0;
+  for (int p = 0; p < NP; ++p) clustered_points += pt_mode[p] == 1;
+  lap("point clusters");
+  // term enumeration over a range of points: f(kind, row_ent, col_ent, x, y)
+  auto enumerate = [&](int p_begin, int p_end, auto&& f) {
+    for (int p = p_begin; p < p_end; ++p) {
+      if (pt_mode[p] != 2) continue;  // clustered points never become terms
+      const int a0 = h_pt_start[p], a1 = h_pt_start[p + 1], q0 = q_start[p], q1 = q_start[p + 1];
+      for (int a = a0; a < a1; ++a) {
+        const int i = h_oimg[a];
+        if (!img_active[i]) continue;
+        for (int bq = a0; bq < a1; ++bq) {
+          const int j = h_oimg[bq];
+          if (img_active[j] && i >= j) f(BLK_PP, i, j, a, bq);
+        }
+      }
+      for (int q = q0; q < q1; ++q) {
+        for (int a = a0; a < a1; ++a)
+          if (img_active[h_oimg[a]]) f(BLK_IP, q_cam[q], h_oimg[a], q, a);
+        for (int q2 = q0; q2 <= q; ++q2) f(BLK_II, q_cam[q], q_cam[q2], q, q2);
+      }
+    }
+  };
+  const long long ncols[3] = {NI, NI, NC};
+  const long long nrows[3] = {NI, NC, NC};
+  size_t nkeys[3], nkeys_tot = 0;
+  for (int k = 0; k < 3; ++k) { nkeys[k] = (size_t)(nrows[k] * ncols[k]); nkeys_tot += nkeys[k]; }
+  // Host threads own contiguous point ranges (balanced by observations). Per-thread counts turn
+  // into per-thread cursors, so the term order inside a block (by point) does not depend on the
+  // number of threads: the device sums stay bit-reproducible.
+  int T = host_threads();
+  if (N < 50000) T = 1;
+  while (T > 1 && (size_t)T * nkeys_tot > (size_t)48 << 20) T /= 2;
+  std::vector<int> range(T + 1, NP);
+  range[0] = 0;
+  for (int t = 1; t < T; ++t) {
+    const long long target = (long long)N * t / T;
+    range[t] = (int)(std::upper_bound(h_pt_start.begin(), h_pt_start.end(), (int)target) - h_pt_start.begin()) - 1;
+    range[t] = std::max(range[t - 1], std::min(range[t], NP));
+  }
+  std::vector<std::vector<int>> tcount(T * 3);
+  auto run_threads = [&](const std::function<void(int)>& body) { host_run(T, body); };
+  run_threads([&](int t) {
+    for (int k = 0; k < 3; ++k) tcount[t * 3 + k].assign(nkeys[k], 0);
+    enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int, int) { tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++; });
+  });
+  std::vector<int> count[3];
+  std::vector<unsigned char> mandatory[3];
+  long long tot[3] = {0, 0, 0};
+  for (int k = 0; k < 3; ++k) {
+    count[k].assign(nkeys[k], 0);
+    mandatory[k].assign(nkeys[k], 0);
+    for (int t = 0; t < T; ++t)
+      for (size_t key = 0; key < nkeys[k]; ++key) count[k][key] += tcount[t * 3 + k][key];
+    for (size_t key = 0; key < nkeys[k]; ++key) tot[k] += count[k][key];
+  }
+  for (int i = 0; i < NI; ++i) {
+    if (!img_active[i]) continue;
+    mandatory[BLK_PP][(size_t)i * NI + i] = 1;
+    if (cam_active[h_img_cam[i]]) mandatory[BLK_IP][(size_t)h_img_cam[i] * NI + i] = 1;
+  }
+  for (int c = 0; c < NC; ++c) if (cam_active[c]) mandatory[BLK_II][(size_t)c * NC + c] = 1;
+  // blocks a cluster touches get one partial slot per cluster
+  std::vector<int> cref[3];
+  for (int k = 0; k < 3; ++k) cref[k].assign(nkeys[k], 0);
+  auto cluster_key = [&](long long cl, int slot, int& kind) -> size_t {
+    const int* imgs = &cl_imgs[(size_t)cl * kClImages];
+    const int* cams = &cl_cams[(size_t)cl * kClCams];
+    if (slot < kClTabIP) {
+      int la = 0;
+      while ((la + 1) * (la + 2) / 2 <= slot) ++la;
+      const int lb = slot - la * (la + 1) / 2;
+      kind = BLK_PP;
+      return (size_t)imgs[la] * NI + imgs[lb];
+    }
+    if (slot < kClTabII) {
+      const int lc = (slot - kClTabIP) / kClImages, la = (slot - kClTabIP) % kClImages;
+      kind = BLK_IP;
+      return (size_t)cams[lc] * NI + imgs[la];
+    }
+    int lc = 0;
+    const int sl = slot - kClTabII;
+    while ((lc + 1) * (lc + 2) / 2 <= sl) ++lc;
+    kind = BLK_II;
+    return (size_t)cams[lc] * NC + cams[sl - lc * (lc + 1) / 2];
+  };
+  cluster_partials = 0;
+  for (long long cl = 0; cl < num_clusters; ++cl)
+    for (int sl = 0; sl < kClTab; ++sl)
+      if (cl_present[(size_t)cl * kClTab + sl]) { int kind; const size_t key = cluster_key(cl, sl, kind); cref[kind][key]++; ++cluster_partials; }
+  lap("count terms");
+  for (int k = 0; k < 3; ++k)
+    if (tot[k] >= (1ll << 31) - 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "more than 2^31 Schur terms of one kind");
+  // One wave per chunk. A block gets ceil(terms / 1024) chunks but never more than 256, so the
+  // finalize pass (which adds a block's chunk partials in order) stays short even for the
+  // intrinsics-intrinsics block, whose term list has one entry per point.
+  auto block_chunk_terms = [](int cnt) {
+    int nch = (cnt + 1023) / 1024;
+    nch = std::max(1, std::min(nch, 256));
+    return std::max(1, (cnt + nch - 1) / nch);
+  };
+  std::vector<SchurBlock> blocks;
+  std::vector<SchurChunk> chunks[3];
+  std::vector<int> cursor[3];
+  // Block order = launch order of the chunk kernels. Pose-pose blocks are visited in 2-D tiles of
+  // kTile x kTile images so that the entry records of ~2*kTile images (a few MB) stay in one XCD's
+  // L2 while all blocks among them are accumulated; the other kinds are ordered by image.
+  int kTile = 4;
+  if (const char* e = std::getenv("MAVBA_PP_TILE")) kTile = std::max(1, std::atoi(e));  // tuning knob
+  for (int k = 0; k < 3; ++k) {
+    cursor[k].assign(count[k].size(), 0);
+    std::vector<size_t> keys;
+    for (size_t key = 0; key < count[k].size(); ++key)
+      if (count[k][key] != 0 || mandatory[k][key] || cref[k][key] != 0) keys.push_back(key);
+    if (k == BLK_PP) {
+      const long long nc = ncols[k];
+      std::stable_sort(keys.begin(), keys.end(), [&](size_t a, size_t b) {
+        const long long ia = a / nc, ja = a % nc, ib = b / nc, jb = b % nc;
+        if (ia / kTile != ib / kTile) return ia / kTile < ib / kTile;
+        if (ja / kTile != jb / kTile) return ja / kTile < jb / kTile;
+        return a < b;
+      });
+    } else if (k == BLK_IP) {
+      const long long nc = ncols[k];
+      std::stable_sort(keys.begin(), keys.end(), [&](size_t a, size_t b) { return a % nc < b % nc; });
+    }
+    int off = 0, slot = 0;
+    for (size_t key : keys) {
+      const int cnt = count[k][key];
+      SchurBlock B;
+      B.kind = k; B.row_ent = (int)(key / ncols[k]); B.col_ent = (int)(key % ncols[k]);
+      // the block's partials: its term-list chunks, then one slot per cluster that touches it
+      B.chunk_begin = slot;
+      const int ct = block_chunk_terms(cnt);
+      for (int b0 = off; b0 < off + cnt; b0 += ct)
+        chunks[k].push_back(SchurChunk{b0, std::min(b0 + ct, off + cnt), slot++});
+      const int nref = cref[k][key];
+      cref[k][key] = slot;  // from here on: the next free cluster slot of this block
+      slot += nref;
+      B.chunk_end = slot;
+      blocks.push_back(B);
+      cursor[k][key] = off;
+      off += cnt;
+    }
+    num_slots[k] = slot;
+  }
+  // long partial runs are pre-reduced in groups of 32 into extra slots; the block then points at those
+  std::vector<PartialReduce> reduce_tasks;
+  for (SchurBlock& B : blocks) {
+    const int n = B.chunk_end - B.chunk_begin;
+    if (n <= 64) continue;
+    const int first = num_slots[B.kind];
+    for (int b0 = B.chunk_begin; b0 < B.chunk_end; b0 += 32)
+      reduce_tasks.push_back(PartialReduce{B.kind, b0, std::min(b0 + 32, B.chunk_end), num_slots[B.kind]++});
+    B.chunk_begin = first; B.chunk_end = num_slots[B.kind];
+  }
+  num_reduce_tasks = (int)reduce_tasks.size();
+  d_reduce_tasks.upload(reduce_tasks, st);
+  // slot tables of the clusters (clusters in order -> a block's partials are added in a fixed order)
+  std::vector<int> cl_tab((size_t)std::max(num_clusters, 1) * kClTab, -1);
+  for (long long cl = 0; cl < num_clusters; ++cl)
+    for (int sl = 0; sl < kClTab; ++sl)
+      if (cl_present[(size_t)cl * kClTab + sl]) { int kind; const size_t key = cluster_key(cl, sl, kind); cl_tab[(size_t)cl * kClTab + sl] = cref[kind][key]++; }
+  lap("order blocks + chunks");
+  std::unique_ptr<int2[]> terms[3];  // uninitialised on purpose: first touched by the filling threads
+  for (int k = 0; k < 3; ++k) terms[k].reset(new int2[std::max<size_t>((size_t)tot[k], 1)]);
+  // per-thread cursors: block offset + what the threads owning earlier points put into the block
+  for (int k = 0; k < 3; ++k)
+    for (size_t key = 0; key < nkeys[k]; ++key) {
+      int run = cursor[k][key];
+      for (int t = 0; t < T; ++t) { const int c = tcount[t * 3 + k][key]; tcount[t * 3 + k][key] = run; run += c; }
+    }
+  run_threads([&](int t) {
+    enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int x, int y) {
+      terms[kind][(size_t)tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++] = make_int2(x, y);
+    });
+  });
+  lap("fill terms");
+  choose_elimination_order(blocks);
+  lap("elimination order");
+  num_blocks = (int)blocks.size();
+  d_blocks.upload(blocks, st);
+  for (int k = 0; k < 3; ++k) {
+    num_chunks[k] = (int)chunks[k].size();
+    num_terms[k] = tot[k];
+    d_chunks[k].upload(chunks[k], st);
+    d_terms[k].alloc(std::max<size_t>((size_t)tot[k], 1));
+    if (tot[k]) HIP_OK(hipMemcpyAsync(d_terms[k].p, terms[k].get(), (size_t)tot[k] * sizeof(int2), hipMemcpyHostToDevice, st));
+    d_part[k].alloc((size_t)std::max(num_slots[k], 1) * schur_partial_stride(k));
+  }
+  {
+    std::vector<unsigned char> ptc(std::max(NP, 1), 0);
+    for (int p = 0; p < NP; ++p) ptc[p] = pt_mode[p] == 1;
+    d_clusters.upload(clusters, st); d_cl_tab.upload(cl_tab, st);
+    d_obs_meta.upload(obs_meta, st); d_q_meta.upload(q_meta, st); d_pt_clustered.upload(ptc, st);
+  }
+  sync();
+  lap("upload terms");
+}
+
+void mavba_session::reset_state() {
+  HIP_OK(hipMemcpyAsync(d_poses.p, d_poses0.p, (size_t)NI * 6 * 8, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(d_intr.p, d_intr0.p, (size_t)NC * 9 * 8, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(d_points.p, d_points0.p, (size_t)NP * 3 * 8, hipMemcpyDeviceToDevice, st));
+  evaluated = scales_ready = started = assembled = false;
+  camrec_current = false;
+  radius = opt.initial_trust_region_radius; decrease_factor = 2.0;
+  cost = x_norm = grad_max = abs_gtol = initial_cost = 0.0;
+  iteration = invalid_steps = n_success = n_fail = 0;
+  termination = MAVBA_TERM_RUNNING;
+  solve_seconds = 0.0;
+}

@@ -1,0 +1,287 @@
+// session_lm.hip — the Levenberg-Marquardt trust-region loop of the MI355X bundle-adjustment backend
+// (evaluation, Schur assembly, reduced solve, candidate step, accept / reject).
+//
+// The LM loop runs on the host in C++ and drives the HIP kernels of kernels.hip /
+// dense_chol.hip through one stream; one 128-byte scalar read-back per evaluation and per
+// candidate step is the only device->host traffic inside the loop.
+//
+// Semantics restated (reference file:line, /root/reference):
+//   src/base3d/bundle_adjustment.cc:553-569  ceres::Solve, LM + SPARSE_SCHUR, options
+//   Ceres 1.8 trust_region_minimizer.cc / levenberg_marquardt_strategy.cc  
+//   src/base3d/bundle_adjustment.cc:575-598  point3D_errors
+//   src/base3d/bundle_adjustment.cc:139-225  pose_refinement
+#include "session.h"
+
+using namespace mavba;
+
+
+// ===========================================================================
+// Evaluation at the current x: residuals, Jacobian, cost, gradient norm (ceres
+// Evaluator::Evaluate with jacobian != NULL).
+// ===========================================================================
+void mavba_session::evaluate_enqueue() {
+  if (!camrec_current) timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
+  camrec_current = true;
+  SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
+  timed("jacobian_sweep", [&] { launch_jacobian_sweep(st, a); });
+  timed("point_reduce", [&] {
+    launch_point_reduce(st, NP, NPs, Nstride, KMAX, d_pt_start.p, d_q_start.p, d_q_cam.p, d_obs_img.p, d_img_cam.p,
+                        d_R.p, d_Jp.p, d_Jk.p, d_Cu.p, d_gu.p, d_Wk.p);
+  });
+  CamSweepArgs c;
+  c.NI = NI; c.NC = NC; c.chunks = d_sweep_chunks.p; c.num_chunks = num_sweep_chunks;
+  c.im_uv = d_im_uv.p; c.im_pt = d_im_pt.p; c.camrec = d_camrec.p; c.intr = d_intr.p;
+  c.img_cam = d_img_cam.p; c.cam_model = d_cam_model.p; c.points = d_points.p;
+  c.loss_b = a.loss_b; c.loss_inv_b = a.loss_inv_b; c.partial = d_cam_partial.p;
+  timed("camera_sweep", [&] { launch_camera_sweep(st, c, KMAX, any_intr_free); });
+  if (num_priors > 0)
+    timed("rot_prior", [&] {
+      launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_poses.p, d_prior_res.p,
+                       d_prior_jac.p, d_prior_cost.p);
+    });
+  timed("camera_reduce", [&] {
+    launch_camera_reduce(st, NI, NC, d_img_chunk_start.p, d_cam_partial.p, num_priors > 0 ? d_prior_start.p : nullptr,
+                         d_prior_res.p, d_prior_jac.p, d_cam_img_start.p, d_cam_imgs.p, d_img_rec, d_cam_rec,
+                         d_img_intr_tmp.p);
+  });
+  allreduce(d_camsum.p, (long long)NI * kImgRec + (long long)NC * kCamRec, 0);
+  if (!scales_ready) {
+    timed("scales", [&] {
+      launch_scales(st, NI, NC, NP, NPs, opt.jacobi_scaling, d_pose_free.p, d_intr_free.p, d_pt_free.p, d_img_rec,
+                    d_cam_rec, d_Cu.p, d_scale_cam.p, d_scale_pt.p);
+    });
+    scales_ready = true;
+  }
+  int rows = 0;
+  timed("state_norms", [&] {
+    launch_state_norms(st, NI, NC, NP, NPs, rank == 0, d_pose_free.p, d_intr_free.p, d_pt_free.p, d_poses.p,
+                       d_intr.p, d_points.p, d_img_rec, d_cam_rec, d_gu.p, d_norm_partial.p, &rows);
+  });
+  timed("reduce", [&] {
+    const int nsweep = N > 0 ? jacobian_sweep_grid(N) : 0;
+    ReduceTasks T;
+    T.t[0] = ReduceTask{d_norm_partial.p, rows, 2, 1, nullptr, 0, d_scal.p + SC_GRAD_MAX};
+    T.t[1] = ReduceTask{d_norm_partial.p + 1, rows, 2, 0, nullptr, 0, d_scal.p + SC_XNORM2};
+    T.t[2] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
+    launch_reduce_tasks(st, T, 3);
+  });
+  if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS + 1, 2);  // sums, then max|g| in the last slot
+  evaluated = true; assembled = false;
+}
+void mavba_session::evaluate() {
+  evaluate_enqueue();
+  double h[SC_COUNT];
+  read_scalars(h);
+  take_evaluation(h);
+}
+
+// Schur complement for the current Jacobian at trust-region radius r:
+// rows [0, n_pad) of d_M <- S, row n_pad <- v   (SchurEliminator::Eliminate).
+void mavba_session::assemble(double r) {
+  const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
+  HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, sizeof(double), st));
+  timed("point_factor", [&] {
+    launch_point_factor(st, NP, NPs, r, dmin, dmax, d_pt_free.p, d_Cu.p, d_gu.p, d_scale_pt.p, d_Gi.p, d_h.p,
+                        d_scal.p + SC_FAIL);
+  });
+  timed("entries_pose", [&] {
+    launch_entries_pose(st, N, Nstride, NPs, d_obs_img.p, d_obs_pt.p, d_pt_free.p, d_Jc.p, d_Jp.p, d_scale_cam.p,
+                        d_scale_pt.p, d_Gi.p, d_h.p, d_Epose.p);
+  });
+  timed("entries_intr", [&] {
+    launch_entries_intr(st, Q, NI, NPs, d_q_pt.p, d_q_cam.p, d_Wk.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p,
+                        d_Eintr.p);
+  });
+  timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st)); });
+  timed("schur_clusters", [&] {
+    launch_schur_clusters(st, cl_shape, num_clusters, d_clusters.p, d_cl_tab.p, d_pt_start.p, d_q_start.p, d_obs_meta.p,
+                          d_q_meta.p, d_pt_clustered.p, d_Epose.p, d_Eintr.p, d_h.p, NPs, d_part[0].p, d_part[1].p,
+                          d_part[2].p);
+  });
+  if (num_chunks[0] > 0) timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
+  if (num_chunks[1] > 0) timed("schur_chunks_ip", [&] { launch_schur_chunks(st, BLK_IP, num_chunks[1], d_chunks[1].p, d_terms[1].p, d_Epose.p, d_Eintr.p, d_part[1].p); });
+  if (num_chunks[2] > 0) timed("schur_chunks_ii", [&] { launch_schur_chunks(st, BLK_II, num_chunks[2], d_chunks[2].p, d_terms[2].p, d_Epose.p, d_Eintr.p, d_part[2].p); });
+  double* v = d_M.p + (size_t)n_mat * n_mat;
+  timed("schur_finalize", [&] {
+    launch_partial_reduce(st, num_reduce_tasks, d_reduce_tasks.p, d_part[0].p, d_part[1].p, d_part[2].p);
+    launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, n_mat, rank == 0,
+                          r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p, v);
+    launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
+  });
+  if (world > 1 && ar_fn) {
+    // only the tiles the factorisation reads (lower, inside the structure) and the right-hand side travel
+    double* rhs = d_ar_buf.p + (size_t)num_ar_tiles * 4096;
+    launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, d_M.p, n_mat, d_ar_buf.p, true);
+    HIP_OK(hipMemcpyAsync(rhs, v, (size_t)n_mat * 8, hipMemcpyDeviceToDevice, st));
+    allreduce(d_ar_buf.p, (long long)num_ar_tiles * 4096 + n_mat, 0);
+    launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, d_M.p, n_mat, d_ar_buf.p, false);
+    HIP_OK(hipMemcpyAsync(v, rhs, (size_t)n_mat * 8, hipMemcpyDeviceToDevice, st));
+  }
+  assembled = true;
+}
+
+void mavba_session::solve_linear(double r) {
+  assemble(r);
+  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p); });
+  assembled = false;  // the factorisation overwrote S
+}
+
+// Back-substitution, candidate x + delta, and its cost. Leaves the scalars on the host.
+void mavba_session::candidate(double r, double* h) {
+  const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
+  int rows = 0;
+  timed("backsub_points", [&] {
+    launch_backsub_points(st, NP, NPs, NI, r, dmin, dmax, d_pt_start.p, d_obs_img.p, d_q_start.p, d_q_cam.p,
+                          d_pt_free.p, d_Epose.p, d_Eintr.p, d_y.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p,
+                          d_points.p, d_cpoints.p, d_delta_pts.p, d_step_partial.p, &rows);
+  });
+  timed("update_cameras", [&] {
+    launch_update_cameras(st, NI, NC, rank == 0, r, dmin, dmax, d_y.p, d_scale_cam.p, d_img_rec, d_cam_rec,
+                          d_poses.p, d_intr.p, d_cposes.p, d_cintr.p, d_delta_cam.p, d_step_partial.p + 3 * (size_t)rows);
+  });
+  timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_cposes.p, d_ccamrec.p); });
+  SweepArgs a = sweep_args(d_ccamrec.p, d_cintr.p, d_cpoints.p);
+  timed("cost_only", [&] { launch_cost_only(st, a); });
+  if (num_priors > 0)
+    timed("rot_prior", [&] {
+      launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_cposes.p, d_prior_res.p,
+                       d_prior_jac.p, d_prior_cost.p);
+    });
+  timed("reduce", [&] {
+    const int nsweep = N > 0 ? jacobian_sweep_grid(N) : 0;
+    ReduceTasks T;
+    T.t[0] = ReduceTask{d_step_partial.p, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_STEP_NORM2};
+    T.t[1] = ReduceTask{d_step_partial.p + 1, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_MODEL_CHANGE};
+    T.t[2] = ReduceTask{d_step_partial.p + 2, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_CAND_XNORM2};
+    T.t[3] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_NEW_COST};
+    launch_reduce_tasks(st, T, 4);
+  });
+  if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS, 0);
+  read_scalars(h);
+}
+
+void mavba_session::start() {
+  evaluate();
+  initial_cost = cost + fixed_cost;
+  const double g0 = std::max(grad_max, std::numeric_limits<double>::epsilon());
+  abs_gtol = opt.gradient_tolerance * g0;
+  started = true;
+  if (num_residuals_reduced == 0 || num_parameters_reduced == 0) { termination = MAVBA_TERM_FUNCTION_TOLERANCE; return; }
+  if (grad_max <= abs_gtol) { termination = MAVBA_TERM_GRADIENT_TOLERANCE; return; }
+  if (opt.print_progress) {
+    std::printf("%4s %14s %12s %10s %10s %10s %10s\n", "iter", "cost", "cost_change", "|gradient|", "|step|", "tr_ratio", "tr_radius");
+    std::printf("%4d %14.6e %12.2e %10.2e %10.2e %10.2e %10.2e\n", 0, cost + fixed_cost, 0.0, grad_max, 0.0, 0.0, radius);
+  }
+}
+
+// TrustRegionMinimizer::Minimize main loop (Ceres 1.8), one pass per LM iteration.
+int mavba_session::iterate(int max_iters, int* done) {
+  const double t0 = now_s();
+  int n = 0;
+  if (!started) start();
+  // Single process: the scalars of the evaluation at an accepted point are read back together with those of
+  // the NEXT candidate (one host synchronisation per iteration instead of two): the next linear solve is
+  // enqueued right behind the evaluation, and the tests that follow an evaluation in Ceres' loop (gradient
+  // tolerance) are applied when its scalars arrive - before anything of the speculative iteration counts.
+  const bool defer = world == 1 && !opt.print_progress;
+  bool pending_eval = false;
+  while (termination == MAVBA_TERM_RUNNING && n < max_iters) {
+    if (iteration >= opt.max_num_iterations) { termination = MAVBA_TERM_NO_CONVERGENCE; break; }
+    ++iteration; ++n;
+    solve_linear(radius);
+    double h[SC_COUNT];
+    candidate(radius, h);
+    if (pending_eval) {
+      pending_eval = false;
+      take_evaluation(h);
+      if (grad_max <= abs_gtol) {  // the previous iteration ended the solve: this one never happened
+        termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+        --iteration; --n;
+        break;
+      }
+    }
+    const double mcc = h[SC_MODEL_CHANGE];
+    const bool solved = h[SC_FAIL] == 0.0 && std::isfinite(mcc) && std::isfinite(h[SC_STEP_NORM2]);
+    const bool valid = solved && !(mcc < 0.0);
+    bool successful = false;
+    double rel = 0.0, step_norm = 0.0, cost_change = 0.0;
+    if (!valid) {
+      if (++invalid_steps >= opt.max_num_consecutive_invalid_steps) { termination = MAVBA_TERM_NUMERICAL_FAILURE; ++n_fail; break; }
+    } else {
+      invalid_steps = 0;
+      step_norm = std::sqrt(h[SC_STEP_NORM2]);
+      const double new_cost = h[SC_NEW_COST];
+      if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { termination = MAVBA_TERM_PARAMETER_TOLERANCE; break; }
+      cost_change = cost - new_cost;
+      if (std::fabs(cost_change) < opt.function_tolerance * cost) { termination = MAVBA_TERM_FUNCTION_TOLERANCE; break; }
+      rel = cost_change / mcc;
+      successful = rel > opt.min_relative_decrease;
+    }
+    if (successful) {
+      ++n_success;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+      radius = std::min(opt.max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
+      std::swap(d_camrec.p, d_ccamrec.p);  // the candidate's camera records are the new point's (camrec_current stays true)
+      if (defer) {
+        evaluate_enqueue();
+        pending_eval = true;
+      } else {
+        evaluate();
+        if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+      }
+    } else {
+      ++n_fail;
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+    }
+    if (opt.print_progress)
+      std::printf("%4d %14.6e %12.2e %10.2e %10.2e %10.2e %10.2e\n", iteration, cost + fixed_cost, successful ? cost_change : 0.0,
+                  grad_max, step_norm, rel, radius);
+    if (termination == MAVBA_TERM_RUNNING && radius < opt.min_trust_region_radius) termination = MAVBA_TERM_PARAMETER_TOLERANCE;
+  }
+  if (pending_eval) {
+    // the evaluation's own test comes before whatever ended the loop after it was enqueued
+    double h[SC_COUNT];
+    read_scalars(h);
+    take_evaluation(h);
+    if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+  }
+  if (termination == MAVBA_TERM_RUNNING && iteration >= opt.max_num_iterations) termination = MAVBA_TERM_NO_CONVERGENCE;
+  if (done) *done = n;
+  solve_seconds += now_s() - t0;
+  return MAVBA_OK;
+}
+
+void mavba_session::point_errors(double* out) {
+  launch_cam_prepare(st, NI, d_poses.p, d_camrec.p);
+  SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
+  launch_raw_residual_norm(st, a, d_rnorm.p);
+  launch_point_errors(st, NP, d_pt_start.p, d_rnorm.p, d_pt_count.p, d_perr.p);
+  std::vector<double> h(NP);
+  if (NP) HIP_OK(hipMemcpyAsync(h.data(), d_perr.p, (size_t)NP * 8, hipMemcpyDeviceToHost, st));
+  sync();
+  evaluated = false;  // camrec still matches x, but keep the contract simple
+  // Only points that have observations in the problem are touched (bundle_adjustment.cc:578-581);
+  // observations dropped as all-constant blocks still count (they are residual blocks there).
+  for (int p = 0; p < NP; ++p)
+    if (h_pt_count_all[p] > 0) out[h_pt_orig[p]] = h[p];
+}
+
+void mavba_session::fill_result(mavba_result* r) {
+  std::memset(r, 0, sizeof(*r));
+  r->initial_cost = initial_cost;
+  r->final_cost = cost + fixed_cost;
+  r->fixed_cost = fixed_cost;
+  r->num_residuals = num_residuals;
+  r->num_residuals_reduced = num_residuals_reduced;
+  r->num_parameters_reduced = num_parameters_reduced;
+  r->num_successful_steps = n_success;
+  r->num_unsuccessful_steps = n_fail;
+  r->termination = termination;
+  r->final_gradient_max_norm = grad_max;
+  r->final_trust_region_radius = radius;
+  r->setup_seconds = setup_seconds;
+  r->solve_seconds = solve_seconds;
+}

@@ -5,7 +5,7 @@
 #include <vector>
 #include <cmath>
 namespace mavba {
-hipError_t device_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }  // (the product's pool lives in session.hip)
+hipError_t device_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }  // (the product's pool lives in host_util.hip)
 void device_free(void* p) { (void)hipFree(p); }
 namespace {
 // (the first blocked variant, kept here for comparison: 18 barriers, per-wave scratch)
