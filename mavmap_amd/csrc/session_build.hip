@@ -832,7 +832,19 @@ void mavba_session::finish_structure() {
   {
     std::vector<unsigned char> ptc(std::max(NP, 1), 0);
     for (int p = 0; p < NP; ++p) ptc[p] = pt_mode[p] == 1;
-    d_clusters.upload(clusters, st); d_cl_tab.upload(cl_tab, st);
+    // launch order: longest clusters first (work-groups are handed out in index order, so the tail of the launch is
+    // made of short clusters); the slot tables travel with their clusters, the partial order inside a block is
+    // the slot order and does not change
+    std::vector<int> order(num_clusters);
+    for (int c = 0; c < num_clusters; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return clusters[a].p1 - clusters[a].p0 > clusters[b].p1 - clusters[b].p0; });
+    std::vector<SchurCluster> cl_sorted(clusters.size());
+    std::vector<int> tab_sorted(cl_tab.size(), -1);
+    for (int c = 0; c < num_clusters; ++c) {
+      cl_sorted[c] = clusters[order[c]];
+      std::copy(cl_tab.begin() + (size_t)order[c] * kClTab, cl_tab.begin() + (size_t)(order[c] + 1) * kClTab, tab_sorted.begin() + (size_t)c * kClTab);
+    }
+    d_clusters.upload(cl_sorted, st); d_cl_tab.upload(tab_sorted, st);
     d_obs_meta.upload(obs_meta, st); d_q_meta.upload(q_meta, st); d_pt_clustered.upload(ptc, st);
   }
   sync();
