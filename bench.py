@@ -54,22 +54,24 @@ def algorithmic_work(stats_name, prob, sess_info):
         kmax = int(K.max())
         return "hbm", (64.0 + 16.0 * kmax) * n_obs + 72.0 * n_pts + 216.0 * sess_info["intr_entries"], "B"
     if stats_name == "schur_clusters":
-        # E E^T on the matrix cores, structural zeros of the stacked entry matrix included
-        return "mfma", sess_info["cluster_flops"], "FLOP"
+        # Schur formation = sum_p (6 L_p + K_p)^2 * 3 * 2 flops (L_p observations of point p,
+        # K_p refined intrinsics of the cameras that see it). The matrix-instruction flops the kernel really
+        # executes (structural zeros of the stacked entry matrix included) are reported beside it as executed_flops.
+        return "mfma", schur_algorithmic_flops(prob), "FLOP"
     if stats_name == "camera_sweep":
         return "hbm", 44.0 * n_obs, "B"
     if stats_name == "entries_pose":
         return "hbm", (96 + 48 + 8 + 192.0) * n_obs, "B"
     if stats_name == "backsub_points":
-        return "hbm", 192.0 * n_obs + 48.0 * n_pts, "B"
+        # pose entry records (192 B / observation) + intrinsics entry records (288 B / (point, camera)) + 48 B / point
+        return "hbm", 192.0 * n_obs + 288.0 * sess_info["intr_entries"] + 48.0 * n_pts, "B"
     if stats_name == "schur_chunks_pp":
         return "hbm", 296.0 * sess_info["schur_terms"][0], "B"
     if stats_name == "dense_cholesky":
-        # The flops the factorisation really executes on the matrix cores (tiles inside the envelope of the
-        # nested-dissection order, panel solves, right-hand side). SURVEY.md 8(d)'s dense-equivalent
-        # n^3/3 + 2 n^2 is reported next to it ("reduced_system" in the JSON): pricing the solve with that
-        # figure would credit the matrix cores with work the structure lets us skip.
-        return "mfma", sess_info["factor_flops"], "FLOP"
+        # n^3/3 flops for the Cholesky factorisation of the n x n reduced system + 2 n^2 per
+        # triangular solve pair. The flops the structured factorisation really executes (tiles inside the envelope
+        # of the nested-dissection order) are reported beside it as executed_flops.
+        return "mfma", sess_info["dense_factor_flops"], "FLOP"
     return None, 0.0, ""
 
 
@@ -81,10 +83,24 @@ PMC_KERNEL = {  # bench timer name -> rocprofv3 kernel-name prefix in profiles/*
 }
 
 
+PMC_ROUND = "r02"
+
+
+def mfma_counters(config, scale, world):
+    """MFMA utilisation of the reduced solve / cluster kernels from the committed rocprofv3 counter pass
+    (scripts/pmc_mfma.sh -> profiles/<round>_pmc_mfma_<config>.json), or None."""
+    path = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_mfma_{config}.json")
+    if scale != 1.0 or world != 1 or not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("summary")
+
+
 def pmc_traffic(name, config, scale, world):
     """HBM bytes per launch of one bench kernel from the committed rocprofv3 --pmc passes (separate
     FETCH_SIZE / WRITE_SIZE runs of this same command, scripts/pmc_traffic.sh), or None."""
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{config}.json")
+    path = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_traffic_{config}.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{config}.json")
     if scale != 1.0 or world != 1 or not os.path.exists(path):
         return None
     k = json.load(open(path))["kernels"]
@@ -95,6 +111,18 @@ def pmc_traffic(name, config, scale, world):
     pre = PMC_KERNEL.get(name)
     hit = [v for n, v in k.items() if pre and n.startswith(pre)]
     return hit[0]["hbm_bytes_per_launch"] if hit else None
+
+
+def schur_algorithmic_flops(prob):
+    """sum over points of (6 L_p + K_p)^2 * 3 * 2."""
+    from mavmap_amd import _abi as A
+    K = np.array([A.MODEL_NUM_PARAMS[int(m)] for m in prob.camera_model], np.int64)
+    K = np.where(np.asarray(prob.intr_const) != 0, 0, K)
+    L = np.bincount(prob.obs_point, minlength=prob.num_points).astype(np.int64)
+    cam = prob.image_camera[prob.obs_image].astype(np.int64)
+    pair = np.unique(prob.obs_point.astype(np.int64) * prob.num_cameras + cam)   # distinct (point, camera)
+    Kp = np.bincount(pair // prob.num_cameras, weights=K[pair % prob.num_cameras], minlength=prob.num_points)
+    return float(np.sum((6 * L + Kp) ** 2 * 6.0))
 
 
 def count_pp_terms(prob):
@@ -137,6 +165,17 @@ def main():
 
     import mavmap_amd
     from mavmap_amd import synth, _abi as A
+    from mavmap_amd import build as mavba_build
+    if rank == 0 and not mavba_build.is_current():
+        # never measure a stale library: rebuild from the sources that travel with it, or refuse
+        log("bench.py: libmavba.so does not match mavmap_amd/csrc (build stamp) - rebuilding")
+        try:
+            mavba_build.build(force=True)
+        except Exception as e:  # noqa: BLE001
+            log(f"bench.py: rebuild failed ({e}); refusing to benchmark a stale library")
+            sys.exit(4)
+    if world > 1:
+        dist.barrier()
     mavmap_amd.load()
 
     t0 = time.time()
@@ -224,30 +263,37 @@ def main():
                 (f"{row['achieved']} {row['unit']} ({row['frac']:.1%} of {row['bound']} peak)" if bound else ""))
         # `roofline` = the single KERNEL with the largest share of the timed region (a name rocprofv3's kernel stats
         # list too, so its average duration can be checked against profiles/). "dense_cholesky" is a timer around the
-        # ~50 launches of one reduced-system solve: it gets its own object (`reduced_solve`).
+        # launches of one reduced-system solve: it is the MFMA-graded `reduced_solve` object.
+        traffic_src = f"profiles/{PMC_ROUND}_pmc_traffic_{args.config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)"
         dominant = next((r for r in table if r.get("bound") and r["kernel"] != "dense_cholesky"), None)
         roofline = None
         if dominant:
             roofline = dict(kernel=dominant["kernel"], bound=dominant["bound"], achieved=dominant["achieved"],
                             peak=dominant["peak"], unit=dominant["unit"], frac=dominant["frac"],
-                            traffic=pmc_traffic(dominant["kernel"], args.config, args.scale, world))
+                            traffic=pmc_traffic(dominant["kernel"], args.config, args.scale, world), traffic_source=traffic_src)
             if dominant["kernel"] == "schur_clusters":
-                roofline["note"] = ("k_schur_clusters: Schur complement of point clusters as E E^T on v_mfma_f64_16x16x4_f64; flops "
-                                    "= executed matrix-instruction flops incl. the structural zeros of the stacked entry matrix "
-                                    "(~2.75x the useful flops); traffic = HBM bytes per launch (rocprofv3 PMC passes in profiles/)")
+                ex = info["cluster_flops"] / (dominant["avg_ms"] * 1e-3) / 1e12
+                roofline.update(executed_flops=info["cluster_flops"], executed_tflops=round(ex, 3),
+                                executed_frac=round(ex / FP64_MFMA_PEAK_TFLOPS, 4))
+                roofline["note"] = ("k_schur_clusters: Schur complement of point clusters as E E^T on v_mfma_f64_16x16x4_f64; achieved = "
+                                    "SURVEY 8(d) algorithmic flops sum_p (6 L_p + K_p)^2 * 6 / kernel time; executed_* = the matrix-"
+                                    "instruction flops really issued (structural zeros of the stacked entry matrix included); traffic "
+                                    "= HBM bytes per launch")
         chol = next((r for r in table if r["kernel"] == "dense_cholesky"), None)
         reduced_solve = None
         if chol:
-            de = info["dense_factor_flops"] / (chol["avg_ms"] * 1e-3) / 1e12
+            ex = info["factor_flops"] / (chol["avg_ms"] * 1e-3) / 1e12
             reduced_solve = dict(avg_ms=chol["avg_ms"], share=chol["share"], bound="mfma", achieved=chol["achieved"],
                                  peak=chol["peak"], unit=chol["unit"], frac=chol["frac"],
-                                 traffic=pmc_traffic("dense_cholesky", args.config, args.scale, world),
-                                 note=(f"one timer around the launches of a solve (k_chol_*); flops executed by the structured "
-                                       f"factorisation ({info['factor_flops'] / 1e9:.2f} GFLOP: {info['envelope_tiles']} of "
-                                       f"{info['dense_tiles']} tiles, {info['nd_parts']} concurrent fronts) / time; SURVEY 8(d)'s "
-                                       f"dense-equivalent n^3/3 + 2n^2 = {info['dense_factor_flops'] / 1e9:.2f} GFLOP would read "
-                                       f"{de:.2f} TFLOP/s. Bound by the dependent chain of {info['chain_steps']} 64-column panel "
-                                       "steps (tile factor + inverse, ~20 us each), not by MFMA throughput"))
+                                 executed_flops=info["factor_flops"], executed_tflops=round(ex, 3),
+                                 executed_frac=round(ex / FP64_MFMA_PEAK_TFLOPS, 4),
+                                 traffic=pmc_traffic("dense_cholesky", args.config, args.scale, world), traffic_source=traffic_src,
+                                 mfma_counters=mfma_counters(args.config, args.scale, world),
+                                 note=(f"one timer around the launches of a solve (k_chol_*); achieved = SURVEY 8(d)'s dense-equivalent "
+                                       f"n^3/3 + 2n^2 = {info['dense_factor_flops'] / 1e9:.2f} GFLOP / time; executed_* = flops of the "
+                                       f"structured factorisation ({info['factor_flops'] / 1e9:.2f} GFLOP: {info['envelope_tiles']} of "
+                                       f"{info['dense_tiles']} tiles, {info['nd_parts']} concurrent fronts). Bound by the dependent chain "
+                                       f"of {info['chain_steps']} 64-column panel steps, not by MFMA throughput"))
         sweep = next((r for r in table if r["kernel"] == "jacobian_sweep"), None)
 
         cpu_baseline = None

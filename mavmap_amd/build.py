@@ -26,6 +26,30 @@ def _hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libmavba.so)")
 
 
+STAMP = os.path.join(LIBDIR, "build_stamp.json")
+
+
+def source_digest():
+    """sha256 over the sources and headers the library is built from (content, not mtimes: the snapshot that
+    travels to the GPU box need not preserve them)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.normpath(os.path.join(CSRC, f)), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def is_current():
+    """True when libmavba.so exists and was built from exactly the sources present now."""
+    import json
+    try:
+        return os.path.exists(LIB) and json.load(open(STAMP))["digest"] == source_digest()
+    except (OSError, ValueError, KeyError):
+        return False
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -52,6 +76,10 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    if not is_current():
+        import json
+        with open(STAMP, "w") as fh:
+            json.dump(dict(digest=source_digest()), fh)
     return LIB
 
 

@@ -143,6 +143,7 @@ struct mavba_session {
   std::vector<int> h_cam_model, h_img_cam, h_pt_start, h_oimg;
   std::vector<long long> perm;      // point-major position -> caller observation index
   std::vector<int> h_pt_count_all;  // observations per point in the caller's problem
+  std::vector<double> h_dropped_rnorm;  // caller's point index -> sum |r_raw| of its all-constant (dropped) observations; empty if none
   // Points are renumbered at session creation (sorted by their image lists, so that neighbours in the order
   // see the same images: the Schur-complement clusters rely on it). h_pt_orig[internal] = caller's index.
   std::vector<int> h_pt_orig;

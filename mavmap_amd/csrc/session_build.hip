@@ -86,6 +86,7 @@ void mavba_session::build(const mavba_problem* P) {
   // Residual blocks without a free parameter block leave the program (ceres
   // RemoveFixedBlocksFromProgram); their cost is the fixed cost.
   h_pt_count_all.assign(NP, 0);
+  h_dropped_rnorm.clear();
   std::vector<long long> kept;
   kept.reserve((size_t)NO_all);
   fixed_cost = 0.0;
@@ -113,6 +114,10 @@ void mavba_session::build(const mavba_problem* P) {
                      P->obs_uv[2 * o + 1], r);
         cauchy_weight(r[0] * r[0] + r[1] * r[1], b, 1.0 / b, w, hr);
         fixed_cost += hr;
+        // its raw residual never changes (every block is constant) but it still counts in the point's error
+        // (problem.Evaluate covers all residual blocks, bundle_adjustment.cc:583-596)
+        if (h_dropped_rnorm.empty()) h_dropped_rnorm.assign(NP, 0.0);
+        h_dropped_rnorm[p] += std::sqrt(r[0] * r[0] + r[1] * r[1]);
         continue;
       }
       kept.push_back(o);

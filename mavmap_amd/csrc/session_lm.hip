@@ -266,7 +266,10 @@ void mavba_session::point_errors(double* out) {
   // Only points that have observations in the problem are touched (bundle_adjustment.cc:578-581);
   // observations dropped as all-constant blocks still count (they are residual blocks there).
   for (int p = 0; p < NP; ++p)
-    if (h_pt_count_all[p] > 0) out[h_pt_orig[p]] = h[p];
+    if (h_pt_count_all[p] > 0) {
+      const int po = h_pt_orig[p];
+      out[po] = h_dropped_rnorm.empty() ? h[p] : h[p] + h_dropped_rnorm[po] / (double)h_pt_count_all[p];
+    }
 }
 
 void mavba_session::fill_result(mavba_result* r) {

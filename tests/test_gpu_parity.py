@@ -203,11 +203,17 @@ def test_fixed_cost_blocks(mavba, oracle):
                          refine_camera_params=False)
     seen0 = np.unique(p.obs_point[p.obs_image == 0])
     p.point_const[seen0[:20]] = 1
-    po, ro, _, pg, rg, _ = _solve_both(mavba, oracle, p, **global_opts())
+    po, ro, eo, pg, rg, eg = _solve_both(mavba, oracle, p, **global_opts())
     assert ro["fixed_cost"] > 0
     assert abs(rg["fixed_cost"] - ro["fixed_cost"]) <= 1e-12 * ro["fixed_cost"]
     assert rg["num_residuals_reduced"] == ro["num_residuals_reduced"] < ro["num_residuals"]
     assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+    # the dropped (all-constant) residual blocks still count in point3D_errors (bundle_adjustment.cc:583-596):
+    # a GCP seen by a FIXED image under refine_camera_params = false
+    m = ~np.isnan(eo)
+    assert np.array_equal(m, ~np.isnan(eg))
+    assert rel_err(eg[m], eo[m]) < 1e-6
+    assert rel_err(eg[seen0[:20]], eo[seen0[:20]]) < 1e-6
 
 
 def test_session_iterate_reset_and_determinism(mavba):
