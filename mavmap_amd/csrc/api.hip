@@ -214,9 +214,8 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, 
                               double* model_cost_change) {
   MAVBA_TRY
   if (!s->evaluated) s->evaluate();
-  s->solve_linear(radius);
   double h[SC_COUNT];
-  s->candidate(radius, h);
+  s->linear_step(radius, h);
   if (model_cost_change) *model_cost_change = h[SC_MODEL_CHANGE];
   if (d_poses && s->NI) HIP_OK(hipMemcpyAsync(d_poses, s->d_delta_cam.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
   if (d_intr && s->NC) HIP_OK(hipMemcpyAsync(d_intr, s->d_delta_cam.p + 6 * (size_t)s->NI, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
@@ -357,12 +356,17 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
     dM.upload(M, st); dL.alloc(M.size()); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
     CholStructure cs;
     HIP_OK(cs.build_dense(n_pad / 64));
-    dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p, dL.p, cs);
     std::vector<double> y(n_pad);
     double fail = 0.0;
-    HIP_OK(hipMemcpyAsync(y.data(), dy.p, (size_t)n_pad * 8, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(&fail, dfail.p, 8, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p, dL.p, cs, nullptr, nullptr, attempt == 0);
+      HIP_OK(hipMemcpyAsync(y.data(), dy.p, (size_t)n_pad * 8, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(&fail, dfail.p, 8, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      if (fail < 1e29) break;
+      // the persistent launch gave up (it leaves M untouched): once more with the launch-per-panel schedule
+      dfail.zero(st);
+    }
     std::memcpy(x, y.data(), (size_t)n * 8);
     if (fail != 0.0) { g_last_error = "matrix is not positive definite"; rc = MAVBA_ERR_INVALID_ARGUMENT; }
   }

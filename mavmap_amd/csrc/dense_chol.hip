@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
                                                             const int* __restrict__ seg_first,
                                                             const double* __restrict__ inv,
                                                             const double* __restrict__ z, double* y,
-                                                            unsigned* flags, const int* __restrict__ scatter,
+                                                            unsigned* flags, unsigned epoch, const int* __restrict__ scatter,
                                                             double* __restrict__ y_nat) {
   const int k = nb - 1 - (int)blockIdx.x;
   const int sk = seg_of_tile[k];
@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
 #pragma unroll
       for (int q = 0; q < 16; ++q) ln[q] = Lt[(size_t)q * ld];
     }
-    while (__hip_atomic_load(&flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(&flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
     const double* xi = y + (size_t)i * NB + 16 * wv;
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -609,8 +609,229 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) __hip_atomic_store(&flags[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&flags[k], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+
+// ===========================================================================================================
+// Persistent forward factorisation: ONE launch for the whole factorisation + forward substitution.
+//
+// The launch-per-panel schedule above pays a launch + drain, one redundant 64^3 product and the tile loads on
+// every one of the dependent panel steps. Here the work-groups stay resident (one per CU) and hand tiles to
+// each other through memory:
+//   * owner-computes, left-looking by tile: the owner of tile (i, j) applies the updates -P_ik P_jk^T of all
+//     columns k that reach it in a FIXED order (by availability: schedule step of k, then k), then solves it
+//     against L_jj^-1 and publishes it. No two work-groups ever write the same tile, so the concurrent fronts
+//     of the elimination tree need no shadow blocks and no merge pass; results do not depend on timing.
+//   * one CHAIN work-group per node of the tree walks the node's diagonal: L_jj^-1 never leaves its LDS between
+//     column j and column j + 1 (panel solve of tile (j+1, j), its contribution to tile (j+1, j+1), tile factor +
+//     inverse). The updates of those two tiles by earlier columns are applied by helper tasks (PRE) while the
+//     chain is inside the previous tile factorisation.
+//   * hand-off protocol (placement independent): payload tiles are written and read with system-scope
+//     write-through accesses (sc0 sc1: they bypass the non-coherent per-XCD L2s and the per-CU L1), the
+//     producer drains its stores (s_waitcnt vmcnt(0)) before a relaxed agent-scope flag store, the consumer
+//     polls the flag with relaxed agent-scope loads. No fences. Flags carry the solve's epoch, so nothing has
+//     to be cleared between solves.
+//   * static schedule, built on the host (CholStructure::build): work-groups are partitioned by tree level and
+//     every work-group runs its task list in an order that is topological for the whole task graph, so the
+//     launch cannot dead-lock as long as all work-groups are resident (grid <= number of CUs, 1 work-group per
+//     CU by LDS size). Every wait is bounded: on a time-out the launch raises the abort flag, adds 1e30 to
+//     *fail and exits; the host then repeats the solve with the launch-per-panel schedule.
+// ===========================================================================================================
+namespace {
+typedef int i4v __attribute__((ext_vector_type(4)));
+constexpr int kCoherent = 17;  // buffer cache policy: sc0 | sc1
+constexpr int kSpinLimit = 400000;  // polls of one wait (~0.3 s) before the launch gives up
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00020000);
+}
+// 64x64 tile, global (leading dimension ld) <-> LDS (pitch GLD), 256 threads, 16 B system-scope accesses
+__device__ __forceinline__ void load_tile_coh(const double* G, size_t ld, double* S, int tid) {
+  const __amdgpu_buffer_rsrc_t r = tile_rsrc(G);
+  i4v v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx >> 5, c2 = (idx & 31) * 2;
+    v[q] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(((size_t)row * ld + c2) * 8), 0, kCoherent);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx >> 5, c2 = (idx & 31) * 2;
+    *reinterpret_cast<i4v*>(S + row * GLD + c2) = v[q];
+  }
+}
+__device__ __forceinline__ void store_tile_coh(double* G, size_t ld, const double* S, int tid) {
+  const __amdgpu_buffer_rsrc_t r = tile_rsrc(G);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx >> 5, c2 = (idx & 31) * 2;
+    const i4v v = *reinterpret_cast<const i4v*>(S + row * GLD + c2);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(((size_t)row * ld + c2) * 8), 0, kCoherent);
+  }
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void publish(unsigned* f, unsigned epoch) {
+  __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane polls; false = the launch is being abandoned
+__device__ __forceinline__ bool wait_flag(const unsigned* f, unsigned epoch, unsigned* abort_flag) {
+  for (int spin = 0;; ++spin) {
+    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    if ((spin & 31) == 31) {
+      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return false;
+      if (spin > kSpinLimit) { publish(abort_flag, epoch); return false; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+// the wave's 2x2 MFMA tiles (D layout) of a 64x64 LDS tile
+__device__ __forceinline__ void quadrant_from_lds(const double* S, int wr, int wc, int lane, d4 acc[2][2]) {
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][n][r] = S[(wr + 16 * m + lk + 4 * r) * GLD + wc + 16 * n + li];
+}
+__device__ __forceinline__ void quadrant_sub(d4 acc[2][2], const d4 p[2][2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] -= p[m][n];
+}
+}  // namespace
+
+struct CholPersistArgs {
+  const double* M; double* L; double* inv; double* pre;
+  int ld, nb;
+  const CholTask* tasks; const int* wg_begin; const int* upd; const int* tile_id; const int* chain_info;
+  unsigned* lflag; unsigned* dflag; unsigned* pflag; unsigned* abort_flag;
+  unsigned epoch;
+  double* fail;
+};
+
+__global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
+  __shared__ __attribute__((aligned(16))) double As[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double Bs[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double Cs[NB * GLD];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+  const int nb = A.nb;
+  const size_t ld = (size_t)A.ld;
+  const unsigned ep = A.epoch;
+  // waits: lane 0 polls, everyone learns the outcome behind a barrier (which also orders the LDS reuse)
+  auto wait2 = [&](const unsigned* f0, const unsigned* f1) -> bool {
+    if (tid == 0) {
+      bool ok = f0 ? wait_flag(f0, ep, A.abort_flag) : true;
+      if (ok && f1) ok = wait_flag(f1, ep, A.abort_flag);
+      s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool ok = s_ok != 0;
+    __syncthreads();  // s_ok may be rewritten by the next wait
+    return ok;
+  };
+  bool alive = true;
+  for (int ti = A.wg_begin[blockIdx.x]; alive && ti < A.wg_begin[blockIdx.x + 1]; ++ti) {
+    const CholTask T = A.tasks[ti];
+    if (T.kind != CHOL_TASK_CHAIN) {
+      // ---- owner-computes tile task: tile (i, j), updates upd[ub, ue) ----
+      const int i = T.i, j = T.j;
+      d4 acc[2][2], p[2][2];
+      {
+        const double* C = A.M + (size_t)i * NB * ld + (size_t)j * NB;  // written before this launch: plain loads
+        const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][n][r] = C[(size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li];
+      }
+      for (int u = T.ub; u < T.ue; ++u) {
+        const int k = A.upd[u];
+        const unsigned* f0 = A.lflag + A.tile_id[(size_t)i * nb + k];
+        const unsigned* f1 = i != j ? A.lflag + A.tile_id[(size_t)j * nb + k] : nullptr;
+        if (!wait2(f0, f1)) { alive = false; break; }
+        load_tile_coh(A.L + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
+        if (i != j) load_tile_coh(A.L + (size_t)j * NB * ld + (size_t)k * NB, ld, Bs, tid);
+        __syncthreads();
+        mfma_quadrant_nt(As, i != j ? Bs : As, wr, wc, lane, p);
+        quadrant_sub(acc, p);
+      }
+      if (!alive) break;
+      if (T.kind == CHOL_TASK_TILE) {
+        // panel solve against L_jj^-1, publish L_ij
+        if (!wait2(A.dflag + j, nullptr)) { alive = false; break; }
+        quadrant_to_lds(As, wr, wc, lane, acc);
+        load_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
+        __syncthreads();
+        mfma_quadrant_nt(As, Bs, wr, wc, lane, p);
+        quadrant_to_lds(Cs, wr, wc, lane, p);
+        __syncthreads();
+        store_tile_coh(A.L + (size_t)i * NB * ld + (size_t)j * NB, ld, Cs, tid);
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) publish(A.lflag + A.tile_id[(size_t)i * nb + j], ep);
+      } else {
+        // PRE: the chain's tile with every update but the chain's own; slot 2 j (diagonal) / 2 j + 1 (sub-diagonal)
+        const int slot = T.kind == CHOL_TASK_PRE_DIAG ? 2 * j : 2 * i + 1;
+        __syncthreads();  // the last product's LDS reads are done
+        quadrant_to_lds(As, wr, wc, lane, acc);
+        __syncthreads();
+        store_tile_coh(A.pre + (size_t)slot * NB * NB, NB, As, tid);
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) publish(A.pflag + slot, ep);
+      }
+      continue;
+    }
+    // ---- chain task: the diagonal of one tree node, tile columns [T.i, T.j) ----
+    // LDS roles: Bs = L_jj^-1 of the column just factorised, Cs = the panel tile P_{j, j-1}, As = loads / diagonal tile
+    for (int j = T.i; j < T.j; ++j) {
+      const int info = A.chain_info[j];
+      d4 acc[2][2], p[2][2];
+      const bool sub = j > T.i;
+      if (sub) {
+        if ((info & 2) && !wait2(A.pflag + 2 * j + 1, nullptr)) { alive = false; break; }
+        if (info & 2) load_tile_coh(A.pre + (size_t)(2 * j + 1) * NB * NB, NB, As, tid);
+        else load_tile(A.M + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, As, tid);
+        __syncthreads();
+        mfma_quadrant_nt(As, Bs, wr, wc, lane, p);  // P = A_{j,j-1} L_{j-1,j-1}^-T
+        quadrant_to_lds(Cs, wr, wc, lane, p);
+        __syncthreads();
+        store_tile_coh(A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, Cs, tid);
+      }
+      if ((info & 1) && !wait2(A.pflag + 2 * j, nullptr)) { alive = false; break; }
+      if (info & 1) load_tile_coh(A.pre + (size_t)(2 * j) * NB * NB, NB, As, tid);
+      else load_tile(A.M + (size_t)j * NB * ld + (size_t)j * NB, ld, As, tid);
+      drain_stores();  // (the loads had to land anyway; the panel tile's stores are out as well)
+      __syncthreads();
+      if (sub && tid == 0) publish(A.lflag + A.tile_id[(size_t)j * nb + (j - 1)], ep);
+      quadrant_from_lds(As, wr, wc, lane, acc);
+      if (sub) {
+        mfma_quadrant_nt(Cs, Cs, wr, wc, lane, p);
+        quadrant_sub(acc, p);
+      }
+      __syncthreads();
+      quadrant_to_lds(As, wr, wc, lane, acc);
+      __syncthreads();
+      const bool ok = tile_potrf_inv_la(As, Bs, tid);
+      if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
+      store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
+      drain_stores();
+      __syncthreads();
+      if (tid == 0) publish(A.dflag + j, ep);
+    }
+  }
+  if (!alive && tid == 0) atomicAdd(A.fail, 1e30);
 }
 
 void CholStructure::release() {
@@ -618,7 +839,13 @@ void CholStructure::release() {
   if (d_fronts) device_free(d_fronts);
   if (d_shadow) device_free(d_shadow);
   if (d_merges) device_free(d_merges);
+  if (d_tasks) device_free(d_tasks);
+  if (d_pints) device_free(d_pints);
+  if (d_pflags) device_free(d_pflags);
+  if (d_pre) device_free(d_pre);
   d_ints = nullptr; d_fronts = nullptr; d_shadow = nullptr; d_merges = nullptr;
+  d_tasks = nullptr; d_pints = nullptr; d_pflags = nullptr; d_pre = nullptr;
+  persist_ok = false;
 }
 CholStructure::~CholStructure() { release(); }
 
@@ -787,6 +1014,185 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   d_seg_first = d_ints + o_first;
   d_init = d_ints + o_init;
   d_flags = reinterpret_cast<unsigned*>(d_ints + o_flags);
+  // persistent schedule: rows that couple to every column, schedule step of every column
+  std::vector<std::vector<int>> col_rows(nb);
+  std::vector<int> col_step(nb, 0);
+  int ordinal = 0;
+  for (const CholStep& S : steps) {
+    if (S.kind != 0) continue;
+    for (int f = S.front_off; f < S.front_off + S.nf + S.nf0; ++f) {
+      const CholFront& F = fronts[f];
+      col_rows[F.k].assign(rows.begin() + F.act_off, rows.begin() + F.act_off + F.na);
+      col_step[F.k] = ordinal;
+    }
+    ++ordinal;
+  }
+  e = build_persistent(col_rows, col_step, height, st);
+  if (e != hipSuccess) { release(); return e; }
+  return hipSuccess;
+}
+
+namespace {
+int device_cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chol_persist, 256, 0) != hipSuccess || per_cu < 1) return 0;
+    cus[dev] = prop.multiProcessorCount;
+  }
+  return cus[dev];
+}
+}  // namespace
+
+hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& col_rows, const std::vector<int>& col_step,
+                                           const std::vector<int>& height, hipStream_t st) {
+  persist_ok = false;
+  static const bool enabled = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST"); return !e || std::atoi(e) != 0; }();
+  static const int grid_cap = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST_GRID"); return e ? std::atoi(e) : 0; }();
+  if (!enabled || nb < 1 || nb > 512) return hipSuccess;  // (dense tile-id table)
+  int G = device_cu_count();
+  if (grid_cap > 0) G = std::min(G, grid_cap);
+  // ---- tiles with a 'published' flag: diagonal, coupled rows, right-hand-side row of every column ----
+  std::vector<int> tile_id((size_t)(nb + 1) * nb, -1);
+  long long nt = 0;
+  for (int k = 0; k < nb; ++k) {
+    tile_id[(size_t)k * nb + k] = (int)nt++;
+    for (int i : col_rows[k]) tile_id[(size_t)i * nb + k] = (int)nt++;
+    tile_id[(size_t)nb * nb + k] = (int)nt++;
+  }
+  // ---- the updates every tile receives, in a fixed order: by availability (schedule step of k), then k ----
+  std::vector<std::vector<int>> upd_of((size_t)nt);
+  std::vector<int> R;
+  long long nupd = 0;
+  for (int k = 0; k < nb; ++k) {
+    R.assign(col_rows[k].begin(), col_rows[k].end());
+    R.push_back(nb);
+    for (size_t a = 0; a < R.size(); ++a)
+      for (size_t b = 0; b <= a; ++b) {
+        if (R[b] == nb) continue;  // (the right-hand-side row is no column)
+        const int id = tile_id[(size_t)R[a] * nb + R[b]];
+        if (id < 0) return hipSuccess;  // fill outside the envelope: keep the launch-per-panel schedule
+        upd_of[id].push_back(k);
+        ++nupd;
+      }
+  }
+  for (auto& l : upd_of)
+    std::sort(l.begin(), l.end(), [&](int a, int b) { return col_step[a] != col_step[b] ? col_step[a] < col_step[b] : a < b; });
+  // ---- tasks ----
+  struct Gen { CholTask t; long long key; int level; long long work; };
+  std::vector<Gen> gen;
+  std::vector<int> upd, chain_info(nb, 0);
+  auto add_task = [&](int kind, int i, int j, const std::vector<int>& list, long long key) {
+    CholTask t{kind, i, j, (int)upd.size(), (int)(upd.size() + list.size())};
+    upd.insert(upd.end(), list.begin(), list.end());
+    gen.push_back(Gen{t, key, height[seg_of_tile[j]], 2 + (long long)list.size()});
+  };
+  for (int j = 0; j < nb; ++j) {
+    const int n = seg_of_tile[j];
+    const bool first = j == nodes[n].begin, last = j + 1 == nodes[n].end;
+    const long long sj = col_step[j];
+    std::vector<int> dl = upd_of[tile_id[(size_t)j * nb + j]];
+    if (!first) {
+      if (dl.empty() || dl.back() != j - 1) return hipSuccess;  // (the chain's own update must come last)
+      dl.pop_back();
+    }
+    if (!dl.empty()) { add_task(CHOL_TASK_PRE_DIAG, j, j, dl, (sj - 1) * 8 + 2); chain_info[j] |= 1; }
+    if (!first) {
+      const int id = tile_id[(size_t)j * nb + (j - 1)];
+      if (id < 0) return hipSuccess;
+      if (!upd_of[id].empty()) { add_task(CHOL_TASK_PRE_SUB, j, j - 1, upd_of[id], (sj - 1) * 8 + 2); chain_info[j] |= 2; }
+    }
+    for (int i : col_rows[j]) {
+      if (i == j + 1 && !last) continue;  // the chain's sub-diagonal tile
+      add_task(CHOL_TASK_TILE, i, j, upd_of[tile_id[(size_t)i * nb + j]], sj * 8 + (i <= j + 2 ? 4 : 5));
+    }
+    add_task(CHOL_TASK_TILE, nb, j, upd_of[tile_id[(size_t)nb * nb + j]], sj * 8 + 6);
+  }
+  // ---- work-groups: one chain per concurrent node, the helpers partitioned by tree level ----
+  const int H = *std::max_element(height.begin(), height.end());
+  std::vector<int> chain_wg(nseg, -1);
+  int nch = 0;
+  {
+    std::vector<int> first_child(nseg, -1);
+    for (int n = 0; n < nseg; ++n)
+      if (nodes[n].parent >= 0 && first_child[nodes[n].parent] < 0) first_child[nodes[n].parent] = n;
+    for (int n = 0; n < nseg; ++n) chain_wg[n] = first_child[n] >= 0 ? chain_wg[first_child[n]] : nch++;
+  }
+  std::vector<long long> work(H + 1, 0);
+  std::vector<int> ntasks(H + 1, 0), alloc(H + 1, 0);
+  long long total = 0;
+  for (const Gen& g : gen) { work[g.level] += g.work; ntasks[g.level]++; total += g.work; }
+  int levels_used = 0;
+  for (int h = 0; h <= H; ++h) levels_used += ntasks[h] > 0;
+  const int helpers = std::min<long long>(G - nch, (long long)gen.size());
+  if (helpers < levels_used || helpers < 1) return hipSuccess;
+  int given = 0;
+  for (int h = 0; h <= H; ++h)
+    if (ntasks[h] > 0) { alloc[h] = (int)std::max<long long>(1, std::min<long long>(ntasks[h], helpers * work[h] / std::max<long long>(total, 1))); given += alloc[h]; }
+  while (given > helpers) {  // (rounding up of small levels)
+    int best = -1;
+    for (int h = 0; h <= H; ++h) if (alloc[h] > 1 && (best < 0 || alloc[h] > alloc[best])) best = h;
+    if (best < 0) return hipSuccess;
+    --alloc[best]; --given;
+  }
+  while (given < helpers) {  // leftovers go where a work-group carries the most work
+    int best = -1;
+    for (int h = 0; h <= H; ++h)
+      if (alloc[h] > 0 && alloc[h] < ntasks[h] && (best < 0 || work[h] * alloc[best] > work[best] * alloc[h])) best = h;
+    if (best < 0) break;
+    ++alloc[best]; ++given;
+  }
+  const int grid = nch + given;
+  std::vector<std::vector<CholTask>> wg_tasks(grid);
+  for (int n = 0; n < nseg; ++n) wg_tasks[chain_wg[n]].push_back(CholTask{CHOL_TASK_CHAIN, nodes[n].begin, nodes[n].end, 0, 0});
+  {
+    int base = nch;
+    for (int h = 0; h <= H; ++h) {
+      if (alloc[h] == 0) continue;
+      std::vector<const Gen*> lv;
+      for (const Gen& g : gen) if (g.level == h) lv.push_back(&g);
+      std::stable_sort(lv.begin(), lv.end(), [](const Gen* a, const Gen* b) {
+        if (a->key != b->key) return a->key < b->key;
+        if (a->t.j != b->t.j) return a->t.j < b->t.j;
+        return a->t.i < b->t.i;
+      });
+      for (size_t q = 0; q < lv.size(); ++q) wg_tasks[base + (int)(q % alloc[h])].push_back(lv[q]->t);
+      base += alloc[h];
+    }
+  }
+  std::vector<CholTask> tasks;
+  std::vector<int> wg_begin(grid + 1, 0);
+  for (int w = 0; w < grid; ++w) {
+    wg_begin[w] = (int)tasks.size();
+    tasks.insert(tasks.end(), wg_tasks[w].begin(), wg_tasks[w].end());
+  }
+  wg_begin[grid] = (int)tasks.size();
+  // ---- device copies ----
+  std::vector<int> pack(wg_begin);
+  const size_t o_upd = pack.size();
+  pack.insert(pack.end(), upd.begin(), upd.end());
+  const size_t o_tid = pack.size();
+  pack.insert(pack.end(), tile_id.begin(), tile_id.end());
+  const size_t o_ci = pack.size();
+  pack.insert(pack.end(), chain_info.begin(), chain_info.end());
+  const size_t nflags = (size_t)nt + 3 * (size_t)nb + 1;
+  hipError_t e = device_alloc(reinterpret_cast<void**>(&d_pints), pack.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pints, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_tasks), tasks.size() * sizeof(CholTask));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(CholTask), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_pflags), nflags * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemsetAsync(d_pflags, 0, nflags * sizeof(unsigned), st);
+  if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_pre), (size_t)2 * nb * NB * NB * sizeof(double));
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  d_wg_begin = d_pints; d_upd = d_pints + o_upd; d_tile_id = d_pints + o_tid; d_chain_info = d_pints + o_ci;
+  persist_grid = grid; persist_chain_wgs = nch; persist_tiles = nt; persist_updates = nupd;
+  epoch = 0;
+  persist_ok = true;
   return hipSuccess;
 }
 
@@ -795,9 +1201,18 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
 // forward-substituted right-hand side. `cs` = tile structure + launch schedule of the matrix.
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws, double* L, const CholStructure& cs,
-                            const int* y_scatter, double* y_nat) {
+                            const int* y_scatter, double* y_nat, bool allow_persistent) {
   const int nb = n_pad / NB, ld = n_pad;
   double* inv = diag_ws;
+  const unsigned epoch = ++cs.epoch;  // flags of this solve (forward hand-offs and backward substitution)
+  if (allow_persistent && cs.persist_ok) {
+    CholPersistArgs A;
+    A.M = M; A.L = L; A.inv = inv; A.pre = cs.d_pre; A.ld = ld; A.nb = nb;
+    A.tasks = cs.d_tasks; A.wg_begin = cs.d_wg_begin; A.upd = cs.d_upd; A.tile_id = cs.d_tile_id; A.chain_info = cs.d_chain_info;
+    A.lflag = cs.d_pflags; A.dflag = cs.d_pflags + cs.persist_tiles; A.pflag = A.dflag + nb; A.abort_flag = A.pflag + 2 * nb;
+    A.epoch = epoch; A.fail = fail;
+    hipLaunchKernelGGL(k_chol_persist, dim3(cs.persist_grid), dim3(256), 0, st, A);
+  } else {
   if (cs.shadow_doubles) (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);
   static const int fuse_below = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE"); return e ? std::atoi(e) : kFuseBelow; }();  // tuning knobs
   static const int fuse_tasks = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE_TASKS"); return e ? std::atoi(e) : kFuseTasks; }();
@@ -826,10 +1241,11 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
     if (S.nf0)  // fronts with nothing below their tile: only the right-hand-side block is left
       hipLaunchKernelGGL(k_chol_trsm, dim3(1, 1, S.nf0), dim3(256), 0, st, M, L, ld, F + S.nf, inv, cs.d_rows, nb);
   }
+  }
   double* z = L + (size_t)n_pad * ld;
   if (nb <= kMaxBacksolveGroups) {
     hipLaunchKernelGGL(k_chol_backsolve_all, dim3(nb), dim3(256), 0, st, L, ld, nb, cs.nseg, cs.d_seg_of_tile, cs.d_seg_first,
-                       inv, z, y, cs.d_flags, y_scatter, y_nat);
+                       inv, z, y, cs.d_flags, epoch, y_scatter, y_nat);
   } else {
     // more tile rows than work-groups that are certainly resident: one small launch per tile (single segment)
     for (int k = nb - 1; k >= 0; --k)

@@ -236,6 +236,11 @@ struct CholMerge { int sh_begin; long long sh_off; };
 // Node of the elimination tree: tile columns [begin, end); parent = index of the separator it hangs under
 // (-1: root). Nodes are listed in column order, children before parents.
 struct CholNode { int begin, end, parent; };
+// Persistent schedule (k_chol_persist, dense_chol.hip): a task is one tile owned by one work-group (TILE: apply the
+// updates upd[ub, ue), solve against L_jj^-1, publish; PRE_*: a chain tile with every update but the chain's own) or
+// the diagonal of one tree node (CHAIN: tile columns [i, j)).
+enum { CHOL_TASK_TILE = 0, CHOL_TASK_PRE_DIAG = 1, CHOL_TASK_PRE_SUB = 2, CHOL_TASK_CHAIN = 3 };
+struct CholTask { int kind, i, j, ub, ue; };
 struct CholStructure {
   int nb = 0, nseg = 1;
   std::vector<CholNode> nodes;
@@ -257,6 +262,18 @@ struct CholStructure {
   CholFront* d_fronts = nullptr;
   CholMerge* d_merges = nullptr;
   double* d_shadow = nullptr;
+  // persistent schedule
+  bool persist_ok = false;        // a schedule exists (structure consistent, fits the resident grid)
+  int persist_grid = 0;           // work-groups (<= CUs of the device, all resident)
+  int persist_chain_wgs = 0;      // the first persist_chain_wgs work-groups walk the nodes' diagonals
+  long long persist_tiles = 0;    // tiles with a 'published' flag
+  long long persist_updates = 0;  // tile updates of one factorisation
+  CholTask* d_tasks = nullptr;
+  int* d_pints = nullptr;         // wg_begin | upd | tile_id | chain_info
+  int *d_wg_begin = nullptr, *d_upd = nullptr, *d_tile_id = nullptr, *d_chain_info = nullptr;
+  unsigned* d_pflags = nullptr;   // lflag[persist_tiles] | dflag[nb] | pflag[2 nb] | abort[1]
+  double* d_pre = nullptr;        // [2 nb] 64x64 tiles: the chain's tiles after the helpers' updates
+  mutable unsigned epoch = 0;     // flags are compared with the solve's epoch: nothing is cleared between solves
   CholStructure() {}
   CholStructure(const CholStructure&) = delete;
   CholStructure& operator=(const CholStructure&) = delete;
@@ -268,12 +285,14 @@ struct CholStructure {
   hipError_t build(int nb, const std::vector<std::pair<int, int>>& tile_pairs, const std::vector<CholNode>& tree,
                    hipStream_t st);
   hipError_t build_dense(int nb);
+  hipError_t build_persistent(const std::vector<std::vector<int>>& col_rows, const std::vector<int>& col_step,
+                              const std::vector<int>& height, hipStream_t st);
 };
 // y_scatter (may be null): y_nat[y_scatter[t]] = y[t] for every t with y_scatter[t] >= 0 (the solution in
 // the caller's variable order when the matrix was assembled in a permuted order).
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws, double* L, const CholStructure& cs,
-                            const int* y_scatter = nullptr, double* y_nat = nullptr);
+                            const int* y_scatter = nullptr, double* y_nat = nullptr, bool allow_persistent = true);
 
 }  // namespace mavba
 #endif

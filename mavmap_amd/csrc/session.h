@@ -193,6 +193,7 @@ struct mavba_session {
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
+  bool allow_persistent = true;  // cleared when a persistent factorisation launch had to give up
   // The reduced camera matrix is assembled in the factorisation's elimination order: n_mat (multiple of 64)
   // columns, image i's pose block at h_off_img[i], camera c's intrinsics block at h_off_cam[c]; col_var maps a
   // matrix column back to the variable (index into the length-n_pad camera vectors), -1 for padding.
@@ -290,6 +291,7 @@ struct mavba_session {
   void take_evaluation(const double* h) { cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]); }
   void assemble(double r);
   void solve_linear(double r);
+  void linear_step(double r, double* h_scal);
   void candidate(double r, double* h_scal);
   void start();
   int iterate(int max_iters, int* done);

@@ -122,8 +122,22 @@ void mavba_session::assemble(double r) {
 
 void mavba_session::solve_linear(double r) {
   assemble(r);
-  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p); });
+  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p, allow_persistent); });
   assembled = false;  // the factorisation overwrote S
+}
+
+// One LM linear step: reduced solve + candidate. The persistent factorisation bounds every wait; should a launch ever
+// give up (its work-groups were not all resident: another persistent launch on the device, CU masking), the solve is
+// repeated once with the launch-per-panel schedule and the session stays on that schedule.
+void mavba_session::linear_step(double r, double* h) {
+  solve_linear(r);
+  candidate(r, h);
+  if (h[SC_FAIL] >= 1e29 && allow_persistent) {
+    std::fprintf(stderr, "mavba: persistent factorisation timed out, falling back to the launch-per-panel schedule\n");
+    allow_persistent = false;
+    solve_linear(r);
+    candidate(r, h);
+  }
 }
 
 // Back-substitution, candidate x + delta, and its cost. Leaves the scalars on the host.
@@ -188,9 +202,8 @@ int mavba_session::iterate(int max_iters, int* done) {
   while (termination == MAVBA_TERM_RUNNING && n < max_iters) {
     if (iteration >= opt.max_num_iterations) { termination = MAVBA_TERM_NO_CONVERGENCE; break; }
     ++iteration; ++n;
-    solve_linear(radius);
     double h[SC_COUNT];
-    candidate(radius, h);
+    linear_step(radius, h);
     if (pending_eval) {
       pending_eval = false;
       take_evaluation(h);
