@@ -19,6 +19,7 @@
 // At BA sizes the cost is the chain of dependent panel steps, not the flops (DESIGN.md sections 4 and 6).
 #include "internal.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace mavba {
@@ -103,6 +104,76 @@ __device__ __forceinline__ bool potrf_inv16(d4& acc, d4& xacc, int lane) {
   return ok;
 }
 
+// The same factorisation FOUR pivots at a time. Rows 4b..4b+3 of the block are register b of the four 16-lane
+// groups, i.e. exactly the k = 0..3 slices of one matrix instruction's B operand. With D4 = the 4x4 diagonal
+// block of those rows, D4 = L4 L4^T and X4 = L4^-1 (ten wave-uniform values, computed redundantly by every lane
+// from ten v_readlane pairs):
+//   U  = X4 * rows(acc)    one instruction: A operand = X4 placed in rows 0..3, B operand = register b as it is;
+//                          U (4 x 16, = rows 4b..4b+3 of L^T) lands in register 0 of the result, already in
+//                          operand position for the next instruction
+//   Xn = X4 * rows(xacc)   the same for the running inverse (final rows 4b..4b+3 of L^-1)
+//   acc  -= U^T U          one instruction, rank 4
+//   xacc -= U^T Xn         one instruction
+// Four dependent matrix instructions + one 4x4 scalar factorisation per FOUR pivots instead of two dependent
+// matrix instructions + rsqrt chain per pivot (measured: the 16-pivot block 4200 -> ~2000 cycles).
+template <int B>
+__device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, int lane, bool& ok) {
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int c0 = 4 * B;
+  // D4[a][b], a >= b: register B of lane (a << 4 | c0 + b)
+  const double d00 = readlane_d(acc[B], 0 * 16 + c0 + 0);
+  const double d10 = readlane_d(acc[B], 1 * 16 + c0 + 0), d11 = readlane_d(acc[B], 1 * 16 + c0 + 1);
+  const double d20 = readlane_d(acc[B], 2 * 16 + c0 + 0), d21 = readlane_d(acc[B], 2 * 16 + c0 + 1), d22 = readlane_d(acc[B], 2 * 16 + c0 + 2);
+  const double d30 = readlane_d(acc[B], 3 * 16 + c0 + 0), d31 = readlane_d(acc[B], 3 * 16 + c0 + 1), d32 = readlane_d(acc[B], 3 * 16 + c0 + 2),
+               d33 = readlane_d(acc[B], 3 * 16 + c0 + 3);
+  // 4x4 Cholesky, reciprocal diagonal r_k = 1 / l_kk
+  const double r0 = rsqrt_halley(d00);
+  const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+  const double t11 = __builtin_fma(-l10, l10, d11);
+  const double r1 = rsqrt_halley(t11);
+  const double l21 = __builtin_fma(-l20, l10, d21) * r1, l31 = __builtin_fma(-l30, l10, d31) * r1;
+  const double t22 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, d22));
+  const double r2 = rsqrt_halley(t22);
+  const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, d32)) * r2;
+  const double t33 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, d33)));
+  const double r3 = rsqrt_halley(t33);
+  ok = ok && (d00 > 0.0) && (t11 > 0.0) && (t22 > 0.0) && (t33 > 0.0);
+  // X4 = L4^-1 (lower)
+  const double x10 = -(l10 * r0) * r1;
+  const double x21 = -(l21 * r1) * r2;
+  const double x32 = -(l32 * r2) * r3;
+  const double x20 = -__builtin_fma(l21, x10, l20 * r0) * r2;
+  const double x31 = -__builtin_fma(l32, x21, l31 * r1) * r3;
+  const double x30 = -__builtin_fma(l32, x20, __builtin_fma(l31, x10, l30 * r0)) * r3;
+  // A operand: lane (k = lk, i = li) supplies X4[i][k] for i < 4, k <= i
+  double xa = 0.0;
+  if (li == 0) xa = lk == 0 ? r0 : 0.0;
+  else if (li == 1) xa = lk == 0 ? x10 : (lk == 1 ? r1 : 0.0);
+  else if (li == 2) xa = lk == 0 ? x20 : (lk == 1 ? x21 : (lk == 2 ? r2 : 0.0));
+  else if (li == 3) xa = lk == 0 ? x30 : (lk == 1 ? x31 : (lk == 2 ? x32 : r3));
+  const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
+  const double ba = li >= c0 ? acc[B] : 0.0;  // columns left of the block are stale (never needed again)
+  const d4 U = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, ba, zero, 0, 0, 0);
+  const d4 Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xacc[B], zero, 0, 0, 0);
+  const double u = li >= c0 + lk ? U[0] : 0.0;  // row m of L^T is zero left of column c0 + m (rounding residue otherwise)
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, u, acc, 0, 0, 0);
+  xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, Xn[0], xacc, 0, 0, 0);
+  xfin[B] = Xn[0];
+}
+__device__ __forceinline__ bool potrf_inv16_b4(d4& acc, d4& xacc, int lane) {
+  bool ok = true;
+  const int li = lane & 15, lk = lane >> 4;
+  d4 xfin = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xacc[r] = (lk + 4 * r == li) ? 1.0 : 0.0;
+  potrf_inv16_block4<0>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_block4<1>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_block4<2>(acc, xacc, xfin, lane, ok);
+  potrf_inv16_block4<3>(acc, xacc, xfin, lane, ok);
+  xacc = xfin;
+  return ok;
+}
+
 // acc += A(16x16, row-major lda) * B^T  (NT)   or   A * B (NN), K = 16, operands in LDS.
 // v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][k = l >> 4], B[k = l >> 4][l & 15];
 // reg r of lane l holds D[(l >> 4) + 4 r][l & 15].
@@ -130,6 +201,7 @@ __device__ __forceinline__ void store_d16(double* C, int ldc, d4 v, int lane) {
   for (int r = 0; r < 4; ++r) C[(lk + 4 * r) * ldc + li] = v[r];
 }
 
+constexpr bool kPivot4 = true;  // four pivots per matrix-instruction step in the 16x16 diagonal blocks (false: one)
 constexpr int kFuseBelow = 24;  // fuse the panel solve into the update when <= this many row blocks remain ...
 constexpr int kFuseTasks = 256;  // ... and the step (all fronts) has at most this many tile updates
 constexpr int kMaxBacksolveGroups = 2048;  // single-launch backward substitution up to this many tile rows
@@ -176,7 +248,7 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
   auto chain = [&](double* C, const double* P, int c) -> bool {
     d4 a = load_d16(C, GLD, lane), x;
     if (P) a = gemm16(P, GLD, P, GLD, true, -1.0, a, lane);
-    const bool ok = potrf_inv16(a, x, lane);
+    const bool ok = kPivot4 ? potrf_inv16_b4(a, x, lane) : potrf_inv16(a, x, lane);
     store_d16(Xb(c, c), GLD, x, lane);
     return ok;
   };
@@ -530,11 +602,10 @@ __global__ void k_scatter_y(int n, const int* __restrict__ scatter, const double
   if (t < n && scatter[t] >= 0) y_nat[scatter[t]] = y[t];
 }
 
-// Backward substitution L^T x = z in ONE launch: work-group b owns tile row k = nb - 1 - b,
+// Backward substitution L^T x = z in ONE launch: a work-group owns tile rows k,
 //   x_k = L_kk^-T (z_k - sum_{i > k} L_ik^T x_i),
-// and consumes the x_i in decreasing i as their owners publish them (flag per tile, release/acquire at
-// agent scope). Owners of later rows have smaller block indices, so they are dispatched first and the
-// wait can never dead-lock. Each of the 4 waves takes 16 of the 64 rows of every tile; the tile values
+// and consumes the x_i in decreasing i as their owners publish them (flag per tile carrying the solve's epoch,
+// release/acquire at agent scope). Each of the 4 waves takes 16 of the 64 rows of every tile; the tile values
 // are fetched BEFORE the wait, so a step of the chain is {flag + 64 values of x, 16 FMAs, two LDS
 // reductions}, not a kernel launch. Tile (i, k) takes part iff k is inside row i's envelope for k's
 // segment - uncoupled parts of a nested-dissection ordering therefore never wait for each other.
@@ -545,10 +616,13 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
                                                             const double* __restrict__ z, double* y,
                                                             unsigned* flags, unsigned epoch, const int* __restrict__ scatter,
                                                             double* __restrict__ y_nat) {
-  const int k = nb - 1 - (int)blockIdx.x;
-  const int sk = seg_of_tile[k];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  // Work-group b owns tile rows nb-1-b, nb-1-b-G, ... (decreasing): every row it waits for belongs to a work-group
+  // that reaches it without waiting for this one, so a resident grid (G <= 2 per CU) cannot dead-lock whatever the
+  // dispatch order.
+  for (int k = nb - 1 - (int)blockIdx.x; k >= 0; k -= (int)gridDim.x) {
+  const int sk = seg_of_tile[k];
   double acc = (wv == 0) ? z[(size_t)k * NB + lane] : 0.0;
   // this wave's 16 rows of L_kk^-1 (lower, compact 64 x 64)
   double li[16];
@@ -610,6 +684,8 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(&flags[k], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();  // `part` is reused by the next row
   }
 }
 
@@ -714,6 +790,7 @@ struct CholPersistArgs {
   unsigned* lflag; unsigned* dflag; unsigned* pflag; unsigned* abort_flag;
   unsigned epoch;
   double* fail;
+  unsigned long long* trace;  // MAVBA_CHOL_TRACE: 100 MHz wall-clock stamps, [8 per chain column | 4 per task], else null
 };
 
 __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
@@ -739,9 +816,12 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
     return ok;
   };
   bool alive = true;
+  auto stamp = [&](size_t slot) { if (A.trace && tid == 0) A.trace[slot] = wall_clock64(); };
   for (int ti = A.wg_begin[blockIdx.x]; alive && ti < A.wg_begin[blockIdx.x + 1]; ++ti) {
     const CholTask T = A.tasks[ti];
+    const size_t tslot = (size_t)8 * nb + (size_t)4 * ti;
     if (T.kind != CHOL_TASK_CHAIN) {
+      stamp(tslot);
       // ---- owner-computes tile task: tile (i, j), updates upd[ub, ue) ----
       const int i = T.i, j = T.j;
       d4 acc[2][2], p[2][2];
@@ -767,9 +847,11 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         quadrant_sub(acc, p);
       }
       if (!alive) break;
+      stamp(tslot + 1);
       if (T.kind == CHOL_TASK_TILE) {
         // panel solve against L_jj^-1, publish L_ij
         if (!wait2(A.dflag + j, nullptr)) { alive = false; break; }
+        stamp(tslot + 2);
         quadrant_to_lds(As, wr, wc, lane, acc);
         load_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
         __syncthreads();
@@ -780,6 +862,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         drain_stores();
         __syncthreads();
         if (tid == 0) publish(A.lflag + A.tile_id[(size_t)i * nb + j], ep);
+        stamp(tslot + 3);
       } else {
         // PRE: the chain's tile with every update but the chain's own; slot 2 j (diagonal) / 2 j + 1 (sub-diagonal)
         const int slot = T.kind == CHOL_TASK_PRE_DIAG ? 2 * j : 2 * i + 1;
@@ -790,6 +873,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         drain_stores();
         __syncthreads();
         if (tid == 0) publish(A.pflag + slot, ep);
+        stamp(tslot + 3);
       }
       continue;
     }
@@ -799,8 +883,10 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       const int info = A.chain_info[j];
       d4 acc[2][2], p[2][2];
       const bool sub = j > T.i;
+      stamp((size_t)8 * j);
       if (sub) {
         if ((info & 2) && !wait2(A.pflag + 2 * j + 1, nullptr)) { alive = false; break; }
+        stamp((size_t)8 * j + 1);
         if (info & 2) load_tile_coh(A.pre + (size_t)(2 * j + 1) * NB * NB, NB, As, tid);
         else load_tile(A.M + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, As, tid);
         __syncthreads();
@@ -808,13 +894,16 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         quadrant_to_lds(Cs, wr, wc, lane, p);
         __syncthreads();
         store_tile_coh(A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, Cs, tid);
+        stamp((size_t)8 * j + 2);
       }
       if ((info & 1) && !wait2(A.pflag + 2 * j, nullptr)) { alive = false; break; }
+      stamp((size_t)8 * j + 3);
       if (info & 1) load_tile_coh(A.pre + (size_t)(2 * j) * NB * NB, NB, As, tid);
       else load_tile(A.M + (size_t)j * NB * ld + (size_t)j * NB, ld, As, tid);
       drain_stores();  // (the loads had to land anyway; the panel tile's stores are out as well)
       __syncthreads();
       if (sub && tid == 0) publish(A.lflag + A.tile_id[(size_t)j * nb + (j - 1)], ep);
+      stamp((size_t)8 * j + 4);
       quadrant_from_lds(As, wr, wc, lane, acc);
       if (sub) {
         mfma_quadrant_nt(Cs, Cs, wr, wc, lane, p);
@@ -823,18 +912,45 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       __syncthreads();
       quadrant_to_lds(As, wr, wc, lane, acc);
       __syncthreads();
+      stamp((size_t)8 * j + 5);
       const bool ok = tile_potrf_inv_la(As, Bs, tid);
       if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
+      stamp((size_t)8 * j + 6);
       store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
       drain_stores();
       __syncthreads();
       if (tid == 0) publish(A.dflag + j, ep);
+      stamp((size_t)8 * j + 7);
     }
   }
   if (!alive && tid == 0) atomicAdd(A.fail, 1e30);
 }
 
 void CholStructure::release() {
+  if (d_trace) {
+    // MAVBA_CHOL_TRACE=<file>: the stamps of the LAST solve, with the schedule they belong to
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)8 * nb + (size_t)4 * h_tasks.size());
+    if (hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+      if (FILE* f = std::fopen(std::getenv("MAVBA_CHOL_TRACE"), "w")) {
+        std::fprintf(f, "# nb %d grid %d chain_wgs %d tiles %lld updates %lld\n", nb, persist_grid, persist_chain_wgs, persist_tiles, persist_updates);
+        for (int j = 0; j < nb; ++j) {
+          std::fprintf(f, "C %d %d", j, seg_of_tile[j]);
+          for (int q = 0; q < 8; ++q) std::fprintf(f, " %llu", h[(size_t)8 * j + q]);
+          std::fprintf(f, "\n");
+        }
+        for (size_t t = 0; t < h_tasks.size(); ++t) {
+          int wg = 0;
+          while (wg + 1 < (int)h_wg_begin.size() && h_wg_begin[wg + 1] <= (int)t) ++wg;
+          std::fprintf(f, "T %d %d %d %d %d", wg, h_tasks[t].kind, h_tasks[t].i, h_tasks[t].j, h_tasks[t].ue - h_tasks[t].ub);
+          for (int q = 0; q < 4; ++q) std::fprintf(f, " %llu", h[(size_t)8 * nb + 4 * t + q]);
+          std::fprintf(f, "\n");
+        }
+        std::fclose(f);
+      }
+    device_free(d_trace);
+    d_trace = nullptr;
+  }
   if (d_ints) device_free(d_ints);
   if (d_fronts) device_free(d_fronts);
   if (d_shadow) device_free(d_shadow);
@@ -1189,6 +1305,12 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_pre), (size_t)2 * nb * NB * NB * sizeof(double));
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
+  if (std::getenv("MAVBA_CHOL_TRACE")) {
+    h_tasks = tasks; h_wg_begin = wg_begin;
+    const size_t ntr = (size_t)8 * nb + (size_t)4 * tasks.size();
+    if (device_alloc(reinterpret_cast<void**>(&d_trace), ntr * 8) == hipSuccess) (void)hipMemset(d_trace, 0, ntr * 8);
+    else d_trace = nullptr;
+  }
   d_wg_begin = d_pints; d_upd = d_pints + o_upd; d_tile_id = d_pints + o_tid; d_chain_info = d_pints + o_ci;
   persist_grid = grid; persist_chain_wgs = nch; persist_tiles = nt; persist_updates = nupd;
   epoch = 0;
@@ -1210,7 +1332,7 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
     A.M = M; A.L = L; A.inv = inv; A.pre = cs.d_pre; A.ld = ld; A.nb = nb;
     A.tasks = cs.d_tasks; A.wg_begin = cs.d_wg_begin; A.upd = cs.d_upd; A.tile_id = cs.d_tile_id; A.chain_info = cs.d_chain_info;
     A.lflag = cs.d_pflags; A.dflag = cs.d_pflags + cs.persist_tiles; A.pflag = A.dflag + nb; A.abort_flag = A.pflag + 2 * nb;
-    A.epoch = epoch; A.fail = fail;
+    A.epoch = epoch; A.fail = fail; A.trace = cs.d_trace;
     hipLaunchKernelGGL(k_chol_persist, dim3(cs.persist_grid), dim3(256), 0, st, A);
   } else {
   if (cs.shadow_doubles) (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);
@@ -1244,7 +1366,8 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
   }
   double* z = L + (size_t)n_pad * ld;
   if (nb <= kMaxBacksolveGroups) {
-    hipLaunchKernelGGL(k_chol_backsolve_all, dim3(nb), dim3(256), 0, st, L, ld, nb, cs.nseg, cs.d_seg_of_tile, cs.d_seg_first,
+    const int cus = device_cu_count();
+    hipLaunchKernelGGL(k_chol_backsolve_all, dim3(std::min(nb, cus > 0 ? 2 * cus : 64)), dim3(256), 0, st, L, ld, nb, cs.nseg, cs.d_seg_of_tile, cs.d_seg_first,
                        inv, z, y, cs.d_flags, epoch, y_scatter, y_nat);
   } else {
     // more tile rows than work-groups that are certainly resident: one small launch per tile (single segment)

@@ -273,6 +273,9 @@ struct CholStructure {
   int *d_wg_begin = nullptr, *d_upd = nullptr, *d_tile_id = nullptr, *d_chain_info = nullptr;
   unsigned* d_pflags = nullptr;   // lflag[persist_tiles] | dflag[nb] | pflag[2 nb] | abort[1]
   double* d_pre = nullptr;        // [2 nb] 64x64 tiles: the chain's tiles after the helpers' updates
+  unsigned long long* d_trace = nullptr;  // MAVBA_CHOL_TRACE=<file>: stamps of the last solve, dumped on release
+  std::vector<CholTask> h_tasks;          // (kept for the trace dump only)
+  std::vector<int> h_wg_begin;
   mutable unsigned epoch = 0;     // flags are compared with the solve's epoch: nothing is cleared between solves
   CholStructure() {}
   CholStructure(const CholStructure&) = delete;
