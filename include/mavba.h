@@ -176,6 +176,17 @@ int mavba_solve(const mavba_problem* problem, const mavba_options* options,
                 mavba_result* result, double* point_error);
 
 /*
+ * Global BA, point filter, global BA again on ONE resident session (reference src/mapper.cc:1206 + 1218-1224:
+ * adjust_global_bundle, filter_point_cloud, adjust_global_bundle). Parameters are written back in place after
+ * the second solve; `removed` [num_points] (may be NULL) marks the filtered points, whose FeatureManager entries
+ * the caller deletes; `point_error` (may be NULL) receives the errors of the points that remain.
+ * `first` / `second` (may be NULL) summarise the two solves.
+ */
+int mavba_solve_filter_solve(const mavba_problem* problem, const mavba_options* options, double filter_max_error,
+                             const uint8_t* keep, mavba_result* first, mavba_result* second, double* point_error,
+                             uint8_t* removed, int64_t* num_removed);
+
+/*
  * Single-camera 6-DoF refinement with points and intrinsics held constant.
  * `uv` [n][2], `xyz` [n][3], `inlier_mask` [n] (NULL = all inliers).
  * Replaces: pose_refinement(), bundle_adjustment.cc:139-225.
@@ -214,6 +225,27 @@ int mavba_session_get_params(mavba_session* s, double* poses,
 
 /* Per-point mean raw reprojection error at the current parameters. */
 int mavba_session_point_errors(mavba_session* s, double* point_error);
+
+/* Overwrite current parameters on the device (any array may be NULL = keep). The structure of the problem does
+ * not change, so nothing of the set-up is repeated; the LM state is NOT touched (call mavba_session_restart). */
+int mavba_session_set_params(mavba_session* s, const double* poses, const double* intrinsics, const double* points);
+
+/* Begin a new solve from the current parameters: what a second bundle_adjustment() call on the same data does
+ * (fresh trust region, Jacobi scaling re-estimated, counters zeroed) without repeating the set-up. */
+int mavba_session_restart(mavba_session* s);
+
+/*
+ * Point filtering on the resident session. Replaces: filter_point_cloud(), reference src/mapper.cc:382-402, whose
+ * callers run a global BA, filter, and run the global BA again (src/mapper.cc:1206, 1218-1224).
+ * Every point whose point3D error (mean raw reprojection error at the current parameters,
+ * bundle_adjustment.cc:575-598) exceeds `max_error` leaves the problem - all its residual blocks are removed -
+ * unless keep[point] != 0 (`keep` may be NULL; the reference's keep_point3D_ids). Counts, used / constant
+ * blocks and the fixed cost are re-derived and the session is restarted, ready for mavba_session_iterate.
+ *   removed   [num_points] (may be NULL): 1 for every point filtered so far
+ *   errors    [num_points] (may be NULL): the errors the decision was taken on (untouched for points without observations)
+ */
+int mavba_session_filter_points(mavba_session* s, double max_error, const uint8_t* keep, uint8_t* removed,
+                                double* errors, int64_t* num_removed);
 
 /*
  * Multi-GPU hook. When the points are sharded over several processes (one

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "mavba_session_set_allreduce", "mavba_session_eval_jacobian", "mavba_session_reduced_dim",
     "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian",
     "mavba_session_kernel_stats", "mavba_session_get_info", "mavba_dense_spd_solve",
+    "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -81,6 +82,10 @@ def load():
     L.mavba_session_kernel_stats.argtypes = [sp, C.POINTER(A.CKernelStat), C.c_int32]
     L.mavba_session_get_info.argtypes = [sp, C.POINTER(A.CSessionInfo)]
     L.mavba_dense_spd_solve.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
+    L.mavba_session_set_params.argtypes = [sp, dp, dp, dp]
+    L.mavba_session_restart.argtypes = [sp]
+    L.mavba_session_filter_points.argtypes = [sp, C.c_double, bp, bp, dp, C.POINTER(C.c_int64)]
+    L.mavba_solve_filter_solve.argtypes = [pp, op, C.c_double, bp, rp, rp, dp, bp, C.POINTER(C.c_int64)]
     for f in EXPORTED_SYMBOLS:
         if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy"):
             getattr(L, f).restype = C.c_int
@@ -182,6 +187,23 @@ def bundle_adjustment(problem: BAProblem, options=None, point3D_errors=None, **k
     return float(np.sqrt(out["final_cost"] / out["num_residuals"])) if out["num_residuals"] else float("nan"), out
 
 
+def bundle_adjustment_filter_rebundle(problem: BAProblem, filter_max_error, options=None, keep=None, point3D_errors=None, **kw):
+    """Global BA, filter_point_cloud, global BA again on one resident session (reference src/mapper.cc:1206,
+    1218-1224). Solves IN PLACE; returns (removed mask [num_points] uint8, first result, second result)."""
+    copt = make_options(options, **kw)
+    first, second = A.CResult(), A.CResult()
+    cp = problem.c_struct()
+    removed = np.zeros(problem.num_points, np.uint8)
+    keep_arr = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+    n = C.c_int64()
+    _check(load().mavba_solve_filter_solve(C.byref(cp), C.byref(copt), float(filter_max_error), A.ptr(keep_arr, C.c_uint8),
+                                           C.byref(first), C.byref(second),
+                                           _d(point3D_errors) if point3D_errors is not None else None,
+                                           A.ptr(removed, C.c_uint8), C.byref(n)))
+    assert int(removed.sum()) == n.value
+    return removed, first.as_dict(), second.as_dict()
+
+
 def pose_refinement(rvec, tvec, camera_params, points2D, points3D, inlier_mask=None, options=None, **kw):
     """Mirror of pose_refinement() (bundle_adjustment.h:212-218). `camera_params` carries the model
     code as its last element, exactly like FeatureManager.camera_params
@@ -253,6 +275,25 @@ class Session:
         e = np.full(self.problem.num_points, np.nan)
         _check(load().mavba_session_point_errors(self._h, _d(e)))
         return e
+
+    def set_params(self, poses=None, intrinsics=None, points=None):
+        p = self.problem
+        arrs = [None if a is None else A.as_f64(a, shape) for a, shape in
+                ((poses, (p.num_images, 6)), (intrinsics, (p.num_cameras, 9)), (points, (p.num_points, 3)))]
+        _check(load().mavba_session_set_params(self._h, *[None if a is None else _d(a) for a in arrs]))
+
+    def restart(self):
+        _check(load().mavba_session_restart(self._h))
+
+    def filter_points(self, max_error, keep=None):
+        """filter_point_cloud on the resident session: returns (removed mask, errors the decision used)."""
+        n = self.problem.num_points
+        removed, errors = np.zeros(n, np.uint8), np.full(n, np.nan)
+        keep_arr = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        cnt = C.c_int64()
+        _check(load().mavba_session_filter_points(self._h, float(max_error), A.ptr(keep_arr, C.c_uint8),
+                                                  A.ptr(removed, C.c_uint8), _d(errors), C.byref(cnt)))
+        return removed, errors
 
     def set_allreduce(self, fn, rank, world_size):
         """fn(device_ptr:int, count:int, op:int) -> None; must all-reduce in place and return when done."""

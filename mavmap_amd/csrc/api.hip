@@ -74,6 +74,7 @@ void mavba_session_destroy(mavba_session* s) { delete s; }
 
 int mavba_session_reset(mavba_session* s) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   s->reset_state();
   s->sync();
   return MAVBA_OK;
@@ -82,6 +83,7 @@ int mavba_session_reset(mavba_session* s) {
 
 int mavba_session_iterate(mavba_session* s, int32_t max_iters, int32_t* iters_done, int32_t* termination) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   int done = 0;
   s->iterate(max_iters, &done);
   if (iters_done) *iters_done = done;
@@ -92,6 +94,7 @@ int mavba_session_iterate(mavba_session* s, int32_t max_iters, int32_t* iters_do
 
 int mavba_session_result(mavba_session* s, mavba_result* result) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   s->fill_result(result);
   return MAVBA_OK;
   MAVBA_CATCH
@@ -99,6 +102,7 @@ int mavba_session_result(mavba_session* s, mavba_result* result) {
 
 int mavba_session_get_params(mavba_session* s, double* poses, double* intrinsics, double* points) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   if (poses && s->NI) HIP_OK(hipMemcpyAsync(poses, s->d_poses.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
   if (intrinsics && s->NC) HIP_OK(hipMemcpyAsync(intrinsics, s->d_intr.p, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
   std::vector<double> hp;
@@ -111,14 +115,52 @@ int mavba_session_get_params(mavba_session* s, double* poses, double* intrinsics
 
 int mavba_session_point_errors(mavba_session* s, double* point_error) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   if (!point_error) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null point_error");
   s->point_errors(point_error);
   return MAVBA_OK;
   MAVBA_CATCH
 }
 
+int mavba_session_set_params(mavba_session* s, const double* poses, const double* intrinsics, const double* points) {
+  MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  if (poses && s->NI) HIP_OK(hipMemcpyAsync(s->d_poses.p, poses, (size_t)s->NI * 48, hipMemcpyHostToDevice, s->st));
+  if (intrinsics && s->NC) HIP_OK(hipMemcpyAsync(s->d_intr.p, intrinsics, (size_t)s->NC * 72, hipMemcpyHostToDevice, s->st));
+  std::vector<double> hp;
+  if (points && s->NP) {
+    hp.resize((size_t)s->NP * 3);
+    for (int q = 0; q < s->NP; ++q)
+      for (int e = 0; e < 3; ++e) hp[(size_t)q * 3 + e] = points[(size_t)s->h_pt_orig[q] * 3 + e];
+    HIP_OK(hipMemcpyAsync(s->d_points.p, hp.data(), hp.size() * 8, hipMemcpyHostToDevice, s->st));
+  }
+  s->camrec_current = false; s->evaluated = false;
+  s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_restart(mavba_session* s) {
+  MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  s->restart();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_filter_points(mavba_session* s, double max_error, const uint8_t* keep, uint8_t* removed, double* errors,
+                                int64_t* num_removed) {
+  MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  const long long n = s->filter_points(max_error, keep, removed, errors);
+  if (num_removed) *num_removed = n;
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
 int mavba_session_set_allreduce(mavba_session* s, mavba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world_size) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_allreduce must precede the first iteration");
   s->ar_fn = fn; s->ar_ctx = ctx; s->rank = rank; s->world = world_size;
   if (fn && world_size > 1) {
@@ -157,6 +199,7 @@ int mavba_session_set_allreduce(mavba_session* s, mavba_allreduce_fn fn, void* c
 
 int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, double* Jc, double* Jp, double* Jk) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   s->evaluate();
   if (cost) *cost = s->cost + s->fixed_cost;
   const size_t S = s->Nstride, N = s->N;
@@ -189,6 +232,7 @@ int mavba_session_reduced_dim(mavba_session* s) { return s ? s->n_full : 0; }
 
 int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, double* vout) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   if (!s->evaluated) s->evaluate();
   s->assemble(radius);
   // the device matrix is in elimination order; hand it out in the variables' order
@@ -213,6 +257,7 @@ int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, 
 int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, double* d_intr, double* d_points,
                               double* model_cost_change) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   if (!s->evaluated) s->evaluate();
   double h[SC_COUNT];
   s->linear_step(radius, h);
@@ -230,6 +275,7 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, 
 
 int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   MAVBA_TRY
+  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   if (reps < 1) reps = 1;
   launch_cam_prepare(s->st, s->NI, s->d_poses.p, s->d_camrec.p);
   SweepArgs a = s->sweep_args(s->d_camrec.p, s->d_intr.p, s->d_points.p);
@@ -298,6 +344,25 @@ int mavba_solve(const mavba_problem* problem, const mavba_options* options, mavb
   if (rc == MAVBA_OK && term != MAVBA_TERM_NUMERICAL_FAILURE)
     rc = mavba_session_get_params(s, problem->poses, problem->intrinsics, problem->points);
   if (rc == MAVBA_OK && point_error && options->update_point_errors) rc = mavba_session_point_errors(s, point_error);
+  mavba_session_destroy(s);
+  return rc;
+}
+
+int mavba_solve_filter_solve(const mavba_problem* problem, const mavba_options* options, double filter_max_error,
+                             const uint8_t* keep, mavba_result* first, mavba_result* second, double* point_error,
+                             uint8_t* removed, int64_t* num_removed) {
+  mavba_session* s = nullptr;
+  int rc = mavba_session_create(problem, options, &s);
+  if (rc != MAVBA_OK) return rc;
+  int done = 0, term = 0;
+  rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &term);
+  if (rc == MAVBA_OK && first) rc = mavba_session_result(s, first);
+  if (rc == MAVBA_OK) rc = mavba_session_filter_points(s, filter_max_error, keep, removed, nullptr, num_removed);
+  if (rc == MAVBA_OK) rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &term);
+  if (rc == MAVBA_OK && second) rc = mavba_session_result(s, second);
+  if (rc == MAVBA_OK && term != MAVBA_TERM_NUMERICAL_FAILURE)
+    rc = mavba_session_get_params(s, problem->poses, problem->intrinsics, problem->points);
+  if (rc == MAVBA_OK && point_error) rc = mavba_session_point_errors(s, point_error);
   mavba_session_destroy(s);
   return rc;
 }

@@ -91,6 +91,7 @@ struct SweepArgs {
   const double2* uv; const int* obs_img; const int* obs_pt;
   const double* camrec; const double* intr; const int* img_cam; const int* cam_model;
   const double* points;
+  const unsigned char* pt_active;                    // null, or 0 for points filtered out of the resident problem (their rows are zero)
   double loss_b, loss_inv_b;
   double* R; double* Jp; double* Jc; double* Jk;   // SoA planes, stride Nstride
   double* cost_partial;                              // [grid]
@@ -111,7 +112,7 @@ struct CamSweepArgs {
   const SweepChunk* chunks; int num_chunks;
   const double2* im_uv; const int* im_pt;
   const double* camrec; const double* intr; const int* img_cam; const int* cam_model;
-  const double* points; double loss_b, loss_inv_b;
+  const double* points; const unsigned char* pt_active; double loss_b, loss_inv_b;
   double* partial;  // [num_chunks][kSweepAcc]
 };
 void launch_camera_sweep(hipStream_t st, const CamSweepArgs& a, int kmax, bool any_intr_free);

@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(256) k_jacobian_sweep(SweepArgs a) {
       obs_jacobian(model, rec, kin, X, uo[j], vo[j], r, Jc, Jp, Jk);
       double w, half_rho;
       cauchy_weight(r[0] * r[0] + r[1] * r[1], a.loss_b, a.loss_inv_b, w, half_rho);
+      if (a.pt_active && !a.pt_active[pt[j]]) { w = 0.0; half_rho = 0.0; }  // filtered point: no residual block
       if (j == 0 || two) cost += half_rho;
       out[j][0] = w * r[0]; out[j][1] = w * r[1];
 #pragma unroll
@@ -220,6 +221,7 @@ __global__ void __launch_bounds__(256) k_cost_only(SweepArgs a) {
     obs_residual(T.model[cam], rec, kin, X, m.x, m.y, r);
     double w, half_rho;
     cauchy_weight(r[0] * r[0] + r[1] * r[1], a.loss_b, a.loss_inv_b, w, half_rho);
+    if (a.pt_active && !a.pt_active[pt]) half_rho = 0.0;
     cost += half_rho;
   }
   const double tot = block_sum_256(cost, smem);
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) k_raw_residual_norm(SweepArgs a, double* 
   const int cam = a.img_cam[im];
   double r[2];
   obs_residual(a.cam_model[cam], a.camrec + 9 * im, a.intr + 9 * cam, a.points + 3 * (long long)pt, m.x, m.y, r);
-  out[o] = sqrt(r[0] * r[0] + r[1] * r[1]);
+  out[o] = (a.pt_active && !a.pt_active[pt]) ? 0.0 : sqrt(r[0] * r[0] + r[1] * r[1]);
 }
 
 void launch_jacobian_sweep(hipStream_t st, const SweepArgs& a) {
@@ -444,23 +446,28 @@ __global__ void __launch_bounds__(256) k_camera_sweep(CamSweepArgs a) {
   double2 m = make_double2(0.0, 0.0), m_n = m;
   int pt_n = 0;
   double X[3] = {0.0, 0.0, 1.0};
+  double act = 1.0, act_n = 1.0;
   if (o < ch.end) {
     m = a.im_uv[o];
     const int pt = a.im_pt[o];
     X[0] = a.points[3 * (long long)pt]; X[1] = a.points[3 * (long long)pt + 1]; X[2] = a.points[3 * (long long)pt + 2];
+    if (a.pt_active) act = a.pt_active[pt] ? 1.0 : 0.0;
   }
   if (o + 256 < ch.end) { m_n = a.im_uv[o + 256]; pt_n = a.im_pt[o + 256]; }
   for (; o < ch.end; o += 256) {
     double Xn[3] = {0.0, 0.0, 1.0};
     double2 m_nn = make_double2(0.0, 0.0);
     int pt_nn = 0;
-    if (o + 256 < ch.end) { Xn[0] = a.points[3 * (long long)pt_n]; Xn[1] = a.points[3 * (long long)pt_n + 1]; Xn[2] = a.points[3 * (long long)pt_n + 2]; }
+    if (o + 256 < ch.end) {
+      Xn[0] = a.points[3 * (long long)pt_n]; Xn[1] = a.points[3 * (long long)pt_n + 1]; Xn[2] = a.points[3 * (long long)pt_n + 2];
+      if (a.pt_active) act_n = a.pt_active[pt_n] ? 1.0 : 0.0;
+    }
     if (o + 512 < ch.end) { m_nn = a.im_uv[o + 512]; pt_nn = a.im_pt[o + 512]; }
     double r[2], Jc[12], Jp[6], Jk[18];
     obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
     double w, half_rho;
     cauchy_weight(r[0] * r[0] + r[1] * r[1], a.loss_b, a.loss_inv_b, w, half_rho);
-    const double w2 = w * w;  // every product below carries two weighted factors
+    const double w2 = act * w * w;  // every product below carries two weighted factors (0 for a filtered point)
 #pragma unroll
     for (int x = 0; x < 6; ++x) {
 #pragma unroll
@@ -481,6 +488,7 @@ __global__ void __launch_bounds__(256) k_camera_sweep(CamSweepArgs a) {
       }
     }
     X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
+    act = act_n;
     m = m_n; m_n = m_nn; pt_n = pt_nn;
   }
   // block reduction into the fixed 135-slot layout

@@ -144,11 +144,19 @@ struct mavba_session {
   std::vector<long long> perm;      // point-major position -> caller observation index
   std::vector<int> h_pt_count_all;  // observations per point in the caller's problem
   std::vector<double> h_dropped_rnorm;  // caller's point index -> sum |r_raw| of its all-constant (dropped) observations; empty if none
+  std::vector<double> h_dropped_cost;   // caller's point index -> their part of the fixed cost; empty if none
+  double fixed_cost_priors = 0.0;       // the constant rotation priors' part of the fixed cost
+  int num_priors_all = 0;               // rotation priors in the caller's problem
+  // Points filtered out of the resident problem (mavba_session_filter_points): internal order, empty = none.
+  // Their observations stay in the arrays with zero weight, their blocks are not free.
+  std::vector<unsigned char> h_pt_removed;
+  DevBuf<unsigned char> d_pt_active;
   // Points are renumbered at session creation (sorted by their image lists, so that neighbours in the order
   // see the same images: the Schur-complement clusters rely on it). h_pt_orig[internal] = caller's index.
   std::vector<int> h_pt_orig;
   std::vector<unsigned char> h_pose_const, h_intr_const_in, h_pt_const_in;
   std::vector<unsigned char> h_img_used, h_cam_used, h_pt_used;
+  std::vector<unsigned char> h_prior_on_img;  // image carries a (non-constant) rotation prior
   std::vector<unsigned char> h_pose_free, h_intr_free, h_pt_free;
   double fixed_cost = 0.0;
   long long num_residuals = 0, num_residuals_reduced = 0, num_parameters_reduced = 0;
@@ -272,6 +280,7 @@ struct mavba_session {
     a.uv = d_uv.p; a.obs_img = d_obs_img.p; a.obs_pt = d_obs_pt.p;
     a.camrec = camrec; a.intr = intr; a.img_cam = d_img_cam.p; a.cam_model = d_cam_model.p;
     a.points = points;
+    a.pt_active = h_pt_removed.empty() ? nullptr : d_pt_active.p;
     a.loss_b = opt.loss_scale_factor * opt.loss_scale_factor; a.loss_inv_b = 1.0 / a.loss_b;
     a.R = d_R.p; a.Jp = d_Jp.p; a.Jc = d_Jc.p; a.Jk = d_Jk.p; a.cost_partial = d_sweep_partial.p;
     return a;
@@ -296,6 +305,8 @@ struct mavba_session {
   void start();
   int iterate(int max_iters, int* done);
   void point_errors(double* out);
+  void restart();  // a new solve from the current parameters (LM state, Jacobi scales; the structure stays)
+  long long filter_points(double max_error, const unsigned char* keep, unsigned char* removed_out, double* errors_out);
   void to_caller_points(const double* internal, double* out, int width) const {
     for (int q = 0; q < NP; ++q)
       for (int e = 0; e < width; ++e) out[(size_t)h_pt_orig[q] * width + e] = internal[(size_t)q * width + e];

@@ -72,6 +72,8 @@ void mavba_session::build(const mavba_problem* P) {
     });
     if (bad) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
   }
+  if (P->num_rot_priors < 0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "negative num_rot_priors");
+  if (P->num_rot_priors > 0 && (!P->rot_prior_image || !P->rot_prior_rvec)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null rotation-prior arrays");
   for (int q = 0; q < P->num_rot_priors; ++q)
     if (P->rot_prior_image[q] < 0 || P->rot_prior_image[q] >= NI) throw Failure(MAVBA_ERR_BAD_INDEX, "rot_prior_image out of range");
 
@@ -86,7 +88,7 @@ void mavba_session::build(const mavba_problem* P) {
   // Residual blocks without a free parameter block leave the program (ceres
   // RemoveFixedBlocksFromProgram); their cost is the fixed cost.
   h_pt_count_all.assign(NP, 0);
-  h_dropped_rnorm.clear();
+  h_dropped_rnorm.clear(); h_dropped_cost.clear(); h_pt_removed.clear();
   std::vector<long long> kept;
   kept.reserve((size_t)NO_all);
   fixed_cost = 0.0;
@@ -116,8 +118,9 @@ void mavba_session::build(const mavba_problem* P) {
         fixed_cost += hr;
         // its raw residual never changes (every block is constant) but it still counts in the point's error
         // (problem.Evaluate covers all residual blocks, bundle_adjustment.cc:583-596)
-        if (h_dropped_rnorm.empty()) h_dropped_rnorm.assign(NP, 0.0);
+        if (h_dropped_rnorm.empty()) { h_dropped_rnorm.assign(NP, 0.0); h_dropped_cost.assign(NP, 0.0); }
         h_dropped_rnorm[p] += std::sqrt(r[0] * r[0] + r[1] * r[1]);
+        h_dropped_cost[p] += hr;
         continue;
       }
       kept.push_back(o);
@@ -131,6 +134,9 @@ void mavba_session::build(const mavba_problem* P) {
 
   // rotation priors: kept when the image's rvec block is free, sorted by image
   std::vector<std::pair<int, int>> pri;  // (image, index)
+  h_prior_on_img.assign(NI, 0);
+  fixed_cost_priors = 0.0;
+  num_priors_all = P->num_rot_priors;
   for (int q = 0; q < P->num_rot_priors; ++q) {
     const int i = P->rot_prior_image[q];
     if (h_pose_const[i] & MAVBA_CONST_RVEC) {
@@ -138,10 +144,12 @@ void mavba_session::build(const mavba_problem* P) {
       rot_matrix_colmajor(&P->rot_prior_rvec[3 * q], R0);
       rot_prior_eval(&h_poses0[(size_t)i * 6], R0, P->rot_prior_weight, r, j);
       fixed_cost += 0.5 * r * r;
+      fixed_cost_priors += 0.5 * r * r;
       continue;
     }
     pri.push_back({i, q});
     h_img_used[i] = 1;
+    h_prior_on_img[i] = 1;
   }
   std::stable_sort(pri.begin(), pri.end());
   num_priors = (int)pri.size();

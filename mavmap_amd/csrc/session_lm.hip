@@ -32,6 +32,7 @@ void mavba_session::evaluate_enqueue() {
   c.NI = NI; c.NC = NC; c.chunks = d_sweep_chunks.p; c.num_chunks = num_sweep_chunks;
   c.im_uv = d_im_uv.p; c.im_pt = d_im_pt.p; c.camrec = d_camrec.p; c.intr = d_intr.p;
   c.img_cam = d_img_cam.p; c.cam_model = d_cam_model.p; c.points = d_points.p;
+  c.pt_active = a.pt_active;
   c.loss_b = a.loss_b; c.loss_inv_b = a.loss_inv_b; c.partial = d_cam_partial.p;
   timed("camera_sweep", [&] { launch_camera_sweep(st, c, KMAX, any_intr_free); });
   if (num_priors > 0)
@@ -279,10 +280,69 @@ void mavba_session::point_errors(double* out) {
   // Only points that have observations in the problem are touched (bundle_adjustment.cc:578-581);
   // observations dropped as all-constant blocks still count (they are residual blocks there).
   for (int p = 0; p < NP; ++p)
-    if (h_pt_count_all[p] > 0) {
+    if (h_pt_count_all[p] > 0 && (h_pt_removed.empty() || !h_pt_removed[p])) {
       const int po = h_pt_orig[p];
       out[po] = h_dropped_rnorm.empty() ? h[p] : h[p] + h_dropped_rnorm[po] / (double)h_pt_count_all[p];
     }
+}
+
+// A new solve from the current parameters: what a second bundle_adjustment() call on the same data does (ceres::Solve
+// starts with a fresh trust region and re-estimates the Jacobi scaling), without any of the set-up.
+void mavba_session::restart() {
+  evaluated = scales_ready = started = assembled = false;
+  radius = opt.initial_trust_region_radius; decrease_factor = 2.0;
+  cost = x_norm = grad_max = abs_gtol = initial_cost = 0.0;
+  iteration = invalid_steps = n_success = n_fail = 0;
+  termination = MAVBA_TERM_RUNNING;
+  solve_seconds = 0.0;
+}
+
+// filter_point_cloud (reference src/mapper.cc:382-402): points whose mean raw reprojection error exceeds max_error leave
+// the problem (unless kept). On the resident session their observations get zero weight and their blocks stop being
+// free - the index structure of the set-up is a superset of what the smaller problem needs and stays as it is - then
+// the counts, the used / free flags of images and cameras and the fixed cost are re-derived and the solve restarts.
+long long mavba_session::filter_points(double max_error, const unsigned char* keep, unsigned char* removed_out,
+                                       double* errors_out) {
+  if (world > 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "filter_points on a sharded session is not supported");
+  const double t0 = now_s();
+  std::vector<double> err((size_t)std::max(NP, 1), 0.0);
+  // (NaN marks points without observations in the problem: never filtered, like points BA never reported on)
+  std::fill(err.begin(), err.end(), std::numeric_limits<double>::quiet_NaN());
+  point_errors(err.data());
+  if (errors_out) std::memcpy(errors_out, err.data(), (size_t)NP * 8);
+  if (h_pt_removed.empty()) h_pt_removed.assign((size_t)std::max(NP, 1), 0);
+  long long removed = 0;
+  for (int q = 0; q < NP; ++q) {
+    const int po = h_pt_orig[q];
+    const bool out = !h_pt_removed[q] && !(keep && keep[po]) && err[po] > max_error;
+    if (out) { h_pt_removed[q] = 1; ++removed; }
+    if (removed_out) removed_out[po] = h_pt_removed[q];
+  }
+  if (removed == 0 && d_pt_active.p) { restart(); return 0; }
+  // re-derive what depends on the set of residual blocks
+  std::vector<unsigned char> active((size_t)std::max(NP, 1), 1);
+  std::fill(h_img_used.begin(), h_img_used.end(), 0);
+  std::fill(h_cam_used.begin(), h_cam_used.end(), 0);
+  long long n_all = 0, n_kept = 0;
+  fixed_cost = fixed_cost_priors;
+  for (int q = 0; q < NP; ++q) {
+    if (h_pt_removed[q]) { active[q] = 0; h_pt_used[q] = 0; continue; }
+    n_all += h_pt_count_all[q];
+    n_kept += h_pt_start[q + 1] - h_pt_start[q];
+    if (!h_dropped_cost.empty()) fixed_cost += h_dropped_cost[h_pt_orig[q]];
+    for (int a = h_pt_start[q]; a < h_pt_start[q + 1]; ++a) { h_img_used[h_oimg[a]] = 1; h_cam_used[h_img_cam[h_oimg[a]]] = 1; }
+  }
+  for (int i = 0; i < NI; ++i) if (h_prior_on_img[i]) h_img_used[i] = 1;
+  num_residuals = 2 * n_all + num_priors_all;
+  num_residuals_reduced = 2 * n_kept + num_priors;
+  derive_free_flags();
+  d_pose_free.upload(h_pose_free, st); d_intr_free.upload(h_intr_free, st); d_pt_free.upload(h_pt_free, st);
+  d_pt_active.upload(active, st);
+  // constant / unused columns get their unit diagonal from the scales (k_fix_diag) once they are re-estimated
+  sync();
+  restart();
+  setup_seconds += now_s() - t0;
+  return removed;
 }
 
 void mavba_session::fill_result(mavba_result* r) {
