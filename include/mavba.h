@@ -196,6 +196,26 @@ int mavba_pose_refine(double rvec[3], double tvec[3], const double* intrinsics,
                       const uint8_t* inlier_mask, int64_t n,
                       const mavba_options* options, mavba_result* result);
 
+/*
+ * Many pose refinements in ONE launch: the inlier sets of several RANSAC hypotheses of one image, or the image
+ * pairs of several images (reference call site: src/sfm/sequential_mapper.cc:709-732, one call per processed
+ * pair). Each item is an independent pose_refinement() problem; one work-group runs the whole trust-region
+ * loop of one item on the device. rvec / tvec of every item are updated in place; `results` [count] may be NULL.
+ * mavba_pose_refine() is this call with count = 1.
+ */
+typedef struct mavba_pose_refine_item {
+  double rvec[3];              /* in/out */
+  double tvec[3];              /* in/out */
+  const double* intrinsics;    /* first K values of the camera's parameters */
+  int32_t camera_model;        /* MAVBA_MODEL_*                             */
+  const double* uv;            /* [n][2]                                    */
+  const double* xyz;           /* [n][3]                                    */
+  const uint8_t* inlier_mask;  /* [n], NULL = all inliers                   */
+  int64_t n;
+} mavba_pose_refine_item;
+int mavba_pose_refine_batch(int32_t count, mavba_pose_refine_item* items, const mavba_options* options,
+                            mavba_result* results);
+
 /* ------------------------------------------------------------------------
  * Session API: the same solver with device-resident state, for callers that
  * iterate (local BA after every image), for the parity tests (intermediate

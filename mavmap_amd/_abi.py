@@ -75,6 +75,11 @@ class CResult(C.Structure):
         return d
 
 
+class CPoseRefineItem(C.Structure):
+    _fields_ = [("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("intrinsics", _dp), ("camera_model", C.c_int32),
+                ("uv", _dp), ("xyz", _dp), ("inlier_mask", _bp), ("n", C.c_int64)]
+
+
 class CSessionInfo(C.Structure):
     _fields_ = [("num_obs_kept", C.c_int64), ("reduced_dim", C.c_int32), ("padded_dim", C.c_int32),
                 ("schur_terms", C.c_int64 * 3), ("schur_blocks", C.c_int64), ("intr_entries", C.c_int64),

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "mavba_session_set_allreduce", "mavba_session_eval_jacobian", "mavba_session_reduced_dim",
     "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian",
     "mavba_session_kernel_stats", "mavba_session_get_info", "mavba_dense_spd_solve",
-    "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
+    "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -82,6 +82,7 @@ def load():
     L.mavba_session_kernel_stats.argtypes = [sp, C.POINTER(A.CKernelStat), C.c_int32]
     L.mavba_session_get_info.argtypes = [sp, C.POINTER(A.CSessionInfo)]
     L.mavba_dense_spd_solve.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
+    L.mavba_pose_refine_batch.argtypes = [C.c_int32, C.POINTER(A.CPoseRefineItem), op, rp]
     L.mavba_session_set_params.argtypes = [sp, dp, dp, dp]
     L.mavba_session_restart.argtypes = [sp]
     L.mavba_session_filter_points.argtypes = [sp, C.c_double, bp, bp, dp, C.POINTER(C.c_int64)]
@@ -222,6 +223,35 @@ def pose_refinement(rvec, tvec, camera_params, points2D, points3D, inlier_mask=N
     np.asarray(tvec)[...] = tv
     out = res.as_dict()
     return float(np.sqrt(out["final_cost"] / out["num_residuals"])) if out["num_residuals"] else float("nan"), out
+
+
+def pose_refinement_batch(items, options=None, **kw):
+    """Many pose_refinement() problems in one launch (mavba_pose_refine_batch). `items`: list of dicts with rvec, tvec
+    (float64 arrays of 3, updated in place), camera_params (model code last), points2D [n,2], points3D [n,3] and an
+    optional inlier_mask [n]. Returns the list of (final_cost_px, result) pairs."""
+    n = len(items)
+    arr = (A.CPoseRefineItem * max(n, 1))()
+    hold = []
+    for q, it in enumerate(items):
+        cp = np.asarray(it["camera_params"], float)
+        intr = A.as_f64(np.pad(cp[:-1], (0, 9 - (len(cp) - 1))))
+        uv, xyz = A.as_f64(it["points2D"], (-1, 2)), A.as_f64(it["points3D"], (-1, 3))
+        mask = None if it.get("inlier_mask") is None else np.ascontiguousarray(it["inlier_mask"], dtype=np.uint8)
+        hold.append((intr, uv, xyz, mask))
+        for k in range(3):
+            arr[q].rvec[k] = float(it["rvec"][k]); arr[q].tvec[k] = float(it["tvec"][k])
+        arr[q].intrinsics = _d(intr); arr[q].camera_model = int(cp[-1])
+        arr[q].uv = _d(uv); arr[q].xyz = _d(xyz); arr[q].inlier_mask = A.ptr(mask, C.c_uint8); arr[q].n = len(uv)
+    res = (A.CResult * max(n, 1))()
+    copt = make_options(options, **kw)
+    _check(load().mavba_pose_refine_batch(n, arr, C.byref(copt), res))
+    out = []
+    for q, it in enumerate(items):
+        np.asarray(it["rvec"])[...] = list(arr[q].rvec)
+        np.asarray(it["tvec"])[...] = list(arr[q].tvec)
+        d = res[q].as_dict()
+        out.append((float(np.sqrt(d["final_cost"] / d["num_residuals"])) if d["num_residuals"] else float("nan"), d))
+    return out
 
 
 class Session:

@@ -367,6 +367,18 @@ int mavba_solve_filter_solve(const mavba_problem* problem, const mavba_options* 
   return rc;
 }
 
+int mavba_pose_refine_batch(int32_t count, mavba_pose_refine_item* items, const mavba_options* options, mavba_result* results) {
+  if (count < 0 || (count > 0 && !items) || !options) { g_last_error = "null argument"; return MAVBA_ERR_INVALID_ARGUMENT; }
+  if (count == 0) return MAVBA_OK;
+  if (mavba_device_count() <= 0) { g_last_error = "no HIP device: the mavba backend has no CPU path"; return MAVBA_ERR_NO_DEVICE; }
+  if (!(options->loss_scale_factor > 0.0)) { g_last_error = "loss_scale_factor must be > 0"; return MAVBA_ERR_INVALID_ARGUMENT; }
+  MAVBA_TRY
+  if (options->device >= 0) HIP_OK(hipSetDevice(options->device));
+  pose_refine_batch(count, items, *options, results);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
 int mavba_pose_refine(double rvec[3], double tvec[3], const double* intrinsics, int32_t camera_model,
                       const double* uv, const double* xyz, const uint8_t* inlier_mask, int64_t n,
                       const mavba_options* options, mavba_result* result) {
@@ -374,6 +386,15 @@ int mavba_pose_refine(double rvec[3], double tvec[3], const double* intrinsics, 
     g_last_error = "null argument"; return MAVBA_ERR_INVALID_ARGUMENT;
   }
   if (camera_model < 1 || camera_model > 3) { g_last_error = "bad camera model"; return MAVBA_ERR_BAD_MODEL; }
+  if (!options->print_progress && !std::getenv("MAVBA_POSE_REFINE_SESSION")) {
+    // the on-device trust-region loop (pose_refine.hip); the per-iteration table needs the host loop below
+    mavba_pose_refine_item it;
+    for (int k = 0; k < 3; ++k) { it.rvec[k] = rvec[k]; it.tvec[k] = tvec[k]; }
+    it.intrinsics = intrinsics; it.camera_model = camera_model; it.uv = uv; it.xyz = xyz; it.inlier_mask = inlier_mask; it.n = n;
+    const int rc = mavba_pose_refine_batch(1, &it, options, result);
+    if (rc == MAVBA_OK) for (int k = 0; k < 3; ++k) { rvec[k] = it.rvec[k]; tvec[k] = it.tvec[k]; }
+    return rc;
+  }
   // One image, one (constant) camera, every inlier a constant point: pose_refinement(),
   // bundle_adjustment.cc:160-193.
   std::vector<double> pose = {rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]};

@@ -1,0 +1,33 @@
+// dev_reduce.h - wave-level reductions shared by the kernel files (gfx950, wave64).
+#ifndef MAVBA_DEV_REDUCE_H_
+#define MAVBA_DEV_REDUCE_H_
+#include <hip/hip_runtime.h>
+
+namespace mavba {
+
+// Sum over the 64 lanes, result in EVERY lane: DPP row rotations (8, 4, 2, 1) give each 16-lane row
+// its total, four v_readlane pairs combine the rows in a fixed order. No LDS traffic.
+__device__ __forceinline__ double wave_sum(double v) {
+#define MAVBA_ROR_ADD(N)                                                                                   \
+  {                                                                                                        \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 | (N), 0xf, 0xf, false);        \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 | (N), 0xf, 0xf, false);        \
+    v += __hiloint2double(hi, lo);                                                                         \
+  }
+  MAVBA_ROR_ADD(8) MAVBA_ROR_ADD(4) MAVBA_ROR_ADD(2) MAVBA_ROR_ADD(1)
+#undef MAVBA_ROR_ADD
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+}  // namespace mavba
+#endif

@@ -65,6 +65,9 @@ struct DevBuf {
   void zero(hipStream_t st) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
 };
 
+// pose_refine.hip
+void pose_refine_batch(int count, mavba_pose_refine_item* items, const mavba_options& opt, mavba_result* results);
+
 // host_util.hip
 hipError_t stream_acquire(hipStream_t* st);
 void stream_release(hipStream_t st, int dev);

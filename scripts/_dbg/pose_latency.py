@@ -18,3 +18,14 @@ for n in (100, 1000):
     for _ in range(5):
         t = time.time(); out = api.pose_refinement(r0.copy(), t0.copy(), cp, uv, X); ts.append(time.time() - t)
     print(n, "points: gpu pose_refinement %.2f ms" % (1e3 * min(ts)), {k: out[1][k] for k in ("num_successful_steps", "num_unsuccessful_steps", "setup_seconds", "solve_seconds")})
+    # batches: N inlier sets in ONE launch (mavba_pose_refine_batch)
+    for count in (16, 256):
+        items = [dict(rvec=r0.copy(), tvec=t0.copy(), camera_params=cp, points2D=uv, points3D=X,
+                      inlier_mask=(rng.random(n) > 0.2).astype(np.uint8)) for _ in range(count)]
+        api.pose_refinement_batch([dict(it, rvec=it["rvec"].copy(), tvec=it["tvec"].copy()) for it in items])
+        t = time.time(); out = api.pose_refinement_batch(items); dt = time.time() - t
+        print(n, "points: batch of %d in %.2f ms = %.1f us per refinement" % (count, 1e3 * dt, 1e6 * dt / count))
+    os.environ["MAVBA_POSE_REFINE_SESSION"] = "1"
+    t = time.time(); out = api.pose_refinement(r0.copy(), t0.copy(), cp, uv, X); dt = time.time() - t
+    print(n, "points: general session path %.2f ms" % (1e3 * dt))
+    del os.environ["MAVBA_POSE_REFINE_SESSION"]

@@ -421,3 +421,74 @@ def test_stepwise_iteration_equals_one_call(mavba):
     assert rb["num_unsuccessful_steps"] == ra["num_unsuccessful_steps"] and rb["final_cost"] == ra["final_cost"]
     for x, y in zip(pa, pb):
         assert np.array_equal(x, y)
+
+
+# ---- batched pose refinement (on-device trust-region loop) ----------------------------------------------
+
+def _pose_items(seed, count, model=A.MODEL_OPENCV):
+    """`count` pose-refinement problems as MAVMAP poses them: one image, RANSAC inlier masks, perturbed start."""
+    g = synth.make_scene(num_images=6, num_points=500, track_len=3, models=[model], seed=seed)
+    rng = np.random.default_rng(seed)
+    items = []
+    for q in range(count):
+        img = 1 + q % (g.num_images - 1)
+        sel = g.obs_image == img
+        uv, xyz = g.obs_uv[sel], g.truth["points"][g.obs_point[sel]]
+        mask = (rng.random(len(uv)) > 0.15).astype(np.uint8)   # a different inlier set per hypothesis
+        K = A.MODEL_NUM_PARAMS[model]
+        cam = np.concatenate([g.truth["intrinsics"][g.image_camera[img]][:K], [float(model)]])
+        pose = g.truth["poses"][img] + rng.normal(0, [0.01] * 3 + [0.3] * 3)
+        items.append(dict(rvec=pose[:3].copy(), tvec=pose[3:].copy(), camera_params=cam, points2D=uv, points3D=xyz, inlier_mask=mask))
+    return items
+
+
+def _oracle_pose(oracle, it, **optkw):
+    from mavmap_amd.problem import BAProblem
+    keep = np.asarray(it["inlier_mask"], bool)
+    cam = np.asarray(it["camera_params"], float)
+    model = int(cam[-1])
+    q = BAProblem(poses=np.concatenate([it["rvec"], it["tvec"]])[None].copy(), pose_const=[0], image_camera=[0],
+                  intrinsics=np.pad(cam[:-1], (0, 9 - (len(cam) - 1)))[None].copy(), camera_model=[model], intr_const=[1],
+                  points=it["points3D"][keep].copy(), point_const=np.ones(keep.sum(), np.uint8), obs_uv=it["points2D"][keep].copy(),
+                  obs_image=np.zeros(keep.sum(), np.int32), obs_point=np.arange(keep.sum(), dtype=np.int32))
+    ro, _ = oracle.solve(q, oracle.options(**optkw))
+    return q.poses[0], ro
+
+
+@pytest.mark.parametrize("model", [A.MODEL_PINHOLE, A.MODEL_OPENCV, A.MODEL_CATA])
+def test_pose_refinement_batch_matches_oracle(mavba, oracle, model):
+    items = _pose_items(71 + model, 12, model)
+    ref = [_oracle_pose(oracle, it) for it in items]      # BundleAdjustmentOptions defaults, like the reference call
+    out = mavba.pose_refinement_batch(items)
+    for it, (cost, res), (pose_o, ro) in zip(items, out, ref):
+        assert res["termination"] == ro["termination"], (res["termination_name"], ro["termination_name"])
+        assert res["num_successful_steps"] == ro["num_successful_steps"] and res["num_unsuccessful_steps"] == ro["num_unsuccessful_steps"]
+        assert res["num_residuals"] == ro["num_residuals"] and res["num_parameters_reduced"] == ro["num_parameters_reduced"]
+        assert abs(res["initial_cost"] - ro["initial_cost"]) <= 1e-10 * ro["initial_cost"]
+        assert abs(res["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+        assert rel_err(np.concatenate([it["rvec"], it["tvec"]]), pose_o) < 1e-6
+        assert abs(cost - np.sqrt(ro["final_cost"] / ro["num_residuals"])) < 1e-6 * cost
+
+
+def test_pose_refinement_batch_equals_single_calls_and_the_session_path(mavba, monkeypatch):
+    items = _pose_items(5, 7)
+    singles = [dict(it, rvec=it["rvec"].copy(), tvec=it["tvec"].copy()) for it in items]
+    sess = [dict(it, rvec=it["rvec"].copy(), tvec=it["tvec"].copy()) for it in items]
+    out = mavba.pose_refinement_batch(items, max_num_iterations=50, function_tolerance=1e-10)
+    for it, s, (c, r) in zip(items, singles, out):
+        c1, r1 = mavba.pose_refinement(s["rvec"], s["tvec"], s["camera_params"], s["points2D"], s["points3D"], s["inlier_mask"],
+                                       max_num_iterations=50, function_tolerance=1e-10)
+        assert c1 == c and np.array_equal(s["rvec"], it["rvec"]) and np.array_equal(s["tvec"], it["tvec"])  # bit-identical
+        assert r1["num_successful_steps"] == r["num_successful_steps"]
+    # the general session (host trust-region loop) walks the same path
+    monkeypatch.setenv("MAVBA_POSE_REFINE_SESSION", "1")
+    for it, s, (c, r) in zip(items, sess, out):
+        c2, r2 = mavba.pose_refinement(s["rvec"], s["tvec"], s["camera_params"], s["points2D"], s["points3D"], s["inlier_mask"],
+                                       max_num_iterations=50, function_tolerance=1e-10)
+        assert r2["termination"] == r["termination"] and r2["num_successful_steps"] == r["num_successful_steps"]
+        assert abs(c2 - c) < 1e-9 * c and rel_err(np.concatenate([s["rvec"], s["tvec"]]), np.concatenate([it["rvec"], it["tvec"]])) < 1e-9
+    # empty inlier set and an empty batch
+    e = dict(items[0], inlier_mask=np.zeros(len(items[0]["points2D"]), np.uint8))
+    (c, r), = mavba.pose_refinement_batch([e])
+    assert r["num_residuals"] == 0 and np.isnan(c)
+    assert mavba.pose_refinement_batch([]) == []
