@@ -195,9 +195,19 @@ def main():
                 device=local_rank, profile_kernels=1)
     sess = mavmap_amd.Session(prob, opts)
 
+    exchange = "none"
     if world > 1:
-        from mavmap_amd.dist import make_allreduce
-        sess.set_allreduce(make_allreduce(torch.device(f"cuda:{local_rank}")), rank, world)
+        # the reduced camera system is summed over ranks once per linear solve: natively (ncclAllReduce enqueued on the
+        # session's stream by the library itself) unless MAVBA_DIST=torch asks for the torch.distributed hook
+        if os.environ.get("MAVBA_DIST", "rccl") == "rccl" and os.environ.get("MAVBA_DIST_BACKEND", "nccl") == "nccl":
+            uid = [mavmap_amd.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            sess.set_rccl(uid[0], rank, world)
+            exchange = "RCCL all-reduce inside the library (stream-ordered)"
+        else:
+            from mavmap_amd.dist import make_allreduce
+            sess.set_allreduce(make_allreduce(torch.device(f"cuda:{local_rank}")), rank, world)
+            exchange = "torch.distributed all-reduce hook (host-synchronised)"
 
     def run_steps(k):
         remaining, solves, idle = k, 0, 0
@@ -320,8 +330,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.problem else "replay file",
             "config": {"workload": WORKLOADS[args.config] + ("" if args.scale == 1.0 else f" (scaled x{args.scale})"),
                        "images": full.num_images, "points": full.num_points, "observations": full.num_obs,
-                       "parallelism": "single GPU" if world == 1 else f"points sharded over {world} ranks, "
-                       "RCCL all-reduce of the reduced camera system",
+                       "parallelism": "single GPU" if world == 1 else f"points sharded over {world} ranks, " + exchange +
+                       " of the reduced camera system",
                        "options": "max_iter 200, ftol 1e-6, gtol 1e-10, ptol 1e-8, Cauchy a=1, refine intrinsics"},
             "roofline": roofline,
             "reduced_solve": reduced_solve,

@@ -283,6 +283,17 @@ typedef int (*mavba_allreduce_fn)(void* ctx, void* device_ptr, int64_t count,
 int mavba_session_set_allreduce(mavba_session* s, mavba_allreduce_fn fn,
                                 void* ctx, int32_t rank, int32_t world_size);
 
+/*
+ * Native collective: the same exchange through RCCL inside the library. ncclAllReduce is enqueued on the
+ * session's own HIP stream (no host synchronisation, no callback), so the LM loop keeps its one read-back per
+ * iteration. One process per GPU: rank 0 obtains an id with mavba_rccl_unique_id() (128 bytes, ncclUniqueId),
+ * the launcher hands it to every rank (bench.py broadcasts it with torch.distributed), every rank then calls
+ * mavba_session_set_rccl() - collectively, like ncclCommInitRank - before the first iteration. librccl.so is
+ * loaded on first use.
+ */
+int mavba_rccl_unique_id(void* out128);
+int mavba_session_set_rccl(mavba_session* s, const void* unique_id128, int32_t rank, int32_t world_size);
+
 /* ---- probes used by tests/ and bench.py -------------------------------- */
 
 /* Evaluate residuals + Jacobians at the current parameters (the Jacobian

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "mavba_session_set_allreduce", "mavba_session_eval_jacobian", "mavba_session_reduced_dim",
     "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian",
     "mavba_session_kernel_stats", "mavba_session_get_info", "mavba_dense_spd_solve",
-    "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
+    "mavba_rccl_unique_id", "mavba_session_set_rccl", "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -82,6 +82,8 @@ def load():
     L.mavba_session_kernel_stats.argtypes = [sp, C.POINTER(A.CKernelStat), C.c_int32]
     L.mavba_session_get_info.argtypes = [sp, C.POINTER(A.CSessionInfo)]
     L.mavba_dense_spd_solve.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
+    L.mavba_rccl_unique_id.argtypes = [C.c_void_p]
+    L.mavba_session_set_rccl.argtypes = [sp, C.c_void_p, C.c_int32, C.c_int32]
     L.mavba_pose_refine_batch.argtypes = [C.c_int32, C.POINTER(A.CPoseRefineItem), op, rp]
     L.mavba_session_set_params.argtypes = [sp, dp, dp, dp]
     L.mavba_session_restart.argtypes = [sp]
@@ -337,6 +339,11 @@ class Session:
         self._cb = ALLREDUCE_FN(trampoline)
         _check(load().mavba_session_set_allreduce(self._h, self._cb, None, rank, world_size))
 
+    def set_rccl(self, unique_id, rank, world_size):
+        """Native RCCL exchange (mavba_session_set_rccl); `unique_id` = the 128 bytes of rccl_unique_id() from rank 0."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(load().mavba_session_set_rccl(self._h, buf, rank, world_size))
+
     def eval_jacobian(self):
         n = self.problem.num_obs
         r, Jc, Jp, Jk = np.zeros((n, 2)), np.zeros((n, 2, 6)), np.zeros((n, 2, 3)), np.zeros((n, 2, 9))
@@ -374,6 +381,13 @@ class Session:
         n = load().mavba_session_kernel_stats(self._h, buf, 64)
         return {buf[i].name.decode(): dict(launches=int(buf[i].launches), total_ms=float(buf[i].total_ms))
                 for i in range(min(n, 64))}
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId for Session.set_rccl (call on rank 0, distribute to every rank)."""
+    buf = C.create_string_buffer(128)
+    _check(load().mavba_rccl_unique_id(buf))
+    return buf.raw
 
 
 def dense_spd_solve(Amat, b, device=-1):

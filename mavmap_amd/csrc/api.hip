@@ -158,41 +158,68 @@ int mavba_session_filter_points(mavba_session* s, double max_error, const uint8_
   MAVBA_CATCH
 }
 
+// After the collective is in place: what every rank must agree on before the first iteration.
+static void join_ranks(mavba_session* s) {
+  if (!s->sharded()) return;
+  // A camera block is in the problem if ANY rank has a residual block on it; the counts
+  // reported in mavba_result become global.
+  const size_t n = (size_t)s->NI + s->NC + 4;
+  std::vector<double> h(n, 0.0);
+  for (int i = 0; i < s->NI; ++i) h[i] = s->h_img_used[i];
+  for (int c = 0; c < s->NC; ++c) h[s->NI + c] = s->h_cam_used[c];
+  DevBuf<double> d;
+  d.upload(h, s->st);
+  s->allreduce(d.p, (long long)s->NI + s->NC, 1);
+  std::vector<double> g(4, 0.0);
+  long long free_pts = 0;
+  for (unsigned char f : s->h_pt_free) free_pts += f;
+  g[0] = s->fixed_cost; g[1] = (double)s->num_residuals; g[2] = (double)s->num_residuals_reduced; g[3] = (double)free_pts;
+  HIP_OK(hipMemcpyAsync(d.p + s->NI + s->NC, g.data(), 32, hipMemcpyHostToDevice, s->st));
+  s->allreduce(d.p + s->NI + s->NC, 4, 0);
+  HIP_OK(hipMemcpyAsync(h.data(), d.p, n * 8, hipMemcpyDeviceToHost, s->st));
+  s->sync();
+  for (int i = 0; i < s->NI; ++i) s->h_img_used[i] = h[i] != 0.0;
+  for (int c = 0; c < s->NC; ++c) s->h_cam_used[c] = h[s->NI + c] != 0.0;
+  s->derive_free_flags();
+  long long cam_params = 0;
+  for (unsigned char f : s->h_pose_free) cam_params += f;
+  for (unsigned char f : s->h_intr_free) cam_params += f;
+  s->fixed_cost = h[s->NI + s->NC];
+  s->num_residuals = (long long)h[s->NI + s->NC + 1];
+  s->num_residuals_reduced = (long long)h[s->NI + s->NC + 2];
+  s->num_parameters_reduced = cam_params + 3 * (long long)h[s->NI + s->NC + 3];
+  s->finish_structure();
+}
+
 int mavba_session_set_allreduce(mavba_session* s, mavba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world_size) {
   MAVBA_TRY
   if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
   if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_allreduce must precede the first iteration");
   s->ar_fn = fn; s->ar_ctx = ctx; s->rank = rank; s->world = world_size;
-  if (fn && world_size > 1) {
-    // A camera block is in the problem if ANY rank has a residual block on it; the counts
-    // reported in mavba_result become global.
-    const size_t n = (size_t)s->NI + s->NC + 4;
-    std::vector<double> h(n, 0.0);
-    for (int i = 0; i < s->NI; ++i) h[i] = s->h_img_used[i];
-    for (int c = 0; c < s->NC; ++c) h[s->NI + c] = s->h_cam_used[c];
-    DevBuf<double> d;
-    d.upload(h, s->st);
-    s->allreduce(d.p, (long long)s->NI + s->NC, 1);
-    std::vector<double> g(4, 0.0);
-    long long free_pts = 0;
-    for (unsigned char f : s->h_pt_free) free_pts += f;
-    g[0] = s->fixed_cost; g[1] = (double)s->num_residuals; g[2] = (double)s->num_residuals_reduced; g[3] = (double)free_pts;
-    HIP_OK(hipMemcpyAsync(d.p + s->NI + s->NC, g.data(), 32, hipMemcpyHostToDevice, s->st));
-    s->allreduce(d.p + s->NI + s->NC, 4, 0);
-    HIP_OK(hipMemcpyAsync(h.data(), d.p, n * 8, hipMemcpyDeviceToHost, s->st));
-    s->sync();
-    for (int i = 0; i < s->NI; ++i) s->h_img_used[i] = h[i] != 0.0;
-    for (int c = 0; c < s->NC; ++c) s->h_cam_used[c] = h[s->NI + c] != 0.0;
-    s->derive_free_flags();
-    long long cam_params = 0;
-    for (unsigned char f : s->h_pose_free) cam_params += f;
-    for (unsigned char f : s->h_intr_free) cam_params += f;
-    s->fixed_cost = h[s->NI + s->NC];
-    s->num_residuals = (long long)h[s->NI + s->NC + 1];
-    s->num_residuals_reduced = (long long)h[s->NI + s->NC + 2];
-    s->num_parameters_reduced = cam_params + 3 * (long long)h[s->NI + s->NC + 3];
-    s->finish_structure();
-  }
+  s->force_exchange = world_size == 1 && std::getenv("MAVBA_FORCE_EXCHANGE") != nullptr;
+  join_ranks(s);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_rccl_unique_id(void* out128) {
+  MAVBA_TRY
+  if (!out128) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
+  rccl_unique_id(out128);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+int mavba_session_set_rccl(mavba_session* s, const void* unique_id128, int32_t rank, int32_t world_size) {
+  MAVBA_TRY
+  if (!s || !unique_id128) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
+  if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_rccl must precede the first iteration");
+  if (rank < 0 || rank >= world_size) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "rank out of range");
+  HIP_OK(hipSetDevice(s->device));
+  s->rccl_comm = rccl_comm_create(unique_id128, rank, world_size);
+  s->ar_fn = nullptr; s->rank = rank; s->world = world_size;
+  s->force_exchange = world_size == 1 && std::getenv("MAVBA_FORCE_EXCHANGE") != nullptr;
+  join_ranks(s);
   return MAVBA_OK;
   MAVBA_CATCH
 }

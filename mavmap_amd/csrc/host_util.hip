@@ -1,7 +1,69 @@
 // host_util.hip - process-wide helpers of the host side: caching device allocator, stream cache, worker threads.
 #include "session.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 namespace mavba {
+
+// ---- RCCL, loaded on first use (a single-GPU process never maps the 570 MB library) --------------------------------
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+RcclApi& rccl() {
+  static RcclApi* api = [] {
+    RcclApi* a = new RcclApi;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) if ((a->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!a->lib) { a->error = std::string("librccl.so not found: ") + dlerror(); return a; }
+    a->GetUniqueId = reinterpret_cast<decltype(a->GetUniqueId)>(dlsym(a->lib, "ncclGetUniqueId"));
+    a->CommInitRank = reinterpret_cast<decltype(a->CommInitRank)>(dlsym(a->lib, "ncclCommInitRank"));
+    a->AllReduce = reinterpret_cast<decltype(a->AllReduce)>(dlsym(a->lib, "ncclAllReduce"));
+    a->CommDestroy = reinterpret_cast<decltype(a->CommDestroy)>(dlsym(a->lib, "ncclCommDestroy"));
+    a->GetErrorString = reinterpret_cast<decltype(a->GetErrorString)>(dlsym(a->lib, "ncclGetErrorString"));
+    if (!a->GetUniqueId || !a->CommInitRank || !a->AllReduce || !a->CommDestroy) a->error = "librccl.so lacks an expected symbol";
+    return a;
+  }();
+  return *api;
+}
+void rccl_ok(ncclResult_t r, const char* what) {
+  if (r != ncclSuccess)
+    throw Failure(MAVBA_ERR_HIP, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error"));
+}
+}  // namespace
+
+void rccl_unique_id(void* out128) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!rccl().error.empty()) throw Failure(MAVBA_ERR_HIP, rccl().error);
+  ncclUniqueId id;
+  rccl_ok(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(out128, &id, sizeof(id));
+}
+void* rccl_comm_create(const void* id128, int rank, int world) {
+  if (!rccl().error.empty()) throw Failure(MAVBA_ERR_HIP, rccl().error);
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm = nullptr;
+  rccl_ok(rccl().CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+  return comm;
+}
+void rccl_comm_destroy(void* comm) { if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm)); }
+// in place on `stream`; op 0 = sum, 1 = max, 2 = sum over the first count - 1 doubles and max over the last
+void rccl_allreduce(void* comm, double* p, long long count, int op, hipStream_t stream) {
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
+  if (op == 2) {
+    if (count > 1) rccl_ok(rccl().AllReduce(p, p, (size_t)(count - 1), ncclDouble, ncclSum, c, stream), "ncclAllReduce");
+    rccl_ok(rccl().AllReduce(p + count - 1, p + count - 1, 1, ncclDouble, ncclMax, c, stream), "ncclAllReduce");
+  } else {
+    rccl_ok(rccl().AllReduce(p, p, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, c, stream), "ncclAllReduce");
+  }
+}
 
 // ---- caching device allocator (declared in internal.h) ----------------------------------------------------
 namespace {

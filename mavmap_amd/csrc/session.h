@@ -69,6 +69,10 @@ struct DevBuf {
 void pose_refine_batch(int count, mavba_pose_refine_item* items, const mavba_options& opt, mavba_result* results);
 
 // host_util.hip
+void rccl_unique_id(void* out128);
+void* rccl_comm_create(const void* id128, int rank, int world);
+void rccl_comm_destroy(void* comm);
+void rccl_allreduce(void* comm, double* p, long long count, int op, hipStream_t stream);
 hipError_t stream_acquire(hipStream_t* st);
 void stream_release(hipStream_t st, int dev);
 int host_threads();
@@ -225,8 +229,11 @@ struct mavba_session {
   int termination = MAVBA_TERM_RUNNING;
 
   // ---- multi-GPU ----
-  mavba_allreduce_fn ar_fn = nullptr;
+  mavba_allreduce_fn ar_fn = nullptr;  // hook: the caller's collective (host-synchronised)
   void* ar_ctx = nullptr;
+  void* rccl_comm = nullptr;           // native: ncclAllReduce enqueued on the session's stream, no host synchronisation
+  bool sharded() const { return (ar_fn || rccl_comm) && (world > 1 || force_exchange); }
+  bool force_exchange = false;         // run the multi-rank protocol even with one rank (tests of the native path)
   int rank = 0, world = 1;
 
   // ---- profiling ----
@@ -238,6 +245,7 @@ struct mavba_session {
   ~mavba_session() {
     // the buffers go back to the process-wide pool: nothing may still be running on them
     if (st) (void)hipStreamSynchronize(st);
+    if (rccl_comm) rccl_comm_destroy(rccl_comm);
     for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& e : ev_pool) (void)hipEventDestroy(e);
     if (st) stream_release(st, device);
@@ -272,7 +280,8 @@ struct mavba_session {
   void sync() { HIP_OK(hipStreamSynchronize(st)); HIP_OK(hipGetLastError()); flush_timers(); }
 
   void allreduce(double* dptr, long long count, int op) {
-    if (!ar_fn || world <= 1) return;
+    if (!sharded()) return;
+    if (rccl_comm) { rccl_allreduce(rccl_comm, dptr, count, op, st); return; }
     sync();
     if (ar_fn(ar_ctx, dptr, count, op) != 0) throw Failure(MAVBA_ERR_HIP, "all-reduce hook failed");
   }

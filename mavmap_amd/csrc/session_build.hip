@@ -356,7 +356,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   if (can_dissect) {
     // image adjacency (lower: col < row) from the pose-pose blocks; with shards, the union over ranks
     std::vector<std::vector<int>> lower(NI);
-    if (world > 1 && ar_fn) {
+    if (sharded()) {
       std::vector<double> a((size_t)NI * NI, 0.0);
       for (const SchurBlock& B : blocks)
         if (B.kind == BLK_PP && B.row_ent != B.col_ent) a[(size_t)std::max(B.row_ent, B.col_ent) * NI + std::min(B.row_ent, B.col_ent)] = 1.0;
@@ -474,7 +474,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
     for (int tr = r0 / 64; tr <= r1 / 64; ++tr)
       for (int tc = c0 / 64; tc <= c1 / 64; ++tc) mark[(size_t)std::max(tr, tc) * nbt + std::min(tr, tc)] = 1;
   }
-  if (world > 1 && ar_fn) {
+  if (sharded()) {
     // The matrix that gets factorised is the SUM over ranks: its structure is the union of the ranks'.
     std::vector<double> h(mark.begin(), mark.end());
     DevBuf<double> d;
@@ -489,7 +489,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
     for (int tc = 0; tc <= tr; ++tc) if (mark[(size_t)tr * nbt + tc]) tile_pairs.emplace_back(tr, tc);
   HIP_OK(chol_struct.build(nbt, tile_pairs, tree, st));
   nd_parts = chol_struct.nseg > 1 ? chol_struct.num_fronts_max : 0;
-  if (world > 1) {
+  if (sharded()) {
     std::vector<int2> tl;
     std::vector<unsigned char> have((size_t)nbt * nbt, 0);
     for (int t = 0; t < nbt; ++t) { tl.push_back(make_int2(t, t)); have[(size_t)t * nbt + t] = 1; }

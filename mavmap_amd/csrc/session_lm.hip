@@ -66,7 +66,7 @@ void mavba_session::evaluate_enqueue() {
     T.t[2] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
     launch_reduce_tasks(st, T, 3);
   });
-  if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS + 1, 2);  // sums, then max|g| in the last slot
+  if (sharded()) allreduce(d_scal.p, SC_NUM_SUMS + 1, 2);  // sums, then max|g| in the last slot
   evaluated = true; assembled = false;
 }
 void mavba_session::evaluate() {
@@ -109,7 +109,7 @@ void mavba_session::assemble(double r) {
                           r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p, v);
     launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
   });
-  if (world > 1 && ar_fn) {
+  if (sharded()) {
     // only the tiles the factorisation reads (lower, inside the structure) and the right-hand side travel
     double* rhs = d_ar_buf.p + (size_t)num_ar_tiles * 4096;
     launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, d_M.p, n_mat, d_ar_buf.p, true);
@@ -171,7 +171,7 @@ void mavba_session::candidate(double r, double* h) {
     T.t[3] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_NEW_COST};
     launch_reduce_tasks(st, T, 4);
   });
-  if (world > 1) allreduce(d_scal.p, SC_NUM_SUMS, 0);
+  if (sharded()) allreduce(d_scal.p, SC_NUM_SUMS, 0);
   read_scalars(h);
 }
 
@@ -198,7 +198,8 @@ int mavba_session::iterate(int max_iters, int* done) {
   // the NEXT candidate (one host synchronisation per iteration instead of two): the next linear solve is
   // enqueued right behind the evaluation, and the tests that follow an evaluation in Ceres' loop (gradient
   // tolerance) are applied when its scalars arrive - before anything of the speculative iteration counts.
-  const bool defer = world == 1 && !opt.print_progress;
+  // (with the hook every collective synchronises the host anyway; RCCL collectives are stream-ordered)
+  const bool defer = (!sharded() || rccl_comm) && !opt.print_progress;
   bool pending_eval = false;
   while (termination == MAVBA_TERM_RUNNING && n < max_iters) {
     if (iteration >= opt.max_num_iterations) { termination = MAVBA_TERM_NO_CONVERGENCE; break; }
@@ -303,7 +304,7 @@ void mavba_session::restart() {
 // the counts, the used / free flags of images and cameras and the fixed cost are re-derived and the solve restarts.
 long long mavba_session::filter_points(double max_error, const unsigned char* keep, unsigned char* removed_out,
                                        double* errors_out) {
-  if (world > 1) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "filter_points on a sharded session is not supported");
+  if (sharded()) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "filter_points on a sharded session is not supported");
   const double t0 = now_s();
   std::vector<double> err((size_t)std::max(NP, 1), 0.0);
   // (NaN marks points without observations in the problem: never filtered, like points BA never reported on)

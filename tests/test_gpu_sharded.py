@@ -174,3 +174,26 @@ def test_torch_zero_copy_view_of_a_device_pointer(mavba):
     assert hip.hipMemcpy(host.ctypes.data, base.data_ptr(), 16 * 8, 2) == 0
     expect = np.arange(16.0); expect[4:12] *= 2
     assert np.array_equal(host, expect)
+
+
+def test_native_rccl_exchange_single_rank(mavba, monkeypatch):
+    """The native collective (librccl loaded by the library, ncclAllReduce enqueued on the session's stream, deferred
+    read-back kept) with the only communicator one GPU allows: one rank. MAVBA_FORCE_EXCHANGE makes that rank run the
+    whole multi-rank protocol (structure agreement, packed tiles, scalar reductions); the solve must be the plain one."""
+    p = synth.make_config("C3", scale=0.02, seed=3)
+    with mavba.Session(p, global_opts()) as s:
+        ref = s.solve()
+        xref = s.get_params()
+    monkeypatch.setenv("MAVBA_FORCE_EXCHANGE", "1")
+    uid = mavba.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with mavba.Session(p, global_opts()) as s:
+        s.set_rccl(uid, 0, 1)
+        got = s.solve()
+        xgot = s.get_params()
+        with pytest.raises(mavba.MavbaError):
+            s.set_rccl(uid, 0, 1)  # after the first iteration
+    assert got["termination"] == ref["termination"] and got["num_successful_steps"] == ref["num_successful_steps"]
+    assert got["final_cost"] == ref["final_cost"]
+    for a, b in zip(xgot, xref):
+        assert np.array_equal(a, b)
