@@ -320,6 +320,22 @@ def main():
                                 sample=f"first {its} LM iterations of the same {args.config} solve by the CPU oracle "
                                        f"(analytic Jacobians, OpenMP, dense Schur + Cholesky), {ro['solve_seconds']:.1f}s "
                                        f"of {time.time() - tc:.1f}s wall")
+            # the reference's own solver, where the box has it; otherwise said explicitly
+            from tests import ceres_harness
+            ceres = "unavailable"
+            if ceres_harness.build() is not None:
+                try:
+                    rc = ceres_harness.solve(full, dict(max_num_iterations=args.cpu_iters, function_tolerance=1e-6, gradient_tolerance=1e-10,
+                                                        loss_scale_factor=1.0), threads=cores)
+                    its_c = rc["num_successful_steps"] + rc["num_unsuccessful_steps"]
+                    ceres = dict(value=round(its_c / rc["solve_seconds"], 4), unit="iter/s", cores=cores, kind="reference",
+                                 sample=f"first {its_c} LM iterations of the same solve by Ceres (SPARSE_SCHUR) through oracle/ceres_check")
+                except Exception as e:  # noqa: BLE001
+                    ceres = f"failed: {e}"
+            cpu_baseline["ceres"] = ceres
+            if ceres == "unavailable":
+                cpu_baseline["note"] = ("Ceres is not installed on this box: the baseline is the build's own CPU restatement, NOT the "
+                                        "reference's Ceres path; the north star's >= 10x-over-Ceres target is unmeasured")
             log("cpu_baseline:", cpu_baseline)
 
         value = args.steps / elapsed

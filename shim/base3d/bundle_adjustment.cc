@@ -98,6 +98,13 @@ void fill_options(const BundleAdjustmentOptions& o, mavba_options* m) {
   m->print_progress = o.print_progress ? 1 : 0;
 }
 
+// Error policy at the boundary. The reference never fails inside ceres::Solve, so mapper.cc has no handler beyond the
+// two std::invalid_argument checks it can trigger itself. Argument errors of the flat problem (a bug in this file or a
+// corrupt FeatureManager) become std::invalid_argument like those; a device-side failure (HIP error, out of device
+// memory) is retried ONCE by the callers below - the session is rebuilt from the untouched host data - and only then
+// surfaces as std::runtime_error, which ends the run like any other uncaught exception there.
+bool transient(int code) { return code == MAVBA_ERR_HIP || code == MAVBA_ERR_OUT_OF_MEMORY; }
+
 [[noreturn]] void raise(int code) {
   const std::string msg = std::string("mavba: ") + mavba_last_error();
   if (code == MAVBA_ERR_INVALID_ARGUMENT || code == MAVBA_ERR_BAD_INDEX || code == MAVBA_ERR_BAD_MODEL)
@@ -135,8 +142,10 @@ double pose_refinement(Eigen::Vector3d& rvec, Eigen::Vector3d& tvec, std::vector
   mavba_options mo;
   fill_options(options, &mo);
   mavba_result res;
-  const int rc = mavba_pose_refine(rvec.data(), tvec.data(), camera_params.data(), model, uv.data(), xyz.data(),
-                                   mask.data(), (int64_t)n, &mo, &res);
+  int rc = mavba_pose_refine(rvec.data(), tvec.data(), camera_params.data(), model, uv.data(), xyz.data(),
+                             mask.data(), (int64_t)n, &mo, &res);
+  if (transient(rc))  // (inputs are only written on success)
+    rc = mavba_pose_refine(rvec.data(), tvec.data(), camera_params.data(), model, uv.data(), xyz.data(), mask.data(), (int64_t)n, &mo, &res);
   if (rc != MAVBA_OK) raise(rc);
   if (options.print_progress) std::cout << std::endl;
   if (options.print_summary) {
@@ -164,16 +173,23 @@ static void dump_problem(const mavba_problem& P, const mavba_options& mo) {
   const int32_t dims[4] = {P.num_images, P.num_cameras, P.num_points, P.num_rot_priors};
   const int64_t no = P.num_obs;
   const double opts[4] = {(double)mo.max_num_iterations, mo.function_tolerance, mo.gradient_tolerance, mo.loss_scale_factor};
-  std::fwrite(magic, 1, 8, f); std::fwrite(dims, 4, 4, f); std::fwrite(&no, 8, 1, f);
-  std::fwrite(&P.rot_prior_weight, 8, 1, f); std::fwrite(opts, 8, 4, f);
+  bool ok = true;
+  auto put = [&](const void* p, size_t size, size_t count) { if (count && std::fwrite(p, size, count, f) != count) ok = false; };
+  put(magic, 1, 8); put(dims, 4, 4); put(&no, 8, 1);
+  put(&P.rot_prior_weight, 8, 1); put(opts, 8, 4);
   const size_t NI = (size_t)P.num_images, NC = (size_t)P.num_cameras, NP = (size_t)P.num_points, NO = (size_t)P.num_obs, NR = (size_t)P.num_rot_priors;
-  std::fwrite(P.poses, 8, NI * 6, f); std::fwrite(P.pose_const, 1, NI, f); std::fwrite(P.image_camera, 4, NI, f);
-  std::fwrite(P.intrinsics, 8, NC * MAVBA_MAX_INTR, f); std::fwrite(P.camera_model, 4, NC, f); std::fwrite(P.intr_const, 1, NC, f);
-  std::fwrite(P.points, 8, NP * 3, f); std::fwrite(P.point_const, 1, NP, f);
-  std::fwrite(P.obs_uv, 8, NO * 2, f); std::fwrite(P.obs_image, 4, NO, f); std::fwrite(P.obs_point, 4, NO, f);
-  std::fwrite(P.rot_prior_image, 4, NR, f); std::fwrite(P.rot_prior_rvec, 8, NR * 3, f);
-  std::fclose(f);
+  put(P.poses, 8, NI * 6); put(P.pose_const, 1, NI); put(P.image_camera, 4, NI);
+  put(P.intrinsics, 8, NC * MAVBA_MAX_INTR); put(P.camera_model, 4, NC); put(P.intr_const, 1, NC);
+  put(P.points, 8, NP * 3); put(P.point_const, 1, NP);
+  put(P.obs_uv, 8, NO * 2); put(P.obs_image, 4, NO); put(P.obs_point, 4, NO);
+  put(P.rot_prior_image, 4, NR); put(P.rot_prior_rvec, 8, NR * 3);
+  if (std::fclose(f) != 0) ok = false;
+  if (!ok) {  // a truncated replay file would silently benchmark a different problem
+    std::remove(path);
+    std::cerr << "mavba: could not write the replay file " << path << " (disk full?) - removed" << std::endl;
+  }
 }
+
 
 double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_image_ids,
                          const std::vector<size_t>& fixed_image_ids, const std::vector<size_t>& fixed_x_image_ids,
@@ -257,6 +273,12 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
         const size_t point3D_id = it3->second;
         if (point3D_num_points2D[point3D_id] < options.min_track_len) continue;   // :330
         if (img < 0) {
+          // An image id listed twice (in one list or in two) is ONE set of parameter blocks in the reference: its
+          // residual blocks are added again on the same blocks and the constancy settings accumulate.
+          auto known = image_index.find(image_id);
+          if (known != image_index.end()) img = known->second;
+        }
+        if (img < 0) {
           // first residual of this image: register the image (and its camera)
           auto ic = camera_index.find(camera_id);
           if (ic == camera_index.end()) {
@@ -292,8 +314,8 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
       }
       // Constancy is applied only if the image contributed more than one residual (:361).
       if (num_residuals > 1) {
-        if (fill_state[l] == BA_POSE_FIXED) pose_const[img] = MAVBA_CONST_POSE;
-        if (fill_state[l] == BA_POSE_FIXED_X) pose_const[img] = MAVBA_CONST_TX;
+        if (fill_state[l] == BA_POSE_FIXED) pose_const[img] |= MAVBA_CONST_POSE;
+        if (fill_state[l] == BA_POSE_FIXED_X) pose_const[img] |= MAVBA_CONST_TX;
         if (!options.refine_camera_params) intr_const[image_camera[img]] = 1;
       }
     }
@@ -353,7 +375,9 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
   std::vector<double> perr(point_ids.size(), 0.0);
   mavba_result res;
   dump_problem(P, mo);
-  const int rc = mavba_solve(&P, &mo, &res, options.update_point3D_errors ? perr.data() : nullptr);
+  int rc = mavba_solve(&P, &mo, &res, options.update_point3D_errors ? perr.data() : nullptr);
+  if (transient(rc))  // (the flat arrays are only written back after a completed solve)
+    rc = mavba_solve(&P, &mo, &res, options.update_point3D_errors ? perr.data() : nullptr);
   if (rc != MAVBA_OK) raise(rc);
 
   // ---- write back in place (the reference lets Ceres write through raw pointers)

@@ -1,0 +1,49 @@
+"""Opportunistic parity against the reference's real solver (Ceres) - SURVEY.md 8(c)(iv).
+
+Where CMake finds Ceres, oracle/ceres_check solves the same flat problem through the Ceres API exactly like reference
+src/base3d/bundle_adjustment.cc and this test compares the device result with it at the north star's tolerance
+(final RMSE / cameras / points within 1e-6 relative). Where Ceres is not installed - this build image and, so far,
+the GPU boxes - the test SKIPS with an explicit message: nothing here implies a Ceres comparison that did not run,
+and the solver half of the oracle stays "parity unpinned" (DESIGN.md section 2)."""
+import numpy as np
+import pytest
+
+from mavmap_amd import _abi as A
+from mavmap_amd import synth
+from tests import ceres_harness
+from tests.conftest import global_opts, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_harness_reports_availability_explicitly():
+    exe = ceres_harness.build()
+    print("ceres:", exe if exe else "unavailable (find_package(Ceres) failed or no cmake)")
+    assert exe is None or exe.endswith("mavba_ceres_check")
+
+
+@pytest.mark.parametrize("kind", ["mixed", "priors", "gcp_fixed_intr"])
+def test_device_solve_matches_ceres(mavba, kind):
+    if ceres_harness.build() is None:
+        pytest.skip("Ceres unavailable on this machine: the reference's solver could not be run (parity unpinned)")
+    if kind == "mixed":
+        p = synth.make_config("C3", scale=0.01, seed=12)
+    elif kind == "priors":
+        p = synth.make_scene(num_images=8, num_points=500, track_len=4, models=[A.MODEL_PINHOLE], seed=14, rot_priors=True)
+    else:
+        p = synth.make_scene(num_images=8, num_points=500, track_len=4, models=[A.MODEL_OPENCV], seed=15, refine_camera_params=False)
+        p.point_const[::7] = 1
+    opts = global_opts()
+    ref = ceres_harness.solve(p, dict(opts, loss_scale_factor=1.0))
+    g = p.copy()
+    eg = np.full(p.num_points, np.nan)
+    cost, res = mavba.bundle_adjustment(g, opts, point3D_errors=eg)
+    rmse_ref = np.sqrt(ref["final_cost"] / ref["num_residuals"])
+    assert res["num_residuals"] == ref["num_residuals"]
+    assert abs(cost - rmse_ref) <= 1e-6 * rmse_ref
+    assert rel_err(g.poses, ref["poses"]) < 1e-6 and rel_err(g.points, ref["points"]) < 1e-6
+    assert rel_err(g.intrinsics, ref["intrinsics"]) < 1e-6
+    m = ~np.isnan(ref["point_errors"])
+    assert rel_err(eg[m], ref["point_errors"][m]) < 1e-6
+    # the recalled Ceres 1.8 loop of the oracle is pinned by the same run: identical step counts
+    assert res["num_successful_steps"] == ref["num_successful_steps"]

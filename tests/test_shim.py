@@ -334,3 +334,75 @@ def test_shim_end_to_end_on_gpu(mavba, oracle):
                                 mask.ctypes.data_as(bp), C.c_double(1.0), C.byref(out))
     assert rc == 0, L.shim_last_exception()
     assert np.abs(np.concatenate([rvec, tvec]) - q.poses[3]).max() < 5e-2   # single-image robust refit stays at the BA pose
+
+
+def test_print_report_matches_the_reference_layout(mock, capfd):
+    """_print_report (reference src/base3d/bundle_adjustment.cc:114-136) + the header of :604-607, character for
+    character: labels right-aligned in 18 columns, counts left-aligned, costs sqrt(cost / num_residuals) at 6
+    significant digits followed by ' [px]', one empty line at the end."""
+    sc = Scene(small_scene(seed=9))
+    capfd.readouterr()
+    rc, ret, *_ = run(mock, sc, [2, 3, 4, 5], [0], [1], print_summary=1)
+    assert rc == 0
+    out = capfd.readouterr().out
+    r = recorded(mock)
+    # the mock reports zero reduced counts / steps and cost = 2 * num_residuals -> sqrt(2) = 1.41421
+    assert out == ("Bundle Adjustment Report\n"
+                   "------------------------\n"
+                   "      Residuals : 0\n"
+                   "     Parameters : 0\n"
+                   "     Iterations : 0\n"
+                   "   Initial cost : 1.41421 [px]\n"
+                   "     Final cost : 1.41421 [px]\n"
+                   "\n"), out
+    assert abs(ret - np.sqrt(2.0)) < 1e-15 and r["no"] > 0
+    rc, *_ = run(mock, sc, [2, 3, 4, 5], [0], [1], print_summary=0)
+    assert capfd.readouterr().out == ""
+
+
+def test_an_image_id_listed_twice_is_one_set_of_blocks(mock):
+    """Image 3 in the free AND the fixed list: in the reference both loops add residual blocks on the SAME parameter
+    blocks and the fixed list's SetParameterBlockConstant applies - one pose block, observations twice, FIXED."""
+    sc = Scene(small_scene(seed=11))
+    rc, *_ = run(mock, sc, [2, 3, 4], [0, 3], [1])
+    assert rc == 0
+    r = recorded(mock)
+    exp_once = expected_flat(sc, [2, 3, 4], [0], [1], (), 2, 0)
+    assert r["ni"] == len(exp_once["images"])                      # no second block for image 3
+    i3 = exp_once["images"].index(3)
+    assert r["pose_const"][i3] == A.CONST_POSE
+    n3 = int(np.sum((sc.obs_img == 3) & (sc.obs_pt >= 0)))
+    assert int(np.sum(r["obs_image"] == i3)) == 2 * n3              # its residual blocks were added by both loops
+
+
+@pytest.mark.gpu
+def test_shim_rotation_constraints_end_to_end_on_gpu(mavba, oracle):
+    """constrain_rotation through the reference-signature call into the real library: global pre-rotation of the whole
+    FeatureManager (src/base3d/bundle_adjustment.cc:399-425), one prior per FREE image (:428-444), solve; against
+    the oracle on the equivalent flat problem (pre-rotated scene + rot_prior arrays)."""
+    from scipy.spatial.transform import Rotation
+    L = _build(real=True)
+    L.shim_last_exception.restype = C.c_char_p
+    p = synth.make_scene(num_images=8, num_points=600, track_len=4, models=[A.MODEL_PINHOLE], seed=63)
+    sc = Scene(p)
+    rng = np.random.default_rng(4)
+    rot = np.array([(Rotation.from_rotvec(rng.normal(0, 0.01, 3)) * Rotation.from_rotvec(w)).as_rotvec() for w in sc.poses[:, :3]])
+    free, fixed, fixed_x = list(range(2, 8)), [0], [1]
+    opts = dict(max_num_iterations=200, function_tolerance=1e-6, gradient_tolerance=1e-10)
+    rc, ret, cam, poses, points, perr = run(L, sc, free, fixed, fixed_x, rot=rot, constrain_rotation=1, constrain_rotation_weight=50.0,
+                                            refine_camera_params=1, update_point3D_errors=1, **opts)
+    assert rc == 0, L.shim_last_exception()
+    # the oracle's flat problem: the scene after the pre-rotation S = R_fm^T R_c of the first fixed image
+    S = Rotation.from_rotvec(sc.poses[0, :3]).as_matrix().T @ Rotation.from_rotvec(rot[0]).as_matrix()
+    q = p.copy()
+    q.poses[:, :3] = np.array([Rotation.from_matrix(Rotation.from_rotvec(w).as_matrix() @ S.T).as_rotvec() for w in sc.poses[:, :3]])
+    q.points = np.ascontiguousarray(sc.points @ S.T)
+    q.rot_prior_image = np.array(free, np.int32)
+    q.rot_prior_rvec = np.ascontiguousarray(rot[free])
+    q.rot_prior_weight = 50.0
+    ro, eo = oracle.solve(q, oracle.options(**opts), want_point_errors=True)
+    assert ro["num_residuals"] == 2 * p.num_obs + len(free)
+    assert abs(ret - np.sqrt(ro["final_cost"] / ro["num_residuals"])) < 1e-6 * ret
+    assert np.abs(poses - q.poses).max() < 1e-6 * np.abs(q.poses).max()
+    assert np.abs(points - q.points).max() < 1e-6 * np.abs(q.points).max()
+    assert np.abs(perr - eo).max() < 1e-6 * np.abs(eo).max()
