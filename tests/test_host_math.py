@@ -42,6 +42,25 @@ def _case(rng, model, scale):
     return pose, X, cam, rng.normal(300, 50, 2)
 
 
+def test_kernel_projection_jacobian_matches_reference_template_derivatives(host):
+    """The KERNEL maths (csrc/ba_math.h, compiled for the host) against the golden derivatives of the reference's own
+    world2image<T> templates (tests/golden/world2image_jet_kat.json): no oracle in between."""
+    import json
+    jet = json.load(open(os.path.join(HERE, "golden", "world2image_jet_kat.json")))
+    pose, uv0 = np.zeros(6), np.zeros(2)
+    for c in jet["vectors"]:
+        K = A.MODEL_NUM_PARAMS[c["code"]]
+        cam = np.zeros(9); cam[:K] = c["params"]
+        X = np.array(c["Xc"])
+        r, Jc, Jp, Jk = np.zeros(2), np.zeros((2, 6)), np.zeros((2, 3)), np.zeros((2, 9))
+        host.hm_obs_jacobian(c["code"], d(pose), d(cam), d(X), d(uv0), d(r), d(Jc), d(Jp), d(Jk))
+        assert np.abs(r - np.array(c["uv"])).max() <= 1e-12 * np.abs(c["uv"]).max()
+        ref_p, ref_k = np.array([c["du"][:3], c["dv"][:3]]), np.array([c["du"][3:], c["dv"][3:]])
+        assert np.abs(Jp - ref_p).max() <= 1e-11 * np.abs(ref_p).max(), c["model"]
+        assert np.abs(Jk[:, :K] - ref_k).max() <= 1e-11 * np.abs(ref_k).max(), c["model"]
+        assert not Jk[:, K:].any()
+
+
 @pytest.mark.parametrize("model", [1, 2, 3])
 def test_obs_jacobian_matches_oracle_jets(host, oracle, model):
     rng = np.random.default_rng(model)

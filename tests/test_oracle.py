@@ -18,12 +18,42 @@ REFERENCE_TEST_SETS = [(1, P4), (3, P8 + [0.0]), (3, P8 + [1.0]), (3, P8 + [0.5]
 
 
 def test_world2image_known_answers(oracle):
+    """The reference-compiled world2image<double> (tests/golden/make_world2image_kat.py): the 10 vectors at the
+    parameter sets of camera_models_test.cc:60-82 (the values SURVEY.md 8(c) records) and 300 seeded ones."""
     kat = json.load(open(os.path.join(HERE, "golden", "world2image_kat.json")))
-    for c in kat["cases"]:
-        params = list(kat[c["params"]]) + ([c["xi"]] if c["xi"] is not None else [])
-        u, v = oracle.world2image(c["model"], params, *c["X"])
+    assert len(kat["vectors"]) == 10
+    assert kat["vectors"][0]["uv"] == [711.68450000000007, 661.80128999999999]      # SURVEY.md 8(c), PINHOLE (0.5, 0.23, 1)
+    assert kat["vectors"][4]["uv"] == [533.65136146442774, 579.33976752377532]      # CATA xi = 1
+    jet = json.load(open(os.path.join(HERE, "golden", "world2image_jet_kat.json")))
+    assert len(jet["vectors"]) == 310
+    for c in kat["vectors"] + jet["vectors"]:
+        u, v = oracle.world2image(c["code"], c["params"], *c["Xc"])
         assert abs(u - c["uv"][0]) <= 1e-12 * abs(c["uv"][0]), c
         assert abs(v - c["uv"][1]) <= 1e-12 * abs(c["uv"][1]), c
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_projection_jacobian_matches_reference_template_derivatives(oracle, mode):
+    """d(u, v) / d(Xc, intrinsics) of the reference's OWN world2image<T> templates differentiated by forward-mode
+    dual numbers (what ceres::AutoDiffCostFunction does with them; fixture world2image_jet_kat.json) against the oracle's
+    Jets (mode 0) and its hand-derived analytic Jacobian (mode 1): with an identity pose the point block of the
+    residual Jacobian IS d(u,v)/dXc and the intrinsics block IS d(u,v)/d kappa."""
+    jet = json.load(open(os.path.join(HERE, "golden", "world2image_jet_kat.json")))
+    pose = np.zeros(6)
+    worst = 0.0
+    for c in jet["vectors"]:
+        K = A.MODEL_NUM_PARAMS[c["code"]]
+        r, Jc, Jp, Jk = oracle.obs_jacobian(mode, c["code"], pose, np.array(c["Xc"]), c["params"], np.zeros(2))
+        ref_p = np.array([c["du"][:3], c["dv"][:3]])
+        ref_k = np.array([c["du"][3:], c["dv"][3:]])
+        assert np.abs(r - np.array(c["uv"])).max() <= 1e-12 * np.abs(c["uv"]).max()
+        for got, ref in ((Jp, ref_p), (Jk[:, :K], ref_k)):
+            err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
+            worst = max(worst, err)
+            assert err <= 1e-11, (c["model"], err)
+        assert not Jk[:, K:].any()
+        # the translation block is the same matrix (Xc = R X + t)
+        assert np.abs(Jc[:, 3:] - ref_p).max() <= 1e-11 * np.abs(ref_p).max()
 
 
 @pytest.mark.parametrize("model,params", REFERENCE_TEST_SETS)
