@@ -361,17 +361,25 @@ int mavba_session_kernel_stats(mavba_session* s, mavba_kernel_stat* out, int32_t
 }
 
 int mavba_solve(const mavba_problem* problem, const mavba_options* options, mavba_result* result, double* point_error) {
+  const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
+  double t0 = now_s();
+  auto lap = [&](const char* what) { if (tt) { const double t = now_s(); std::fprintf(stderr, "[solve] %-28s %8.2f ms\n", what, 1e3 * (t - t0)); t0 = t; } };
   mavba_session* s = nullptr;
   int rc = mavba_session_create(problem, options, &s);
   if (rc != MAVBA_OK) return rc;
+  lap("session create");
   int done = 0, term = 0;
   rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &term);
+  lap("iterate");
   if (rc == MAVBA_OK && result) rc = mavba_session_result(s, result);
   // ceres leaves the user's parameter blocks untouched after NUMERICAL_FAILURE
   if (rc == MAVBA_OK && term != MAVBA_TERM_NUMERICAL_FAILURE)
     rc = mavba_session_get_params(s, problem->poses, problem->intrinsics, problem->points);
+  lap("write-back");
   if (rc == MAVBA_OK && point_error && options->update_point_errors) rc = mavba_session_point_errors(s, point_error);
+  lap("point errors");
   mavba_session_destroy(s);
+  lap("session destroy");
   return rc;
 }
 

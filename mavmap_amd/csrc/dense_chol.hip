@@ -751,6 +751,96 @@ __device__ __forceinline__ void store_tile_coh(double* G, size_t ld, const doubl
   }
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the same tile traffic in two halves: global -> registers (loads stay in flight), registers -> LDS later
+struct TileRegs { i4v v[8]; };
+__device__ __forceinline__ void load_tile_regs(const double* G, size_t ld, TileRegs& R, int tid, bool coherent) {
+  const __amdgpu_buffer_rsrc_t r = tile_rsrc(G);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx >> 5, c2 = (idx & 31) * 2;
+    const int off = (int)(((size_t)row * ld + c2) * 8);
+    R.v[q] = coherent ? __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kCoherent) : __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  }
+}
+__device__ __forceinline__ void tile_regs_to_lds(const TileRegs& R, double* S, int tid) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx >> 5, c2 = (idx & 31) * 2;
+    *reinterpret_cast<i4v*>(S + row * GLD + c2) = R.v[q];
+  }
+}
+// Out = As * Li^T for a LOWER-triangular Li (the inverse of a diagonal factor tile): column block n of the product
+// only takes the first 16 (n + 1) columns of As. Wave w: rows 32 (w >> 1) .. + 31, column blocks {0, 3} or {1, 2}
+// (20 of the 16 x 4 k-steps each: balanced). 160 matrix instructions instead of 256, 40 per wave instead of 64.
+// Everything is unrolled at compile time: all operand reads of the wave are issued first (one LDS latency), then the
+// matrix instructions run back to back on four independent accumulators.
+template <int N0, int N1>
+__device__ __forceinline__ void trsm_tri_pair(const double* As, const double* Li, double* Out, int r0, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int K0 = 4 * (N0 + 1), K1 = 4 * (N1 + 1);
+  double a0[K1], a1[K1], b0[K0], b1[K1];
+  const double* pa0 = As + (r0 + li) * GLD + lk;
+  const double* pa1 = As + (r0 + 16 + li) * GLD + lk;
+  const double* pb0 = Li + (16 * N0 + li) * GLD + lk;
+  const double* pb1 = Li + (16 * N1 + li) * GLD + lk;
+#pragma unroll
+  for (int s = 0; s < K1; ++s) { a0[s] = pa0[4 * s]; a1[s] = pa1[4 * s]; b1[s] = pb1[4 * s]; }
+#pragma unroll
+  for (int s = 0; s < K0; ++s) b0[s] = pb0[4 * s];
+  d4 c00 = (d4){0.0, 0.0, 0.0, 0.0}, c10 = c00, c01 = c00, c11 = c00;
+#pragma unroll
+  for (int s = 0; s < K1; ++s) {
+    if (s < K0) {
+      c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b0[s], c00, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b0[s], c10, 0, 0, 0);
+    }
+    c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b1[s], c01, 0, 0, 0);
+    c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b1[s], c11, 0, 0, 0);
+  }
+  store_d16(Out + r0 * GLD + 16 * N0, GLD, c00, lane);
+  store_d16(Out + (r0 + 16) * GLD + 16 * N0, GLD, c10, lane);
+  store_d16(Out + r0 * GLD + 16 * N1, GLD, c01, lane);
+  store_d16(Out + (r0 + 16) * GLD + 16 * N1, GLD, c11, lane);
+}
+__device__ __forceinline__ void trsm_lower_tri(const double* As, const double* Li, double* Out, int wv, int lane) {
+  const int r0 = 32 * (wv >> 1);
+  if (wv & 1) trsm_tri_pair<1, 2>(As, Li, Out, r0, lane);
+  else trsm_tri_pair<0, 3>(As, Li, Out, r0, lane);
+}
+// Ds(lower 16x16 blocks, diagonal blocks complete) -= Ps Ps^T: what the tile factorisation reads. The ten blocks are
+// dealt 3 / 3 / 2 / 2 to the waves (48 matrix instructions at most instead of 64); a wave reads each 16-row block of
+// Ps it needs once (NR of them), then runs its NBLK accumulators interleaved.
+template <int NR, int R0, int R1, int R2, int NBLK, int A0, int B0, int A1, int B1, int A2, int B2>
+__device__ __forceinline__ void syrk_plan(double* Ds, const double* Ps, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int rows[3] = {R0, R1, R2};
+  constexpr int ba[3] = {A0, A1, A2}, bb[3] = {B0, B1, B2};  // blocks as indices into rows[]: (rows[ba], rows[bb])
+  double p[NR][16];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) p[r][s] = Ps[(16 * rows[r] + li) * GLD + 4 * s + lk];
+  d4 acc[NBLK];
+#pragma unroll
+  for (int q = 0; q < NBLK; ++q) acc[q] = load_d16(Ds + 16 * rows[ba[q]] * GLD + 16 * rows[bb[q]], GLD, lane);
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int q = 0; q < NBLK; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-p[ba[q]][s], p[bb[q]][s], acc[q], 0, 0, 0);
+#pragma unroll
+  for (int q = 0; q < NBLK; ++q) store_d16(Ds + 16 * rows[ba[q]] * GLD + 16 * rows[bb[q]], GLD, acc[q], lane);
+}
+__device__ __forceinline__ void syrk_lower_blocks(double* Ds, const double* Ps, int wv, int lane) {
+  switch (wv) {
+    case 0: syrk_plan<2, 0, 1, 0, 3, 0, 0, 1, 0, 1, 1>(Ds, Ps, lane); break;   // (0,0) (1,0) (1,1)
+    case 1: syrk_plan<3, 0, 1, 2, 3, 2, 0, 2, 1, 2, 2>(Ds, Ps, lane); break;   // (2,0) (2,1) (2,2)
+    case 2: syrk_plan<3, 0, 1, 3, 2, 2, 0, 2, 1, 0, 0>(Ds, Ps, lane); break;   // (3,0) (3,1)
+    default: syrk_plan<2, 2, 3, 0, 2, 1, 0, 1, 1, 0, 0>(Ds, Ps, lane); break;  // (3,2) (3,3)
+  }
+}
+
 __device__ __forceinline__ void publish(unsigned* f, unsigned epoch) {
   __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -855,8 +945,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         quadrant_to_lds(As, wr, wc, lane, acc);
         load_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
         __syncthreads();
-        mfma_quadrant_nt(As, Bs, wr, wc, lane, p);
-        quadrant_to_lds(Cs, wr, wc, lane, p);
+        trsm_lower_tri(As, Bs, Cs, wv, lane);
         __syncthreads();
         store_tile_coh(A.L + (size_t)i * NB * ld + (size_t)j * NB, ld, Cs, tid);
         drain_stores();
@@ -878,42 +967,67 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       continue;
     }
     // ---- chain task: the diagonal of one tree node, tile columns [T.i, T.j) ----
-    // LDS roles: Bs = L_jj^-1 of the column just factorised, Cs = the panel tile P_{j, j-1}, As = loads / diagonal tile
+    // LDS roles: Bs = L_jj^-1 of the column just factorised, Cs = the panel tile P_{j, j-1}, As = sub-diagonal tile,
+    // then the diagonal tile. The two tiles of the NEXT column (left by the helpers' PRE tasks, or untouched in M)
+    // are requested before the tile factorisation starts whenever their flags are already up - the usual case - and
+    // travel while the matrix cores factorise; otherwise the chain waits for them afterwards.
+    TileRegs Rsub, Rdiag;
+    bool have_next = false;  // Rsub / Rdiag hold column j's tiles
     for (int j = T.i; j < T.j; ++j) {
       const int info = A.chain_info[j];
-      d4 acc[2][2], p[2][2];
       const bool sub = j > T.i;
       stamp((size_t)8 * j);
+      if (!have_next) {
+        const unsigned* f0 = (sub && (info & 2)) ? A.pflag + 2 * j + 1 : nullptr;
+        const unsigned* f1 = (info & 1) ? A.pflag + 2 * j : nullptr;
+        if ((f0 || f1) && !wait2(f0, f1)) { alive = false; break; }
+        if (sub) {
+          if (info & 2) load_tile_regs(A.pre + (size_t)(2 * j + 1) * NB * NB, NB, Rsub, tid, true);
+          else load_tile_regs(A.M + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, Rsub, tid, false);
+        }
+        if (info & 1) load_tile_regs(A.pre + (size_t)(2 * j) * NB * NB, NB, Rdiag, tid, true);
+        else load_tile_regs(A.M + (size_t)j * NB * ld + (size_t)j * NB, ld, Rdiag, tid, false);
+      }
+      have_next = false;
+      stamp((size_t)8 * j + 1);
       if (sub) {
-        if ((info & 2) && !wait2(A.pflag + 2 * j + 1, nullptr)) { alive = false; break; }
-        stamp((size_t)8 * j + 1);
-        if (info & 2) load_tile_coh(A.pre + (size_t)(2 * j + 1) * NB * NB, NB, As, tid);
-        else load_tile(A.M + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, As, tid);
+        tile_regs_to_lds(Rsub, As, tid);
         __syncthreads();
-        mfma_quadrant_nt(As, Bs, wr, wc, lane, p);  // P = A_{j,j-1} L_{j-1,j-1}^-T
-        quadrant_to_lds(Cs, wr, wc, lane, p);
+        trsm_lower_tri(As, Bs, Cs, wv, lane);  // P = A_{j,j-1} L_{j-1,j-1}^-T
         __syncthreads();
         store_tile_coh(A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, Cs, tid);
         stamp((size_t)8 * j + 2);
       }
-      if ((info & 1) && !wait2(A.pflag + 2 * j, nullptr)) { alive = false; break; }
+      tile_regs_to_lds(Rdiag, As, tid);
+      __syncthreads();
       stamp((size_t)8 * j + 3);
-      if (info & 1) load_tile_coh(A.pre + (size_t)(2 * j) * NB * NB, NB, As, tid);
-      else load_tile(A.M + (size_t)j * NB * ld + (size_t)j * NB, ld, As, tid);
-      drain_stores();  // (the loads had to land anyway; the panel tile's stores are out as well)
-      __syncthreads();
-      if (sub && tid == 0) publish(A.lflag + A.tile_id[(size_t)j * nb + (j - 1)], ep);
+      if (sub) syrk_lower_blocks(As, Cs, wv, lane);
       stamp((size_t)8 * j + 4);
-      quadrant_from_lds(As, wr, wc, lane, acc);
-      if (sub) {
-        mfma_quadrant_nt(Cs, Cs, wr, wc, lane, p);
-        quadrant_sub(acc, p);
+      // next column's tiles: ask for them now if the helpers are done (one poll, no waiting)
+      const bool more = j + 1 < T.j;
+      if (tid == 0) {
+        int ready = 0;
+        if (more) {
+          const int ni = A.chain_info[j + 1];
+          ready = 1;
+          if ((ni & 2) && __hip_atomic_load(A.pflag + 2 * (j + 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
+          if ((ni & 1) && __hip_atomic_load(A.pflag + 2 * (j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
+        }
+        s_ok = ready;
       }
-      __syncthreads();
-      quadrant_to_lds(As, wr, wc, lane, acc);
-      __syncthreads();
+      if (sub) drain_stores();  // the panel tile's stores
+      __syncthreads();          // (also: the diagonal tile is complete in As)
+      if (sub && tid == 0) publish(A.lflag + A.tile_id[(size_t)j * nb + (j - 1)], ep);
+      if (s_ok) {
+        const int ni = A.chain_info[j + 1];
+        if (ni & 2) load_tile_regs(A.pre + (size_t)(2 * (j + 1) + 1) * NB * NB, NB, Rsub, tid, true);
+        else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)j * NB, ld, Rsub, tid, false);
+        if (ni & 1) load_tile_regs(A.pre + (size_t)(2 * (j + 1)) * NB * NB, NB, Rdiag, tid, true);
+        else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB, ld, Rdiag, tid, false);
+        have_next = true;
+      }
       stamp((size_t)8 * j + 5);
-      const bool ok = tile_potrf_inv_la(As, Bs, tid);
+      const bool ok = tile_potrf_inv_la(As, Bs, tid);  // (ends with a barrier: s_ok is free again)
       if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
       stamp((size_t)8 * j + 6);
       store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);

@@ -512,22 +512,40 @@ void mavba_session::finish_structure() {
   for (int i = 0; i < NI; ++i) for (int e = 0; e < 6; ++e) img_active[i] |= h_pose_free[(size_t)i * 6 + e];
   for (int c = 0; c < NC; ++c) for (int k = 0; k < 9; ++k) cam_active[c] |= h_intr_free[(size_t)c * 9 + k];
 
-  // intrinsics entries
+  // intrinsics entries: one per (free point, free camera that sees it), cameras ascending; two parallel passes
+  // over the points (count, then fill at the scanned offsets)
   std::vector<int> q_start(NP + 1, 0), q_pt, q_cam;
   {
-    std::vector<int> seen;
-    for (int p = 0; p < NP; ++p) {
-      q_start[p] = (int)q_pt.size();
-      if (!h_pt_free[p]) continue;
-      seen.clear();
+    bool any_cam_active = false;
+    for (int c = 0; c < NC; ++c) any_cam_active |= cam_active[c] != 0;
+    auto cams_of = [&](int p, int* out) {  // distinct active cameras of point p, ascending; returns their number (<= NC)
+      int n = 0;
       for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
         const int c = h_img_cam[h_oimg[a]];
-        if (cam_active[c] && std::find(seen.begin(), seen.end(), c) == seen.end()) seen.push_back(c);
+        if (!cam_active[c]) continue;
+        int k = 0;
+        while (k < n && out[k] != c) ++k;
+        if (k == n) out[n++] = c;
       }
-      std::sort(seen.begin(), seen.end());
-      for (int c : seen) { q_pt.push_back(p); q_cam.push_back(c); }
+      std::sort(out, out + n);
+      return n;
+    };
+    if (any_cam_active) {
+      parallel_ranges(NP, [&](long long p0, long long p1) {
+        std::vector<int> tmp(std::max(NC, 1));
+        for (long long p = p0; p < p1; ++p) q_start[p + 1] = h_pt_free[p] ? cams_of((int)p, tmp.data()) : 0;
+      }, 20000);
+      for (int p = 0; p < NP; ++p) q_start[p + 1] += q_start[p];
+      q_pt.resize((size_t)q_start[NP]); q_cam.resize((size_t)q_start[NP]);
+      parallel_ranges(NP, [&](long long p0, long long p1) {
+        std::vector<int> tmp(std::max(NC, 1));
+        for (long long p = p0; p < p1; ++p) {
+          if (q_start[p + 1] == q_start[p]) continue;
+          const int n = cams_of((int)p, tmp.data());
+          for (int k = 0; k < n; ++k) { q_pt[(size_t)q_start[p] + k] = (int)p; q_cam[(size_t)q_start[p] + k] = tmp[k]; }
+        }
+      }, 20000);
     }
-    q_start[NP] = (int)q_pt.size();
   }
   Q = (int)q_pt.size();
   d_q_start.upload(q_start, st); d_q_pt.upload(q_pt, st); d_q_cam.upload(q_cam, st);
@@ -682,8 +700,12 @@ void mavba_session::finish_structure() {
   // Host threads own contiguous point ranges (balanced by observations). Per-thread counts turn
   // into per-thread cursors, so the term order inside a block (by point) does not depend on the
   // number of threads: the device sums stay bit-reproducible.
+  // (global BA of short tracks: every point sits in a cluster and there is nothing to enumerate - one thread, and the
+  // per-thread count tables below stay empty)
+  long long generic_points = 0;
+  for (int p = 0; p < NP; ++p) generic_points += pt_mode[p] == 2;
   int T = host_threads();
-  if (N < 50000) T = 1;
+  if (N < 50000 || generic_points == 0) T = 1;
   while (T > 1 && (size_t)T * nkeys_tot > (size_t)48 << 20) T /= 2;
   std::vector<int> range(T + 1, NP);
   range[0] = 0;
@@ -694,19 +716,22 @@ void mavba_session::finish_structure() {
   }
   std::vector<std::vector<int>> tcount(T * 3);
   auto run_threads = [&](const std::function<void(int)>& body) { host_run(T, body); };
-  run_threads([&](int t) {
-    for (int k = 0; k < 3; ++k) tcount[t * 3 + k].assign(nkeys[k], 0);
-    enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int, int) { tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++; });
-  });
+  if (generic_points > 0)
+    run_threads([&](int t) {
+      for (int k = 0; k < 3; ++k) tcount[t * 3 + k].assign(nkeys[k], 0);
+      enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int, int) { tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++; });
+    });
   std::vector<int> count[3];
   std::vector<unsigned char> mandatory[3];
   long long tot[3] = {0, 0, 0};
   for (int k = 0; k < 3; ++k) {
     count[k].assign(nkeys[k], 0);
     mandatory[k].assign(nkeys[k], 0);
-    for (int t = 0; t < T; ++t)
-      for (size_t key = 0; key < nkeys[k]; ++key) count[k][key] += tcount[t * 3 + k][key];
-    for (size_t key = 0; key < nkeys[k]; ++key) tot[k] += count[k][key];
+    if (generic_points > 0) {
+      for (int t = 0; t < T; ++t)
+        for (size_t key = 0; key < nkeys[k]; ++key) count[k][key] += tcount[t * 3 + k][key];
+      for (size_t key = 0; key < nkeys[k]; ++key) tot[k] += count[k][key];
+    }
   }
   for (int i = 0; i < NI; ++i) {
     if (!img_active[i]) continue;
@@ -819,16 +844,18 @@ void mavba_session::finish_structure() {
   std::unique_ptr<int2[]> terms[3];  // uninitialised on purpose: first touched by the filling threads
   for (int k = 0; k < 3; ++k) terms[k].reset(new int2[std::max<size_t>((size_t)tot[k], 1)]);
   // per-thread cursors: block offset + what the threads owning earlier points put into the block
-  for (int k = 0; k < 3; ++k)
-    for (size_t key = 0; key < nkeys[k]; ++key) {
-      int run = cursor[k][key];
-      for (int t = 0; t < T; ++t) { const int c = tcount[t * 3 + k][key]; tcount[t * 3 + k][key] = run; run += c; }
-    }
-  run_threads([&](int t) {
-    enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int x, int y) {
-      terms[kind][(size_t)tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++] = make_int2(x, y);
+  if (generic_points > 0) {
+    for (int k = 0; k < 3; ++k)
+      for (size_t key = 0; key < nkeys[k]; ++key) {
+        int run = cursor[k][key];
+        for (int t = 0; t < T; ++t) { const int c = tcount[t * 3 + k][key]; tcount[t * 3 + k][key] = run; run += c; }
+      }
+    run_threads([&](int t) {
+      enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int x, int y) {
+        terms[kind][(size_t)tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++] = make_int2(x, y);
+      });
     });
-  });
+  }
   lap("fill terms");
   choose_elimination_order(blocks);
   lap("elimination order");
