@@ -227,7 +227,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 // LDS use: T lower blocks = the matrix (column c stays raw, blocks right of it are updated in place
 // by their owner wave); T upper blocks = per-wave scratch; Ti diagonal + lower = the inverse;
 // Ti upper block (c, j) = L_jc while the factorisation runs (zeroed at the end).
-__device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid) {
+struct NoPhaseHook { __device__ __forceinline__ void operator()(int) const {} };
+// `hook(ph)`: called by every thread right after the barrier that ends phase ph (1..4): lets the caller slip a flag poll /
+// a prefetch into the factorisation (the persistent chain asks for its next tiles there).
+template <class Hook = NoPhaseHook>
+__device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid, Hook hook = Hook()) {
   const int wv = tid >> 6, lane = tid & 63;
   const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
   auto Tb = [&](int i, int j) { return T + (16 * i) * GLD + 16 * j; };
@@ -280,6 +284,7 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
     downdate(Tb(3, 2), Tb(1, 2), Tb(1, 3));
   }
   __syncthreads();
+  hook(1);
   // ---- phase 2: panel 1; wave 0 goes on to D_2; wave 3 starts on the inverse
   if (wv == 0) {
     panel(Tb(2, 1), Xb(1, 1), Lb(2, 1));
@@ -303,6 +308,7 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
     store_d16(Xb(1, 0), GLD, m, lane);
   }
   __syncthreads();
+  hook(2);
   // ---- phase 3: panel 2; wave 0 goes on to D_3
   if (wv == 0) {
     panel(Tb(3, 2), Xb(2, 2), Lb(3, 2));
@@ -325,6 +331,7 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
     store_d16(Xb(2, 0), GLD, m, lane);
   }
   __syncthreads();
+  hook(3);
   // ---- phase 4: last block row of the inverse, X_3j = -Dinv_3 sum_{k=j}^{2} L_3k X_kj
   if (wv < 3) {
     const int j = 2 - wv;  // wave 0: X_32, wave 1: X_31, wave 2: X_30
@@ -1027,7 +1034,28 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         have_next = true;
       }
       stamp((size_t)8 * j + 5);
-      const bool ok = tile_potrf_inv_la(As, Bs, tid);  // (ends with a barrier: s_ok is free again)
+      // The helpers usually finish the next column's tiles while this factorisation runs: wave 3 (idle in phase 3)
+      // polls once more after phase 2, the loads go out after phase 3 and land during the last phase.
+      auto late_prefetch = [&](int ph) {
+        if (!more || have_next) return;
+        if (ph == 2) {
+          if (tid == 192) {
+            const int ni = A.chain_info[j + 1];
+            int ready = 1;
+            if ((ni & 2) && __hip_atomic_load(A.pflag + 2 * (j + 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
+            if ((ni & 1) && __hip_atomic_load(A.pflag + 2 * (j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
+            s_ok = ready;
+          }
+        } else if (ph == 3 && s_ok) {
+          const int ni = A.chain_info[j + 1];
+          if (ni & 2) load_tile_regs(A.pre + (size_t)(2 * (j + 1) + 1) * NB * NB, NB, Rsub, tid, true);
+          else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)j * NB, ld, Rsub, tid, false);
+          if (ni & 1) load_tile_regs(A.pre + (size_t)(2 * (j + 1)) * NB * NB, NB, Rdiag, tid, true);
+          else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB, ld, Rdiag, tid, false);
+          have_next = true;
+        }
+      };
+      const bool ok = tile_potrf_inv_la(As, Bs, tid, late_prefetch);  // (ends with a barrier: s_ok is free again)
       if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
       stamp((size_t)8 * j + 6);
       store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
