@@ -103,7 +103,9 @@ static size_t cam_lds_limit() {
   return v;
 }
 
-template <int KMAX, bool LDS_CAM>
+// MASK: the session has filtered points (pt_active != null); a separate instantiation so that the common path keeps
+// its register budget (the extra byte load costs the unmasked kernel a wave of occupancy: 0.106 -> 0.127 ms at C3).
+template <int KMAX, bool LDS_CAM, bool MASK>
 __global__ void __launch_bounds__(256) k_jacobian_sweep(SweepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const CamTables T = stage_cameras<LDS_CAM>(smem, a.NI, a.NC, a.camrec, a.intr, a.img_cam, a.cam_model);
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(256) k_jacobian_sweep(SweepArgs a) {
       obs_jacobian(model, rec, kin, X, uo[j], vo[j], r, Jc, Jp, Jk);
       double w, half_rho;
       cauchy_weight(r[0] * r[0] + r[1] * r[1], a.loss_b, a.loss_inv_b, w, half_rho);
-      if (a.pt_active && !a.pt_active[pt[j]]) { w = 0.0; half_rho = 0.0; }  // filtered point: no residual block
+      if constexpr (MASK) { if (!a.pt_active[pt[j]]) { w = 0.0; half_rho = 0.0; } }  // filtered point: no residual block
       if (j == 0 || two) cost += half_rho;
       out[j][0] = w * r[0]; out[j][1] = w * r[1];
 #pragma unroll
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256) k_jacobian_sweep(SweepArgs a) {
   if (tid == 0) a.cost_partial[blockIdx.x] = tot;
 }
 
-template <bool LDS_CAM>
+template <bool LDS_CAM, bool MASK>
 __global__ void __launch_bounds__(256) k_cost_only(SweepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const CamTables T = stage_cameras<LDS_CAM>(smem, a.NI, a.NC, a.camrec, a.intr, a.img_cam, a.cam_model);
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(256) k_cost_only(SweepArgs a) {
     obs_residual(T.model[cam], rec, kin, X, m.x, m.y, r);
     double w, half_rho;
     cauchy_weight(r[0] * r[0] + r[1] * r[1], a.loss_b, a.loss_inv_b, w, half_rho);
-    if (a.pt_active && !a.pt_active[pt]) half_rho = 0.0;
+    if constexpr (MASK) { if (!a.pt_active[pt]) half_rho = 0.0; }
     cost += half_rho;
   }
   const double tot = block_sum_256(cost, smem);
@@ -221,9 +223,12 @@ void launch_jacobian_sweep(hipStream_t st, const SweepArgs& a) {
   const size_t lds = camera_lds_bytes(a.NI, a.NC);
   const bool use_lds = lds <= cam_lds_limit();
   const size_t shm = use_lds ? lds : 64;
-#define MAVBA_SWEEP(K)                                                                              \
-  if (use_lds) hipLaunchKernelGGL((k_jacobian_sweep<K, true>), dim3(grid), dim3(256), shm, st, a);  \
-  else hipLaunchKernelGGL((k_jacobian_sweep<K, false>), dim3(grid), dim3(256), shm, st, a);
+#define MAVBA_SWEEP(K)                                                                                           \
+  if (a.pt_active) {                                                                                             \
+    if (use_lds) hipLaunchKernelGGL((k_jacobian_sweep<K, true, true>), dim3(grid), dim3(256), shm, st, a);       \
+    else hipLaunchKernelGGL((k_jacobian_sweep<K, false, true>), dim3(grid), dim3(256), shm, st, a);              \
+  } else if (use_lds) hipLaunchKernelGGL((k_jacobian_sweep<K, true, false>), dim3(grid), dim3(256), shm, st, a); \
+  else hipLaunchKernelGGL((k_jacobian_sweep<K, false, false>), dim3(grid), dim3(256), shm, st, a);
   if (a.KMAX <= 4) { MAVBA_SWEEP(4) } else if (a.KMAX <= 8) { MAVBA_SWEEP(8) } else { MAVBA_SWEEP(9) }
 #undef MAVBA_SWEEP
 }
@@ -232,8 +237,11 @@ void launch_cost_only(hipStream_t st, const SweepArgs& a) {
   const int grid = jacobian_sweep_grid(a.N);  // same partial count as the sweep
   const size_t lds = camera_lds_bytes(a.NI, a.NC);
   const bool use_lds = lds <= cam_lds_limit();
-  if (use_lds) hipLaunchKernelGGL((k_cost_only<true>), dim3(grid), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((k_cost_only<false>), dim3(grid), dim3(256), 64, st, a);
+  if (a.pt_active) {
+    if (use_lds) hipLaunchKernelGGL((k_cost_only<true, true>), dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_cost_only<false, true>), dim3(grid), dim3(256), 64, st, a);
+  } else if (use_lds) hipLaunchKernelGGL((k_cost_only<true, false>), dim3(grid), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((k_cost_only<false, false>), dim3(grid), dim3(256), 64, st, a);
 }
 void launch_raw_residual_norm(hipStream_t st, const SweepArgs& a, double* out_norm) {
   if (a.N <= 0) return;
