@@ -1309,7 +1309,9 @@ int device_cu_count() {
 hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& col_rows, const std::vector<int>& col_step,
                                            const std::vector<int>& height, hipStream_t st) {
   persist_ok = false;
-  static const bool enabled = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST"); return !e || std::atoi(e) != 0; }();
+  // MAVBA_CHOL_PERSIST: 0 = never, 1 (default) = when it pays, 2 = whenever a schedule exists
+  static const int mode = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST"); return e ? std::atoi(e) : 1; }();
+  const bool enabled = mode != 0;
   static const int grid_cap = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST_GRID"); return e ? std::atoi(e) : 0; }();
   if (!enabled || nb < 1 || nb > 512) return hipSuccess;  // (dense tile-id table)
   int G = device_cu_count();
@@ -1405,6 +1407,11 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     ++alloc[best]; ++given;
   }
   const int grid = nch + given;
+  // The persistent schedule wins where the dependent chain is the cost (C3: 4 499 tile updates, 18 per helper, solve
+  // 0.71 -> 0.47 ms). A tile update costs a helper ~3.5 us (two flag polls, two write-through tile loads, one 64^3
+  // product), so with hundreds of updates per helper the launch-per-panel schedule - whose trailing updates are plain
+  // wide launches - is faster again (C5: 75 582 updates, 300 per helper: 3.45 ms against 4.96 ms).
+  if (mode == 1 && nupd > 100ll * given) return hipSuccess;
   std::vector<std::vector<CholTask>> wg_tasks(grid);
   for (int n = 0; n < nseg; ++n) wg_tasks[chain_wg[n]].push_back(CholTask{CHOL_TASK_CHAIN, nodes[n].begin, nodes[n].end, 0, 0});
   {
