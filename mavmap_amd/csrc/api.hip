@@ -70,7 +70,19 @@ int mavba_session_create(const mavba_problem* problem, const mavba_options* opti
   catch (const std::exception& e) { g_last_error = e.what(); delete s; return MAVBA_ERR_HIP; }
 }
 
-void mavba_session_destroy(mavba_session* s) { delete s; }
+void mavba_session_destroy(mavba_session* s) {
+  if (!s) return;
+  if (!std::getenv("MAVBA_SETUP_TIMING")) { delete s; return; }
+  // phase timing of the tear-down (profiling aid)
+  double t0 = now_s();
+  auto lap = [&](const char* what) { const double t = now_s(); std::fprintf(stderr, "[destroy] %-26s %8.2f ms\n", what, 1e3 * (t - t0)); t0 = t; };
+  if (s->st) (void)hipStreamSynchronize(s->st);
+  lap("stream sync");
+  s->chol_struct.release();
+  lap("factorisation structure");
+  delete s;
+  lap("rest (device buffers -> pool)");
+}
 
 int mavba_session_reset(mavba_session* s) {
   MAVBA_TRY
@@ -103,12 +115,21 @@ int mavba_session_result(mavba_session* s, mavba_result* result) {
 int mavba_session_get_params(mavba_session* s, double* poses, double* intrinsics, double* points) {
   MAVBA_TRY
   if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
-  if (poses && s->NI) HIP_OK(hipMemcpyAsync(poses, s->d_poses.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
-  if (intrinsics && s->NC) HIP_OK(hipMemcpyAsync(intrinsics, s->d_intr.p, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
-  std::vector<double> hp;
-  if (points && s->NP) { hp.resize((size_t)s->NP * 3); HIP_OK(hipMemcpyAsync(hp.data(), s->d_points.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st)); }
+  // one pinned staging block: poses | intrinsics | points (already in the caller's order, permuted on the device)
+  const size_t nI = (size_t)s->NI * 6, nC = (size_t)s->NC * 9, nP = (size_t)s->NP * 3;
+  double* stage = nullptr;
+  HIP_OK(pinned_alloc(reinterpret_cast<void**>(&stage), (nI + nC + nP + 1) * 8));
+  struct Give { void* p; ~Give() { pinned_free(p); } } give{stage};
+  if (poses && nI) HIP_OK(hipMemcpyAsync(stage, s->d_poses.p, nI * 8, hipMemcpyDeviceToHost, s->st));
+  if (intrinsics && nC) HIP_OK(hipMemcpyAsync(stage + nI, s->d_intr.p, nC * 8, hipMemcpyDeviceToHost, s->st));
+  if (points && nP) {
+    launch_points_to_caller(s->st, s->NP, 3, s->d_pt_orig.p, s->d_points.p, s->d_pts_out.p);
+    HIP_OK(hipMemcpyAsync(stage + nI + nC, s->d_pts_out.p, nP * 8, hipMemcpyDeviceToHost, s->st));
+  }
   s->sync();
-  if (points) s->to_caller_points(hp.data(), points, 3);
+  if (poses && nI) std::memcpy(poses, stage, nI * 8);
+  if (intrinsics && nC) std::memcpy(intrinsics, stage + nI, nC * 8);
+  if (points && nP) std::memcpy(points, stage + nI + nC, nP * 8);
   return MAVBA_OK;
   MAVBA_CATCH
 }

@@ -192,6 +192,7 @@ struct ReduceTask { const double* src; int rows, stride, is_max; const double* s
 struct ReduceTasks { ReduceTask t[6]; };
 void launch_reduce_tasks(hipStream_t st, const ReduceTasks& tasks, int n);
 
+void launch_points_to_caller(hipStream_t st, int NP, int width, const int* orig, const double* in, double* out);
 void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,
                          const int* pt_count, double* perr);
 

@@ -1488,6 +1488,18 @@ void launch_reduce_tasks(hipStream_t st, const ReduceTasks& T, int n) {
   if (n > 0) hipLaunchKernelGGL(k_reduce_tasks, dim3(n), dim3(256), 0, st, T);
 }
 
+// read-back of per-point values in the caller's order: out[orig[q]][e] = in[q][e]
+__global__ void k_points_to_caller(int NP, int width, const int* __restrict__ orig, const double* __restrict__ in, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= NP * width) return;
+  const int q = t / width, e = t - q * width;
+  out[(size_t)orig[q] * width + e] = in[t];
+}
+void launch_points_to_caller(hipStream_t st, int NP, int width, const int* orig, const double* in, double* out) {
+  if (NP <= 0) return;
+  hipLaunchKernelGGL(k_points_to_caller, dim3((NP * width + 255) / 256), dim3(256), 0, st, NP, width, orig, in, out);
+}
+
 // point3D_errors: sum |r_raw| / count over a point's observations (bundle_adjustment.cc:590-596)
 __global__ void k_point_errors(int NP, const int* __restrict__ pt_start, const double* __restrict__ rnorm,
                                const int* __restrict__ pt_count, double* __restrict__ perr) {

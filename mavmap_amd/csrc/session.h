@@ -73,10 +73,32 @@ void rccl_unique_id(void* out128);
 void* rccl_comm_create(const void* id128, int rank, int world);
 void rccl_comm_destroy(void* comm);
 void rccl_allreduce(void* comm, double* p, long long count, int op, hipStream_t stream);
+hipError_t pinned_alloc(void** out, size_t bytes);
+void pinned_free(void* p);
 hipError_t stream_acquire(hipStream_t* st);
 void stream_release(hipStream_t st, int dev);
 int host_threads();
 void host_run(int T, const std::function<void(int)>& body);
+
+// The three big per-observation / per-point host arrays of a session are handed from a dying session to the next one
+// (capacity reuse): freeing and re-faulting ~30 MB per bundle_adjustment() call cost 14 ms of tear-down at C3.
+template <typename T>
+struct HostSpare {
+  static std::mutex& mtx() { static std::mutex m; return m; }
+  static std::vector<std::vector<T>>& slots() { static std::vector<std::vector<T>>* s = new std::vector<std::vector<T>>; return *s; }
+  static void give(std::vector<T>& v) {
+    if (v.capacity() < (1u << 16)) return;
+    std::lock_guard<std::mutex> g(mtx());
+    if (slots().size() < 4) { slots().emplace_back(); slots().back().swap(v); }
+  }
+  static void take(std::vector<T>& v, size_t want) {  // v gets the spare with the largest capacity (if any)
+    std::lock_guard<std::mutex> g(mtx());
+    int best = -1;
+    for (size_t i = 0; i < slots().size(); ++i)
+      if (best < 0 || slots()[i].capacity() > slots()[best].capacity()) best = (int)i;
+    if (best >= 0 && slots()[best].capacity() >= want / 2) { v.swap(slots()[best]); slots().erase(slots().begin() + best); }
+  }
+};
 
 // Host scratch array WITHOUT value-initialisation (std::vector<T>(n) clears the memory first: ~1 ms per 10 MB,
 // and the set-up shuffles ~100 MB of such arrays that are fully overwritten anyway).
@@ -205,6 +227,8 @@ struct mavba_session {
   DevBuf<double> d_Epose, d_Eintr, d_Wk, d_part[3];
   DevBuf<double> d_M, d_L, d_y, d_diag_ws, d_delta_cam, d_delta_pts, d_norm_partial, d_step_partial, d_scal;
   DevBuf<double> d_rnorm, d_perr;
+  DevBuf<int> d_pt_orig;      // internal point -> caller's index (read-backs are permuted on the device)
+  DevBuf<double> d_pts_out;   // [NP][3] staging in the caller's order
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
@@ -246,6 +270,7 @@ struct mavba_session {
     // the buffers go back to the process-wide pool: nothing may still be running on them
     if (st) (void)hipStreamSynchronize(st);
     if (rccl_comm) rccl_comm_destroy(rccl_comm);
+    HostSpare<long long>::give(perm); HostSpare<int>::give(h_oimg); HostSpare<double>::give(h_points0);
     for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& e : ev_pool) (void)hipEventDestroy(e);
     if (st) stream_release(st, device);

@@ -79,6 +79,7 @@ void mavba_session::build(const mavba_problem* P) {
 
   h_poses0.assign(P->poses, P->poses + (size_t)NI * 6);
   h_intr0.assign(P->intrinsics, P->intrinsics + (size_t)NC * 9);
+  HostSpare<double>::take(h_points0, (size_t)NP * 3);
   h_points0.assign(P->points, P->points + (size_t)NP * 3);
   h_pose_const.assign(NI, 0); h_intr_const_in.assign(NC, 0); h_pt_const_in.assign(NP, 0);
   if (P->pose_const) h_pose_const.assign(P->pose_const, P->pose_const + NI);
@@ -231,10 +232,12 @@ void mavba_session::build(const mavba_problem* P) {
   // ---- point-major order: the buckets in the new point order ----
   h_pt_start.assign(NP + 1, 0);
   for (int q = 0; q < NP; ++q) h_pt_start[q + 1] = h_pt_start[q] + (cstart[h_pt_orig[q] + 1] - cstart[h_pt_orig[q]]);
-  perm.assign(N, 0);
+  HostSpare<long long>::take(perm, (size_t)N);
+  HostSpare<int>::take(h_oimg, (size_t)N);
+  perm.resize(N);    // (every element is written by the pass below)
   HostBuf<double2> uv(N);
   HostBuf<int> opt_(N);
-  h_oimg.assign(N, 0);
+  h_oimg.resize(N);
   parallel_ranges(NP, [&](long long q0, long long q1) {
     for (long long q = q0; q < q1; ++q) {
       const int src = cstart[h_pt_orig[q]], cnt = h_pt_start[q + 1] - h_pt_start[q];
@@ -296,6 +299,7 @@ void mavba_session::build(const mavba_problem* P) {
   d_cam_img_start.upload(cam_img_start, st); d_cam_imgs.upload(cam_imgs, st);
   d_prior_img.upload(prior_img, st); d_prior_start.upload(prior_start, st); d_prior_R0.upload(prior_R0, st);
   d_pt_count.upload(h_pt_count_all, st);
+  d_pt_orig.upload(h_pt_orig, st); d_pts_out.alloc((size_t)std::max(NP, 1) * 3);
   d_poses0.upload(h_poses0, st); d_intr0.upload(h_intr0, st); d_points0.upload(h_points0, st);
   const size_t nI = std::max(NI, 1), nC = std::max(NC, 1), nP = std::max(NP, 1);
   d_poses.alloc(nI * 6); d_intr.alloc(nC * 9); d_points.alloc(nP * 3);

@@ -11,6 +11,8 @@ for rep in range(3):
     s = mavmap_amd.Session(p, opts)
     print("create %.1f ms" % (1e3 * (time.time() - t)), file=sys.stderr)
     s.close()
-q = p.copy()
-t = time.time(); cost, res = mavmap_amd.bundle_adjustment(q, opts); dt = time.time() - t
+for rep in range(3):
+    q = p.copy()
+    print("---- mavba_solve call", rep, file=sys.stderr)
+    t = time.time(); cost, res = mavmap_amd.bundle_adjustment(q, opts); dt = time.time() - t
 print("mavba_solve end to end %.1f ms: setup %.1f, solve %.1f, iterations %d" % (1e3 * dt, 1e3 * res["setup_seconds"], 1e3 * res["solve_seconds"], res["num_successful_steps"] + res["num_unsuccessful_steps"]), file=sys.stderr)
