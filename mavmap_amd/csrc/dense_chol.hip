@@ -887,6 +887,7 @@ struct CholPersistArgs {
   unsigned* lflag; unsigned* dflag; unsigned* pflag; unsigned* abort_flag;
   unsigned epoch;
   double* fail;
+  int drop_wg;                // test hook (MAVBA_CHOL_TEST_DROP_WG): this work-group does nothing, as if it were never resident
   unsigned long long* trace;  // MAVBA_CHOL_TRACE: 100 MHz wall-clock stamps, [8 per chain column | 4 per task], else null
 };
 
@@ -912,6 +913,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
     __syncthreads();  // s_ok may be rewritten by the next wait
     return ok;
   };
+  if ((int)blockIdx.x == A.drop_wg) return;
   bool alive = true;
   auto stamp = [&](size_t slot) { if (A.trace && tid == 0) A.trace[slot] = wall_clock64(); };
   for (int ti = A.wg_begin[blockIdx.x]; alive && ti < A.wg_begin[blockIdx.x + 1]; ++ti) {
@@ -1482,6 +1484,8 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
     A.tasks = cs.d_tasks; A.wg_begin = cs.d_wg_begin; A.upd = cs.d_upd; A.tile_id = cs.d_tile_id; A.chain_info = cs.d_chain_info;
     A.lflag = cs.d_pflags; A.dflag = cs.d_pflags + cs.persist_tiles; A.pflag = A.dflag + nb; A.abort_flag = A.pflag + 2 * nb;
     A.epoch = epoch; A.fail = fail; A.trace = cs.d_trace;
+    static const int drop = [] { const char* e = std::getenv("MAVBA_CHOL_TEST_DROP_WG"); return e ? std::atoi(e) : -1; }();
+    A.drop_wg = drop;
     hipLaunchKernelGGL(k_chol_persist, dim3(cs.persist_grid), dim3(256), 0, st, A);
   } else {
   if (cs.shadow_doubles) (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);

@@ -239,7 +239,11 @@ class HostWorkers {
   }
 };
 int host_threads() {
-  static const int n = (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+  static const int n = [] {
+    const char* e = std::getenv("MAVBA_HOST_THREADS");
+    const int cap = e ? std::max(1, std::atoi(e)) : 16;
+    return (int)std::min<size_t>((size_t)cap, std::max(1u, std::thread::hardware_concurrency()));
+  }();
   return n;
 }
 void host_run(int T, const std::function<void(int)>& body) {

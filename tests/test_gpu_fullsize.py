@@ -143,3 +143,41 @@ def test_dense_spd_solve_with_the_other_panel_schedule(mavba, fuse):
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float(out.stdout.split("WORST")[1])
     assert worst < 1e-10, worst
+
+
+_ABORT_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import mavmap_amd
+from mavmap_amd import synth
+from tests.test_gpu_fullsize import _spd
+A, b = _spd(700, 7)
+x = mavmap_amd.dense_spd_solve(A, b)
+x0 = np.linalg.solve(A, b)
+print("DENSE", float(np.abs(x - x0).max() / np.abs(x0).max()))
+p = synth.make_scene(num_images=130, num_points=5000, track_len=4, models=[1, 2], seed=5, long_track_frac=0.01, long_track_len=12, spacing=6.0)
+opts = dict(max_num_iterations=200, function_tolerance=1e-6, gradient_tolerance=1e-10)
+q = p.copy()
+cost, res = mavmap_amd.bundle_adjustment(q, opts)
+print("SOLVE", cost, res["num_successful_steps"], res["termination"])
+"""
+
+
+def test_persistent_factorisation_gives_up_cleanly_and_the_solve_falls_back(mavba):
+    """A work-group of the persistent launch that never runs (here: told to return at once; in the field: CU masking or a
+    second persistent launch competing for the CUs) must not hang the device: the waits time out, the launch reports it,
+    and the solve is repeated with the launch-per-panel schedule - same answers as an undisturbed process."""
+    outs = []
+    for drop in (None, "5"):
+        env = dict(os.environ)
+        env.pop("MAVBA_CHOL_TEST_DROP_WG", None)
+        if drop:
+            env["MAVBA_CHOL_TEST_DROP_WG"] = drop
+        out = subprocess.run([sys.executable, "-c", _ABORT_SNIPPET.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out)
+    assert "falling back" in outs[1].stderr and "falling back" not in outs[0].stderr
+    d0, d1 = (float(o.stdout.split("DENSE")[1].split()[0]) for o in outs)
+    assert d0 < 1e-10 and d1 < 1e-10
+    s0, s1 = (o.stdout.split("SOLVE")[1].split() for o in outs)
+    assert s0[1:] == s1[1:] and abs(float(s0[0]) - float(s1[0])) < 1e-9 * float(s0[0])
