@@ -611,8 +611,8 @@ __global__ void k_scatter_y(int n, const int* __restrict__ scatter, const double
 
 // Backward substitution L^T x = z in ONE launch: a work-group owns tile rows k,
 //   x_k = L_kk^-T (z_k - sum_{i > k} L_ik^T x_i),
-// and consumes the x_i in decreasing i as their owners publish them (flag per tile carrying the solve's epoch,
-// release/acquire at agent scope). Each of the 4 waves takes 16 of the 64 rows of every tile; the tile values
+// and consumes the x_i in decreasing i as their owners publish them (flag per tile carrying the solve's epoch; the
+// segments travel by system-scope write-through stores / loads, the flags are relaxed: no fences). Each of the 4 waves takes 16 of the 64 rows of every tile; the tile values
 // are fetched BEFORE the wait, so a step of the chain is {flag + 64 values of x, 16 FMAs, two LDS
 // reductions}, not a kernel launch. Tile (i, k) takes part iff k is inside row i's envelope for k's
 // segment - uncoupled parts of a nested-dissection ordering therefore never wait for each other.
@@ -624,6 +624,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
                                                             unsigned* flags, unsigned epoch, const int* __restrict__ scatter,
                                                             double* __restrict__ y_nat) {
   __shared__ double part[4][NB];
+  __shared__ double xs[4][16];  // a wave's 16 values of the published segment it is consuming
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   // Work-group b owns tile rows nb-1-b, nb-1-b-G, ... (decreasing): every row it waits for belongs to a work-group
   // that reaches it without waiting for this one, so a resident grid (G <= 2 per CU) cannot dead-lock whatever the
@@ -652,8 +653,13 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
 #pragma unroll
       for (int q = 0; q < 16; ++q) ln[q] = Lt[(size_t)q * ld];
     }
-    while (__hip_atomic_load(&flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
-    const double* xi = y + (size_t)i * NB + 16 * wv;
+    // hand-off: the owner wrote x_i with system-scope (write-through) stores, drained them and raised the flag; the
+    // poll is relaxed and the values are read with system-scope loads - no fences (an agent-scope release / acquire
+    // pair costs 3-8 us per hop here), placement independent
+    while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+    if (lane < 16) xs[wv][lane] = __hip_atomic_load(y + (size_t)i * NB + 16 * wv + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    wave_lds_sync();
+    const double* xi = xs[wv];
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; q += 2) {
@@ -661,6 +667,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
       a1 = __builtin_fma(l[q + 1], xi[q + 1], a1);
     }
     acc -= a0 + a1;
+    wave_lds_sync();  // xs[wv] is rewritten in the next round
 #pragma unroll
     for (int q = 0; q < 16; ++q) l[q] = ln[q];
     i = nx;
@@ -683,14 +690,14 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
   __syncthreads();
   if (wv == 0) {
     const double x = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-    y[(size_t)k * NB + lane] = x;
-    if (scatter) {
+    __hip_atomic_store(y + (size_t)k * NB + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(&flags[k], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (scatter) {  // (read by later launches only)
       const int t = scatter[k * NB + lane];
       if (t >= 0) y_nat[t] = x;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) __hip_atomic_store(&flags[k], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();  // `part` is reused by the next row
   }

@@ -355,7 +355,11 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   std::vector<TNode> tn;
   int forced = -1, max_depth = 2;
   if (const char* e = std::getenv("MAVBA_ND_PARTS")) forced = std::atoi(e);  // 0/1 = off, n = force n flat parts
-  if (const char* e = std::getenv("MAVBA_ND_DEPTH")) max_depth = std::atoi(e);  // recursion depth of the automatic choice
+  // Depth of the recursive bisection. The persistent factorisation has no barrier between tree levels, so what counts is
+  // the longest root-to-leaf path and a third level pays (C3: 0.44 -> 0.41 ms); large systems run the launch-per-panel
+  // schedule, whose per-level launches make depth 3 slightly slower (C5: 3.46 -> 3.58 ms).
+  if (tiles0 <= 96) max_depth = 3;
+  if (const char* e = std::getenv("MAVBA_ND_DEPTH")) max_depth = std::atoi(e);
   const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && max_depth > 0 && (world == 1 || NI <= 4096);
   if (can_dissect) {
     // image adjacency (lower: col < row) from the pose-pose blocks; with shards, the union over ranks
@@ -399,22 +403,34 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
         tn.clear();
       }
     } else {
-      // recursive bisection: M (ascending) -> [A | B | S], S = the members of the second run that have a neighbour
-      // in the first; the cut is scanned for the shortest chain max(A, B) + S, and a split must pay
-      std::vector<int> pos(NI, -1);
+      // recursive bisection: M (ascending) -> [A | B | S] with A and B uncoupled. Two candidates per set, the one with
+      // the shorter chain max(A, B) + S wins (and a split must pay):
+      //  * by acquisition order: S = the members of the second run that have a neighbour in the first (a flight strip is
+      //    banded in that order); the cut is scanned;
+      //  * by a level structure: breadth-first levels from a pseudo-peripheral image - edges only join adjacent
+      //    levels, so one level (thinned to its members with a neighbour in the next level) separates what lies before
+      //    from what lies behind; on a 2-D block of images this cuts ACROSS the short side, where the order-based cut
+      //    can only take whole rows (C3: separators of 4 instead of 8 tile columns).
+      std::vector<std::vector<int>> adj(NI);
+      for (int r = 0; r < NI; ++r)
+        for (int c : lower[r]) { adj[r].push_back(c); adj[c].push_back(r); }
+      for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+      bool use_levels = true;
+      if (const char* e = std::getenv("MAVBA_ND_LEVELS")) use_levels = std::atoi(e) != 0;
+      std::vector<int> pos(NI, -1), level(NI, -1);
       std::function<std::pair<int, int>(std::vector<int>&&, int, int)> rec = [&](std::vector<int>&& M, int depth, int tl) {
         const int n = (int)M.size();
         const int leaf_tiles = tiles_of(6 * n + tl);
         auto make_leaf = [&]() { tn.push_back(TNode{std::move(M), -1}); return std::make_pair((int)tn.size() - 1, leaf_tiles); };
         if (depth >= max_depth || n < 32 || leaf_tiles < 6) return make_leaf();
         for (int t = 0; t < n; ++t) pos[M[t]] = t;
+        // ---- candidate 1: cut of the acquisition order
         std::vector<int> mnp(n);
         for (int t = 0; t < n; ++t) {
           int m = t;
           for (int c : lower[M[t]]) if (pos[c] >= 0) m = std::min(m, pos[c]);
           mnp[t] = m;
         }
-        for (int t = 0; t < n; ++t) pos[M[t]] = -1;
         int best = leaf_tiles, best_c = -1;
         for (int c = n / 4; c <= 3 * n / 4; c += std::max(1, n / 64)) {
           int ns = 0;
@@ -423,9 +439,78 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
           const int est = std::max(tiles_of(6 * c), tiles_of(6 * (n - c - ns))) + tiles_of(6 * ns + tl);
           if (est < best) { best = est; best_c = c; }
         }
-        if (best_c < 0 || best > leaf_tiles - std::max(2, leaf_tiles / 8)) return make_leaf();
-        std::vector<int> A(M.begin(), M.begin() + best_c), B, S;
-        for (int t = best_c; t < n; ++t) (mnp[t] < best_c ? S : B).push_back(M[t]);
+        // ---- candidate 2: a level of a breadth-first level structure
+        int best_lv = leaf_tiles, best_m = -1, nlev = 0;
+        if (use_levels) {
+          auto bfs = [&](int start) {  // levels of the sub-graph induced by M; a further component starts two levels on
+            for (int t = 0; t < n; ++t) level[M[t]] = -1;
+            std::vector<int> queue;
+            queue.reserve(n);
+            size_t head = 0;
+            int seed = start, base = 0, scan = 0;
+            for (;;) {
+              level[seed] = base;
+              queue.push_back(seed);
+              while (head < queue.size()) {
+                const int v = queue[head++];
+                for (int w : adj[v]) if (pos[w] >= 0 && level[w] < 0) { level[w] = level[v] + 1; queue.push_back(w); }
+              }
+              if ((int)queue.size() == n) break;
+              base = level[queue.back()] + 2;
+              while (level[M[scan]] >= 0) ++scan;
+              seed = M[scan];
+            }
+            return queue;
+          };
+          // pseudo-peripheral start: the lowest-degree image of the last level, twice
+          int start = M[0];
+          for (int round = 0; round < 2; ++round) {
+            const std::vector<int> q = bfs(start);
+            const int last = level[q.back()];
+            int pick = -1;
+            for (int v : q)
+              if (level[v] == last && (pick < 0 || adj[v].size() < adj[pick].size() || (adj[v].size() == adj[pick].size() && v < pick))) pick = v;
+            start = pick;
+          }
+          bfs(start);
+          for (int t = 0; t < n; ++t) nlev = std::max(nlev, level[M[t]] + 1);
+          // per level: size, and how many members have a neighbour in the NEXT level (the thinned separator)
+          std::vector<int> lsize(nlev, 0), lsep(nlev, 0);
+          for (int t = 0; t < n; ++t) {
+            const int v = M[t];
+            lsize[level[v]]++;
+            bool fwd = false;
+            for (int w : adj[v]) if (pos[w] >= 0 && level[w] == level[v] + 1) { fwd = true; break; }
+            lsep[level[v]] += fwd;
+          }
+          int before = 0;
+          for (int m = 0; m < nlev; ++m) {
+            const int ns = lsep[m], na = before + lsize[m] - ns, nbh = n - before - lsize[m];
+            before += lsize[m];
+            if (na < 8 || nbh < 8 || (ns == 0 && tl == 0)) continue;
+            const int est = std::max(tiles_of(6 * na), tiles_of(6 * nbh)) + tiles_of(6 * ns + tl);
+            if (est < best_lv) { best_lv = est; best_m = m; }
+          }
+        }
+        std::vector<int> A, B, S;
+        if (best_m >= 0 && best_lv < best) {
+          for (int t = 0; t < n; ++t) {
+            const int v = M[t];
+            if (level[v] < best_m) A.push_back(v);
+            else if (level[v] > best_m) B.push_back(v);
+            else {
+              bool fwd = false;
+              for (int w : adj[v]) if (pos[w] >= 0 && level[w] == best_m + 1) { fwd = true; break; }
+              (fwd ? S : A).push_back(v);
+            }
+          }
+          best = best_lv;
+        } else if (best_c >= 0) {
+          A.assign(M.begin(), M.begin() + best_c);
+          for (int t = best_c; t < n; ++t) (mnp[t] < best_c ? S : B).push_back(M[t]);
+        }
+        for (int t = 0; t < n; ++t) pos[M[t]] = -1;
+        if (A.empty() || best > leaf_tiles - std::max(2, leaf_tiles / 8)) return make_leaf();
         if (A.size() < 8 || B.size() < 8) return make_leaf();
         const auto ra = rec(std::move(A), depth + 1, 0);
         const auto rb = rec(std::move(B), depth + 1, 0);
