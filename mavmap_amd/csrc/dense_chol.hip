@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 namespace mavba {
 
@@ -1493,7 +1494,21 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
     A.epoch = epoch; A.fail = fail; A.trace = cs.d_trace;
     static const int drop = [] { const char* e = std::getenv("MAVBA_CHOL_TEST_DROP_WG"); return e ? std::atoi(e) : -1; }();
     A.drop_wg = drop;
-    hipLaunchKernelGGL(k_chol_persist, dim3(cs.persist_grid), dim3(256), 0, st, A);
+    // Two persistent launches must never share the device (each needs every CU for its resident grid): launches of
+    // this process - sessions on other streams / threads - are chained through an event.
+    {
+      static std::mutex chain_m;
+      static hipEvent_t last[64] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      std::lock_guard<std::mutex> g(chain_m);
+      if (dev >= 0 && dev < 64 && last[dev]) (void)hipStreamWaitEvent(st, last[dev], 0);
+      hipLaunchKernelGGL(k_chol_persist, dim3(cs.persist_grid), dim3(256), 0, st, A);
+      if (dev >= 0 && dev < 64) {
+        if (!last[dev]) (void)hipEventCreateWithFlags(&last[dev], hipEventDisableTiming);
+        if (last[dev]) (void)hipEventRecord(last[dev], st);
+      }
+    }
   } else {
   if (cs.shadow_doubles) (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);
   static const int fuse_below = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE"); return e ? std::atoi(e) : kFuseBelow; }();  // tuning knobs

@@ -232,6 +232,7 @@ struct mavba_session {
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
+  bool M_is_clean = false;       // d_M holds zeros outside the entries the assembly writes
   bool allow_persistent = true;  // cleared when a persistent factorisation launch had to give up
   // The reduced camera matrix is assembled in the factorisation's elimination order: n_mat (multiple of 64)
   // columns, image i's pose block at h_off_img[i], camera c's intrinsics block at h_off_cam[c]; col_var maps a

@@ -589,6 +589,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
     d_ar_buf.alloc((size_t)num_ar_tiles * 4096 + n_mat);
   }
   d_M.alloc((size_t)(n_mat + 64) * n_mat); d_L.alloc((size_t)(n_mat + 64) * n_mat);
+  M_is_clean = false;
   d_ymat.alloc(n_mat); d_diag_ws.alloc((size_t)n_mat * 64);
 }
 

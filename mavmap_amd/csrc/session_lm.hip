@@ -93,7 +93,13 @@ void mavba_session::assemble(double r) {
     launch_entries_intr(st, Q, NI, NPs, d_q_pt.p, d_q_cam.p, d_Wk.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p,
                         d_Eintr.p);
   });
-  timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st)); });
+  // The assembly writes the same (structural) entries every time and the persistent factorisation only reads the
+  // matrix: its zeros survive from one linear solve to the next. Only the launch-per-panel schedule, which factorises
+  // in place, makes a fresh clear necessary.
+  if (!M_is_clean) {
+    timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st)); });
+    M_is_clean = true;
+  }
   timed("schur_clusters", [&] {
     launch_schur_clusters(st, cl_shape, num_clusters, d_clusters.p, d_cl_tab.p, d_pt_start.p, d_q_start.p, d_obs_meta.p,
                           d_q_meta.p, d_pt_clustered.p, d_Epose.p, d_Eintr.p, d_h.p, NPs, d_part[0].p, d_part[1].p,
@@ -125,6 +131,8 @@ void mavba_session::solve_linear(double r) {
   assemble(r);
   timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p, allow_persistent); });
   assembled = false;  // the factorisation overwrote S
+  // (in place; and with shards the exchange leaves the SUM over ranks in tiles this rank's assembly does not rewrite)
+  if (!(allow_persistent && chol_struct.persist_ok) || sharded()) M_is_clean = false;
 }
 
 // One LM linear step: reduced solve + candidate. The persistent factorisation bounds every wait; should a launch ever
