@@ -125,13 +125,31 @@ static void counting_sort_parallel(long long n, int nkeys, KeyFn key, std::vecto
     hist[t].assign((size_t)nkeys, 0);
     for (long long i = n * t / T; i < n * (t + 1) / T; ++i) hist[t][key(i)]++;
   });
+  // per-thread counts -> per-thread cursors (key-major, thread-minor), over key ranges in parallel: the serial version
+  // of this loop was 3 ms of the C3 set-up (200 000 keys x 16 threads)
   start.assign((size_t)nkeys + 1, 0);
-  int pos = 0;
-  for (int k = 0; k < nkeys; ++k) {
-    start[k] = pos;
-    for (int t = 0; t < T; ++t) { const int c = hist[t][k]; hist[t][k] = pos; pos += c; }
-  }
-  start[nkeys] = pos;
+  std::vector<long long> range_sum((size_t)T + 1, 0);
+  run([&](int r) {
+    long long sum = 0;
+    for (long long k = (long long)nkeys * r / T; k < (long long)nkeys * (r + 1) / T; ++k) {
+      int within = 0;
+      for (int t = 0; t < T; ++t) { const int c = hist[t][k]; hist[t][k] = within; within += c; }
+      start[k] = within;  // (the key's total, turned into its first position below)
+      sum += within;
+    }
+    range_sum[r + 1] = sum;
+  });
+  for (int r = 0; r < T; ++r) range_sum[r + 1] += range_sum[r];
+  run([&](int r) {
+    int pos = (int)range_sum[r];
+    for (long long k = (long long)nkeys * r / T; k < (long long)nkeys * (r + 1) / T; ++k) {
+      const int tot = start[k];
+      start[k] = pos;
+      for (int t = 0; t < T; ++t) hist[t][k] += pos;
+      pos += tot;
+    }
+  });
+  start[nkeys] = (int)range_sum[T];
   run([&](int t) {
     for (long long i = n * t / T; i < n * (t + 1) / T; ++i) emit(i, hist[t][key(i)]++);
   });

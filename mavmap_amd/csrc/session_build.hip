@@ -164,10 +164,17 @@ void mavba_session::build(const mavba_problem* P) {
   std::vector<int> pt_new(NP);
   std::vector<int> cstart;
   HostBuf<long long> bucket(N);  // kept observation ids, grouped by caller's point, input order inside
+  // (pixel and image travel with it: the caller's arrays are read once, in order, instead of being gathered again)
+  HostBuf<double2> buv(N);
+  HostBuf<int> bimg(N);
   {
     HostBuf<int> simg(N);
     counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept[k]]; }, cstart,
-                           [&](long long k, int at) { bucket[at] = kept[k]; simg[at] = P->obs_image[kept[k]]; });
+                           [&](long long k, int at) {
+                             const long long o = kept[k];
+                             bucket[at] = o; simg[at] = bimg[at] = P->obs_image[o];
+                             buv[at] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
+                           });
     lap("  buckets by point");
     if (all_kept)
       for (int p = 0; p < NP; ++p) { h_pt_count_all[p] = cstart[p + 1] - cstart[p]; h_pt_used[p] = h_pt_count_all[p] > 0; }
@@ -201,18 +208,23 @@ void mavba_session::build(const mavba_problem* P) {
       if (a.first != b.first) return a.first < b.first;
       return before_full(a.second, b.second);
     };
-    // sorted runs on a few threads, then pairwise merges
-    const int T = NP >= 100000 ? host_threads() : 1;
-    std::vector<int> cut(T + 1);
-    for (int t = 0; t <= T; ++t) cut[t] = (int)((long long)NP * t / T);
-    host_run(T, [&](int t) { std::sort(keyed.data() + cut[t], keyed.data() + cut[t + 1], before); });
-    for (int w = 1; w < T; w *= 2) {
-      const int pairs = (T + 2 * w - 1) / (2 * w);
-      host_run(pairs, [&](int q) {
-        const int t = q * 2 * w;
-        if (t + w < T)
-          std::inplace_merge(keyed.data() + cut[t], keyed.data() + cut[t + w], keyed.data() + cut[std::min(t + 2 * w, T)], before);
-      });
+    // Points are first dealt into buckets by their FIRST image (the key's leading 16 bits; a stable counting sort),
+    // then every bucket is sorted on its own - no merge passes, and the result still does not depend on the number of
+    // threads (`before` is a strict total order).
+    if (packable && NP >= 20000) {
+      std::vector<int> fstart;
+      HostBuf<KeyId> dealt(NP);
+      // (bucket NI: points without observations, whose key starts with 0xFFFF)
+      counting_sort_parallel(NP, NI + 1, [&](long long p) { return std::min((int)(keyed[p].first >> 48), NI); }, fstart,
+                             [&](long long p, int at) { dealt[at] = keyed[p]; });
+      std::vector<int> nonempty;
+      for (int k = 0; k <= NI; ++k) if (fstart[k + 1] > fstart[k]) nonempty.push_back(k);
+      parallel_ranges((long long)nonempty.size(), [&](long long k0, long long k1) {
+        for (long long k = k0; k < k1; ++k) std::sort(dealt.data() + fstart[nonempty[k]], dealt.data() + fstart[nonempty[k] + 1], before);
+      }, 2);
+      parallel_ranges(NP, [&](long long b0, long long b1) { for (long long q = b0; q < b1; ++q) keyed[q] = dealt[q]; }, 20000);
+    } else {
+      std::sort(keyed.data(), keyed.data() + NP, before);
     }
     lap("  sort points");
     h_pt_orig.resize(NP);
@@ -242,11 +254,10 @@ void mavba_session::build(const mavba_problem* P) {
     for (long long q = q0; q < q1; ++q) {
       const int src = cstart[h_pt_orig[q]], cnt = h_pt_start[q + 1] - h_pt_start[q];
       for (int j = 0; j < cnt; ++j) {
-        const long long o = bucket[src + j];
         const int a = h_pt_start[q] + j;
-        perm[a] = o;
-        uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
-        h_oimg[a] = P->obs_image[o]; opt_[a] = (int)q;
+        perm[a] = bucket[src + j];
+        uv[a] = buv[src + j];
+        h_oimg[a] = bimg[src + j]; opt_[a] = (int)q;
       }
     }
   });
