@@ -15,6 +15,8 @@
 //   pose_refinement                :139-225
 #include "base3d/bundle_adjustment.h"
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,10 +24,30 @@
 #include <iostream>
 #include <limits>
 #include <string>
+#include <thread>
 
 #include "mavba.h"
 
 namespace {
+
+// ---- a few host threads for the read-only walks over the FeatureManager's hash maps ----------------------------------
+int host_threads() {
+  static const int n = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  return n;
+}
+// body(begin, end, thread) over [0, n) in contiguous ranges; small jobs stay on the calling thread
+template <class F>
+void parallel_for(size_t n, F body) {
+  const int T = n < 64 ? 1 : host_threads();
+  if (T == 1) { body((size_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  // ranges of 1/(4T) of the work, dealt round-robin: images differ a lot in their number of 2-D points
+  const size_t chunks = (size_t)4 * T;
+  for (int t = 1; t < T; ++t)
+    th.emplace_back([&, t] { for (size_t c = t; c < chunks; c += T) body(n * c / chunks, n * (c + 1) / chunks, t); });
+  for (size_t c = 0; c < chunks; c += T) body(n * c / chunks, n * (c + 1) / chunks, 0);
+  for (auto& x : th) x.join();
+}
 
 const double kEps = std::numeric_limits<double>::epsilon();
 
@@ -234,93 +256,140 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
     }
   }
 
-  // ---- which observations enter (extract_data, :228-286): count, per 3-D point, its
-  // observations inside the selected image set
-  std::unordered_map<size_t, size_t> point3D_num_points2D;
-  const std::vector<size_t>* extract_order[3] = {&free_image_ids, &fixed_x_image_ids, &fixed_image_ids};
-  for (int l = 0; l < 3; ++l) {
-    for (size_t image_id : *extract_order[l]) {
-      const std::vector<size_t>& p2d = fm.image_to_points2D[image_id];
-      for (size_t point2D_id : p2d) {
-        auto it = fm.point2D_to_point3D.find(point2D_id);
-        if (it == fm.point2D_to_point3D.end()) continue;
-        point3D_num_points2D[it->second] += 1;
+  // ---- which observations enter (extract_data, :228-286) and the flat problem in the reference's residual-block
+  // order FREE, FIXED, FIXED_X (:511-533).
+  // The reference (and the first version of this file) walks the FeatureManager's hash maps observation by observation
+  // on one thread: ~3 look-ups per 2-D point, 0.4 s for a 2 M-observation global BA - several times the device solve.
+  // Here the look-ups run on a few threads (the maps are only read), everything else works on dense arrays:
+  //   1. per listed image (parallel): its 2-D points that have a 3-D point               (point2D_to_point3D)
+  //   2. per 3-D point: observations inside the selected image set                         (dense counter)
+  //   3. per listed image (parallel): keep count >= min_track_len, fetch the pixels       (points2D)
+  //   4. serial, no hashing: concatenate in list order, number points by first appearance
+  //   5. per point (parallel): coordinates                                                 (points3D)
+  // The result is the same flat problem, element for element, as the serial walk produced.
+  const bool timing = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_lap = now();
+  auto lap = [&](const char* what) { if (timing) { const double t = now(); std::fprintf(stderr, "[shim] %-30s %8.2f ms\n", what, 1e3 * (t - t_lap)); t_lap = t; } };
+  struct Entry { size_t image_id; int state; std::vector<size_t> p2d, p3d; std::vector<double> xy; size_t kept = 0; };
+  std::vector<Entry> entries;
+  {
+    const std::vector<size_t>* fill_order[3] = {&free_image_ids, &fixed_image_ids, &fixed_x_image_ids};
+    const int fill_state[3] = {BA_POSE_FREE, BA_POSE_FIXED, BA_POSE_FIXED_X};
+    for (int l = 0; l < 3; ++l)
+      for (size_t image_id : *fill_order[l]) { Entry e; e.image_id = image_id; e.state = fill_state[l]; entries.push_back(std::move(e)); }
+  }
+  size_t max_p3d = 0;
+  {
+    std::vector<size_t> tmax(host_threads(), 0);
+    parallel_for(entries.size(), [&](size_t e0, size_t e1, int t) {
+      for (size_t e = e0; e < e1; ++e) {
+        Entry& E = entries[e];
+        auto it = fm.image_to_points2D.find(E.image_id);
+        if (it == fm.image_to_points2D.end()) continue;
+        for (size_t point2D_id : it->second) {
+          auto it3 = fm.point2D_to_point3D.find(point2D_id);
+          if (it3 == fm.point2D_to_point3D.end()) continue;
+          E.p2d.push_back(point2D_id); E.p3d.push_back(it3->second);
+          if (it3->second > tmax[t]) tmax[t] = it3->second;
+        }
+      }
+    });
+    for (size_t m : tmax) max_p3d = std::max(max_p3d, m);
+  }
+  lap("2-D points with a 3-D point");
+  std::vector<uint32_t> point3D_num_points2D(max_p3d + 1, 0);  // an image listed twice counts twice, as in the reference
+  for (const Entry& E : entries) for (size_t id : E.p3d) point3D_num_points2D[id] += 1;
+  parallel_for(entries.size(), [&](size_t e0, size_t e1, int) {
+    for (size_t e = e0; e < e1; ++e) {
+      Entry& E = entries[e];
+      size_t k = 0;
+      for (size_t i = 0; i < E.p3d.size(); ++i) {
+        if (point3D_num_points2D[E.p3d[i]] < options.min_track_len) continue;   // :330
+        E.p2d[k] = E.p2d[i]; E.p3d[k] = E.p3d[i]; ++k;
+      }
+      E.kept = k;
+      E.xy.resize(2 * k);
+      for (size_t i = 0; i < k; ++i) {
+        auto ixy = fm.points2D.find(E.p2d[i]);  // (a missing entry reads as (0, 0): what operator[] gives the reference)
+        if (ixy == fm.points2D.end()) continue;
+        E.xy[2 * i] = ixy->second(0); E.xy[2 * i + 1] = ixy->second(1);
       }
     }
-  }
+  });
 
-  // ---- flatten in the reference's residual-block order: FREE, FIXED, FIXED_X (:511-533)
+  lap("counts, filter, pixels");
   std::vector<size_t> image_ids, camera_ids, point_ids;           // flat index -> feature-manager id
-  std::unordered_map<size_t, int32_t> image_index, camera_index, point_index;
+  std::unordered_map<size_t, int32_t> image_index, camera_index;
+  std::vector<int32_t> point_index(max_p3d + 1, -1);
   std::vector<double> poses, intrinsics, points, obs_uv;
   std::vector<uint8_t> pose_const, intr_const, point_const;
   std::vector<int32_t> image_camera, camera_model, obs_image, obs_point;
-  const std::vector<size_t>* fill_order[3] = {&free_image_ids, &fixed_image_ids, &fixed_x_image_ids};
-  const int fill_state[3] = {BA_POSE_FREE, BA_POSE_FIXED, BA_POSE_FIXED_X};
-  for (int l = 0; l < 3; ++l) {
-    for (size_t image_id : *fill_order[l]) {
+  {
+    size_t total = 0;
+    for (const Entry& E : entries) total += E.kept;
+    obs_uv.reserve(2 * total); obs_image.reserve(total); obs_point.reserve(total);
+  }
+  for (Entry& E : entries) {
+    if (E.kept == 0) continue;  // no residual block: the image does not enter the problem here
+    const size_t image_id = E.image_id;
+    // An image id listed twice (in one list or in two) is ONE set of parameter blocks in the reference: its
+    // residual blocks are added again on the same blocks and the constancy settings accumulate.
+    int32_t img;
+    auto known = image_index.find(image_id);
+    if (known != image_index.end()) {
+      img = known->second;
+    } else {
       const size_t camera_id = fm.image_to_camera[image_id];
       std::vector<double>& cam = fm.camera_params[camera_id];
       const int model = (int)cam.back();
       const int K = model_num_params(model);
       if (K < 0) throw std::invalid_argument("unknown camera model code");
-      size_t num_residuals = 0;
-      int32_t img = -1;
-      const std::vector<size_t>& p2d = fm.image_to_points2D[image_id];
-      for (size_t point2D_id : p2d) {
-        auto it3 = fm.point2D_to_point3D.find(point2D_id);
-        if (it3 == fm.point2D_to_point3D.end()) continue;
-        const size_t point3D_id = it3->second;
-        if (point3D_num_points2D[point3D_id] < options.min_track_len) continue;   // :330
-        if (img < 0) {
-          // An image id listed twice (in one list or in two) is ONE set of parameter blocks in the reference: its
-          // residual blocks are added again on the same blocks and the constancy settings accumulate.
-          auto known = image_index.find(image_id);
-          if (known != image_index.end()) img = known->second;
-        }
-        if (img < 0) {
-          // first residual of this image: register the image (and its camera)
-          auto ic = camera_index.find(camera_id);
-          if (ic == camera_index.end()) {
-            ic = camera_index.emplace(camera_id, (int32_t)camera_ids.size()).first;
-            camera_ids.push_back(camera_id);
-            camera_model.push_back(model);
-            intr_const.push_back(0);
-            for (int k = 0; k < MAVBA_MAX_INTR; ++k) intrinsics.push_back(k < K ? cam[k] : 0.0);
-          }
-          img = (int32_t)image_ids.size();
-          image_index[image_id] = img;
-          image_ids.push_back(image_id);
-          image_camera.push_back(ic->second);
-          pose_const.push_back(0);
-          const double* r = fm.rvecs[image_id].data();
-          const double* t = fm.tvecs[image_id].data();
-          poses.insert(poses.end(), r, r + 3);
-          poses.insert(poses.end(), t, t + 3);
-        }
-        auto ip = point_index.find(point3D_id);
-        if (ip == point_index.end()) {
-          ip = point_index.emplace(point3D_id, (int32_t)point_ids.size()).first;
-          point_ids.push_back(point3D_id);
-          const double* X = fm.points3D[point3D_id].data();
-          points.insert(points.end(), X, X + 3);
-          point_const.push_back(gcp_ids.count(point3D_id) ? 1 : 0);  // :545-549
-        }
-        const double* xy = fm.points2D[point2D_id].data();
-        obs_uv.push_back(xy[0]); obs_uv.push_back(xy[1]);
-        obs_image.push_back(img);
-        obs_point.push_back(ip->second);
-        ++num_residuals;
+      auto ic = camera_index.find(camera_id);
+      if (ic == camera_index.end()) {
+        ic = camera_index.emplace(camera_id, (int32_t)camera_ids.size()).first;
+        camera_ids.push_back(camera_id);
+        camera_model.push_back(model);
+        intr_const.push_back(0);
+        for (int k = 0; k < MAVBA_MAX_INTR; ++k) intrinsics.push_back(k < K ? cam[k] : 0.0);
       }
-      // Constancy is applied only if the image contributed more than one residual (:361).
-      if (num_residuals > 1) {
-        if (fill_state[l] == BA_POSE_FIXED) pose_const[img] |= MAVBA_CONST_POSE;
-        if (fill_state[l] == BA_POSE_FIXED_X) pose_const[img] |= MAVBA_CONST_TX;
-        if (!options.refine_camera_params) intr_const[image_camera[img]] = 1;
-      }
+      img = (int32_t)image_ids.size();
+      image_index[image_id] = img;
+      image_ids.push_back(image_id);
+      image_camera.push_back(ic->second);
+      pose_const.push_back(0);
+      const double* r = fm.rvecs[image_id].data();
+      const double* t = fm.tvecs[image_id].data();
+      poses.insert(poses.end(), r, r + 3);
+      poses.insert(poses.end(), t, t + 3);
     }
+    for (size_t i = 0; i < E.kept; ++i) {
+      int32_t& ip = point_index[E.p3d[i]];
+      if (ip < 0) { ip = (int32_t)point_ids.size(); point_ids.push_back(E.p3d[i]); }
+      obs_uv.push_back(E.xy[2 * i]); obs_uv.push_back(E.xy[2 * i + 1]);
+      obs_image.push_back(img);
+      obs_point.push_back(ip);
+    }
+    // Constancy is applied only if the image contributed more than one residual (:361).
+    if (E.kept > 1) {
+      if (E.state == BA_POSE_FIXED) pose_const[img] |= MAVBA_CONST_POSE;
+      if (E.state == BA_POSE_FIXED_X) pose_const[img] |= MAVBA_CONST_TX;
+      if (!options.refine_camera_params) intr_const[image_camera[img]] = 1;
+    }
+    std::vector<size_t>().swap(E.p2d); std::vector<size_t>().swap(E.p3d); std::vector<double>().swap(E.xy);
   }
+  lap("assembly in list order");
+  points.resize(3 * point_ids.size());
+  point_const.resize(point_ids.size());
+  parallel_for(point_ids.size(), [&](size_t p0, size_t p1, int) {
+    for (size_t p = p0; p < p1; ++p) {
+      auto iX = fm.points3D.find(point_ids[p]);
+      if (iX != fm.points3D.end()) { points[3 * p] = iX->second(0); points[3 * p + 1] = iX->second(1); points[3 * p + 2] = iX->second(2); }
+      point_const[p] = gcp_ids.count(point_ids[p]) ? 1 : 0;  // :545-549
+    }
+  });
 
+  lap("point coordinates");
   // rotation-prior residuals for the FREE images (:428-444)
   std::vector<int32_t> prior_image;
   std::vector<double> prior_rvec;
@@ -380,6 +449,7 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
     rc = mavba_solve(&P, &mo, &res, options.update_point3D_errors ? perr.data() : nullptr);
   if (rc != MAVBA_OK) raise(rc);
 
+  lap("mavba_solve");
   // ---- write back in place (the reference lets Ceres write through raw pointers)
   for (size_t i = 0; i < image_ids.size(); ++i) {
     double* r = fm.rvecs[image_ids[i]].data();
@@ -391,17 +461,22 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
     const int K = model_num_params(camera_model[c]);
     for (int k = 0; k < K; ++k) cam[k] = intrinsics[MAVBA_MAX_INTR * c + k];  // the model code (last slot) is never written
   }
-  for (size_t p = 0; p < point_ids.size(); ++p) {
-    double* X = fm.points3D[point_ids[p]].data();
-    for (int k = 0; k < 3; ++k) X[k] = points[3 * p + k];
-  }
+  parallel_for(point_ids.size(), [&](size_t p0, size_t p1, int) {  // (values of existing nodes: no rehash, safe in parallel)
+    for (size_t p = p0; p < p1; ++p) {
+      auto iX = fm.points3D.find(point_ids[p]);
+      if (iX == fm.points3D.end()) continue;
+      for (int k = 0; k < 3; ++k) iX->second(k) = points[3 * p + k];
+    }
+  });
 
   if (obs_image.empty()) {
     std::cout << "No observations in bundle adjustment. Consider relaxing the constraints." << std::endl;
   }
   if (options.update_point3D_errors) {
+    point3D_errors.reserve(point3D_errors.size() + point_ids.size());
     for (size_t p = 0; p < point_ids.size(); ++p) point3D_errors[point_ids[p]] = perr[p];
   }
+  lap("write-back + point3D_errors");
   if (options.print_progress) std::cout << std::endl;
   if (options.print_summary) {
     std::cout << "Bundle Adjustment Report" << std::endl;

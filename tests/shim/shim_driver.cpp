@@ -2,6 +2,7 @@
 // reference-signature bundle_adjustment() / pose_refinement() of shim/base3d/bundle_adjustment.cc,
 // and copies the mutated scene back. Linked either against the recording mock (CPU tests) or
 // against the real libmavba.so (GPU tests).
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <set>
@@ -11,8 +12,12 @@
 #include "base3d/bundle_adjustment.h"
 
 static std::string g_what;
+static double g_ba_seconds = 0.0;
 
 extern "C" {
+
+// wall time of the last bundle_adjustment() call itself (without building / reading back the FeatureManager)
+double shim_last_ba_seconds(void) { return g_ba_seconds; }
 
 const char* shim_last_exception(void) { return g_what.c_str(); }
 
@@ -72,7 +77,9 @@ int shim_bundle_adjustment(
     o.refine_camera_params = refine_camera_params != 0; o.print_progress = false; o.print_summary = print_summary != 0;
     std::unordered_map<size_t, double> perr;
     perr[999999] = -1.0;  // an unrelated entry must survive untouched
+    const auto t0 = std::chrono::steady_clock::now();
     *ret = bundle_adjustment(fm, fr, fx, fxx, o, perr, rc, gcp);
+    g_ba_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (perr.at(999999) != -1.0) throw std::runtime_error("unrelated point3D_errors entry was modified");
     for (int c = 0; c < n_cam; ++c) {
       const std::vector<double>& v = fm.camera_params[c + 1];

@@ -22,7 +22,7 @@ dp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 def _build(real):
     out = os.path.join(ROOT, "tests", "shim", "_shim_real.so" if real else "_shim_mock.so")
     srcs = [os.path.join(ROOT, "tests", "shim", "shim_driver.cpp"), os.path.join(ROOT, "shim", "base3d", "bundle_adjustment.cc")]
-    cmd = ["g++", "-std=c++11", "-O1", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "tests", "stubs"),
+    cmd = ["g++", "-std=c++11", "-O1", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "tests", "stubs"),
            "-I" + os.path.join(ROOT, "shim"), "-I" + os.path.join(ROOT, "include")] + srcs
     if real:
         libdir = os.path.join(ROOT, "mavmap_amd", "lib")
