@@ -217,6 +217,69 @@ int mavba_pose_refine_batch(int32_t count, mavba_pose_refine_item* items, const 
                             mavba_result* results);
 
 /* ------------------------------------------------------------------------
+ * Scene API: an incremental flat mirror of the FeatureManager.
+ *
+ * The reference re-walks the FeatureManager's hash maps on every bundle_adjustment() call
+ * (src/base3d/bundle_adjustment.cc:228-387; local BA runs after every image, src/mapper.cc:1120-1135).
+ * A scene receives the same information as deltas when the FeatureManager changes - one call per
+ * add_camera / add_image / set_pose / add_point2D / set_point3D / correspondence / delete_point3D
+ * (reference src/fm/feature_management.h:30-60; the hook lines are listed in INTEGRATION.md) - keeps it
+ * in dense arrays indexed by the caller's own ids (the 1-based ids of the FeatureManager are fine) and
+ * builds the flat problem of a call from them without hashing, by the reference's rules
+ * (bundle_adjustment.cc:228-549): observation count inside the selected image set, min_track_len,
+ * residual order FREE / FIXED / FIXED_X, constancy only for images with more than one residual,
+ * GCPs constant, rotation priors incl. the pre-rotation of the WHOLE scene.
+ * ---------------------------------------------------------------------- */
+typedef struct mavba_scene mavba_scene;
+
+/* The BundleAdjustmentOptions members that act on problem construction (bundle_adjustment.h:38-114). */
+typedef struct mavba_scene_options {
+  int32_t min_track_len;            /* 2 */
+  int32_t refine_camera_params;     /* 0 */
+  int32_t constrain_rotation;       /* 0 */
+  double constrain_rotation_weight; /* 0 */
+} mavba_scene_options;
+
+int mavba_scene_create(mavba_scene** out);
+void mavba_scene_destroy(mavba_scene* s);
+/* add or update; `params`: the first K values of the model (FeatureManager::add_camera without the code slot) */
+int mavba_scene_set_camera(mavba_scene* s, int64_t camera_id, int32_t model, const double* params);
+/* add_image / set_pose: camera_id < 0, rvec == NULL or tvec == NULL leave that part as it is */
+int mavba_scene_set_image(mavba_scene* s, int64_t image_id, int64_t camera_id, const double* rvec, const double* tvec);
+/* add_point2D: appended to the image's list (the image_to_points2D order is the residual order inside an image) */
+int mavba_scene_add_point2d(mavba_scene* s, int64_t image_id, int64_t point2D_id, const double* xy);
+/* add_point3D + set_point3D */
+int mavba_scene_set_point3d(mavba_scene* s, int64_t point3D_id, const double* xyz);
+/* point2D_to_point3D[point2D_id] = point3D_id (add_correspondence, merges); point3D_id < 0 removes the entry */
+int mavba_scene_link(mavba_scene* s, int64_t point2D_id, int64_t point3D_id);
+/* delete_point3D: its 2-D points read as unmatched from now on */
+int mavba_scene_delete_point3d(mavba_scene* s, int64_t point3D_id);
+int mavba_scene_get_image(mavba_scene* s, int64_t image_id, double* rvec, double* tvec);
+int mavba_scene_get_point3d(mavba_scene* s, int64_t point3D_id, double* xyz);
+int mavba_scene_get_camera(mavba_scene* s, int64_t camera_id, int32_t* model, double* params);
+
+/* The flat problem of one bundle_adjustment() call (views into the scene, valid until its next flatten / bundle
+ * adjust): exactly what shim/base3d/bundle_adjustment.cc hands to mavba_solve for the same FeatureManager content.
+ * `image_ids` / `camera_ids` / `point_ids` (may be NULL) receive the flat-index -> caller-id tables. The two
+ * std::invalid_argument conditions of the reference (:459-471) are MAVBA_ERR_INVALID_ARGUMENT here. With
+ * constrain_rotation the whole scene is rotated first (:399-425), as the reference rotates the whole FeatureManager. */
+int mavba_scene_flatten(mavba_scene* s, const int64_t* free_ids, int64_t n_free, const int64_t* fixed_ids, int64_t n_fixed,
+                        const int64_t* fixed_x_ids, int64_t n_fixed_x, const int64_t* gcp_ids, int64_t n_gcp,
+                        const int64_t* rot_image_ids, const double* rot_rvecs, int64_t n_rot,
+                        const mavba_scene_options* scene_options, mavba_problem* problem, const int64_t** image_ids,
+                        const int64_t** camera_ids, const int64_t** point_ids);
+
+/* bundle_adjustment() on the scene: flatten, mavba_solve, results written back into the scene. `final_cost_px` =
+ * the reference's return value sqrt(final_cost / num_residuals) (:610). With options->update_point_errors the views
+ * `error_point_ids` / `error_values` (`num_errors` entries, valid until the next call) list the point3D errors. */
+int mavba_scene_bundle_adjust(mavba_scene* s, const int64_t* free_ids, int64_t n_free, const int64_t* fixed_ids, int64_t n_fixed,
+                              const int64_t* fixed_x_ids, int64_t n_fixed_x, const int64_t* gcp_ids, int64_t n_gcp,
+                              const int64_t* rot_image_ids, const double* rot_rvecs, int64_t n_rot,
+                              const mavba_scene_options* scene_options, const mavba_options* options, mavba_result* result,
+                              double* final_cost_px, const int64_t** error_point_ids, const double** error_values,
+                              int64_t* num_errors);
+
+/* ------------------------------------------------------------------------
  * Session API: the same solver with device-resident state, for callers that
  * iterate (local BA after every image), for the parity tests (intermediate
  * quantities) and for bench.py (inputs resident in HBM before timing starts).

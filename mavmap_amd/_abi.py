@@ -80,6 +80,11 @@ class CPoseRefineItem(C.Structure):
                 ("uv", _dp), ("xyz", _dp), ("inlier_mask", _bp), ("n", C.c_int64)]
 
 
+class CSceneOptions(C.Structure):
+    _fields_ = [("min_track_len", C.c_int32), ("refine_camera_params", C.c_int32), ("constrain_rotation", C.c_int32),
+                ("constrain_rotation_weight", C.c_double)]
+
+
 class CSessionInfo(C.Structure):
     _fields_ = [("num_obs_kept", C.c_int64), ("reduced_dim", C.c_int32), ("padded_dim", C.c_int32),
                 ("schur_terms", C.c_int64 * 3), ("schur_blocks", C.c_int64), ("intr_entries", C.c_int64),

@@ -31,6 +31,9 @@ EXPORTED_SYMBOLS = [
     "mavba_session_set_allreduce", "mavba_session_eval_jacobian", "mavba_session_reduced_dim",
     "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian",
     "mavba_session_kernel_stats", "mavba_session_get_info", "mavba_dense_spd_solve",
+    "mavba_scene_create", "mavba_scene_destroy", "mavba_scene_set_camera", "mavba_scene_set_image", "mavba_scene_add_point2d",
+    "mavba_scene_set_point3d", "mavba_scene_link", "mavba_scene_delete_point3d", "mavba_scene_get_image", "mavba_scene_get_point3d",
+    "mavba_scene_get_camera", "mavba_scene_flatten", "mavba_scene_bundle_adjust",
     "mavba_rccl_unique_id", "mavba_session_set_rccl", "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
 ]
 
@@ -82,6 +85,23 @@ def load():
     L.mavba_session_kernel_stats.argtypes = [sp, C.POINTER(A.CKernelStat), C.c_int32]
     L.mavba_session_get_info.argtypes = [sp, C.POINTER(A.CSessionInfo)]
     L.mavba_dense_spd_solve.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
+    i64p, i64 = C.POINTER(C.c_int64), C.c_int64
+    sop = C.POINTER(A.CSceneOptions)
+    L.mavba_scene_create.argtypes = [C.POINTER(sp)]
+    L.mavba_scene_destroy.argtypes = [sp]
+    L.mavba_scene_destroy.restype = None
+    L.mavba_scene_set_camera.argtypes = [sp, i64, C.c_int32, dp]
+    L.mavba_scene_set_image.argtypes = [sp, i64, i64, dp, dp]
+    L.mavba_scene_add_point2d.argtypes = [sp, i64, i64, dp]
+    L.mavba_scene_set_point3d.argtypes = [sp, i64, dp]
+    L.mavba_scene_link.argtypes = [sp, i64, i64]
+    L.mavba_scene_delete_point3d.argtypes = [sp, i64]
+    L.mavba_scene_get_image.argtypes = [sp, i64, dp, dp]
+    L.mavba_scene_get_point3d.argtypes = [sp, i64, dp]
+    L.mavba_scene_get_camera.argtypes = [sp, i64, ip, dp]
+    lists = [i64p, i64, i64p, i64, i64p, i64, i64p, i64, i64p, dp, i64]
+    L.mavba_scene_flatten.argtypes = [sp] + lists + [sop, pp, C.POINTER(i64p), C.POINTER(i64p), C.POINTER(i64p)]
+    L.mavba_scene_bundle_adjust.argtypes = [sp] + lists + [sop, op, rp, dp, C.POINTER(i64p), C.POINTER(dp), i64p]
     L.mavba_rccl_unique_id.argtypes = [C.c_void_p]
     L.mavba_session_set_rccl.argtypes = [sp, C.c_void_p, C.c_int32, C.c_int32]
     L.mavba_pose_refine_batch.argtypes = [C.c_int32, C.POINTER(A.CPoseRefineItem), op, rp]
@@ -90,7 +110,7 @@ def load():
     L.mavba_session_filter_points.argtypes = [sp, C.c_double, bp, bp, dp, C.POINTER(C.c_int64)]
     L.mavba_solve_filter_solve.argtypes = [pp, op, C.c_double, bp, rp, rp, dp, bp, C.POINTER(C.c_int64)]
     for f in EXPORTED_SYMBOLS:
-        if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy"):
+        if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy", "mavba_scene_destroy"):
             getattr(L, f).restype = C.c_int
     _lib = L
     return L
@@ -254,6 +274,118 @@ def pose_refinement_batch(items, options=None, **kw):
         d = res[q].as_dict()
         out.append((float(np.sqrt(d["final_cost"] / d["num_residuals"])) if d["num_residuals"] else float("nan"), d))
     return out
+
+
+class Scene:
+    """Incremental flat mirror of a FeatureManager (mavba_scene_*): deltas in, bundle_adjustment() calls out.
+    Ids are the caller's (the FeatureManager's 1-based ids are fine)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(load().mavba_scene_create(C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().mavba_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_camera(self, camera_id, model, params):
+        _check(load().mavba_scene_set_camera(self._h, int(camera_id), int(model), _d(A.as_f64(np.pad(np.asarray(params, float), (0, 9))[:9]))))
+
+    def set_image(self, image_id, camera_id=-1, rvec=None, tvec=None):
+        r = None if rvec is None else A.as_f64(rvec)
+        t = None if tvec is None else A.as_f64(tvec)
+        _check(load().mavba_scene_set_image(self._h, int(image_id), int(camera_id), None if r is None else _d(r), None if t is None else _d(t)))
+
+    def add_point2D(self, image_id, point2D_id, xy):
+        _check(load().mavba_scene_add_point2d(self._h, int(image_id), int(point2D_id), _d(A.as_f64(xy))))
+
+    def set_point3D(self, point3D_id, xyz):
+        _check(load().mavba_scene_set_point3d(self._h, int(point3D_id), _d(A.as_f64(xyz))))
+
+    def link(self, point2D_id, point3D_id):
+        _check(load().mavba_scene_link(self._h, int(point2D_id), int(point3D_id)))
+
+    def delete_point3D(self, point3D_id):
+        _check(load().mavba_scene_delete_point3d(self._h, int(point3D_id)))
+
+    def get_image(self, image_id):
+        r, t = np.zeros(3), np.zeros(3)
+        _check(load().mavba_scene_get_image(self._h, int(image_id), _d(r), _d(t)))
+        return r, t
+
+    def get_point3D(self, point3D_id):
+        x = np.zeros(3)
+        _check(load().mavba_scene_get_point3d(self._h, int(point3D_id), _d(x)))
+        return x
+
+    def get_camera(self, camera_id):
+        m, p = C.c_int32(), np.zeros(9)
+        _check(load().mavba_scene_get_camera(self._h, int(camera_id), C.byref(m), _d(p)))
+        return m.value, p[:A.MODEL_NUM_PARAMS[m.value]]
+
+    @staticmethod
+    def _lists(free, fixed, fixed_x, gcp, rot):
+        arrs = [np.ascontiguousarray(x, dtype=np.int64) for x in (free, fixed, fixed_x, gcp)]
+        rot = rot or {}
+        ri = np.ascontiguousarray(list(rot.keys()), dtype=np.int64)
+        rv = A.as_f64(np.array([rot[k] for k in rot], float).reshape(-1, 3))
+        args = []
+        for a in arrs:
+            args += [A.ptr(a, C.c_int64), len(a)]
+        args += [A.ptr(ri, C.c_int64), _d(rv), len(ri)]
+        return args, (arrs, ri, rv)
+
+    @staticmethod
+    def _scene_options(min_track_len=2, refine_camera_params=False, constrain_rotation=False, constrain_rotation_weight=0.0):
+        return A.CSceneOptions(int(min_track_len), int(bool(refine_camera_params)), int(bool(constrain_rotation)), float(constrain_rotation_weight))
+
+    def flatten(self, free, fixed, fixed_x, gcp=(), rot=None, **scene_opts):
+        """The flat problem of a call as a dict of numpy COPIES (+ the flat-index -> id tables)."""
+        args, hold = self._lists(free, fixed, fixed_x, gcp, rot)
+        so = self._scene_options(**scene_opts)
+        P = A.CProblem()
+        i64p = C.POINTER(C.c_int64)
+        ii, ci, pi = i64p(), i64p(), i64p()
+        _check(load().mavba_scene_flatten(self._h, *args, C.byref(so), C.byref(P), C.byref(ii), C.byref(ci), C.byref(pi)))
+        g = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy() if n else np.zeros(0, dt)  # noqa: E731
+        ni, nc, npt, no, nr = P.num_images, P.num_cameras, P.num_points, P.num_obs, P.num_rot_priors
+        return dict(image_ids=g(ii, ni, np.int64), camera_ids=g(ci, nc, np.int64), point_ids=g(pi, npt, np.int64),
+                    poses=g(P.poses, ni * 6, float).reshape(-1, 6), pose_const=g(P.pose_const, ni, np.uint8),
+                    image_camera=g(P.image_camera, ni, np.int32), intrinsics=g(P.intrinsics, nc * 9, float).reshape(-1, 9),
+                    camera_model=g(P.camera_model, nc, np.int32), intr_const=g(P.intr_const, nc, np.uint8),
+                    points=g(P.points, npt * 3, float).reshape(-1, 3), point_const=g(P.point_const, npt, np.uint8),
+                    obs_uv=g(P.obs_uv, no * 2, float).reshape(-1, 2), obs_image=g(P.obs_image, no, np.int32),
+                    obs_point=g(P.obs_point, no, np.int32), rot_prior_image=g(P.rot_prior_image, nr, np.int32),
+                    rot_prior_rvec=g(P.rot_prior_rvec, nr * 3, float).reshape(-1, 3), rot_prior_weight=P.rot_prior_weight)
+
+    def bundle_adjustment(self, free, fixed, fixed_x, options=None, gcp=(), rot=None, point3D_errors=None, **scene_opts):
+        """bundle_adjustment() on the scene (results are written back into it). Returns (final_cost_px, result);
+        `point3D_errors`: optional dict updated like the reference's map when options.update_point_errors is set."""
+        args, hold = self._lists(free, fixed, fixed_x, gcp, rot)
+        so = self._scene_options(**scene_opts)
+        copt = make_options(options)
+        if point3D_errors is not None:
+            copt.update_point_errors = 1
+        res = A.CResult()
+        cost = C.c_double()
+        i64p = C.POINTER(C.c_int64)
+        eids, evals, n = i64p(), C.POINTER(C.c_double)(), C.c_int64()
+        _check(load().mavba_scene_bundle_adjust(self._h, *args, C.byref(so), C.byref(copt), C.byref(res), C.byref(cost),
+                                                C.byref(eids), C.byref(evals), C.byref(n)))
+        if point3D_errors is not None and n.value:
+            ids = np.ctypeslib.as_array(eids, shape=(n.value,))
+            vals = np.ctypeslib.as_array(evals, shape=(n.value,))
+            point3D_errors.update(zip(ids.tolist(), vals.tolist()))
+        return cost.value, res.as_dict()
 
 
 class Session:
