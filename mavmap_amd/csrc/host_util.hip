@@ -177,6 +177,55 @@ void pinned_free(void* p) {
   P.live.erase(it);
 }
 
+// Big host scratch blocks (the set-up's per-observation temporaries) are cached as well: at most kScratchCacheBytes
+// stay parked, blocks under 256 KiB go straight to malloc (its own free lists handle those without page faults).
+namespace {
+struct ScratchCache {
+  std::mutex m;
+  std::multimap<size_t, void*> free_blocks;  // capacity -> block
+  std::unordered_map<void*, size_t> live;     // block -> capacity (only cached-class blocks)
+  size_t parked = 0;
+};
+ScratchCache& scratch_cache() { static ScratchCache* c = new ScratchCache; return *c; }
+constexpr size_t kScratchMin = (size_t)256 << 10, kScratchCacheBytes = (size_t)1 << 30;
+}  // namespace
+void* host_scratch_alloc(size_t bytes) {
+  if (bytes < kScratchMin) { void* p = std::malloc(bytes); if (!p) throw std::bad_alloc(); return p; }
+  ScratchCache& C = scratch_cache();
+  {
+    std::lock_guard<std::mutex> g(C.m);
+    auto it = C.free_blocks.lower_bound(bytes);
+    if (it != C.free_blocks.end() && it->first <= 2 * bytes + ((size_t)1 << 20)) {
+      void* p = it->second;
+      C.parked -= it->first;
+      C.live[p] = it->first;
+      C.free_blocks.erase(it);
+      return p;
+    }
+  }
+  const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  void* p = std::malloc(cap);
+  if (!p) throw std::bad_alloc();
+  std::lock_guard<std::mutex> g(C.m);
+  C.live[p] = cap;
+  return p;
+}
+void host_scratch_free(void* p, size_t bytes) {
+  if (!p) return;
+  if (bytes < kScratchMin) { std::free(p); return; }
+  ScratchCache& C = scratch_cache();
+  {
+    std::lock_guard<std::mutex> g(C.m);
+    auto it = C.live.find(p);
+    if (it != C.live.end()) {
+      const size_t cap = it->second;
+      C.live.erase(it);
+      if (C.parked + cap <= kScratchCacheBytes) { C.free_blocks.insert({cap, p}); C.parked += cap; return; }
+    }
+  }
+  std::free(p);
+}
+
 // Streams are cached too (hipStreamCreate + hipStreamDestroy cost ~2 ms per session, more than a local-BA solve).
 hipError_t stream_acquire(hipStream_t* st) {
   DevicePool& P = pool();

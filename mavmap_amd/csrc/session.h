@@ -102,14 +102,42 @@ struct HostSpare {
 
 // Host scratch array WITHOUT value-initialisation (std::vector<T>(n) clears the memory first: ~1 ms per 10 MB,
 // and the set-up shuffles ~100 MB of such arrays that are fully overwritten anyway).
+void* host_scratch_alloc(size_t bytes);        // host_util.hip: process-wide cache of big host blocks
+void host_scratch_free(void* p, size_t bytes);
 template <typename T>
 struct HostBuf {
-  std::unique_ptr<T[]> p;
+  // Blocks come from (and go back to) a process-wide cache: a fresh 16-32 MB allocation is an mmap whose pages are
+  // faulted in one by one while 16 threads write it, and an munmap when it dies - at C3 that was a third of the set-up.
+  T* p = nullptr;
   size_t n = 0;
-  explicit HostBuf(size_t count) : p(new T[std::max<size_t>(count, 1)]), n(count) {}
+  explicit HostBuf(size_t count) : p(static_cast<T*>(host_scratch_alloc(std::max<size_t>(count, 1) * sizeof(T)))), n(count) {}
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+  ~HostBuf() { host_scratch_free(p, std::max<size_t>(n, 1) * sizeof(T)); }
   T& operator[](size_t i) { return p[i]; }
   const T& operator[](size_t i) const { return p[i]; }
-  T* data() { return p.get(); }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+};
+
+// The same for arrays that are uploaded: page-locked blocks (from the pinned pool), so hipMemcpyAsync really is
+// asynchronous and the transfer runs while the host builds the block structure.
+template <typename T>
+struct PinnedBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  explicit PinnedBuf(size_t count) : n(count) {
+    void* q = nullptr;
+    HIP_OK(pinned_alloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    p = static_cast<T*>(q);
+  }
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { pinned_free(p); }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* data() { return p; }
 };
 
 // Stable counting sort of items 0..n-1 by key(i) in [0, nkeys) on a few threads (per-thread histograms turned
@@ -119,10 +147,12 @@ template <typename KeyFn, typename EmitFn>
 static void counting_sort_parallel(long long n, int nkeys, KeyFn key, std::vector<int>& start, EmitFn emit) {
   int T = n >= 200000 ? host_threads() : 1;
   while (T > 1 && (size_t)T * nkeys > ((size_t)64 << 20)) T /= 2;
-  std::vector<std::vector<int>> hist(T);
+  HostBuf<int> hist_store((size_t)T * nkeys);  // (cached block: no page faults after the first session)
+  std::vector<int*> hist(T);
+  for (int t = 0; t < T; ++t) hist[t] = hist_store.data() + (size_t)t * nkeys;
   auto run = [&](const std::function<void(int)>& body) { host_run(T, body); };
   run([&](int t) {
-    hist[t].assign((size_t)nkeys, 0);
+    std::memset(hist[t], 0, (size_t)nkeys * sizeof(int));
     for (long long i = n * t / T; i < n * (t + 1) / T; ++i) hist[t][key(i)]++;
   });
   // per-thread counts -> per-thread cursors (key-major, thread-minor), over key ranges in parallel: the serial version

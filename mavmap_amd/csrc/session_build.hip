@@ -91,7 +91,6 @@ void mavba_session::build(const mavba_problem* P) {
   h_pt_count_all.assign(NP, 0);
   h_dropped_rnorm.clear(); h_dropped_cost.clear(); h_pt_removed.clear();
   std::vector<long long> kept;
-  kept.reserve((size_t)NO_all);
   fixed_cost = 0.0;
   const double b = opt.loss_scale_factor * opt.loss_scale_factor;
   h_img_used.assign(NI, 0); h_cam_used.assign(NC, 0); h_pt_used.assign(NP, 0);
@@ -103,9 +102,7 @@ void mavba_session::build(const mavba_problem* P) {
   for (int p = 0; p < NP; ++p) any_const_pt |= h_pt_const_in[p] != 0;
   const bool all_kept = !(any_const_img && any_const_pt);
   if (all_kept) {
-    // (the per-point counts and the used flags then fall out of the counting sorts below)
-    kept.resize((size_t)NO_all);
-    parallel_ranges(NO_all, [&](long long b0, long long b1) { for (long long o = b0; o < b1; ++o) kept[o] = o; });
+    // (the per-point counts and the used flags then fall out of the counting sorts below; `kept` stays empty = identity)
   } else {
     for (long long o = 0; o < NO_all; ++o) {
       const int i = P->obs_image[o], p = P->obs_point[o], c = h_img_cam[i];
@@ -129,7 +126,9 @@ void mavba_session::build(const mavba_problem* P) {
     }
   }
   lap("validate + fixed blocks");
-  N = (int)kept.size();
+  N = all_kept ? (int)NO_all : (int)kept.size();
+  const long long* keptp = all_kept ? nullptr : kept.data();
+  auto kept_at = [keptp](long long k) { return keptp ? keptp[k] : k; };
   Nstride = std::max(32, round_up(N, 32));
   NPs = std::max(32, round_up(NP, 32));
 
@@ -169,9 +168,9 @@ void mavba_session::build(const mavba_problem* P) {
   HostBuf<int> bimg(N);
   {
     HostBuf<int> simg(N);
-    counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept[k]]; }, cstart,
+    counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept_at(k)]; }, cstart,
                            [&](long long k, int at) {
-                             const long long o = kept[k];
+                             const long long o = kept_at(k);
                              bucket[at] = o; simg[at] = bimg[at] = P->obs_image[o];
                              buv[at] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
                            });
@@ -247,8 +246,8 @@ void mavba_session::build(const mavba_problem* P) {
   HostSpare<long long>::take(perm, (size_t)N);
   HostSpare<int>::take(h_oimg, (size_t)N);
   perm.resize(N);    // (every element is written by the pass below)
-  HostBuf<double2> uv(N);
-  HostBuf<int> opt_(N);
+  PinnedBuf<double2> uv(N);   // (uploaded below, asynchronously: they live until the sync at the end of build)
+  PinnedBuf<int> opt_(N);
   h_oimg.resize(N);
   parallel_ranges(NP, [&](long long q0, long long q1) {
     for (long long q = q0; q < q1; ++q) {
@@ -265,8 +264,8 @@ void mavba_session::build(const mavba_problem* P) {
   lap("point-major sort");
   // ---- image-major view for the camera sweep ----
   std::vector<int> img_start;
-  HostBuf<double2> im_uv(N);
-  HostBuf<int> im_pt(N);
+  PinnedBuf<double2> im_uv(N);
+  PinnedBuf<int> im_pt(N);
   counting_sort_parallel(N, NI, [&](long long a) { return h_oimg[a]; }, img_start,
                          [&](long long a, int at) { im_uv[at] = uv[a]; im_pt[at] = opt_[a]; });
   if (all_kept)
