@@ -177,6 +177,14 @@ void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radiu
                            const double* Cu, const double* gu, const double* scale_pt,
                            const double* points, double* cand_points, double* delta_points,
                            double* partial /*[grid][3]*/, int* grid_out);
+int backsub_points_grid(int NP);
+// the same from recomputed Jacobians (no entry records read); `a`: the sweep arguments of the CURRENT state,
+// delta_cam from launch_update_cameras (which runs first)
+void launch_backsub_points_jvp(hipStream_t st, int NP, int NPs, int NI, double radius, double dmin, double dmax,
+                               const SweepArgs& a, const int* pt_start, const double* delta_cam,
+                               const unsigned char* pt_free, const double* Gi, const double* h, const double* Cu,
+                               const double* gu, const double* scale_pt, double* cand_points, double* delta_points,
+                               double* partial /*[grid][3]*/);
 void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double radius, double dmin,
                            double dmax, const double* y, const double* scale_cam,
                            const double* img_rec, const double* cam_rec, const double* poses,

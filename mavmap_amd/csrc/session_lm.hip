@@ -152,15 +152,24 @@ void mavba_session::linear_step(double r, double* h) {
 // Back-substitution, candidate x + delta, and its cost. Leaves the scalars on the host.
 void mavba_session::candidate(double r, double* h) {
   const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
-  int rows = 0;
-  timed("backsub_points", [&] {
-    launch_backsub_points(st, NP, NPs, NI, r, dmin, dmax, d_pt_start.p, d_obs_img.p, d_q_start.p, d_q_cam.p,
-                          d_pt_free.p, d_Epose.p, d_Eintr.p, d_y.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p,
-                          d_points.p, d_cpoints.p, d_delta_pts.p, d_step_partial.p, &rows);
-  });
+  // cameras first: the point back-substitution reads their step (delta_cam)
+  const int rows = backsub_points_grid(NP);
   timed("update_cameras", [&] {
     launch_update_cameras(st, NI, NC, rank == 0, r, dmin, dmax, d_y.p, d_scale_cam.p, d_img_rec, d_cam_rec,
                           d_poses.p, d_intr.p, d_cposes.p, d_cintr.p, d_delta_cam.p, d_step_partial.p + 3 * (size_t)rows);
+  });
+  static const bool from_entries = std::getenv("MAVBA_BACKSUB_ENTRIES") != nullptr;
+  timed("backsub_points", [&] {
+    if (from_entries) {
+      int rows_check = 0;
+      launch_backsub_points(st, NP, NPs, NI, r, dmin, dmax, d_pt_start.p, d_obs_img.p, d_q_start.p, d_q_cam.p,
+                            d_pt_free.p, d_Epose.p, d_Eintr.p, d_y.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p,
+                            d_points.p, d_cpoints.p, d_delta_pts.p, d_step_partial.p, &rows_check);
+    } else {
+      launch_backsub_points_jvp(st, NP, NPs, NI, r, dmin, dmax, sweep_args(d_camrec.p, d_intr.p, d_points.p), d_pt_start.p,
+                                d_delta_cam.p, d_pt_free.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p, d_cpoints.p,
+                                d_delta_pts.p, d_step_partial.p);
+    }
   });
   timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_cposes.p, d_ccamrec.p); });
   SweepArgs a = sweep_args(d_ccamrec.p, d_cintr.p, d_cpoints.p);
