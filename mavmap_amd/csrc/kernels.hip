@@ -1031,8 +1031,8 @@ __global__ void __launch_bounds__(256) k_schur_chunks(int num_chunks, const Schu
 // ---------------------------------------------------------------------------
 namespace {
 typedef double cl_d4 __attribute__((ext_vector_type(4)));
-constexpr int kClK = 3 * kClBatch, kClPitch = kClK + 4;
-constexpr int kClThreads = 256, kClWaves = kClThreads / 64;
+constexpr int kClK = 3 * kClBatch, kClPitch = kClK + 2;  // (2 * pitch) mod 64 dwords = 4: the 32 lanes of a half-wave's operand read hit 64 different banks
+constexpr int kClThreads = 512, kClWaves = kClThreads / 64;  // two waves per SIMD: with one, every instruction of the clear / scatter / fetch phases shows its full latency (~10 cycles per instruction measured)
 template <int I, int C>
 struct ClShape {
   static constexpr int images = I, cams = C, cam_row0 = 6 * I, hrow = 6 * I + 9 * C, rows = (hrow + 16) / 16 * 16;
@@ -1042,6 +1042,17 @@ struct ClShape {
 // false: small batches, two work-groups per CU that hide each other's latencies; true: one work-group per CU that
 // prefetches its next batch and double-buffers the operand reads itself
 constexpr bool kClPipelined = kClBatch >= 32;
+// does wave W (tiles t = W, W + kClWaves, ... of the row-major lower triangle) read row block `row` as an operand?
+template <int NT>
+constexpr bool cluster_row_used(int W, int row) {
+  int t = 0;
+  for (int i = 0; i < NT; ++i)
+    for (int j = 0; j <= i; ++j) {
+      if (t % kClWaves == W && (i == row || j == row)) return true;
+      ++t;
+    }
+  return false;
+}
 template <class SH, int W>
 __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int lane, cl_d4 (&acc)[SH::acc]) {
   constexpr int NT = SH::NT;
@@ -1052,7 +1063,8 @@ __device__ __forceinline__ void cluster_mfma(const double* __restrict__ E, int l
   // compiler wait for the reads at the top of every step).
   auto load = [&](double (&x)[NT], int kk) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) x[i] = base[16 * i * kClPitch + kk];
+    for (int i = 0; i < NT; ++i)
+      if (cluster_row_used<NT>(W, i)) x[i] = base[16 * i * kClPitch + kk];  // (only the row blocks of this wave's tiles)
   };
   auto mma = [&](const double (&x)[NT]) {
     int t = 0;
@@ -1144,7 +1156,7 @@ __device__ __forceinline__ void cluster_emit(int lane, const cl_d4 (&acc)[SH::ac
 }  // namespace
 
 namespace {
-constexpr int kClChunk = kClImagesMax * kClBatch * (kPoseRec / 2) / 256 * 2 / 3, kClQChunk = (2 * kClBatch * (kIntrRec / 2) + 255) / 256;  // value loads a thread has in flight per batch (pose / intrinsics records)
+constexpr int kClChunk = kClImagesMax * kClBatch * (kPoseRec / 2) / kClThreads * 2 / 3, kClQChunk = (2 * kClBatch * (kIntrRec / 2) + kClThreads - 1) / kClThreads;  // value loads a thread has in flight per batch (pose / intrinsics records)
 // Records of one batch, HBM -> LDS matrix. Element e of a record sits at (row e / 3, column e % 3) relative to
 // the record's base (row 6 la or 96 + 9 lc, column 3 * point-in-batch). Thread tid takes the double2 number
 // f = u * 256 + tid of the batch's contiguous record range. The value loads do not wait for the record's local
@@ -1152,9 +1164,56 @@ constexpr int kClChunk = kClImagesMax * kClBatch * (kPoseRec / 2) / 256 * 2 / 3,
 // cores work on the previous batch.
 template <int REC, int USED, int NU>
 struct ClusterRegs { double2 v[NU]; unsigned short meta[NU]; };  // meta = local index << 8 | point in batch (host-packed), 0xFFFF = not in the cluster
+// What thread tid does with its u-th double2 of a batch never changes: record number within the batch, offset in the
+// record range, offset in E relative to the record's base. Computed once per work-group (the divisions by 12 / 18 and 3
+// per element and per batch were ~800 instructions of the scatter and ~350 of the fetch, with the matrix cores idle).
 template <int REC, int USED, int NU>
-__device__ __forceinline__ void cluster_fetch(ClusterRegs<REC, USED, NU>& R, int tid, int u0, int first, int count,
-                                              const unsigned short* __restrict__ rec_meta, const double* __restrict__ rec) {
+struct ClusterPlan {
+  int src[NU];               // double offset of the double2 from the batch's first record
+  short rec_no[NU];          // record number within the batch (32767: this slot is never used)
+  unsigned short dst[NU];    // offset of .x in E from the record's base (row, column); bit 15: .y starts the next row, bit 14: .y is used
+  __device__ __forceinline__ void init(int tid) {
+    constexpr int H = REC / 2;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int f = u * kClThreads + tid, oo = f / H, e2 = (f - oo * H) * 2;
+      rec_no[u] = e2 < USED ? (short)oo : (short)32767;
+      src[u] = oo * REC + e2;
+      dst[u] = (unsigned short)((e2 / 3) * kClPitch + e2 % 3) | (unsigned short)(e2 % 3 == 2 ? 0x8000u : 0u) |
+               (unsigned short)(e2 + 1 < USED ? 0x4000u : 0u);
+    }
+  }
+};
+template <int REC, int USED, int NU>
+__device__ __forceinline__ void cluster_fetch(ClusterRegs<REC, USED, NU>& R, const ClusterPlan<REC, USED, NU>& P, int first,
+                                              int count, const unsigned short* __restrict__ rec_meta,
+                                              const double* __restrict__ rec) {
+  const double* base = rec + (size_t)first * REC;
+  const unsigned short* mbase = rec_meta + first;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    R.meta[u] = 0xFFFFu;
+    if (P.rec_no[u] < count) {  // nothing below depends on a loaded value: the loads just go out
+      R.v[u] = *reinterpret_cast<const double2*>(base + P.src[u]);
+      R.meta[u] = mbase[P.rec_no[u]];
+    }
+  }
+}
+template <int REC, int USED, int NU>
+__device__ __forceinline__ void cluster_scatter(const ClusterRegs<REC, USED, NU>& R, const ClusterPlan<REC, USED, NU>& P,
+                                                double* __restrict__ E, int row0, int row_step) {
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    if (R.meta[u] != 0xFFFFu) {
+      const int at = (row0 + row_step * (R.meta[u] >> 8)) * kClPitch + 3 * (R.meta[u] & 255) + (P.dst[u] & 0x3FFF);
+      E[at] = R.v[u].x;
+      if (P.dst[u] & 0x4000u) E[at + ((P.dst[u] & 0x8000u) ? kClPitch - 2 : 1)] = R.v[u].y;
+    }
+}
+// the generic forms (any u0) for the overflow path
+template <int REC, int USED, int NU>
+__device__ __forceinline__ void cluster_fetch_any(ClusterRegs<REC, USED, NU>& R, int tid, int u0, int first, int count,
+                                                  const unsigned short* __restrict__ rec_meta, const double* __restrict__ rec) {
   constexpr int H = REC / 2;
   const int ntot = count * H;
 #pragma unroll
@@ -1163,7 +1222,7 @@ __device__ __forceinline__ void cluster_fetch(ClusterRegs<REC, USED, NU>& R, int
     R.meta[u] = 0xFFFFu;
     if (f < ntot) {
       const int oo = f / H, e2 = (f - oo * H) * 2, o = first + oo;
-      if (e2 < USED) {  // nothing below depends on a loaded value: the loads just go out
+      if (e2 < USED) {
         R.v[u] = *reinterpret_cast<const double2*>(rec + (size_t)o * REC + e2);
         R.meta[u] = rec_meta[o];
       }
@@ -1171,8 +1230,8 @@ __device__ __forceinline__ void cluster_fetch(ClusterRegs<REC, USED, NU>& R, int
   }
 }
 template <int REC, int USED, int NU>
-__device__ __forceinline__ void cluster_scatter(const ClusterRegs<REC, USED, NU>& R, double* __restrict__ E, int tid, int u0,
-                                                int row0, int row_step) {
+__device__ __forceinline__ void cluster_scatter_any(const ClusterRegs<REC, USED, NU>& R, double* __restrict__ E, int tid, int u0,
+                                                    int row0, int row_step) {
   constexpr int H = REC / 2;
 #pragma unroll
   for (int u = 0; u < NU; ++u)
@@ -1192,8 +1251,8 @@ __device__ __forceinline__ void cluster_overflow(double* __restrict__ E, int tid
   const int u_end = (count * (REC / 2) + kClThreads - 1) / kClThreads;
   for (int uc = NU; uc < u_end; uc += NU) {
     ClusterRegs<REC, USED, NU> R;
-    cluster_fetch(R, tid, uc, first, count, rec_meta, rec);
-    cluster_scatter(R, E, tid, uc, row0, row_step);
+    cluster_fetch_any(R, tid, uc, first, count, rec_meta, rec);
+    cluster_scatter_any(R, E, tid, uc, row0, row_step);
   }
 }
 }  // namespace
@@ -1204,8 +1263,13 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
     const int* __restrict__ q_start, const unsigned short* __restrict__ obs_meta,
     const unsigned short* __restrict__ q_meta, const unsigned char* __restrict__ pt_clustered,
     const double* __restrict__ Epose, const double* __restrict__ Eintr, const double* __restrict__ h, int NPs,
-    double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
+    double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii,
+    long long* __restrict__ trace) {
   __shared__ __attribute__((aligned(16))) double E[SH::rows * kClPitch];
+  long long stamp[24];
+  int nstamp = 0;
+  auto mark = [&]() { if (trace && nstamp < 24) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+  mark();
   __shared__ int s_bounds[2][kClMaxBatches + 1];  // first observation / intrinsics entry of every batch
   __shared__ int s_tab[SH::tab];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -1223,12 +1287,16 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
   __syncthreads();
   ClusterRegs<kPoseRec, 18, kClChunk> RP;
   ClusterRegs<kIntrRec, 27, kClQChunk> RQ;
+  ClusterPlan<kPoseRec, 18, kClChunk> PP;
+  ClusterPlan<kIntrRec, 27, kClQChunk> PQ;
+  PP.init(tid);
+  PQ.init(tid);
   double hv = 0.0;
   unsigned char hon = 0;
   auto fetch = [&](int bi) {
     const int b0 = cl.p0 + bi * kClBatch, b1 = min(b0 + kClBatch, cl.p1);
-    cluster_fetch(RP, tid, 0, s_bounds[0][bi], s_bounds[0][bi + 1] - s_bounds[0][bi], obs_meta, Epose);
-    cluster_fetch(RQ, tid, 0, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], q_meta, Eintr);
+    cluster_fetch(RP, PP, s_bounds[0][bi], s_bounds[0][bi + 1] - s_bounds[0][bi], obs_meta, Epose);
+    cluster_fetch(RQ, PQ, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], q_meta, Eintr);
     hon = 0;
     if (tid < (b1 - b0) * 3) {
       const int pp = tid / 3, t = tid - 3 * pp;
@@ -1241,30 +1309,49 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
     if constexpr (!kClPipelined) fetch(bi);  // all loads of the batch are in flight while E is cleared
     for (int i = tid; i < SH::rows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
     __syncthreads();
-    cluster_scatter(RP, E, tid, 0, 0, 6);
-    cluster_scatter(RQ, E, tid, 0, SH::cam_row0, 9);
+    mark();
+    cluster_scatter(RP, PP, E, 0, 6);
+    cluster_scatter(RQ, PQ, E, SH::cam_row0, 9);
     if (hon) E[SH::hrow * kClPitch + tid] = hv;
     cluster_overflow<kPoseRec, 18, kClChunk>(E, tid, s_bounds[0][bi], s_bounds[0][bi + 1] - s_bounds[0][bi], 0, 6, obs_meta, Epose);
     cluster_overflow<kIntrRec, 27, kClQChunk>(E, tid, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], SH::cam_row0, 9, q_meta, Eintr);
     __syncthreads();
+    mark();
     if constexpr (kClPipelined) {
       if (bi + 1 < nbatch) fetch(bi + 1);  // travels while the matrix cores work on this batch
       __builtin_amdgcn_sched_barrier(0);   // (keep the loads here: the scheduler would sink them to their use)
     }
+    mark();
     switch (wv) {
       case 0: cluster_mfma<SH, 0>(E, lane, acc); break;
       case 1: cluster_mfma<SH, 1>(E, lane, acc); break;
       case 2: cluster_mfma<SH, 2>(E, lane, acc); break;
-      default: cluster_mfma<SH, 3>(E, lane, acc); break;
+      case 3: cluster_mfma<SH, 3>(E, lane, acc); break;
+      case 4: cluster_mfma<SH, 4>(E, lane, acc); break;
+      case 5: cluster_mfma<SH, 5>(E, lane, acc); break;
+      case 6: cluster_mfma<SH, 6>(E, lane, acc); break;
+      default: cluster_mfma<SH, 7>(E, lane, acc); break;
     }
+    mark();
     __syncthreads();
+    mark();
   }
   const int* tab = s_tab;
   switch (wv) {
     case 0: cluster_emit<SH, 0>(lane, acc, tab, part_pp, part_ip, part_ii); break;
     case 1: cluster_emit<SH, 1>(lane, acc, tab, part_pp, part_ip, part_ii); break;
     case 2: cluster_emit<SH, 2>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    default: cluster_emit<SH, 3>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 3: cluster_emit<SH, 3>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 4: cluster_emit<SH, 4>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 5: cluster_emit<SH, 5>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 6: cluster_emit<SH, 6>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    default: cluster_emit<SH, 7>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+  }
+  mark();
+  if (trace && (tid & 63) == 0 && wv < 4 && blockIdx.x < 4096) {  // one line per wave (the first four): [n, stamps...]
+    long long* out = trace + ((size_t)blockIdx.x * 4 + wv) * 32;
+    out[0] = nstamp;
+    for (int i = 0; i < nstamp; ++i) out[1 + i] = stamp[i];
   }
 }
 void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters, const SchurCluster* clusters, const int* tab,
@@ -1273,12 +1360,34 @@ void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters,
                            const double* Eintr, const double* h, int NPs, double* part_pp, double* part_ip,
                            double* part_ii) {
   if (num_clusters <= 0) return;
+  // MAVBA_CLUSTER_TRACE=<file>: the 5th launch of the process records s_memtime stamps per wave (debugging aid)
+  long long* trace = nullptr;
+  static int calls = 0;
+  static const char* trace_file = std::getenv("MAVBA_CLUSTER_TRACE");
+  const size_t trace_n = (size_t)4096 * 4 * 32;
+  if (trace_file && ++calls == 5) { (void)hipMalloc(reinterpret_cast<void**>(&trace), trace_n * 8); (void)hipMemsetAsync(trace, 0, trace_n * 8, st); }
   if (shape.images == 12)
     hipLaunchKernelGGL((k_schur_clusters<ClShape<12, 2>>), dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start,
-                       q_start, obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii);
+                       q_start, obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii, trace);
   else
     hipLaunchKernelGGL((k_schur_clusters<ClShape<16, 3>>), dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start,
-                       q_start, obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii);
+                       q_start, obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii, trace);
+  if (trace) {
+    std::vector<long long> hst(trace_n);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hst.data(), trace, trace_n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(trace);
+    if (FILE* f = std::fopen(trace_file, "w")) {
+      for (int b = 0; b < std::min(num_clusters, 4096); ++b)
+        for (int w = 0; w < 4; ++w) {
+          const long long* r = &hst[((size_t)b * 4 + w) * 32];
+          std::fprintf(f, "%d %d", b, w);
+          for (int i = 0; i < (int)r[0]; ++i) std::fprintf(f, " %lld", r[1 + i]);
+          std::fprintf(f, "\n");
+        }
+      std::fclose(f);
+    }
+  }
 }
 
 int schur_partial_stride(int kind) { return kind == BLK_PP ? 42 : kind == BLK_IP ? 54 : 90; }
