@@ -1477,6 +1477,90 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   return hipSuccess;
 }
 
+// Systems of one or two tile columns (n <= 128: a local bundle-adjustment window of up to ~20 images): ONE work-group
+// factorises, substitutes forward and backward with everything in LDS - no hand-offs between work-groups, one launch
+// instead of two (the persistent launch + the backward substitution cost 43 us for the 128 x 128 system of a 10-image
+// window; this is the same arithmetic: L00, L10 = A10 L00^-T, A11 - L10 L10^T, L11, then the two triangular solves with
+// the inverted diagonal tiles). M is only read.
+__global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M, int ld, int nb_all, int nb,
+                                                    double* __restrict__ fail, double* __restrict__ y,
+                                                    const int* __restrict__ scatter, double* __restrict__ y_nat) {
+  // nb (1 or 2): the leading tile columns that hold free parameters; columns beyond them (up to nb_all tiles) are unit
+  // diagonal with a zero right-hand side: their solution is 0
+  __shared__ __attribute__((aligned(16))) double W[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double I0[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double I1[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double P[NB * GLD];
+  __shared__ double vv[2 * NB], zz[2 * NB], xx[2 * NB];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+  load_tile(M, ld, W, tid);
+  if (nb > 1) load_tile(M + (size_t)NB * ld, ld, P, tid);
+  if (tid < nb * NB) vv[tid] = M[(size_t)nb_all * NB * ld + tid];
+  __syncthreads();
+  bool ok = tile_potrf_inv_la(W, I0, tid);
+  __syncthreads();
+  auto lower_mv = [&](const double* Li, const double* in, double* out) {  // out = Li in   (Li lower, upper part zero)
+    if (wv == 0) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < NB; j += 2) { s0 = __builtin_fma(Li[lane * GLD + j], in[j], s0); s1 = __builtin_fma(Li[lane * GLD + j + 1], in[j + 1], s1); }
+      out[lane] = s0 + s1;
+    }
+  };
+  auto lower_tmv = [&](const double* Li, const double* in, double* out) {  // out = Li^T in
+    if (wv == 0) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < NB; i += 2) { s0 = __builtin_fma(Li[i * GLD + lane], in[i], s0); s1 = __builtin_fma(Li[(i + 1) * GLD + lane], in[i + 1], s1); }
+      out[lane] = s0 + s1;
+    }
+  };
+  lower_mv(I0, vv, zz);  // z0 = L00^-1 v0
+  if (nb > 1) {
+    d4 acc[2][2];
+    mfma_quadrant_nt(P, I0, wr, wc, lane, acc);  // L10 = A10 (L00^-1)^T
+    load_tile(M + (size_t)NB * ld + NB, ld, W, tid);  // A11 (W's L00 is not needed any more)
+    __syncthreads();
+    quadrant_to_lds(P, wr, wc, lane, acc);
+    __syncthreads();
+    d4 upd[2][2], cur[2][2];
+    mfma_quadrant_nt(P, P, wr, wc, lane, upd);  // L10 L10^T
+    quadrant_from_lds(W, wr, wc, lane, cur);
+    quadrant_sub(cur, upd);
+    if (wv == 0) {  // v1 - L10 z0
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < NB; j += 2) { s0 = __builtin_fma(P[lane * GLD + j], zz[j], s0); s1 = __builtin_fma(P[lane * GLD + j + 1], zz[j + 1], s1); }
+      xx[NB + lane] = vv[NB + lane] - (s0 + s1);
+    }
+    __syncthreads();
+    quadrant_to_lds(W, wr, wc, lane, cur);
+    __syncthreads();
+    ok = tile_potrf_inv_la(W, I1, tid) && ok;
+    __syncthreads();
+    lower_mv(I1, xx + NB, zz + NB);   // z1
+    __syncthreads();
+    lower_tmv(I1, zz + NB, xx + NB);  // x1 = L11^-T z1
+    __syncthreads();
+    if (wv == 0) {  // z0 - L10^T x1
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < NB; i += 2) { s0 = __builtin_fma(P[i * GLD + lane], xx[NB + i], s0); s1 = __builtin_fma(P[(i + 1) * GLD + lane], xx[NB + i + 1], s1); }
+      zz[lane] -= s0 + s1;
+    }
+  }
+  __syncthreads();
+  lower_tmv(I0, zz, xx);  // x0
+  __syncthreads();
+  if (tid == 0 && !ok) atomicAdd(fail, 1.0);
+  for (int c = tid; c < nb_all * NB; c += 256) {
+    const double x = c < nb * NB ? xx[c] : 0.0;
+    y[c] = x;
+    if (scatter) { const int t = scatter[c]; if (t >= 0) y_nat[t] = x; }
+  }
+}
+
 // diag_ws: n_pad * 64 doubles (the inverses of the factor's diagonal tiles); L: second
 // (n_pad + 64) x n_pad matrix receiving the factor's off-diagonal tiles and the
 // forward-substituted right-hand side. `cs` = tile structure + launch schedule of the matrix.
@@ -1485,6 +1569,12 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
                             const int* y_scatter, double* y_nat, bool allow_persistent) {
   const int nb = n_pad / NB, ld = n_pad;
   double* inv = diag_ws;
+  static const bool small_path = [] { const char* e = std::getenv("MAVBA_CHOL_SMALL"); return !e || std::atoi(e) != 0; }();
+  const int nb_active = cs.active_tiles > 0 ? std::min(cs.active_tiles, nb) : nb;
+  if (nb_active <= 2 && small_path) {
+    hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), 0, st, M, ld, nb, nb_active, fail, y, y_scatter, y_nat);
+    return;
+  }
   const unsigned epoch = ++cs.epoch;  // flags of this solve (forward hand-offs and backward substitution)
   if (allow_persistent && cs.persist_ok) {
     CholPersistArgs A;

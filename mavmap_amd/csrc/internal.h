@@ -189,7 +189,7 @@ void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double
                            double dmax, const double* y, const double* scale_cam,
                            const double* img_rec, const double* cam_rec, const double* poses,
                            const double* intr, double* cand_poses, double* cand_intr,
-                           double* delta_cam, double* partial3 /*[3]*/);
+                           double* delta_cam, double* partial3, double* cand_camrec /* null: no camera records */ /*[3]*/);
 
 // Deterministic reductions of per-block partials: out[c] = op_c(partial[:, c]).
 // op bit c of `max_mask` set -> max, else sum. Adds into out if accumulate.
@@ -273,6 +273,7 @@ struct CholStructure {
   CholMerge* d_merges = nullptr;
   double* d_shadow = nullptr;
   // persistent schedule
+  int active_tiles = 0;  // leading tile columns that hold a free parameter (0: all); the rest is identity with a zero right-hand side
   bool persist_ok = false;        // a schedule exists (structure consistent, fits the resident grid)
   int persist_grid = 0;           // work-groups (<= CUs of the device, all resident)
   int persist_chain_wgs = 0;      // the first persist_chain_wgs work-groups walk the nodes' diagonals

@@ -1475,7 +1475,10 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
           if (r == c && sr != 0.0) base += clampd(base, dmin, dmax) / radius;
         }
       }
-      const double val = base - s;
+      double val = base - s;
+      // a constant parameter's diagonal entry (its row and column are zero): 1 on the rank that adds the base terms
+      // (what k_fix_diag does for the columns no block covers)
+      if (is_diag && r == c && scale_cam[gr] == 0.0) val = add_base ? 1.0 : 0.0;
       if (!is_diag || r >= c) {
         S[(size_t)(prow0 + r) * ld + pcol0 + c] = val;
         S[(size_t)(pcol0 + c) * ld + prow0 + r] = val;
@@ -1751,7 +1754,8 @@ __global__ void __launch_bounds__(256) k_update_cameras(
     int NI, int NC, int cam_part, double radius, double dmin, double dmax, const double* __restrict__ y,
     const double* __restrict__ scale_cam, const double* __restrict__ img_rec, const double* __restrict__ cam_rec,
     const double* __restrict__ poses, const double* __restrict__ intr, double* __restrict__ cand_poses,
-    double* __restrict__ cand_intr, double* __restrict__ delta_cam, double* __restrict__ partial3) {
+    double* __restrict__ cand_intr, double* __restrict__ delta_cam, double* __restrict__ partial3,
+    double* __restrict__ cand_camrec) {
   __shared__ double s_red[4];
   const int ncam = 6 * NI + 9 * NC;
   double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
@@ -1781,14 +1785,24 @@ __global__ void __launch_bounds__(256) k_update_cameras(
   const double s1 = block_sum_256(a_model, s_red);
   const double s2 = block_sum_256(a_x2, s_red);
   if (threadIdx.x == 0) { partial3[0] = s0; partial3[1] = s1; partial3[2] = s2; }
+  // the candidate's camera records (k_cam_prepare's work; one work-group: its own stores are visible after the barriers above)
+  if (cand_camrec) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < NI; i += 256) {
+      double rec[9];
+      cam_prepare(cand_poses + 6 * i, rec);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cand_camrec[9 * i + k] = rec[k];
+    }
+  }
 }
 void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double radius, double dmin,
                            double dmax, const double* y, const double* scale_cam,
                            const double* img_rec, const double* cam_rec, const double* poses,
                            const double* intr, double* cand_poses, double* cand_intr,
-                           double* delta_cam, double* partial3) {
+                           double* delta_cam, double* partial3, double* cand_camrec) {
   hipLaunchKernelGGL(k_update_cameras, dim3(1), dim3(256), 0, st, NI, NC, cam_part ? 1 : 0, radius, dmin, dmax, y,
-                     scale_cam, img_rec, cam_rec, poses, intr, cand_poses, cand_intr, delta_cam, partial3);
+                     scale_cam, img_rec, cam_rec, poses, intr, cand_poses, cand_intr, delta_cam, partial3, cand_camrec);
 }
 
 // out[c] (op)= reduce over rows of partial[row*stride + c]; single block, fixed order.

@@ -271,7 +271,9 @@ void mavba_session::build(const mavba_problem* P) {
   if (all_kept)
     for (int i = 0; i < NI; ++i)
       if (img_start[i + 1] > img_start[i]) { h_img_used[i] = 1; h_cam_used[h_img_cam[i]] = 1; }
-  const int kSweepChunk = 2048;
+  // observations per camera-sweep work-group: 2048 for large problems, down to 256 for small ones (a local window has
+  // ~10 images: one work-group per image took 13 us of a 170 us iteration)
+  const int kSweepChunk = std::min(2048, std::max(256, round_up(N / 512, 256)));
   std::vector<SweepChunk> sweep_chunks;
   std::vector<int> img_chunk_start(NI + 1, 0);
   for (int i = 0; i < NI; ++i) {
@@ -539,7 +541,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   // column offsets in tree order (every node padded to whole tiles), intrinsics at the end of the root
   h_off_img.assign(NI, 0); h_off_cam.assign(NC, 0);
   std::vector<CholNode> tree;
-  int col = 0;
+  int col = 0, active_cols = -1;  // active_cols: columns before the first entirely constant block (-1: unknown order)
   if (tn.size() >= 3) {
     for (size_t t = 0; t < tn.size(); ++t) {
       const int begin = col;
@@ -549,8 +551,17 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
       tree.push_back(CholNode{begin / 64, col / 64, tn[t].parent});
     }
   } else {
-    for (int i = 0; i < NI; ++i) { h_off_img[i] = col; col += 6; }
-    for (int c = 0; c < NC; ++c) { h_off_cam[c] = col; col += 9; }
+    // No dissection (small systems): blocks with a free parameter first, entirely constant ones (unit diagonal, zero
+    // row and right-hand side) last - the one-work-group solve of small systems then stops at the last tile column
+    // that holds a free parameter (a 10-image window with 2 fixed images and fixed intrinsics: 1 tile instead of 2).
+    // (With shards the free flags were agreed between the ranks before this runs: join_ranks.)
+    auto img_free = [&](int i) { for (int e = 0; e < 6; ++e) if (h_pose_free[(size_t)i * 6 + e]) return true; return false; };
+    auto cam_free = [&](int c) { for (int k = 0; k < 9; ++k) if (h_intr_free[(size_t)c * 9 + k]) return true; return false; };
+    for (int i = 0; i < NI; ++i) if (img_free(i)) { h_off_img[i] = col; col += 6; }
+    for (int c = 0; c < NC; ++c) if (cam_free(c)) { h_off_cam[c] = col; col += 9; }
+    active_cols = col;
+    for (int i = 0; i < NI; ++i) if (!img_free(i)) { h_off_img[i] = col; col += 6; }
+    for (int c = 0; c < NC; ++c) if (!cam_free(c)) { h_off_cam[c] = col; col += 9; }
   }
   n_mat = std::max(64, round_up(col, 64));
   h_col_var.assign(n_mat, -1);
@@ -587,6 +598,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   for (int tr = 0; tr < nbt; ++tr)
     for (int tc = 0; tc <= tr; ++tc) if (mark[(size_t)tr * nbt + tc]) tile_pairs.emplace_back(tr, tc);
   HIP_OK(chol_struct.build(nbt, tile_pairs, tree, st));
+  chol_struct.active_tiles = active_cols >= 0 ? std::max(1, (active_cols + 63) / 64) : nbt;
   nd_parts = chol_struct.nseg > 1 ? chol_struct.num_fronts_max : 0;
   if (sharded()) {
     std::vector<int2> tl;

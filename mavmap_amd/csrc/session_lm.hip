@@ -97,7 +97,12 @@ void mavba_session::assemble(double r) {
   // matrix: its zeros survive from one linear solve to the next. Only the launch-per-panel schedule, which factorises
   // in place, makes a fresh clear necessary.
   if (!M_is_clean) {
-    timed("memset_S", [&] { HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st)); });
+    timed("memset_S", [&] {
+      HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st));
+      // unit diagonal of the columns no block of S covers (padding, entirely constant blocks); the finalize pass
+      // writes the diagonal of the constant parameters inside its blocks itself
+      launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
+    });
     M_is_clean = true;
   }
   timed("schur_clusters", [&] {
@@ -113,7 +118,6 @@ void mavba_session::assemble(double r) {
     launch_partial_reduce(st, num_reduce_tasks, d_reduce_tasks.p, d_part[0].p, d_part[1].p, d_part[2].p);
     launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, n_mat, rank == 0,
                           r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p, v);
-    launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
   });
   if (sharded()) {
     // only the tiles the factorisation reads (lower, inside the structure) and the right-hand side travel
@@ -156,7 +160,8 @@ void mavba_session::candidate(double r, double* h) {
   const int rows = backsub_points_grid(NP);
   timed("update_cameras", [&] {
     launch_update_cameras(st, NI, NC, rank == 0, r, dmin, dmax, d_y.p, d_scale_cam.p, d_img_rec, d_cam_rec,
-                          d_poses.p, d_intr.p, d_cposes.p, d_cintr.p, d_delta_cam.p, d_step_partial.p + 3 * (size_t)rows);
+                          d_poses.p, d_intr.p, d_cposes.p, d_cintr.p, d_delta_cam.p, d_step_partial.p + 3 * (size_t)rows,
+                          d_ccamrec.p);  // (+ the candidate's camera records: no separate cam_prepare launch)
   });
   static const bool from_entries = std::getenv("MAVBA_BACKSUB_ENTRIES") != nullptr;
   timed("backsub_points", [&] {
@@ -171,7 +176,6 @@ void mavba_session::candidate(double r, double* h) {
                                 d_delta_pts.p, d_step_partial.p);
     }
   });
-  timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_cposes.p, d_ccamrec.p); });
   SweepArgs a = sweep_args(d_ccamrec.p, d_cintr.p, d_cpoints.p);
   timed("cost_only", [&] { launch_cost_only(st, a); });
   if (num_priors > 0)
