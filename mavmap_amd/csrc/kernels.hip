@@ -1156,56 +1156,59 @@ __device__ __forceinline__ void cluster_emit(int lane, const cl_d4 (&acc)[SH::ac
 }  // namespace
 
 namespace {
-constexpr int kClChunk = kClImagesMax * kClBatch * (kPoseRec / 2) / kClThreads * 2 / 3, kClQChunk = (2 * kClBatch * (kIntrRec / 2) + kClThreads - 1) / kClThreads;  // value loads a thread has in flight per batch (pose / intrinsics records)
+constexpr int kClChunk = (kClImagesMax * kClBatch * 2 / 3 * 9 + kClThreads - 1) / kClThreads, kClQChunk = (2 * kClBatch * 14 + kClThreads - 1) / kClThreads + 1;  // value loads a thread has in flight per batch (pose / intrinsics records)
 // Records of one batch, HBM -> LDS matrix. Element e of a record sits at (row e / 3, column e % 3) relative to
 // the record's base (row 6 la or 96 + 9 lc, column 3 * point-in-batch). Thread tid takes the double2 number
 // f = u * 256 + tid of the batch's contiguous record range. The value loads do not wait for the record's local
 // index (only the scatter does), so a batch costs ONE memory latency - and that one is spent while the matrix
 // cores work on the previous batch.
 template <int REC, int USED, int NU>
-struct ClusterRegs { double2 v[NU]; unsigned short meta[NU]; };  // meta = local index << 8 | point in batch (host-packed), 0xFFFF = not in the cluster
+struct ClusterRegs { double2 v[NU]; unsigned meta[NU]; };  // meta = local index << 8 | point in batch (host-packed), 0xFFFF = not in the cluster (full registers: 16-bit fields make the compiler merge - and wait)
 // What thread tid does with its u-th double2 of a batch never changes: record number within the batch, offset in the
-// record range, offset in E relative to the record's base. Computed once per work-group (the divisions by 12 / 18 and 3
-// per element and per batch were ~800 instructions of the scatter and ~350 of the fetch, with the matrix cores idle).
+// record range, offset in E relative to the record's base. Computed once per work-group (the divisions per element and
+// per batch were ~800 instructions of the scatter and ~350 of the fetch, with the matrix cores idle). Only the USED
+// double2s of a record are numbered (9 of 12 for a pose record, 14 of 18 for an intrinsics record).
 template <int REC, int USED, int NU>
 struct ClusterPlan {
+  static constexpr int D2 = (USED + 1) / 2;
   int src[NU];               // double offset of the double2 from the batch's first record
-  short rec_no[NU];          // record number within the batch (32767: this slot is never used)
-  unsigned short dst[NU];    // offset of .x in E from the record's base (row, column); bit 15: .y starts the next row, bit 14: .y is used
+  int rec_no[NU];            // record number within the batch
+  unsigned dst[NU];          // offset of .x in E from the record's base (row, column); bit 15: .y starts the next row, bit 14: .y is used
   __device__ __forceinline__ void init(int tid) {
-    constexpr int H = REC / 2;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int f = u * kClThreads + tid, oo = f / H, e2 = (f - oo * H) * 2;
-      rec_no[u] = e2 < USED ? (short)oo : (short)32767;
+      const int f = u * kClThreads + tid, oo = f / D2, e2 = (f - oo * D2) * 2;
+      rec_no[u] = oo;
       src[u] = oo * REC + e2;
-      dst[u] = (unsigned short)((e2 / 3) * kClPitch + e2 % 3) | (unsigned short)(e2 % 3 == 2 ? 0x8000u : 0u) |
-               (unsigned short)(e2 + 1 < USED ? 0x4000u : 0u);
+      dst[u] = (unsigned)((e2 / 3) * kClPitch + e2 % 3) | (e2 % 3 == 2 ? 0x8000u : 0u) | (e2 + 1 < USED ? 0x4000u : 0u);
     }
   }
 };
+// The loads are UNCONDITIONAL (a slot beyond the batch's records reads the last record again and is ignored by the
+// scatter): one basic block, nothing depends on a loaded value, so all of them go out back to back - with a branch per
+// load the compiler guarded re-used registers with s_waitcnt vmcnt(0) and the fetch phase waited out the HBM latency.
 template <int REC, int USED, int NU>
 __device__ __forceinline__ void cluster_fetch(ClusterRegs<REC, USED, NU>& R, const ClusterPlan<REC, USED, NU>& P, int first,
                                               int count, const unsigned short* __restrict__ rec_meta,
                                               const double* __restrict__ rec) {
+  if (count <= 0) return;  // (wave-uniform)
   const double* base = rec + (size_t)first * REC;
   const unsigned short* mbase = rec_meta + first;
+  const int last = count - 1;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    R.meta[u] = 0xFFFFu;
-    if (P.rec_no[u] < count) {  // nothing below depends on a loaded value: the loads just go out
-      R.v[u] = *reinterpret_cast<const double2*>(base + P.src[u]);
-      R.meta[u] = mbase[P.rec_no[u]];
-    }
+    const int over = max(P.rec_no[u] - last, 0);
+    R.v[u] = *reinterpret_cast<const double2*>(base + (P.src[u] - over * REC));
+    R.meta[u] = mbase[P.rec_no[u] - over];
   }
 }
 template <int REC, int USED, int NU>
 __device__ __forceinline__ void cluster_scatter(const ClusterRegs<REC, USED, NU>& R, const ClusterPlan<REC, USED, NU>& P,
-                                                double* __restrict__ E, int row0, int row_step) {
+                                                double* __restrict__ E, int row0, int row_step, int count) {
 #pragma unroll
   for (int u = 0; u < NU; ++u)
-    if (R.meta[u] != 0xFFFFu) {
-      const int at = (row0 + row_step * (R.meta[u] >> 8)) * kClPitch + 3 * (R.meta[u] & 255) + (P.dst[u] & 0x3FFF);
+    if (P.rec_no[u] < count && R.meta[u] != 0xFFFFu) {
+      const int at = (row0 + row_step * (int)(R.meta[u] >> 8)) * kClPitch + 3 * (int)(R.meta[u] & 255u) + (int)(P.dst[u] & 0x3FFFu);
       E[at] = R.v[u].x;
       if (P.dst[u] & 0x4000u) E[at + ((P.dst[u] & 0x8000u) ? kClPitch - 2 : 1)] = R.v[u].y;
     }
@@ -1214,30 +1217,28 @@ __device__ __forceinline__ void cluster_scatter(const ClusterRegs<REC, USED, NU>
 template <int REC, int USED, int NU>
 __device__ __forceinline__ void cluster_fetch_any(ClusterRegs<REC, USED, NU>& R, int tid, int u0, int first, int count,
                                                   const unsigned short* __restrict__ rec_meta, const double* __restrict__ rec) {
-  constexpr int H = REC / 2;
-  const int ntot = count * H;
+  constexpr int D2 = (USED + 1) / 2;
+  const int ntot = count * D2;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int f = (u0 + u) * kClThreads + tid;
     R.meta[u] = 0xFFFFu;
     if (f < ntot) {
-      const int oo = f / H, e2 = (f - oo * H) * 2, o = first + oo;
-      if (e2 < USED) {
-        R.v[u] = *reinterpret_cast<const double2*>(rec + (size_t)o * REC + e2);
-        R.meta[u] = rec_meta[o];
-      }
+      const int oo = f / D2, e2 = (f - oo * D2) * 2, o = first + oo;
+      R.v[u] = *reinterpret_cast<const double2*>(rec + (size_t)o * REC + e2);
+      R.meta[u] = rec_meta[o];
     }
   }
 }
 template <int REC, int USED, int NU>
 __device__ __forceinline__ void cluster_scatter_any(const ClusterRegs<REC, USED, NU>& R, double* __restrict__ E, int tid, int u0,
                                                     int row0, int row_step) {
-  constexpr int H = REC / 2;
+  constexpr int D2 = (USED + 1) / 2;
 #pragma unroll
   for (int u = 0; u < NU; ++u)
     if (R.meta[u] != 0xFFFFu) {
-      const int f = (u0 + u) * kClThreads + tid, e2 = (f % H) * 2;
-      const int at = (row0 + row_step * (R.meta[u] >> 8) + e2 / 3) * kClPitch + 3 * (R.meta[u] & 255) + e2 % 3;
+      const int f = (u0 + u) * kClThreads + tid, e2 = (f % D2) * 2;
+      const int at = (row0 + row_step * (int)(R.meta[u] >> 8) + e2 / 3) * kClPitch + 3 * (int)(R.meta[u] & 255u) + e2 % 3;
       E[at] = R.v[u].x;
       if (e2 + 1 < USED) E[at + ((e2 % 3 == 2) ? kClPitch - 2 : 1)] = R.v[u].y;
     }
@@ -1248,7 +1249,7 @@ template <int REC, int USED, int NU>
 __device__ __forceinline__ void cluster_overflow(double* __restrict__ E, int tid, int first, int count, int row0,
                                                  int row_step, const unsigned short* __restrict__ rec_meta,
                                                  const double* __restrict__ rec) {
-  const int u_end = (count * (REC / 2) + kClThreads - 1) / kClThreads;
+  const int u_end = (count * ((USED + 1) / 2) + kClThreads - 1) / kClThreads;
   for (int uc = NU; uc < u_end; uc += NU) {
     ClusterRegs<REC, USED, NU> R;
     cluster_fetch_any(R, tid, uc, first, count, rec_meta, rec);
@@ -1257,7 +1258,7 @@ __device__ __forceinline__ void cluster_overflow(double* __restrict__ E, int tid
 }
 }  // namespace
 
-template <class SH>
+template <class SH, bool TRACE>
 __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clusters(
     const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ pt_start,
     const int* __restrict__ q_start, const unsigned short* __restrict__ obs_meta,
@@ -1266,9 +1267,10 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
     double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii,
     long long* __restrict__ trace) {
   __shared__ __attribute__((aligned(16))) double E[SH::rows * kClPitch];
-  long long stamp[24];
+  // (TRACE: a separate instantiation - the 24 stamps are 48 registers the production kernel needs for itself)
+  long long stamp[TRACE ? 24 : 1];
   int nstamp = 0;
-  auto mark = [&]() { if (trace && nstamp < 24) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+  auto mark = [&]() { if constexpr (TRACE) { if (nstamp < 24) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
   mark();
   __shared__ int s_bounds[2][kClMaxBatches + 1];  // first observation / intrinsics entry of every batch
   __shared__ int s_tab[SH::tab];
@@ -1310,8 +1312,8 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
     for (int i = tid; i < SH::rows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
     __syncthreads();
     mark();
-    cluster_scatter(RP, PP, E, 0, 6);
-    cluster_scatter(RQ, PQ, E, SH::cam_row0, 9);
+    cluster_scatter(RP, PP, E, 0, 6, s_bounds[0][bi + 1] - s_bounds[0][bi]);
+    cluster_scatter(RQ, PQ, E, SH::cam_row0, 9, s_bounds[1][bi + 1] - s_bounds[1][bi]);
     if (hon) E[SH::hrow * kClPitch + tid] = hv;
     cluster_overflow<kPoseRec, 18, kClChunk>(E, tid, s_bounds[0][bi], s_bounds[0][bi + 1] - s_bounds[0][bi], 0, 6, obs_meta, Epose);
     cluster_overflow<kIntrRec, 27, kClQChunk>(E, tid, s_bounds[1][bi], s_bounds[1][bi + 1] - s_bounds[1][bi], SH::cam_row0, 9, q_meta, Eintr);
@@ -1348,12 +1350,16 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
     default: cluster_emit<SH, 7>(lane, acc, tab, part_pp, part_ip, part_ii); break;
   }
   mark();
-  if (trace && (tid & 63) == 0 && wv < 4 && blockIdx.x < 4096) {  // one line per wave (the first four): [n, stamps...]
-    long long* out = trace + ((size_t)blockIdx.x * 4 + wv) * 32;
-    out[0] = nstamp;
-    for (int i = 0; i < nstamp; ++i) out[1 + i] = stamp[i];
+  if constexpr (TRACE) {
+    if (trace && (tid & 63) == 0 && wv < 4 && blockIdx.x < 4096) {  // one line per wave (the first four): [n, stamps...]
+      long long* out = trace + ((size_t)blockIdx.x * 4 + wv) * 32;
+      out[0] = nstamp;
+      for (int i = 0; i < nstamp; ++i) out[1 + i] = stamp[i];
+    }
   }
 }
+#define MAVBA_CL_S12 ClShape<12, 2>
+#define MAVBA_CL_S16 ClShape<16, 3>
 void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters, const SchurCluster* clusters, const int* tab,
                            const int* pt_start, const int* q_start, const unsigned short* obs_meta,
                            const unsigned short* q_meta, const unsigned char* pt_clustered, const double* Epose,
@@ -1366,12 +1372,12 @@ void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters,
   static const char* trace_file = std::getenv("MAVBA_CLUSTER_TRACE");
   const size_t trace_n = (size_t)4096 * 4 * 32;
   if (trace_file && ++calls == 5) { (void)hipMalloc(reinterpret_cast<void**>(&trace), trace_n * 8); (void)hipMemsetAsync(trace, 0, trace_n * 8, st); }
-  if (shape.images == 12)
-    hipLaunchKernelGGL((k_schur_clusters<ClShape<12, 2>>), dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start,
-                       q_start, obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii, trace);
-  else
-    hipLaunchKernelGGL((k_schur_clusters<ClShape<16, 3>>), dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start,
-                       q_start, obs_meta, q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii, trace);
+#define MAVBA_CL_LAUNCH(SHAPE, TR)                                                                                                    \
+  hipLaunchKernelGGL((k_schur_clusters<SHAPE, TR>), dim3(num_clusters), dim3(kClThreads), 0, st, clusters, tab, pt_start, q_start, obs_meta, \
+                     q_meta, pt_clustered, Epose, Eintr, h, NPs, part_pp, part_ip, part_ii, trace)
+  if (shape.images == 12) { if (trace) MAVBA_CL_LAUNCH(MAVBA_CL_S12, true); else MAVBA_CL_LAUNCH(MAVBA_CL_S12, false); }
+  else { if (trace) MAVBA_CL_LAUNCH(MAVBA_CL_S16, true); else MAVBA_CL_LAUNCH(MAVBA_CL_S16, false); }
+#undef MAVBA_CL_LAUNCH
   if (trace) {
     std::vector<long long> hst(trace_n);
     (void)hipStreamSynchronize(st);
