@@ -63,7 +63,7 @@ def algorithmic_work(stats_name, prob, sess_info):
     if stats_name == "entries_pose":
         return "hbm", (96 + 48 + 8 + 192.0) * n_obs, "B"
     if stats_name == "backsub_points":
-        # k_backsub_points_jvp recomputes the Jacobians: pixel + image index per observation (20 B), per point its
+        # k_backsub_points_packed recomputes the Jacobians: pixel + image index per observation (20 B), per point its
         # coordinates, factor, h, diagonal, gradient, scales in and candidate + step out (216 B). (The entry-record
         # kernel behind MAVBA_BACKSUB_ENTRIES reads 192 B / observation + 288 B / (point, camera) instead.)
         if os.environ.get("MAVBA_BACKSUB_ENTRIES"):

@@ -1642,59 +1642,81 @@ __global__ void __launch_bounds__(256) k_backsub_points(
 // The same back-substitution WITHOUT reading the entry records: for every observation of the point the Jacobian is
 // recomputed (20 bytes of input instead of a 144-byte record + the intrinsics records) and
 //   sum_a U_a^T y_a + sum_q Uk_q^T y_q = Gi ( s_p o sum_obs Jp^T (Jc (s y)_cam + Jk (s y)_intr) ),
-// with (s y) = -delta_cam from k_update_cameras (which therefore runs first). 16 lanes per point as above.
-__global__ void __launch_bounds__(256) k_backsub_points_jvp(
-    int NP, int NPs, int NI, int gp, double radius, double dmin, double dmax, double loss_b, double loss_inv_b,
-    const int* __restrict__ pt_start, const int* __restrict__ obs_img, const double2* __restrict__ uv,
-    const int* __restrict__ img_cam, const int* __restrict__ cam_model, const double* __restrict__ camrec,
-    const double* __restrict__ intr, const double* __restrict__ delta_cam, const unsigned char* __restrict__ pt_free,
-    const double* __restrict__ Gi, const double* __restrict__ h, const double* __restrict__ Cu,
-    const double* __restrict__ gu, const double* __restrict__ scale_pt, const double* __restrict__ points,
-    double* __restrict__ cand_points, double* __restrict__ delta_points, double* __restrict__ partial) {
+// with (s y) = -delta_cam from k_update_cameras (which therefore runs first).
+// ONE observation per lane: a work-group takes `ppb` consecutive points (~224 observations), every lane computes its
+// observation's Jp^T (J_cam delta_cam), the three values go through LDS and the point's owner lane adds its observations
+// in order (a 16-lanes-per-point version kept 10 of 16 lanes busy at 10 observations per point: 0.126 vs 0.102 ms at C3).
+__global__ void __launch_bounds__(256) k_backsub_points_packed(
+    int NP, int NPs, int NI, int ppb, int nblocks, double radius, double dmin, double dmax, double loss_b, double loss_inv_b,
+    const int* __restrict__ pt_start, const int* __restrict__ obs_img, const int* __restrict__ obs_pt,
+    const double2* __restrict__ uv, const int* __restrict__ img_cam, const int* __restrict__ cam_model,
+    const double* __restrict__ camrec, const double* __restrict__ intr, const double* __restrict__ delta_cam,
+    const unsigned char* __restrict__ pt_free, const double* __restrict__ Gi, const double* __restrict__ h,
+    const double* __restrict__ Cu, const double* __restrict__ gu, const double* __restrict__ scale_pt,
+    const double* __restrict__ points, double* __restrict__ cand_points, double* __restrict__ delta_points,
+    double* __restrict__ partial) {
+  __shared__ double s_t[3][256];
   __shared__ double s_red[4];
-  const int g = threadIdx.x & 15;
+  const int tid = threadIdx.x;
   double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
-  for (int p = blockIdx.x * 16 + (threadIdx.x >> 4); p < NP; p += gp * 16) {
-    const bool fr = pt_free[p] != 0;
-    const double X[3] = {points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2]};
-    double t[3] = {0, 0, 0};
-    if (fr) {
-      for (int o = pt_start[p] + g; o < pt_start[p + 1]; o += 16) {
-        const int im = obs_img[o];
-        const double2 m = uv[o];
-        const int cam = img_cam[im];
-        const int model = cam_model[cam];
-        double rec[9], kin[9], dc[6], dk[9];
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int p0 = blk * ppb, p1 = min(p0 + ppb, NP);
+    const int o0 = pt_start[p0], o1 = pt_start[p1];
+    const int p = p0 + tid;
+    const bool owner = p < p1;
+    int mb = 0, me = 0;
+    if (owner) { mb = pt_start[p]; me = pt_start[p + 1]; }
+    double T[3] = {0.0, 0.0, 0.0};
+    for (int base = o0; base < o1; base += 256) {
+      const int o = base + tid;
+      double t[3] = {0.0, 0.0, 0.0};
+      if (o < o1) {
+        const int pt = obs_pt[o];
+        if (pt_free[pt]) {
+          const int im = obs_img[o];
+          const double2 m = uv[o];
+          const int cam = img_cam[im];
+          const int model = cam_model[cam];
+          const double X[3] = {points[3 * (size_t)pt], points[3 * (size_t)pt + 1], points[3 * (size_t)pt + 2]};
+          double rec[9], kin[9], dc[6], dk[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) rec[k] = camrec[9 * im + k];
+          for (int k = 0; k < 9; ++k) rec[k] = camrec[9 * im + k];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) kin[k] = intr[9 * cam + k];
+          for (int k = 0; k < 9; ++k) kin[k] = intr[9 * cam + k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dc[k] = delta_cam[6 * im + k];
+          for (int k = 0; k < 6; ++k) dc[k] = delta_cam[6 * im + k];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dk[k] = delta_cam[6 * NI + 9 * cam + k];
-        double r[2], Jc[12], Jp[6], Jk[18];
-        obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
-        double w, half_rho;
-        cauchy_weight(r[0] * r[0] + r[1] * r[1], loss_b, loss_inv_b, w, half_rho);
-        double tau0 = 0.0, tau1 = 0.0;
+          for (int k = 0; k < 9; ++k) dk[k] = delta_cam[6 * NI + 9 * cam + k];
+          double r[2], Jc[12], Jp[6], Jk[18];
+          obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
+          double w, half_rho;
+          cauchy_weight(r[0] * r[0] + r[1] * r[1], loss_b, loss_inv_b, w, half_rho);
+          double tau0 = 0.0, tau1 = 0.0;
 #pragma unroll
-        for (int e = 0; e < 6; ++e) { tau0 += Jc[e] * dc[e]; tau1 += Jc[6 + e] * dc[e]; }
+          for (int e = 0; e < 6; ++e) { tau0 += Jc[e] * dc[e]; tau1 += Jc[6 + e] * dc[e]; }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { tau0 += Jk[k] * dk[k]; tau1 += Jk[9 + k] * dk[k]; }  // (columns beyond the model's K are zero)
-        const double w2 = w * w;
-        tau0 *= w2; tau1 *= w2;
-        t[0] += Jp[0] * tau0 + Jp[3] * tau1; t[1] += Jp[1] * tau0 + Jp[4] * tau1; t[2] += Jp[2] * tau0 + Jp[5] * tau1;
+          for (int k = 0; k < 9; ++k) { tau0 += Jk[k] * dk[k]; tau1 += Jk[9 + k] * dk[k]; }
+          const double w2 = w * w;
+          tau0 *= w2; tau1 *= w2;
+          t[0] = Jp[0] * tau0 + Jp[3] * tau1; t[1] = Jp[1] * tau0 + Jp[4] * tau1; t[2] = Jp[2] * tau0 + Jp[5] * tau1;
+        }
       }
+      s_t[0][tid] = t[0]; s_t[1][tid] = t[1]; s_t[2][tid] = t[2];
+      __syncthreads();
+      if (owner) {
+        const int b = max(mb, base), e = min(me, base + 256);
+        for (int i = b; i < e; ++i) { T[0] += s_t[0][i - base]; T[1] += s_t[1][i - base]; T[2] += s_t[2][i - base]; }
+      }
+      __syncthreads();
     }
-    t[0] = row16_sum(t[0]); t[1] = row16_sum(t[1]); t[2] = row16_sum(t[2]);
-    if (g == 0) {
+    if (owner) {
+      const bool fr = pt_free[p] != 0;
+      const double X[3] = {points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2]};
       double d[3] = {0, 0, 0};
       if (fr) {
         const double G[6] = {Gi[p], Gi[NPs + p], Gi[2 * NPs + p], Gi[3 * NPs + p], Gi[4 * NPs + p], Gi[5 * NPs + p]};
         const double sp[3] = {scale_pt[p], scale_pt[NPs + p], scale_pt[2 * NPs + p]};
-        // q = s_p o sum Jp^T J_cam (s y) = -(s_p o t)   (delta_cam = -(s y));  z = Gi q
-        const double q0 = -sp[0] * t[0], q1 = -sp[1] * t[1], q2 = -sp[2] * t[2];
+        const double q0 = -sp[0] * T[0], q1 = -sp[1] * T[1], q2 = -sp[2] * T[2];
         const double z[3] = {q0 * G[0], q0 * G[1] + q1 * G[2], q0 * G[3] + q1 * G[4] + q2 * G[5]};
         const double tt[3] = {h[p] - z[0], h[NPs + p] - z[1], h[2 * NPs + p] - z[2]};
         double yp[3];
@@ -1735,8 +1757,12 @@ void launch_backsub_points_jvp(hipStream_t st, int NP, int NPs, int NI, double r
                                const double* gu, const double* scale_pt, double* cand_points, double* delta_points,
                                double* partial) {
   const int gp = backsub_points_grid(NP);
-  hipLaunchKernelGGL(k_backsub_points_jvp, dim3(gp), dim3(256), 0, st, NP, NPs, NI, gp, radius, dmin, dmax, a.loss_b,
-                     a.loss_inv_b, pt_start, a.obs_img, a.uv, a.img_cam, a.cam_model, a.camrec, a.intr, delta_cam, pt_free,
+  // points per work-group: ~224 observations at the problem's average track length (the owner lanes are the first ppb)
+  const double track = NP > 0 ? (double)a.N / NP : 1.0;
+  const int ppb = std::max(1, std::min(128, (int)(224.0 / std::max(track, 1.0))));
+  const int nblocks = (NP + ppb - 1) / ppb;
+  hipLaunchKernelGGL(k_backsub_points_packed, dim3(gp), dim3(256), 0, st, NP, NPs, NI, ppb, nblocks, radius, dmin, dmax, a.loss_b,
+                     a.loss_inv_b, pt_start, a.obs_img, a.obs_pt, a.uv, a.img_cam, a.cam_model, a.camrec, a.intr, delta_cam, pt_free,
                      Gi, h, Cu, gu, scale_pt, a.points, cand_points, delta_points, partial);
 }
 void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radius, double dmin,
