@@ -134,14 +134,15 @@ void launch_state_norms(hipStream_t st, int NI, int NC, int NP, int NPs, bool ca
                         const double* points, const double* img_rec, const double* cam_rec,
                         const double* gu, double* partial /*[grid][2]*/, int* grid_out);
 
-void launch_point_factor(hipStream_t st, int NP, int NPs, double radius, double dmin, double dmax,
-                         const unsigned char* pt_free, const double* Cu, const double* gu,
-                         const double* scale_pt, double* Gi, double* h, double* fail);
 
 void launch_entries_pose(hipStream_t st, int N, int Nstride, int NPs, const int* obs_img,
                          const int* obs_pt, const unsigned char* pt_free, const double* Jc,
                          const double* Jp, const double* scale_cam, const double* scale_pt,
-                         const double* Gi, const double* h, double* Epose);
+                         double* Gi, double* h, double* Epose);
+void launch_factor_entries_pose(hipStream_t st, int N, int Nstride, int NPs, const int* obs_img, const int* obs_pt,
+                                const unsigned char* pt_free, const double* Jc, const double* Jp, const double* scale_cam,
+                                const double* scale_pt, double* Gi, double* h, double* Epose, const int* pt_start,
+                                const double* Cu, const double* gu, double radius, double dmin, double dmax, double* fail);
 void launch_entries_intr(hipStream_t st, int Q, int NI, int NPs, const int* q_pt, const int* q_cam,
                          const double* Wk, const double* scale_cam, const double* scale_pt,
                          const double* Gi, const double* h, double* Eintr);
@@ -185,11 +186,12 @@ void launch_backsub_points_jvp(hipStream_t st, int NP, int NPs, int NI, double r
                                const unsigned char* pt_free, const double* Gi, const double* h, const double* Cu,
                                const double* gu, const double* scale_pt, double* cand_points, double* delta_points,
                                double* partial /*[grid][3]*/);
+int update_cameras_groups(int NI);  // triples launch_update_cameras writes to partial3
 void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double radius, double dmin,
                            double dmax, const double* y, const double* scale_cam,
                            const double* img_rec, const double* cam_rec, const double* poses,
                            const double* intr, double* cand_poses, double* cand_intr,
-                           double* delta_cam, double* partial3, double* cand_camrec /* null: no camera records */ /*[3]*/);
+                           double* delta_cam, double* partial3 /*[groups][3]*/, double* cand_camrec /* null: no camera records */);
 
 // Deterministic reductions of per-block partials: out[c] = op_c(partial[:, c]).
 // op bit c of `max_mask` set -> max, else sum. Adds into out if accumulate.

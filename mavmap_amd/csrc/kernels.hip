@@ -825,56 +825,23 @@ void launch_state_norms(hipStream_t st, int NI, int NC, int NP, int NPs, bool ca
   *grid_out = gp + 1;
 }
 
-// ---------------------------------------------------------------------------
-// Point factor: C_p = S_p Cu S_p + D_p^2, C_p = G G^T, Gi = G^-1, h = Gi (S_p gu).
-// (Schur eliminator e-block step; D^2 = clamp(diag(Js^T Js)) / radius.)
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_point_factor(
-    int NP, int NPs, double radius, double dmin, double dmax, const unsigned char* __restrict__ pt_free,
-    const double* __restrict__ Cu, const double* __restrict__ gu, const double* __restrict__ scale_pt,
-    double* __restrict__ Gi, double* __restrict__ h, double* __restrict__ fail) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= NP) return;
-  double G[6] = {0, 0, 0, 0, 0, 0}, hh[3] = {0, 0, 0};
-  if (pt_free[p]) {
-    const double s0 = scale_pt[p], s1 = scale_pt[NPs + p], s2 = scale_pt[2 * NPs + p];
-    double C[6];
-    C[0] = s0 * s0 * Cu[p];           C[1] = s0 * s1 * Cu[NPs + p];     C[2] = s0 * s2 * Cu[2 * NPs + p];
-    C[3] = s1 * s1 * Cu[3 * NPs + p]; C[4] = s1 * s2 * Cu[4 * NPs + p]; C[5] = s2 * s2 * Cu[5 * NPs + p];
-    C[0] += clampd(C[0], dmin, dmax) / radius;
-    C[3] += clampd(C[3], dmin, dmax) / radius;
-    C[5] += clampd(C[5], dmin, dmax) / radius;
-    const bool ok = chol3_inv(C, G);
-    const double gs[3] = {s0 * gu[p], s1 * gu[NPs + p], s2 * gu[2 * NPs + p]};
-    gi_mul(G, gs, hh);
-    bool fin = ok;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) fin = fin && isfinite(G[k]);
-    if (!fin) atomicAdd(fail, 1.0);
-  }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) Gi[k * NPs + p] = G[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) h[k * NPs + p] = hh[k];
-}
-void launch_point_factor(hipStream_t st, int NP, int NPs, double radius, double dmin, double dmax,
-                         const unsigned char* pt_free, const double* Cu, const double* gu,
-                         const double* scale_pt, double* Gi, double* h, double* fail) {
-  if (NP <= 0) return;
-  hipLaunchKernelGGL(k_point_factor, dim3((NP + 255) / 256), dim3(256), 0, st, NP, NPs, radius, dmin, dmax,
-                     pt_free, Cu, gu, scale_pt, Gi, h, fail);
-}
 
 // ---------------------------------------------------------------------------
 // Pose entries: U_a = (Jc' ^T Jp') Gi^T (6x3), e_a = U_a h. One lane per
 // observation; records are transposed through LDS so the 192-byte records leave
 // the block as one contiguous, fully coalesced 48 KB store.
 // ---------------------------------------------------------------------------
+// FACTOR: the point's damped 3x3 block - C_p = S_p Cu S_p + D_p^2, C_p = G G^T, Gi = G^-1, h = Gi (S_p gu); the Schur
+// eliminator's e-block step, D^2 = clamp(diag(Js^T Js)) / radius - is factorised HERE (by every observation of the point
+// - 9 + 3 values in instead of 6 + 3, ~100 instructions in an HBM-bound kernel) and its first observation stores Gi and h
+// for the later kernels: one launch less per linear solve.
+template <bool FACTOR>
 __global__ void __launch_bounds__(256) k_entries_pose(
     int N, int Nstride, int NPs, const int* __restrict__ obs_img, const int* __restrict__ obs_pt,
     const unsigned char* __restrict__ pt_free, const double* __restrict__ Jc, const double* __restrict__ Jp,
-    const double* __restrict__ scale_cam, const double* __restrict__ scale_pt, const double* __restrict__ Gi,
-    const double* __restrict__ h, double* __restrict__ Epose) {
+    const double* __restrict__ scale_cam, const double* __restrict__ scale_pt, double* __restrict__ Gi,
+    double* __restrict__ h, double* __restrict__ Epose, const int* __restrict__ pt_start, const double* __restrict__ Cu,
+    const double* __restrict__ gu, double radius, double dmin, double dmax, double* __restrict__ fail) {
   __shared__ double s_rec[256 * 25];
   const long long S = Nstride;
   const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -883,13 +850,46 @@ __global__ void __launch_bounds__(256) k_entries_pose(
   for (int k = 0; k < kPoseRec; ++k) rec[k] = 0.0;
   if (o < N) {
     const int p = obs_pt[o];
-    if (pt_free[p]) {
+    const bool fr = pt_free[p] != 0;
+    if constexpr (FACTOR) {
+      if (!fr && o == pt_start[p]) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Gi[k * NPs + p] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) h[k * NPs + p] = 0.0;
+      }
+    }
+    if (fr) {
       const int im = obs_img[o];
       double sp[3], G[6], hh[3], jp[6];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { sp[k] = scale_pt[k * NPs + p]; hh[k] = h[k * NPs + p]; }
+      for (int k = 0; k < 3; ++k) sp[k] = scale_pt[k * NPs + p];
+      if constexpr (FACTOR) {
+        double C[6];
+        C[0] = sp[0] * sp[0] * Cu[p];           C[1] = sp[0] * sp[1] * Cu[NPs + p];     C[2] = sp[0] * sp[2] * Cu[2 * NPs + p];
+        C[3] = sp[1] * sp[1] * Cu[3 * NPs + p]; C[4] = sp[1] * sp[2] * Cu[4 * NPs + p]; C[5] = sp[2] * sp[2] * Cu[5 * NPs + p];
+        C[0] += clampd(C[0], dmin, dmax) / radius;
+        C[3] += clampd(C[3], dmin, dmax) / radius;
+        C[5] += clampd(C[5], dmin, dmax) / radius;
+        const bool ok = chol3_inv(C, G);
+        const double gs[3] = {sp[0] * gu[p], sp[1] * gu[NPs + p], sp[2] * gu[2 * NPs + p]};
+        gi_mul(G, gs, hh);
+        if (o == pt_start[p]) {
+          bool fin = ok;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) G[k] = Gi[k * NPs + p];
+          for (int k = 0; k < 6; ++k) fin = fin && isfinite(G[k]);
+          if (!fin) atomicAdd(fail, 1.0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Gi[k * NPs + p] = G[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) h[k * NPs + p] = hh[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) hh[k] = h[k * NPs + p];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) G[k] = Gi[k * NPs + p];
+      }
 #pragma unroll
       for (int row = 0; row < 2; ++row)
 #pragma unroll
@@ -921,10 +921,19 @@ __global__ void __launch_bounds__(256) k_entries_pose(
 void launch_entries_pose(hipStream_t st, int N, int Nstride, int NPs, const int* obs_img,
                          const int* obs_pt, const unsigned char* pt_free, const double* Jc,
                          const double* Jp, const double* scale_cam, const double* scale_pt,
-                         const double* Gi, const double* h, double* Epose) {
+                         double* Gi, double* h, double* Epose) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_entries_pose, dim3((N + 255) / 256), dim3(256), 0, st, N, Nstride, NPs, obs_img, obs_pt,
-                     pt_free, Jc, Jp, scale_cam, scale_pt, Gi, h, Epose);
+  hipLaunchKernelGGL((k_entries_pose<false>), dim3((N + 255) / 256), dim3(256), 0, st, N, Nstride, NPs, obs_img, obs_pt,
+                     pt_free, Jc, Jp, scale_cam, scale_pt, Gi, h, Epose, nullptr, nullptr, nullptr, 1.0, 0.0, 0.0, nullptr);
+}
+// k_point_factor + k_entries_pose in one launch (points without observations keep whatever Gi / h hold: nothing reads them)
+void launch_factor_entries_pose(hipStream_t st, int N, int Nstride, int NPs, const int* obs_img, const int* obs_pt,
+                                const unsigned char* pt_free, const double* Jc, const double* Jp, const double* scale_cam,
+                                const double* scale_pt, double* Gi, double* h, double* Epose, const int* pt_start,
+                                const double* Cu, const double* gu, double radius, double dmin, double dmax, double* fail) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL((k_entries_pose<true>), dim3((N + 255) / 256), dim3(256), 0, st, N, Nstride, NPs, obs_img, obs_pt,
+                     pt_free, Jc, Jp, scale_cam, scale_pt, Gi, h, Epose, pt_start, Cu, gu, radius, dmin, dmax, fail);
 }
 
 // Intrinsics entries, per linear solve: one lane per (free point p, free camera c seen by p):
@@ -1782,6 +1791,11 @@ void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radiu
 }
 
 // Camera columns: step = -y, delta = s * step, candidate parameters; one block.
+constexpr int kUpdImagesPerGroup = 42;  // 252 pose parameters: one trip of a 256-thread work-group
+int update_cameras_groups(int NI) { return std::max(1, (NI + kUpdImagesPerGroup - 1) / kUpdImagesPerGroup); }
+// Work-group b takes the images [42 b, 42 b + 42) - whole pose blocks, so that it can write their camera records too -
+// and group 0 the intrinsics blocks as well; every group leaves one (|delta|^2, model change, |x + delta|^2) triple.
+// (One work-group looping over all 6 NI + 9 NC parameters took 22 us at C3.)
 __global__ void __launch_bounds__(256) k_update_cameras(
     int NI, int NC, int cam_part, double radius, double dmin, double dmax, const double* __restrict__ y,
     const double* __restrict__ scale_cam, const double* __restrict__ img_rec, const double* __restrict__ cam_rec,
@@ -1789,9 +1803,9 @@ __global__ void __launch_bounds__(256) k_update_cameras(
     double* __restrict__ cand_intr, double* __restrict__ delta_cam, double* __restrict__ partial3,
     double* __restrict__ cand_camrec) {
   __shared__ double s_red[4];
-  const int ncam = 6 * NI + 9 * NC;
+  const int i0 = blockIdx.x * kUpdImagesPerGroup, i1 = min(i0 + kUpdImagesPerGroup, NI);
   double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
-  for (int t = threadIdx.x; t < ncam; t += 256) {
+  auto one = [&](int t) {
     const double s = scale_cam[t];
     double n2, g, x;
     if (t < 6 * NI) {
@@ -1812,15 +1826,18 @@ __global__ void __launch_bounds__(256) k_update_cameras(
     if (s != 0.0 && cam_part) a_x2 += xn * xn;
     delta_cam[t] = d;
     if (t < 6 * NI) cand_poses[t] = xn; else cand_intr[t - 6 * NI] = xn;
-  }
+  };
+  for (int t = 6 * i0 + threadIdx.x; t < 6 * i1; t += 256) one(t);
+  if (blockIdx.x == 0)
+    for (int t = 6 * NI + threadIdx.x; t < 6 * NI + 9 * NC; t += 256) one(t);
   const double s0 = block_sum_256(a_step, s_red);
   const double s1 = block_sum_256(a_model, s_red);
   const double s2 = block_sum_256(a_x2, s_red);
-  if (threadIdx.x == 0) { partial3[0] = s0; partial3[1] = s1; partial3[2] = s2; }
-  // the candidate's camera records (k_cam_prepare's work; one work-group: its own stores are visible after the barriers above)
+  if (threadIdx.x == 0) { partial3[3 * blockIdx.x] = s0; partial3[3 * blockIdx.x + 1] = s1; partial3[3 * blockIdx.x + 2] = s2; }
+  // the candidate's camera records of this group's images (k_cam_prepare's work; the stores above are the group's own)
   if (cand_camrec) {
     __syncthreads();
-    for (int i = threadIdx.x; i < NI; i += 256) {
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
       double rec[9];
       cam_prepare(cand_poses + 6 * i, rec);
 #pragma unroll
@@ -1833,8 +1850,8 @@ void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double
                            const double* img_rec, const double* cam_rec, const double* poses,
                            const double* intr, double* cand_poses, double* cand_intr,
                            double* delta_cam, double* partial3, double* cand_camrec) {
-  hipLaunchKernelGGL(k_update_cameras, dim3(1), dim3(256), 0, st, NI, NC, cam_part ? 1 : 0, radius, dmin, dmax, y,
-                     scale_cam, img_rec, cam_rec, poses, intr, cand_poses, cand_intr, delta_cam, partial3, cand_camrec);
+  hipLaunchKernelGGL(k_update_cameras, dim3(update_cameras_groups(NI)), dim3(256), 0, st, NI, NC, cam_part ? 1 : 0, radius, dmin,
+                     dmax, y, scale_cam, img_rec, cam_rec, poses, intr, cand_poses, cand_intr, delta_cam, partial3, cand_camrec);
 }
 
 // out[c] (op)= reduce over rows of partial[row*stride + c]; single block, fixed order.

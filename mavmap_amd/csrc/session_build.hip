@@ -320,6 +320,7 @@ void mavba_session::build(const mavba_problem* P) {
   d_R.alloc((size_t)2 * Nstride); d_Jp.alloc((size_t)6 * Nstride); d_Jc.alloc((size_t)12 * Nstride);
   d_Jk.alloc((size_t)2 * KMAX * Nstride);
   d_Cu.alloc((size_t)6 * NPs); d_gu.alloc((size_t)3 * NPs); d_Gi.alloc((size_t)6 * NPs); d_h.alloc((size_t)3 * NPs);
+  d_Gi.zero(st); d_h.zero(st);  // (written per linear solve for the points that have observations; the others stay 0)
   d_scale_cam.alloc((size_t)n_pad); d_scale_pt.alloc((size_t)3 * NPs);
   d_scale_cam.zero(st); d_scale_pt.zero(st);
   d_sweep_partial.alloc((size_t)jacobian_sweep_grid(std::max(N, 1)) + 8);
@@ -333,7 +334,7 @@ void mavba_session::build(const mavba_problem* P) {
   d_Epose.alloc((size_t)std::max(N, 1) * kPoseRec);
   d_y.alloc(n_pad); d_y.zero(st);  // the matrix-sized buffers follow the elimination order chosen in finish_structure
   d_delta_cam.alloc(n_pad); d_delta_pts.alloc(nP * 3);
-  d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + 2) * 3);
+  d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + update_cameras_groups(NI) + 2) * 3);
   d_scal.alloc(SC_COUNT); d_scal.zero(st);
   d_rnorm.alloc(std::max(N, 1)); d_perr.alloc(nP);
 

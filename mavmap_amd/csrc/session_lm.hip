@@ -81,13 +81,11 @@ void mavba_session::evaluate() {
 void mavba_session::assemble(double r) {
   const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
   HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, sizeof(double), st));
-  timed("point_factor", [&] {
-    launch_point_factor(st, NP, NPs, r, dmin, dmax, d_pt_free.p, d_Cu.p, d_gu.p, d_scale_pt.p, d_Gi.p, d_h.p,
-                        d_scal.p + SC_FAIL);
-  });
+  // (the points' 3x3 factors are computed inside the entries kernel: one launch; points without observations are not free)
   timed("entries_pose", [&] {
-    launch_entries_pose(st, N, Nstride, NPs, d_obs_img.p, d_obs_pt.p, d_pt_free.p, d_Jc.p, d_Jp.p, d_scale_cam.p,
-                        d_scale_pt.p, d_Gi.p, d_h.p, d_Epose.p);
+    launch_factor_entries_pose(st, N, Nstride, NPs, d_obs_img.p, d_obs_pt.p, d_pt_free.p, d_Jc.p, d_Jp.p, d_scale_cam.p,
+                               d_scale_pt.p, d_Gi.p, d_h.p, d_Epose.p, d_pt_start.p, d_Cu.p, d_gu.p, r, dmin, dmax,
+                               d_scal.p + SC_FAIL);
   });
   timed("entries_intr", [&] {
     launch_entries_intr(st, Q, NI, NPs, d_q_pt.p, d_q_cam.p, d_Wk.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p,
@@ -157,7 +155,7 @@ void mavba_session::linear_step(double r, double* h) {
 void mavba_session::candidate(double r, double* h) {
   const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
   // cameras first: the point back-substitution reads their step (delta_cam)
-  const int rows = backsub_points_grid(NP);
+  const int rows = backsub_points_grid(NP), ugroups = update_cameras_groups(NI);
   timed("update_cameras", [&] {
     launch_update_cameras(st, NI, NC, rank == 0, r, dmin, dmax, d_y.p, d_scale_cam.p, d_img_rec, d_cam_rec,
                           d_poses.p, d_intr.p, d_cposes.p, d_cintr.p, d_delta_cam.p, d_step_partial.p + 3 * (size_t)rows,
@@ -186,9 +184,9 @@ void mavba_session::candidate(double r, double* h) {
   timed("reduce", [&] {
     const int nsweep = N > 0 ? jacobian_sweep_grid(N) : 0;
     ReduceTasks T;
-    T.t[0] = ReduceTask{d_step_partial.p, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_STEP_NORM2};
-    T.t[1] = ReduceTask{d_step_partial.p + 1, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_MODEL_CHANGE};
-    T.t[2] = ReduceTask{d_step_partial.p + 2, rows + 1, 3, 0, nullptr, 0, d_scal.p + SC_CAND_XNORM2};
+    T.t[0] = ReduceTask{d_step_partial.p, rows + ugroups, 3, 0, nullptr, 0, d_scal.p + SC_STEP_NORM2};
+    T.t[1] = ReduceTask{d_step_partial.p + 1, rows + ugroups, 3, 0, nullptr, 0, d_scal.p + SC_MODEL_CHANGE};
+    T.t[2] = ReduceTask{d_step_partial.p + 2, rows + ugroups, 3, 0, nullptr, 0, d_scal.p + SC_CAND_XNORM2};
     T.t[3] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_NEW_COST};
     launch_reduce_tasks(st, T, 4);
   });
