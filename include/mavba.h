@@ -248,6 +248,10 @@ int mavba_scene_set_camera(mavba_scene* s, int64_t camera_id, int32_t model, con
 int mavba_scene_set_image(mavba_scene* s, int64_t image_id, int64_t camera_id, const double* rvec, const double* tvec);
 /* add_point2D: appended to the image's list (the image_to_points2D order is the residual order inside an image) */
 int mavba_scene_add_point2d(mavba_scene* s, int64_t image_id, int64_t point2D_id, const double* xy);
+/* the same for `count` points of one image in one call (mirroring an existing FeatureManager, or add_image with its
+ * features): ids and pixels as arrays, `point3D_ids` (may be NULL) the links, < 0 = none */
+int mavba_scene_add_points2d(mavba_scene* s, int64_t image_id, int64_t count, const int64_t* point2D_ids, const double* xy,
+                             const int64_t* point3D_ids);
 /* add_point3D + set_point3D */
 int mavba_scene_set_point3d(mavba_scene* s, int64_t point3D_id, const double* xyz);
 /* point2D_to_point3D[point2D_id] = point3D_id (add_correspondence, merges); point3D_id < 0 removes the entry */

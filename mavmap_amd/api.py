@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian",
     "mavba_session_kernel_stats", "mavba_session_get_info", "mavba_dense_spd_solve",
     "mavba_scene_create", "mavba_scene_destroy", "mavba_scene_set_camera", "mavba_scene_set_image", "mavba_scene_add_point2d",
-    "mavba_scene_set_point3d", "mavba_scene_link", "mavba_scene_delete_point3d", "mavba_scene_get_image", "mavba_scene_get_point3d",
+    "mavba_scene_add_points2d", "mavba_scene_set_point3d", "mavba_scene_link", "mavba_scene_delete_point3d", "mavba_scene_get_image", "mavba_scene_get_point3d",
     "mavba_scene_get_camera", "mavba_scene_flatten", "mavba_scene_bundle_adjust",
     "mavba_rccl_unique_id", "mavba_session_set_rccl", "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
 ]
@@ -93,6 +93,7 @@ def load():
     L.mavba_scene_set_camera.argtypes = [sp, i64, C.c_int32, dp]
     L.mavba_scene_set_image.argtypes = [sp, i64, i64, dp, dp]
     L.mavba_scene_add_point2d.argtypes = [sp, i64, i64, dp]
+    L.mavba_scene_add_points2d.argtypes = [sp, i64, i64, i64p, dp, i64p]
     L.mavba_scene_set_point3d.argtypes = [sp, i64, dp]
     L.mavba_scene_link.argtypes = [sp, i64, i64]
     L.mavba_scene_delete_point3d.argtypes = [sp, i64]
@@ -307,6 +308,15 @@ class Scene:
 
     def add_point2D(self, image_id, point2D_id, xy):
         _check(load().mavba_scene_add_point2d(self._h, int(image_id), int(point2D_id), _d(A.as_f64(xy))))
+
+    def add_points2D(self, image_id, point2D_ids, xy, point3D_ids=None):
+        """Many 2-D points of one image in one call (`point3D_ids`: their links, < 0 = none)."""
+        ids = np.ascontiguousarray(point2D_ids, dtype=np.int64)
+        uv = A.as_f64(xy, (-1, 2))
+        assert len(uv) == len(ids)
+        l3 = None if point3D_ids is None else np.ascontiguousarray(point3D_ids, dtype=np.int64)
+        _check(load().mavba_scene_add_points2d(self._h, int(image_id), len(ids), A.ptr(ids, C.c_int64), _d(uv),
+                                               None if l3 is None else A.ptr(l3, C.c_int64)))
 
     def set_point3D(self, point3D_id, xyz):
         _check(load().mavba_scene_set_point3d(self._h, int(point3D_id), _d(A.as_f64(xyz))))

@@ -270,6 +270,35 @@ int mavba_scene_add_point2d(mavba_scene* s, int64_t image_id, int64_t point2D_id
   return MAVBA_OK;
   SCENE_CATCH
 }
+int mavba_scene_add_points2d(mavba_scene* s, int64_t image_id, int64_t count, const int64_t* point2D_ids, const double* xy,
+                             const int64_t* point3D_ids) {
+  SCENE_TRY
+  if (!s || count < 0 || (count > 0 && (!point2D_ids || !xy))) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
+  check_id(image_id);
+  if ((size_t)image_id >= s->images.size() || !s->images[(size_t)image_id].set) throw Failure(MAVBA_ERR_BAD_INDEX, "unknown image id");
+  long long top = -1;
+  for (int64_t i = 0; i < count; ++i) { check_id(point2D_ids[i]); top = std::max<long long>(top, point2D_ids[i]); }
+  if (top >= 0) { mavba_scene::grow(s->xy, top, 2); mavba_scene::grow(s->link, top); mavba_scene::grow(s->p2d_set, top); }
+  // (nothing is changed before the whole call is known to be valid)
+  for (int64_t i = 0; i < count; ++i)
+    if (s->p2d_set[(size_t)point2D_ids[i]]) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "2-D point id added twice");
+  {
+    std::vector<int64_t> sorted(point2D_ids, point2D_ids + count);
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "2-D point id twice in one call");
+  }
+  std::vector<long long>& list = s->images[(size_t)image_id].p2d;
+  list.reserve(list.size() + (size_t)count);
+  for (int64_t i = 0; i < count; ++i) {
+    const size_t id = (size_t)point2D_ids[i];
+    s->p2d_set[id] = 1;
+    s->xy[2 * id] = xy[2 * i]; s->xy[2 * id + 1] = xy[2 * i + 1];
+    s->link[id] = point3D_ids && point3D_ids[i] >= 0 ? (long long)point3D_ids[i] : -1;
+    list.push_back((long long)id);
+  }
+  return MAVBA_OK;
+  SCENE_CATCH
+}
 int mavba_scene_set_point3d(mavba_scene* s, int64_t point3D_id, const double* xyz) {
   SCENE_TRY
   if (!s || !xyz) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");

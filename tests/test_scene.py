@@ -29,9 +29,13 @@ def mirror(fm, images=None):
     return sc
 
 
-def add_images(sc, fm, images):
+def add_images(sc, fm, images, bulk=False):
     for i in images:
         sc.set_image(i + 1, int(fm.img_cam[i]) + 1, fm.poses[i, :3], fm.poses[i, 3:])
+        if bulk:  # one call per image (mavba_scene_add_points2d)
+            oo = np.nonzero(fm.obs_img == i)[0]
+            sc.add_points2D(i + 1, oo + 1, fm.obs_uv[oo], np.where(fm.obs_pt[oo] >= 0, fm.obs_pt[oo] + 1, -1))
+            continue
         for o in np.nonzero(fm.obs_img == i)[0]:
             sc.add_point2D(i + 1, int(o) + 1, fm.obs_uv[o])
             if fm.obs_pt[o] >= 0:
@@ -139,6 +143,19 @@ def test_scene_rotation_constraints_prerotate_the_scene_like_the_shim(mock):  # 
         assert np.abs(sc.get_point3D(8) - points[7]).max() < 1e-12
         with pytest.raises(api.MavbaError, match="no rotation constraint"):
             sc.flatten(ids(free), ids(fixed), ids(fixed_x), rot={k: v for k, v in rotmap.items() if k != 4}, constrain_rotation=1)
+
+
+def test_scene_bulk_loading_equals_point_by_point(mock):  # noqa: F811
+    fm = FmScene(small_scene(seed=7), extra_unmatched=8)
+    rc, *_ = run(mock, fm, [2, 3, 4, 5], [0], [1])
+    assert rc == 0
+    with mirror(fm, images=[]) as sc:
+        add_images(sc, fm, range(len(fm.poses)), bulk=True)
+        same_as_shim(mock, sc.flatten(ids([2, 3, 4, 5]), ids([0]), ids([1])))
+        with pytest.raises(api.MavbaError, match="added twice"):
+            sc.add_points2D(1, [3], [[0.0, 0.0]])
+        with pytest.raises(api.MavbaError, match="twice in one call"):
+            sc.add_points2D(1, [9001, 9001], [[0.0, 0.0], [1.0, 1.0]])
 
 
 def test_scene_grown_step_by_step_and_pruned_equals_a_fresh_mirror(mock):  # noqa: F811
