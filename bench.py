@@ -203,10 +203,24 @@ def main():
     if world > 1:
         # the reduced camera system is summed over ranks once per linear solve: natively (ncclAllReduce enqueued on the
         # session's stream by the library itself) unless MAVBA_DIST=torch asks for the torch.distributed hook
-        if os.environ.get("MAVBA_DIST", "rccl") == "rccl" and os.environ.get("MAVBA_DIST_BACKEND", "nccl") == "nccl":
-            uid = [mavmap_amd.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            sess.set_rccl(uid[0], rank, world)
+        native = os.environ.get("MAVBA_DIST", "rccl") == "rccl" and os.environ.get("MAVBA_DIST_BACKEND", "nccl") == "nccl"
+        if native:
+            ok = 1
+            try:
+                uid = [mavmap_amd.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                sess.set_rccl(uid[0], rank, world)
+            except Exception as e:  # librccl not loadable, communicator set-up failed, ...
+                log(f"[rank {rank}] native RCCL exchange unavailable ({e}); falling back to the torch.distributed hook")
+                ok = 0
+            # every rank must take the same path
+            flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native = bool(flag.item())
+            if not native:
+                sess.close()
+                sess = mavmap_amd.Session(prob, opts)
+        if native:
             exchange = "RCCL all-reduce inside the library (stream-ordered)"
         else:
             from mavmap_amd.dist import make_allreduce
@@ -250,8 +264,10 @@ def main():
     # page-locked blocks and host scratch come from the process-wide pools; the first session's set-up, which fills them,
     # is reported beside it).
     first_setup = None
+    info = sess.info()
     if world == 1:
-        first_setup = float(sess.result()["setup_seconds"]) if hasattr(sess, "result") else None
+        first_setup = float(sess.result()["setup_seconds"])
+        sess.close()  # (its buffers go back to the pools: the next session is what a second call of a mapper run sees)
         with mavmap_amd.Session(prob, dict(opts, profile_kernels=0)) as s2:
             final = s2.solve()
     else:
@@ -266,7 +282,6 @@ def main():
             n, ms = s1["launches"] - s0["launches"], s1["total_ms"] - s0["total_ms"]
             if n > 0:
                 per[name] = dict(launches=n, total_ms=ms, avg_ms=ms / n)
-        info = sess.info()
         tot_ms = sum(v["total_ms"] for v in per.values()) or 1.0
         table = []
         for name, v in sorted(per.items(), key=lambda kv: -kv[1]["total_ms"]):
