@@ -125,6 +125,35 @@ def test_local_ba_windows_c1(mavba, oracle):
         assert np.array_equal(pg.poses[out], p.poses[out])
 
 
+@pytest.mark.parametrize("n_images,free", [(30, range(17, 27)), (30, range(2, 22)), (24, [0, 5, 23]), (40, range(0, 40))])
+def test_small_system_paths_match_oracle(mavba, oracle, n_images, free):
+    """The one-work-group solve of small systems (k_chol_small): the blocks with a free parameter are ordered first and
+    only their one or two tile columns are factorised, whatever the matrix size - here 3 to 4 tile columns in all with 10
+    (one active tile), 20 (two), 3 scattered free images, and all 40 images free (four active tiles: the regular path)."""
+    p = synth.make_scene(num_images=n_images, num_points=900, track_len=4, models=[A.MODEL_OPENCV], seed=21 + n_images)
+    p.pose_const[:] = A.CONST_POSE
+    p.pose_const[list(free)] = 0
+    if len(list(free)) == n_images:
+        p.pose_const[0] = A.CONST_POSE
+        p.pose_const[1] = A.CONST_TX
+    p.intr_const[:] = 1
+    with mavba.Session(p) as s:
+        info = s.info()
+        assert info["matrix_dim"] == 64 * ((6 * n_images + 9 + 63) // 64)
+        for radius in (1e4, 10.0):
+            ref = oracle.linear_step(p, radius)
+            st = s.linear_step(radius)
+            assert rel_err(st["d_poses"], ref["d_poses"]) < 1e-8 and rel_err(st["d_points"], ref["d_points"]) < 1e-8
+            assert abs(st["model_cost_change"] - ref["model_cost_change"]) < 1e-9 * abs(ref["model_cost_change"])
+            fixed = np.setdiff1d(np.arange(n_images), list(free))
+            if len(fixed):
+                assert np.all(st["d_poses"][fixed[fixed > 1]] == 0.0)
+    po, ro, _, pg, rg, _ = _solve_both(mavba, oracle, p)
+    assert rg["termination"] == ro["termination"] and rg["num_successful_steps"] == ro["num_successful_steps"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+    assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+
+
 def test_pose_refinement_matches_oracle(mavba, oracle):
     g = synth.make_scene(num_images=4, num_points=300, track_len=3, models=[A.MODEL_OPENCV], seed=21)
     sel = g.obs_image == 2
