@@ -83,7 +83,7 @@ PMC_KERNEL = {  # bench timer name -> rocprofv3 kernel-name prefix in profiles/*
     "jacobian_sweep": "k_jacobian_sweep", "cost_only": "k_cost_only", "point_reduce": "k_point_reduce",
     "camera_sweep": "k_camera_sweep", "entries_pose": "k_entries_pose", "entries_intr": "k_entries_intr",
     "backsub_points": "k_backsub_points", "schur_chunks_pp": "k_schur_chunks<6, 6", "schur_chunks_ip": "k_schur_chunks<9, 6",
-    "schur_chunks_ii": "k_schur_chunks<9, 9", "schur_clusters": "k_schur_clusters", "schur_finalize": "k_schur_finalize", "point_factor": "k_point_factor",
+    "schur_chunks_ii": "k_schur_chunks<9, 9", "schur_clusters": "k_schur_clusters", "schur_finalize": "k_schur_finalize",
 }
 
 

@@ -127,14 +127,20 @@ template <typename T>
 struct PinnedBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool pinned = true;  // false: page-locking failed (locked-memory limit of the process) - an ordinary scratch block, the copy is then staged by the runtime
   explicit PinnedBuf(size_t count) : n(count) {
     void* q = nullptr;
-    HIP_OK(pinned_alloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (pinned_alloc(&q, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      pinned = false;
+      q = host_scratch_alloc(bytes);
+    }
     p = static_cast<T*>(q);
   }
   PinnedBuf(const PinnedBuf&) = delete;
   PinnedBuf& operator=(const PinnedBuf&) = delete;
-  ~PinnedBuf() { pinned_free(p); }
+  ~PinnedBuf() { if (pinned) pinned_free(p); else host_scratch_free(p, std::max<size_t>(n, 1) * sizeof(T)); }
   T& operator[](size_t i) { return p[i]; }
   const T& operator[](size_t i) const { return p[i]; }
   T* data() { return p; }
