@@ -61,6 +61,9 @@ extern "C" {
 #define MAVBA_ERR_OUT_OF_MEMORY (-4)
 #define MAVBA_ERR_BAD_INDEX (-5)   /* obs/image/camera index out of range */
 #define MAVBA_ERR_BAD_MODEL (-6)   /* camera model code not in {1,2,3}     */
+#define MAVBA_ERR_NEEDS_REBUILD (-7) /* mavba_session_filter_points: the filtered problem has a different block structure
+                                        (an image with constant blocks is left with one residual block and becomes free,
+                                        bundle_adjustment.cc:361): the session is unchanged, build the problem afresh */
 
 /* Termination types, mirroring the subset of ceres::SolverTerminationType the
  * trust-region minimizer can produce (Ceres 1.8 semantics). */

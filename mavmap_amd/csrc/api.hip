@@ -10,6 +10,24 @@ using namespace mavba;
 // C ABI
 // ===========================================================================
 #define MAVBA_TRY try {
+// Entry points that work on a session run on the SESSION's device whatever the calling thread's current device is
+// (two sessions on two GPUs driven from one process, or from different threads), and leave the caller's device as it was.
+namespace {
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    if (prev != dev) HIP_OK(hipSetDevice(dev)); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+}  // namespace
+#define MAVBA_SESSION_TRY(s)                                                    \
+  try {                                                                         \
+    if (!(s)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");        \
+    DeviceGuard device_guard_((s)->device);
 #define MAVBA_CATCH                                                              \
   }                                                                              \
   catch (const Failure& f) { g_last_error = f.what(); return f.code; }           \
@@ -58,8 +76,10 @@ int mavba_session_create(const mavba_problem* problem, const mavba_options* opti
   MAVBA_TRY
   s = new mavba_session();
   s->opt = *options;
-  if (options->device >= 0) HIP_OK(hipSetDevice(options->device));
-  HIP_OK(hipGetDevice(&s->device));
+  int dev = options->device;
+  if (dev < 0) HIP_OK(hipGetDevice(&dev));  // the calling thread's current device
+  DeviceGuard device_guard_(dev);            // (the caller's current device is restored on return)
+  s->device = dev;
   HIP_OK(stream_acquire(&s->st));
   s->build(problem);
   *out = s;
@@ -72,6 +92,9 @@ int mavba_session_create(const mavba_problem* problem, const mavba_options* opti
 
 void mavba_session_destroy(mavba_session* s) {
   if (!s) return;
+  int prev = -1;
+  if (hipGetDevice(&prev) == hipSuccess && prev != s->device) (void)hipSetDevice(s->device); else prev = -1;
+  struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
   if (!std::getenv("MAVBA_SETUP_TIMING")) { delete s; return; }
   // phase timing of the tear-down (profiling aid)
   double t0 = now_s();
@@ -85,8 +108,7 @@ void mavba_session_destroy(mavba_session* s) {
 }
 
 int mavba_session_reset(mavba_session* s) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   s->reset_state();
   s->sync();
   return MAVBA_OK;
@@ -94,8 +116,7 @@ int mavba_session_reset(mavba_session* s) {
 }
 
 int mavba_session_iterate(mavba_session* s, int32_t max_iters, int32_t* iters_done, int32_t* termination) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   int done = 0;
   s->iterate(max_iters, &done);
   if (iters_done) *iters_done = done;
@@ -105,16 +126,14 @@ int mavba_session_iterate(mavba_session* s, int32_t max_iters, int32_t* iters_do
 }
 
 int mavba_session_result(mavba_session* s, mavba_result* result) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   s->fill_result(result);
   return MAVBA_OK;
   MAVBA_CATCH
 }
 
 int mavba_session_get_params(mavba_session* s, double* poses, double* intrinsics, double* points) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   // one pinned staging block: poses | intrinsics | points (already in the caller's order, permuted on the device)
   const size_t nI = (size_t)s->NI * 6, nC = (size_t)s->NC * 9, nP = (size_t)s->NP * 3;
   double* stage = nullptr;
@@ -135,8 +154,7 @@ int mavba_session_get_params(mavba_session* s, double* poses, double* intrinsics
 }
 
 int mavba_session_point_errors(mavba_session* s, double* point_error) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   if (!point_error) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null point_error");
   s->point_errors(point_error);
   return MAVBA_OK;
@@ -144,8 +162,7 @@ int mavba_session_point_errors(mavba_session* s, double* point_error) {
 }
 
 int mavba_session_set_params(mavba_session* s, const double* poses, const double* intrinsics, const double* points) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   if (poses && s->NI) HIP_OK(hipMemcpyAsync(s->d_poses.p, poses, (size_t)s->NI * 48, hipMemcpyHostToDevice, s->st));
   if (intrinsics && s->NC) HIP_OK(hipMemcpyAsync(s->d_intr.p, intrinsics, (size_t)s->NC * 72, hipMemcpyHostToDevice, s->st));
   std::vector<double> hp;
@@ -162,8 +179,7 @@ int mavba_session_set_params(mavba_session* s, const double* poses, const double
 }
 
 int mavba_session_restart(mavba_session* s) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   s->restart();
   return MAVBA_OK;
   MAVBA_CATCH
@@ -171,8 +187,7 @@ int mavba_session_restart(mavba_session* s) {
 
 int mavba_session_filter_points(mavba_session* s, double max_error, const uint8_t* keep, uint8_t* removed, double* errors,
                                 int64_t* num_removed) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   const long long n = s->filter_points(max_error, keep, removed, errors);
   if (num_removed) *num_removed = n;
   return MAVBA_OK;
@@ -213,8 +228,7 @@ static void join_ranks(mavba_session* s) {
 }
 
 int mavba_session_set_allreduce(mavba_session* s, mavba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world_size) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_allreduce must precede the first iteration");
   s->ar_fn = fn; s->ar_ctx = ctx; s->rank = rank; s->world = world_size;
   s->force_exchange = world_size == 1 && std::getenv("MAVBA_FORCE_EXCHANGE") != nullptr;
@@ -232,11 +246,10 @@ int mavba_rccl_unique_id(void* out128) {
 }
 
 int mavba_session_set_rccl(mavba_session* s, const void* unique_id128, int32_t rank, int32_t world_size) {
-  MAVBA_TRY
-  if (!s || !unique_id128) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
+  MAVBA_SESSION_TRY(s)
+  if (!unique_id128) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
   if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_rccl must precede the first iteration");
   if (rank < 0 || rank >= world_size) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "rank out of range");
-  HIP_OK(hipSetDevice(s->device));
   s->rccl_comm = rccl_comm_create(unique_id128, rank, world_size);
   s->ar_fn = nullptr; s->rank = rank; s->world = world_size;
   s->force_exchange = world_size == 1 && std::getenv("MAVBA_FORCE_EXCHANGE") != nullptr;
@@ -246,8 +259,7 @@ int mavba_session_set_rccl(mavba_session* s, const void* unique_id128, int32_t r
 }
 
 int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, double* Jc, double* Jp, double* Jk) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   s->evaluate();
   if (cost) *cost = s->cost + s->fixed_cost;
   const size_t S = s->Nstride, N = s->N;
@@ -279,8 +291,7 @@ int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, doubl
 int mavba_session_reduced_dim(mavba_session* s) { return s ? s->n_full : 0; }
 
 int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, double* vout) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   if (!s->evaluated) s->evaluate();
   s->assemble(radius);
   // the device matrix is in elimination order; hand it out in the variables' order
@@ -304,8 +315,7 @@ int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, 
 
 int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, double* d_intr, double* d_points,
                               double* model_cost_change) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   if (!s->evaluated) s->evaluate();
   double h[SC_COUNT];
   s->linear_step(radius, h);
@@ -322,8 +332,7 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, 
 }
 
 int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
-  MAVBA_TRY
-  if (!s) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null session");
+  MAVBA_SESSION_TRY(s)
   if (reps < 1) reps = 1;
   launch_cam_prepare(s->st, s->NI, s->d_poses.p, s->d_camrec.p);
   SweepArgs a = s->sweep_args(s->d_camrec.p, s->d_intr.p, s->d_points.p);
@@ -344,8 +353,8 @@ int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
 }
 
 int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
-  MAVBA_TRY
-  if (!s || !out) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
+  MAVBA_SESSION_TRY(s)
+  if (!out) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");
   std::memset(out, 0, sizeof(*out));
   out->num_obs_kept = s->N;
   out->reduced_dim = s->n_full; out->padded_dim = s->n_pad;
@@ -397,11 +406,47 @@ int mavba_solve(const mavba_problem* problem, const mavba_options* options, mavb
   if (rc == MAVBA_OK && term != MAVBA_TERM_NUMERICAL_FAILURE)
     rc = mavba_session_get_params(s, problem->poses, problem->intrinsics, problem->points);
   lap("write-back");
-  if (rc == MAVBA_OK && point_error && options->update_point_errors) rc = mavba_session_point_errors(s, point_error);
+  if (rc == MAVBA_OK && point_error && options->update_point_errors) {
+    // problem.Evaluate runs on the user's blocks (bundle_adjustment.cc:583-588): after NUMERICAL_FAILURE those still hold
+    // the parameters the call started from
+    if (term == MAVBA_TERM_NUMERICAL_FAILURE) {
+      try { DeviceGuard g(s->device); s->restore_initial_params(); } catch (const std::exception& e) { g_last_error = e.what(); rc = MAVBA_ERR_HIP; }
+    }
+    if (rc == MAVBA_OK) rc = mavba_session_point_errors(s, point_error);
+  }
   lap("point errors");
   mavba_session_destroy(s);
   lap("session destroy");
   return rc;
+}
+
+// The second problem of mavba_solve_filter_solve built afresh on the host: the filtered points' observations leave, and
+// the constancy flags follow the reference's "> 1 residual block" rule (bundle_adjustment.cc:361-385) - an image left
+// with one observation is free, a camera is constant only if an image with more than one observation holds it so.
+static int solve_filtered_afresh(const mavba_problem* problem, const mavba_options* options, const uint8_t* removed,
+                                 mavba_result* second, double* point_error) {
+  const int NI = problem->num_images, NC = problem->num_cameras;
+  const long long NO = problem->num_obs;
+  std::vector<double> uv;
+  std::vector<int32_t> oi, op;
+  std::vector<int> per_img((size_t)std::max(NI, 1), 0);
+  for (long long o = 0; o < NO; ++o) {
+    if (removed[problem->obs_point[o]]) continue;
+    uv.push_back(problem->obs_uv[2 * o]); uv.push_back(problem->obs_uv[2 * o + 1]);
+    oi.push_back(problem->obs_image[o]); op.push_back(problem->obs_point[o]);
+    per_img[problem->obs_image[o]]++;
+  }
+  std::vector<uint8_t> pose_const((size_t)std::max(NI, 1), 0), intr_const((size_t)std::max(NC, 1), 0);
+  for (int i = 0; i < NI; ++i) {
+    if (per_img[i] <= 1) continue;
+    if (problem->pose_const) pose_const[i] = problem->pose_const[i];
+    if (problem->intr_const && problem->intr_const[problem->image_camera[i]]) intr_const[problem->image_camera[i]] = 1;
+  }
+  mavba_problem P = *problem;
+  P.num_obs = (int64_t)oi.size();
+  P.obs_uv = uv.data(); P.obs_image = oi.data(); P.obs_point = op.data();
+  P.pose_const = pose_const.data(); P.intr_const = intr_const.data();
+  return mavba_solve(&P, options, second, point_error);
 }
 
 int mavba_solve_filter_solve(const mavba_problem* problem, const mavba_options* options, double filter_max_error,
@@ -413,12 +458,39 @@ int mavba_solve_filter_solve(const mavba_problem* problem, const mavba_options* 
   int done = 0, term = 0;
   rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &term);
   if (rc == MAVBA_OK && first) rc = mavba_session_result(s, first);
-  if (rc == MAVBA_OK) rc = mavba_session_filter_points(s, filter_max_error, keep, removed, nullptr, num_removed);
+  // (after NUMERICAL_FAILURE the filter and the second solve start from the parameters the call came with, as the
+  // reference's second bundle_adjustment() call would: mavba_session::filter_points restores them)
+  std::vector<double> errors((size_t)std::max(problem->num_points, 1), 0.0);
+  if (rc == MAVBA_OK) rc = mavba_session_filter_points(s, filter_max_error, keep, removed, errors.data(), num_removed);
+  if (rc == MAVBA_ERR_NEEDS_REBUILD) {
+    // the filtered problem has another block structure: write the first solve back, then solve the second problem
+    // the way a second mavba_solve call would
+    std::vector<uint8_t> rem((size_t)std::max(problem->num_points, 1), 0);
+    long long n = 0;
+    for (int p = 0; p < problem->num_points; ++p) {
+      rem[p] = !(keep && keep[p]) && errors[p] > filter_max_error;  // (NaN: no observations, never filtered)
+      n += rem[p];
+    }
+    if (removed) std::memcpy(removed, rem.data(), (size_t)problem->num_points);
+    if (num_removed) *num_removed = n;
+    rc = MAVBA_OK;
+    if (term != MAVBA_TERM_NUMERICAL_FAILURE) rc = mavba_session_get_params(s, problem->poses, problem->intrinsics, problem->points);
+    mavba_session_destroy(s);
+    if (rc != MAVBA_OK) return rc;
+    mavba_options o2 = *options;
+    o2.update_point_errors = point_error ? 1 : 0;
+    return solve_filtered_afresh(problem, &o2, rem.data(), second, point_error);
+  }
   if (rc == MAVBA_OK) rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &term);
   if (rc == MAVBA_OK && second) rc = mavba_session_result(s, second);
   if (rc == MAVBA_OK && term != MAVBA_TERM_NUMERICAL_FAILURE)
     rc = mavba_session_get_params(s, problem->poses, problem->intrinsics, problem->points);
-  if (rc == MAVBA_OK && point_error) rc = mavba_session_point_errors(s, point_error);
+  if (rc == MAVBA_OK && point_error) {
+    if (term == MAVBA_TERM_NUMERICAL_FAILURE) {
+      try { DeviceGuard g(s->device); s->restore_initial_params(); } catch (const std::exception& e) { g_last_error = e.what(); rc = MAVBA_ERR_HIP; }
+    }
+    if (rc == MAVBA_OK) rc = mavba_session_point_errors(s, point_error);
+  }
   mavba_session_destroy(s);
   return rc;
 }

@@ -148,10 +148,15 @@ void device_free(void* p) {
 }
 
 // Pinned host staging for the read-backs (a pageable 4.8 MB device->host copy costs ~3 ms through the runtime's own
-// staging; pinned it is ~0.2 ms + a memcpy): blocks are cached like the device blocks and never returned.
+// staging; pinned it is ~0.2 ms + a memcpy): blocks are cached like the device blocks; at most kPinnedParkedBytes of
+// page-locked memory stay parked (MAVBA_PINNED_POOL_MB, default 1024), what comes back beyond that is unlocked and freed.
 namespace {
-struct PinnedPool { std::mutex m; std::multimap<size_t, void*> free_blocks; std::unordered_map<void*, size_t> live; };
+struct PinnedPool { std::mutex m; std::multimap<size_t, void*> free_blocks; std::unordered_map<void*, size_t> live; size_t parked = 0; };
 PinnedPool& pinned_pool() { static PinnedPool* p = new PinnedPool; return *p; }
+size_t pinned_cap() {
+  static const size_t v = [] { const char* e = std::getenv("MAVBA_PINNED_POOL_MB"); return (size_t)(e ? std::atoll(e) : 1024) << 20; }();
+  return v;
+}
 }  // namespace
 hipError_t pinned_alloc(void** out, size_t bytes) {
   PinnedPool& P = pinned_pool();
@@ -159,7 +164,7 @@ hipError_t pinned_alloc(void** out, size_t bytes) {
   {
     std::lock_guard<std::mutex> g(P.m);
     auto it = P.free_blocks.find(cls);
-    if (it != P.free_blocks.end()) { *out = it->second; P.free_blocks.erase(it); P.live[*out] = cls; return hipSuccess; }
+    if (it != P.free_blocks.end()) { *out = it->second; P.free_blocks.erase(it); P.parked -= cls; P.live[*out] = cls; return hipSuccess; }
   }
   const hipError_t e = hipHostMalloc(out, cls, hipHostMallocDefault);
   if (e != hipSuccess) return e;
@@ -170,11 +175,15 @@ hipError_t pinned_alloc(void** out, size_t bytes) {
 void pinned_free(void* p) {
   if (!p) return;
   PinnedPool& P = pinned_pool();
-  std::lock_guard<std::mutex> g(P.m);
-  auto it = P.live.find(p);
-  if (it == P.live.end()) return;
-  P.free_blocks.insert({it->second, p});
-  P.live.erase(it);
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) return;
+    const size_t cls = it->second;
+    P.live.erase(it);
+    if (P.parked + cls <= pinned_cap()) { P.free_blocks.insert({cls, p}); P.parked += cls; return; }
+  }
+  (void)hipHostFree(p);
 }
 
 // Big host scratch blocks (the set-up's per-observation temporaries) are cached as well: at most kScratchCacheBytes

@@ -71,17 +71,23 @@ constexpr int kClMaxBatches = 64;                // a cluster spans at most kClM
 struct SchurCluster { int p0, p1; };
 
 // Scalars exchanged with the host every LM iteration (device array of doubles).
-// [0, SC_NUM_SUMS) are summed over ranks, SC_GRAD_MAX is max-reduced.
+// Two groups, reduced over ranks SEPARATELY (an evaluation enqueued behind an accepted step and the next candidate
+// are read back together: a collective over one group must never touch - and re-sum - the other group's slots):
+//   evaluation [SC_COST, SC_GRAD_MAX]: two sums, then the max (all-reduce op 2 over SC_EVAL_COUNT doubles)
+//   candidate  [SC_NEW_COST, SC_CAND_END): sums
 enum {
   SC_COST = 0,        // 1/2 sum rho at the evaluation point (no fixed cost)
   SC_XNORM2,          // |x|^2 over free parameters
+  SC_GRAD_MAX,        // max |g_j| over free parameters (unscaled gradient); directly after the evaluation's sums
   SC_NEW_COST,        // candidate cost
   SC_STEP_NORM2,      // |delta|^2
   SC_MODEL_CHANGE,    // model cost change
   SC_CAND_XNORM2,     // |x + delta|^2
   SC_FAIL,            // > 0: linear solve failed (non-SPD point block or pivot)
-  SC_NUM_SUMS,
-  SC_GRAD_MAX = SC_NUM_SUMS,  // max |g_j| over free parameters (unscaled gradient); directly after the sums
+  SC_CAND_END,
+  SC_EVAL_COUNT = SC_GRAD_MAX + 1,
+  SC_CAND_BEGIN = SC_NEW_COST,
+  SC_CAND_COUNT = SC_CAND_END - SC_CAND_BEGIN,
   SC_COUNT = 16
 };
 

@@ -399,6 +399,13 @@ struct mavba_session {
   void point_errors(double* out);
   void restart();  // a new solve from the current parameters (LM state, Jacobi scales; the structure stays)
   long long filter_points(double max_error, const unsigned char* keep, unsigned char* removed_out, double* errors_out);
+  void restore_initial_params() {  // x <- the parameters the session was built with (what ceres leaves the user with after NUMERICAL_FAILURE)
+    HIP_OK(hipMemcpyAsync(d_poses.p, d_poses0.p, (size_t)NI * 6 * 8, hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_intr.p, d_intr0.p, (size_t)NC * 9 * 8, hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_points.p, d_points0.p, (size_t)NP * 3 * 8, hipMemcpyDeviceToDevice, st));
+    camrec_current = false; evaluated = false;
+  }
+  void apply_filter_state();  // counts, used / free flags, fixed cost from h_pt_removed (empty = the problem as built)
   void to_caller_points(const double* internal, double* out, int width) const {
     for (int q = 0; q < NP; ++q)
       for (int e = 0; e < width; ++e) out[(size_t)h_pt_orig[q] * width + e] = internal[(size_t)q * width + e];

@@ -1007,6 +1007,12 @@ void mavba_session::finish_structure() {
 }
 
 void mavba_session::reset_state() {
+  // back to the problem as built: points filtered out of the resident problem return with their initial coordinates
+  if (!h_pt_removed.empty()) {
+    h_pt_removed.clear();
+    apply_filter_state();
+    M_is_clean = false;
+  }
   HIP_OK(hipMemcpyAsync(d_poses.p, d_poses0.p, (size_t)NI * 6 * 8, hipMemcpyDeviceToDevice, st));
   HIP_OK(hipMemcpyAsync(d_intr.p, d_intr0.p, (size_t)NC * 9 * 8, hipMemcpyDeviceToDevice, st));
   HIP_OK(hipMemcpyAsync(d_points.p, d_points0.p, (size_t)NP * 3 * 8, hipMemcpyDeviceToDevice, st));

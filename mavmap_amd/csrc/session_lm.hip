@@ -66,7 +66,7 @@ void mavba_session::evaluate_enqueue() {
     T.t[2] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
     launch_reduce_tasks(st, T, 3);
   });
-  if (sharded()) allreduce(d_scal.p, SC_NUM_SUMS + 1, 2);  // sums, then max|g| in the last slot
+  if (sharded()) allreduce(d_scal.p + SC_COST, SC_EVAL_COUNT, 2);  // the evaluation's two sums, then max|g| (never the candidate's slots)
   evaluated = true; assembled = false;
 }
 void mavba_session::evaluate() {
@@ -190,7 +190,7 @@ void mavba_session::candidate(double r, double* h) {
     T.t[3] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_NEW_COST};
     launch_reduce_tasks(st, T, 4);
   });
-  if (sharded()) allreduce(d_scal.p, SC_NUM_SUMS, 0);
+  if (sharded()) allreduce(d_scal.p + SC_CAND_BEGIN, SC_CAND_COUNT, 0);  // only what the candidate wrote: an evaluation enqueued before it keeps its (already global) sums
   read_scalars(h);
 }
 
@@ -310,6 +310,9 @@ void mavba_session::point_errors(double* out) {
 // starts with a fresh trust region and re-estimates the Jacobi scaling), without any of the set-up.
 void mavba_session::restart() {
   evaluated = scales_ready = started = assembled = false;
+  // The Jacobi scales are re-estimated: which columns are constant (unit diagonal) may differ from the previous solve
+  // (filter_points), so the matrix is cleared and its constant / padding diagonal rewritten once (k_fix_diag).
+  M_is_clean = false;
   radius = opt.initial_trust_region_radius; decrease_factor = 2.0;
   cost = x_norm = grad_max = abs_gtol = initial_cost = 0.0;
   iteration = invalid_steps = n_success = n_fail = 0;
@@ -325,30 +328,58 @@ long long mavba_session::filter_points(double max_error, const unsigned char* ke
                                        double* errors_out) {
   if (sharded()) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "filter_points on a sharded session is not supported");
   const double t0 = now_s();
+  // ceres::Solve leaves the user's parameter blocks untouched after NUMERICAL_FAILURE: the errors the reference's
+  // filter would see are those at the parameters the failed solve STARTED from, and its second solve starts there too
+  if (termination == MAVBA_TERM_NUMERICAL_FAILURE) restore_initial_params();
   std::vector<double> err((size_t)std::max(NP, 1), 0.0);
   // (NaN marks points without observations in the problem: never filtered, like points BA never reported on)
   std::fill(err.begin(), err.end(), std::numeric_limits<double>::quiet_NaN());
   point_errors(err.data());
   if (errors_out) std::memcpy(errors_out, err.data(), (size_t)NP * 8);
-  if (h_pt_removed.empty()) h_pt_removed.assign((size_t)std::max(NP, 1), 0);
+  std::vector<unsigned char> removed_now(h_pt_removed);
+  if (removed_now.empty()) removed_now.assign((size_t)std::max(NP, 1), 0);
   long long removed = 0;
   for (int q = 0; q < NP; ++q) {
     const int po = h_pt_orig[q];
-    const bool out = !h_pt_removed[q] && !(keep && keep[po]) && err[po] > max_error;
-    if (out) { h_pt_removed[q] = 1; ++removed; }
-    if (removed_out) removed_out[po] = h_pt_removed[q];
+    const bool out = !removed_now[q] && !(keep && keep[po]) && err[po] > max_error;
+    if (out) { removed_now[q] = 1; ++removed; }
   }
-  if (removed == 0 && d_pt_active.p) { restart(); return 0; }
-  // re-derive what depends on the set of residual blocks
+  // The caller's constancy flags came out of the reference's rule "a pose state (and, without refine_camera_params, the
+  // constant intrinsics) applies only to an image that contributed MORE THAN ONE residual block"
+  // (bundle_adjustment.cc:361-385). An image that the filter leaves with exactly one would be free in the reference's
+  // second call: this session's structure has no blocks for it, so the caller has to build the second problem afresh.
+  if (removed > 0) {
+    std::vector<int> per_img((size_t)std::max(NI, 1), 0);
+    for (int q = 0; q < NP; ++q)
+      if (!removed_now[q])
+        for (int a = h_pt_start[q]; a < h_pt_start[q + 1]; ++a) per_img[h_oimg[a]]++;
+    for (int i = 0; i < NI; ++i)
+      if (per_img[i] == 1 && (h_pose_const[i] != 0 || h_intr_const_in[h_img_cam[i]]))
+        throw Failure(MAVBA_ERR_NEEDS_REBUILD, "filter_points: an image with constant blocks is left with one residual block "
+                                               "(the reference frees it, bundle_adjustment.cc:361): build the filtered problem afresh");
+  }
+  if (removed_out) for (int q = 0; q < NP; ++q) removed_out[h_pt_orig[q]] = removed_now[q];
+  if (removed == 0) { restart(); return 0; }  // (nothing filtered so far: the kernels keep their unmasked instantiations)
+  h_pt_removed.swap(removed_now);
+  apply_filter_state();
+  restart();
+  setup_seconds += now_s() - t0;
+  return removed;
+}
+
+// Re-derive everything that depends on the set of residual blocks from h_pt_removed (empty: the problem as built).
+void mavba_session::apply_filter_state() {
   std::vector<unsigned char> active((size_t)std::max(NP, 1), 1);
   std::fill(h_img_used.begin(), h_img_used.end(), 0);
   std::fill(h_cam_used.begin(), h_cam_used.end(), 0);
+  const bool any = !h_pt_removed.empty();
   long long n_all = 0, n_kept = 0;
   fixed_cost = fixed_cost_priors;
   for (int q = 0; q < NP; ++q) {
-    if (h_pt_removed[q]) { active[q] = 0; h_pt_used[q] = 0; continue; }
+    if (any && h_pt_removed[q]) { active[q] = 0; h_pt_used[q] = 0; continue; }
     n_all += h_pt_count_all[q];
     n_kept += h_pt_start[q + 1] - h_pt_start[q];
+    h_pt_used[q] = h_pt_start[q + 1] > h_pt_start[q];
     if (!h_dropped_cost.empty()) fixed_cost += h_dropped_cost[h_pt_orig[q]];
     for (int a = h_pt_start[q]; a < h_pt_start[q + 1]; ++a) { h_img_used[h_oimg[a]] = 1; h_cam_used[h_img_cam[h_oimg[a]]] = 1; }
   }
@@ -357,12 +388,9 @@ long long mavba_session::filter_points(double max_error, const unsigned char* ke
   num_residuals_reduced = 2 * n_kept + num_priors;
   derive_free_flags();
   d_pose_free.upload(h_pose_free, st); d_intr_free.upload(h_intr_free, st); d_pt_free.upload(h_pt_free, st);
-  d_pt_active.upload(active, st);
-  // constant / unused columns get their unit diagonal from the scales (k_fix_diag) once they are re-estimated
+  if (any) d_pt_active.upload(active, st);
+  // (constant / unused columns get their unit diagonal back when restart() clears the matrix: M_is_clean = false)
   sync();
-  restart();
-  setup_seconds += now_s() - t0;
-  return removed;
 }
 
 void mavba_session::fill_result(mavba_result* r) {

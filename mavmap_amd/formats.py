@@ -44,7 +44,12 @@ def _num(item, kind=float):
 def read_image_data(path, root_path="", prefix="", suffix="", ext=""):
     """imagedata.txt -> list of dicts. One line per image:
        NAME, ROLL, PITCH, YAW, LAT, LON, ALT, LOCAL_HEIGHT, TX, TY, TZ [, CAM_IDX, CAM_MODEL, CAM_PARAMS...]
-    A line without camera fields reuses the previous line's camera (io.cc:86-97)."""
+    A line without camera fields reuses the previous line's camera (io.cc:86-97).
+
+    Deliberately STRICTER than the reference on malformed lines: a line with fewer than 11 fields raises (the
+    reference's std::getline on the exhausted stream leaves the previous token in place, so it silently casts that
+    token again and accepts the line), and a trailing comma after TZ is an (empty, hence rejected) CAM_IDX rather than
+    a repeat of TZ. Every well-formed file reads the same."""
     images, camera_idxs = [], set()
     with open(path) as fh:
         for line in fh.read().split("\n"):
