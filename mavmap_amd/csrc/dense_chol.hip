@@ -1566,13 +1566,14 @@ __global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M
 // forward-substituted right-hand side. `cs` = tile structure + launch schedule of the matrix.
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws, double* L, const CholStructure& cs,
-                            const int* y_scatter, double* y_nat, bool allow_persistent) {
+                            const int* y_scatter, double* y_nat, bool allow_persistent, hipEvent_t after_factor) {
   const int nb = n_pad / NB, ld = n_pad;
   double* inv = diag_ws;
   static const bool small_path = [] { const char* e = std::getenv("MAVBA_CHOL_SMALL"); return !e || std::atoi(e) != 0; }();
   const int nb_active = cs.active_tiles > 0 ? std::min(cs.active_tiles, nb) : nb;
   if (nb_active <= 2 && small_path) {
     hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), 0, st, M, ld, nb, nb_active, fail, y, y_scatter, y_nat);
+    if (after_factor) (void)hipEventRecord(after_factor, st);  // (one launch does both halves)
     return;
   }
   const unsigned epoch = ++cs.epoch;  // flags of this solve (forward hand-offs and backward substitution)
@@ -1629,6 +1630,7 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
       hipLaunchKernelGGL(k_chol_trsm, dim3(1, 1, S.nf0), dim3(256), 0, st, M, L, ld, F + S.nf, inv, cs.d_rows, nb);
   }
   }
+  if (after_factor) (void)hipEventRecord(after_factor, st);
   double* z = L + (size_t)n_pad * ld;
   if (nb <= kMaxBacksolveGroups) {
     const int cus = device_cu_count();

@@ -314,7 +314,8 @@ struct CholStructure {
 // the caller's variable order when the matrix was assembled in a permuted order).
 void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws, double* L, const CholStructure& cs,
-                            const int* y_scatter = nullptr, double* y_nat = nullptr, bool allow_persistent = true);
+                            const int* y_scatter = nullptr, double* y_nat = nullptr, bool allow_persistent = true,
+                            hipEvent_t after_factor = nullptr /* recorded between the factorisation and the backward substitution */);
 
 }  // namespace mavba
 #endif

@@ -317,7 +317,7 @@ struct mavba_session {
 
   // ---- profiling ----
   std::vector<KernelTimer> timers;
-  struct Pending { int idx; hipEvent_t a, b; };
+  struct Pending { int idx; hipEvent_t a, b; bool own_a = true; };  // own_a false: `a` is the previous bracket's `b`
   std::vector<Pending> pending;
   std::vector<hipEvent_t> ev_pool;
 
@@ -349,11 +349,24 @@ struct mavba_session {
     HIP_OK(hipEventRecord(p.b, st));
     pending.push_back(p);
   }
+  // Two consecutive brackets around ONE call: f(mid) records `mid` on the stream where its first part ends.
+  template <typename F>
+  void timed_split(const char* first, const char* second, F&& f) {
+    if (!opt.profile_kernels) { f(nullptr); return; }
+    Pending p, q;
+    p.idx = timer_index(first); q.idx = timer_index(second);
+    p.a = get_event(); p.b = get_event(); q.a = p.b; q.b = get_event(); q.own_a = false;
+    HIP_OK(hipEventRecord(p.a, st));
+    f(p.b);
+    HIP_OK(hipEventRecord(q.b, st));
+    pending.push_back(p); pending.push_back(q);
+  }
   void flush_timers() {  // only after a stream synchronisation
     for (auto& p : pending) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { timers[p.idx].launches++; timers[p.idx].total_ms += ms; }
-      ev_pool.push_back(p.a); ev_pool.push_back(p.b);
+      if (p.own_a) ev_pool.push_back(p.a);
+      ev_pool.push_back(p.b);
     }
     pending.clear();
   }

@@ -131,7 +131,10 @@ void mavba_session::assemble(double r) {
 
 void mavba_session::solve_linear(double r) {
   assemble(r);
-  timed("dense_cholesky", [&] { dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p, allow_persistent); });
+  // (two timers: the forward factorisation - ONE kernel, k_chol_persist, on the persistent schedule - and the backward substitution)
+  timed_split("chol_factor", "chol_backsolve", [&](hipEvent_t mid) {
+    dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p, allow_persistent, mid);
+  });
   assembled = false;  // the factorisation overwrote S
   // (in place; and with shards the exchange leaves the SUM over ranks in tiles this rank's assembly does not rewrite)
   if (!(allow_persistent && chol_struct.persist_ok) || sharded()) M_is_clean = false;
@@ -218,7 +221,9 @@ int mavba_session::iterate(int max_iters, int* done) {
   // enqueued right behind the evaluation, and the tests that follow an evaluation in Ceres' loop (gradient
   // tolerance) are applied when its scalars arrive - before anything of the speculative iteration counts.
   // (with the hook every collective synchronises the host anyway; RCCL collectives are stream-ordered)
-  const bool defer = (!sharded() || rccl_comm) && !opt.print_progress;
+  // MAVBA_DEFER_WITH_HOOK (tests): run the deferred protocol over the hook too, so that in-process ranks on ONE GPU
+  // exercise the exact sequence of collectives the RCCL path issues (evaluation group, then candidate group, one read-back)
+  const bool defer = (!sharded() || rccl_comm || std::getenv("MAVBA_DEFER_WITH_HOOK") != nullptr) && !opt.print_progress;
   bool pending_eval = false;
   while (termination == MAVBA_TERM_RUNNING && n < max_iters) {
     if (iteration >= opt.max_num_iterations) { termination = MAVBA_TERM_NO_CONVERGENCE; break; }

@@ -419,6 +419,9 @@ struct Program {
   std::vector<int64_t> pt_obs;      // indices into `kept`
   // working state
   std::vector<double> poses, intr, points;
+  // image-major view + row envelope (linear-solver mode 1 only; built on first use)
+  mutable std::vector<int64_t> img_start, img_obs;
+  mutable std::vector<int> env_first;
 };
 
 inline bool pose_col_const(const mavba_problem* P, int img, int c) {
@@ -516,6 +519,10 @@ int build_program(Program& G, const mavba_problem* P, const mavba_options* opt, 
   return MAVBA_OK;
 }
 
+extern int g_linear_solver_mode;
+struct Lin;
+void accumulate_columns_parallel(const Program& G, const Lin& L, bool squares, std::vector<double>& out);
+
 // Linearisation at a point: loss-corrected residuals and Jacobian blocks.
 struct Lin {
   std::vector<double> r;    // [nk][2]
@@ -576,7 +583,10 @@ void evaluate(const Program& G, const double* poses, const double* intr, const d
       cost += 0.5 * res * res;
     }
   }
-  if (jac) {
+  if (jac && g_linear_solver_mode == 1) {
+    accumulate_columns_parallel(G, L, false, L.grad);
+    L.cost = cost;
+  } else if (jac) {
     // gradient = J^T r over the reduced parameter vector [cameras | points]
     L.grad.assign((size_t)G.n_cam + 3 * (size_t)G.n_fp, 0.0);
     for (size_t k = 0; k < nk; ++k) {
@@ -609,6 +619,7 @@ void evaluate(const Program& G, const double* poses, const double* intr, const d
 
 // Squared column norms of the (current) Jacobian over the reduced parameters.
 void column_sq_norms(const Program& G, const Lin& L, std::vector<double>& out) {
+  if (g_linear_solver_mode == 1) { accumulate_columns_parallel(G, L, true, out); return; }
   const mavba_problem* P = G.P;
   out.assign((size_t)G.n_cam + 3 * (size_t)G.n_fp, 0.0);
   for (size_t k = 0; k < G.kept.size(); ++k) {
@@ -830,6 +841,7 @@ void schur_eliminate(const Program& G, const Lin& L, const std::vector<double>& 
 // y_p = ete^-1 (g_p - E^T F y_c)
 void back_substitute(const Program& G, const Lin& L, const std::vector<double>& ete_inv,
                      const std::vector<double>& gp, const double* yc, double* yp) {
+#pragma omp parallel for schedule(static)
   for (int p = 0; p < G.NP; ++p) {
     const int fp = G.idx_point[p];
     if (fp < 0) continue;
@@ -874,6 +886,368 @@ double reduced_norm(const Program& G, const std::vector<double>& poses, const st
   return std::sqrt(s);
 }
 
+// ---------------------------------------------------------------------------
+// Linear-solver mode 1: block-sparse Schur complement + envelope (profile) Cholesky, OpenMP.
+// The same arithmetic as schur_eliminate / dense_cholesky above, organised the way a sparse CPU solver
+// (ceres SPARSE_SCHUR) organises it: S is only touched inside its block structure, every row block has ONE
+// owner thread (no atomics: the sums do not depend on the thread count), and the factorisation skips
+// everything left of the row envelope. Used for the cpu_baseline of bench.py and for oracle steps at
+// sizes where the dense path would take minutes (C5: n = 12 018).
+// ---------------------------------------------------------------------------
+int g_linear_solver_mode = 0;  // 0 = dense (default), 1 = sparse (declared above)
+
+struct SparseIndex {
+  std::vector<int64_t>& img_start;  // [NI+1] into img_obs
+  std::vector<int64_t>& img_obs;    // indices into `kept`, grouped by image, kept order inside
+  std::vector<int>& first;          // [n_cam] first structurally non-zero column of every row of S
+  explicit SparseIndex(const Program& G) : img_start(G.img_start), img_obs(G.img_obs), first(G.env_first) {}
+};
+
+void build_sparse_index(const Program& G, SparseIndex& X) {
+  const mavba_problem* P = G.P;
+  const size_t nk = G.kept.size();
+  if (!X.img_start.empty()) return;  // built already
+  X.img_start.assign((size_t)G.NI + 1, 0);
+  for (size_t k = 0; k < nk; ++k) X.img_start[P->obs_image[G.kept[k]] + 1]++;
+  for (int i = 0; i < G.NI; ++i) X.img_start[i + 1] += X.img_start[i];
+  X.img_obs.resize(nk);
+  std::vector<int64_t> cur(X.img_start.begin(), X.img_start.end() - 1);
+  for (size_t k = 0; k < nk; ++k) X.img_obs[cur[P->obs_image[G.kept[k]]]++] = (int64_t)k;
+  // first column of an image's pose rows: the lowest pose column among the images that share a point with it
+  std::vector<int> img_col(G.NI, -1);
+  for (int i = 0; i < G.NI; ++i)
+    for (int e = 0; e < 6; ++e) if (G.col_pose[i * 6 + e] >= 0) { img_col[i] = G.col_pose[i * 6 + e]; break; }
+  X.first.assign(G.n_cam, 0);
+  std::vector<int> img_first(G.NI, 0);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int i = 0; i < G.NI; ++i) {
+    int f = img_col[i] < 0 ? 0 : img_col[i];
+    for (int64_t t = X.img_start[i]; t < X.img_start[i + 1]; ++t) {
+      const int p = P->obs_point[G.kept[X.img_obs[t]]];
+      if (G.idx_point[p] < 0) continue;
+      for (int64_t u = G.pt_start[p]; u < G.pt_start[p + 1]; ++u) {
+        const int j = P->obs_image[G.kept[G.pt_obs[u]]];
+        if (img_col[j] >= 0) f = std::min(f, img_col[j]);
+      }
+    }
+    img_first[i] = f;
+  }
+  for (int i = 0; i < G.NI; ++i)
+    for (int e = 0; e < 6; ++e) if (G.col_pose[i * 6 + e] >= 0) X.first[G.col_pose[i * 6 + e]] = img_first[i];
+  // (intrinsics rows: dense, first = 0)
+}
+
+// pose part of one kept observation: free pose columns and the 2 x m values
+inline int pose_row(const Program& G, const Lin& L, size_t k, int img, int cols[6], double vals[2][6]) {
+  int m = 0;
+  for (int e = 0; e < 6; ++e) {
+    const int col = G.col_pose[img * 6 + e];
+    if (col >= 0) { cols[m] = col; vals[0][m] = L.Jc[k * 12 + e]; vals[1][m] = L.Jc[k * 12 + 6 + e]; ++m; }
+  }
+  return m;
+}
+
+// Lower triangle of S (rows >= columns in the reduced order) and v; the upper triangle is left zero.
+void schur_eliminate_sparse(const Program& G, const Lin& L, const SparseIndex& X, const std::vector<double>& D,
+                            std::vector<double>& S, std::vector<double>& v, std::vector<double>& ete_inv,
+                            std::vector<double>& gp) {
+  const mavba_problem* P = G.P;
+  const int n = G.n_cam;
+  S.assign((size_t)n * n, 0.0);
+  v.assign(n, 0.0);
+  ete_inv.assign((size_t)G.n_fp * 9, 0.0);
+  gp.assign((size_t)G.n_fp * 3, 0.0);
+  for (int j = 0; j < n; ++j) S[(size_t)j * n + j] = D[j] * D[j];
+  for (size_t q = 0; q < G.kept_prior.size(); ++q) {
+    const int i = P->rot_prior_image[G.kept_prior[q]];
+    for (int a = 0; a < 3; ++a) {
+      const int ca = G.col_pose[i * 6 + a];
+      if (ca < 0) continue;
+      v[ca] += L.pJ[q * 3 + a] * L.pr[q];
+      for (int b = 0; b < 3; ++b) {
+        const int cb = G.col_pose[i * 6 + b];
+        if (cb >= 0 && cb <= ca) S[(size_t)ca * n + cb] += L.pJ[q * 3 + a] * L.pJ[q * 3 + b];
+      }
+    }
+  }
+  // pass 1, per point: damped 3x3 block, its inverse, g_p, inv * g_p
+  std::vector<double> ig((size_t)G.n_fp * 3, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < G.NP; ++p) {
+    const int fp = G.idx_point[p];
+    if (fp < 0) continue;
+    double ete[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int64_t t = G.pt_start[p]; t < G.pt_start[p + 1]; ++t) {
+      const size_t k = (size_t)G.pt_obs[t];
+      for (int row = 0; row < 2; ++row) {
+        const double* e = &L.Jp[k * 6 + row * 3];
+        const double rr = L.r[k * 2 + row];
+        for (int x = 0; x < 3; ++x) { g[x] += e[x] * rr; for (int y = 0; y < 3; ++y) ete[x * 3 + y] += e[x] * e[y]; }
+      }
+    }
+    for (int x = 0; x < 3; ++x) { const double d = D[n + 3 * fp + x]; ete[x * 4] += d * d; }
+    double inv[9];
+    if (!invert3(ete, inv)) for (int x = 0; x < 9; ++x) inv[x] = std::numeric_limits<double>::quiet_NaN();
+    for (int x = 0; x < 9; ++x) ete_inv[(size_t)fp * 9 + x] = inv[x];
+    for (int x = 0; x < 3; ++x) {
+      gp[(size_t)fp * 3 + x] = g[x];
+      ig[(size_t)fp * 3 + x] = inv[x * 3] * g[0] + inv[x * 3 + 1] * g[1] + inv[x * 3 + 2] * g[2];
+    }
+  }
+  // pass 2, pose rows: image i owns its row block
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < G.NI; ++i) {
+    for (int64_t t = X.img_start[i]; t < X.img_start[i + 1]; ++t) {
+      const size_t ka = (size_t)X.img_obs[t];
+      int ca[6]; double fa[2][6];
+      const int ma = pose_row(G, L, ka, i, ca, fa);
+      if (ma == 0) continue;
+      // F^T F and F^T r of this observation (diagonal block, lower part)
+      for (int x = 0; x < ma; ++x) {
+        v[ca[x]] += fa[0][x] * L.r[ka * 2] + fa[1][x] * L.r[ka * 2 + 1];
+        for (int y = 0; y <= x; ++y) S[(size_t)ca[x] * n + ca[y]] += fa[0][x] * fa[0][y] + fa[1][x] * fa[1][y];
+      }
+      const int p = P->obs_point[G.kept[ka]];
+      const int fp = G.idx_point[p];
+      if (fp < 0) continue;
+      const double* inv = &ete_inv[(size_t)fp * 9];
+      // Ta = (F_a^T E_a) inv   (ma x 3)
+      double Wa[6][3], Ta[6][3];
+      for (int x = 0; x < ma; ++x)
+        for (int y = 0; y < 3; ++y) Wa[x][y] = fa[0][x] * L.Jp[ka * 6 + y] + fa[1][x] * L.Jp[ka * 6 + 3 + y];
+      for (int x = 0; x < ma; ++x)
+        for (int y = 0; y < 3; ++y) Ta[x][y] = Wa[x][0] * inv[y] + Wa[x][1] * inv[3 + y] + Wa[x][2] * inv[6 + y];
+      for (int x = 0; x < ma; ++x)
+        v[ca[x]] -= Wa[x][0] * ig[(size_t)fp * 3] + Wa[x][1] * ig[(size_t)fp * 3 + 1] + Wa[x][2] * ig[(size_t)fp * 3 + 2];
+      for (int64_t u = G.pt_start[p]; u < G.pt_start[p + 1]; ++u) {
+        const size_t kb = (size_t)G.pt_obs[u];
+        const int j = P->obs_image[G.kept[kb]];
+        if (j > i) continue;  // lower triangle: the owner of the later image writes the block
+        int cb[6]; double fb[2][6];
+        const int mb = pose_row(G, L, kb, j, cb, fb);
+        for (int y = 0; y < mb; ++y) {
+          const double wb[3] = {fb[0][y] * L.Jp[kb * 6] + fb[1][y] * L.Jp[kb * 6 + 3],
+                                fb[0][y] * L.Jp[kb * 6 + 1] + fb[1][y] * L.Jp[kb * 6 + 4],
+                                fb[0][y] * L.Jp[kb * 6 + 2] + fb[1][y] * L.Jp[kb * 6 + 5]};
+          for (int x = 0; x < ma; ++x)
+            if (cb[y] <= ca[x]) S[(size_t)ca[x] * n + cb[y]] -= Ta[x][0] * wb[0] + Ta[x][1] * wb[1] + Ta[x][2] * wb[2];
+        }
+      }
+    }
+  }
+  // pass 3, intrinsics rows: chunks of points accumulate private strips (K rows x n columns + v), added in chunk order
+  for (int c = 0; c < G.NC; ++c) {
+    const int kc0 = G.col_intr[c];
+    if (kc0 < 0) continue;
+    const int K = G.K[c];
+    const int nchunk = std::max(1, std::min(256, G.NP / 512));
+    std::vector<double> strips((size_t)nchunk * K * (n + 1), 0.0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ch = 0; ch < nchunk; ++ch) {
+      double* strip = &strips[(size_t)ch * K * (n + 1)];
+      const int p0 = (int)((int64_t)G.NP * ch / nchunk), p1 = (int)((int64_t)G.NP * (ch + 1) / nchunk);
+      std::vector<int> cams;
+      for (int p = p0; p < p1; ++p) {
+        const int fp = G.idx_point[p];
+        double Wk[9][3];
+        bool any = false;
+        for (int x = 0; x < K; ++x) Wk[x][0] = Wk[x][1] = Wk[x][2] = 0.0;
+        for (int64_t t = G.pt_start[p]; t < G.pt_start[p + 1]; ++t) {
+          const size_t k = (size_t)G.pt_obs[t];
+          const int i = P->obs_image[G.kept[k]];
+          if (P->image_camera[i] != c) continue;
+          any = true;
+          const double* k0 = &L.Jk[k * 18];
+          const double* k1 = &L.Jk[k * 18 + 9];
+          int ca[6]; double fa[2][6];
+          const int ma = pose_row(G, L, k, i, ca, fa);
+          for (int x = 0; x < K; ++x) {
+            double* row = strip + (size_t)x * (n + 1);
+            row[n] += k0[x] * L.r[k * 2] + k1[x] * L.r[k * 2 + 1];
+            for (int y = 0; y < ma; ++y) row[ca[y]] += k0[x] * fa[0][y] + k1[x] * fa[1][y];
+            for (int y = 0; y <= x; ++y) row[kc0 + y] += k0[x] * k0[y] + k1[x] * k1[y];
+            for (int y = 0; y < 3; ++y) Wk[x][y] += k0[x] * L.Jp[k * 6 + y] + k1[x] * L.Jp[k * 6 + 3 + y];
+          }
+        }
+        if (!any || fp < 0) continue;
+        const double* inv = &ete_inv[(size_t)fp * 9];
+        double Tk[9][3];
+        for (int x = 0; x < K; ++x)
+          for (int y = 0; y < 3; ++y) Tk[x][y] = Wk[x][0] * inv[y] + Wk[x][1] * inv[3 + y] + Wk[x][2] * inv[6 + y];
+        for (int x = 0; x < K; ++x)
+          strip[(size_t)x * (n + 1) + n] -= Wk[x][0] * ig[(size_t)fp * 3] + Wk[x][1] * ig[(size_t)fp * 3 + 1] + Wk[x][2] * ig[(size_t)fp * 3 + 2];
+        // against every pose block of the point, and against the intrinsics blocks of cameras c' <= c it is seen by
+        cams.clear();
+        for (int64_t u = G.pt_start[p]; u < G.pt_start[p + 1]; ++u) {
+          const size_t kb = (size_t)G.pt_obs[u];
+          const int j = P->obs_image[G.kept[kb]];
+          int cb[6]; double fb[2][6];
+          const int mb = pose_row(G, L, kb, j, cb, fb);
+          for (int y = 0; y < mb; ++y) {
+            const double wb[3] = {fb[0][y] * L.Jp[kb * 6] + fb[1][y] * L.Jp[kb * 6 + 3],
+                                  fb[0][y] * L.Jp[kb * 6 + 1] + fb[1][y] * L.Jp[kb * 6 + 4],
+                                  fb[0][y] * L.Jp[kb * 6 + 2] + fb[1][y] * L.Jp[kb * 6 + 5]};
+            for (int x = 0; x < K; ++x) strip[(size_t)x * (n + 1) + cb[y]] -= Tk[x][0] * wb[0] + Tk[x][1] * wb[1] + Tk[x][2] * wb[2];
+          }
+          const int c2 = P->image_camera[j];
+          if (c2 <= c && G.col_intr[c2] >= 0 && std::find(cams.begin(), cams.end(), c2) == cams.end()) cams.push_back(c2);
+        }
+        for (int c2 : cams) {
+          double W2[9][3];
+          const int K2 = G.K[c2];
+          for (int y = 0; y < K2; ++y) W2[y][0] = W2[y][1] = W2[y][2] = 0.0;
+          for (int64_t u = G.pt_start[p]; u < G.pt_start[p + 1]; ++u) {
+            const size_t kb = (size_t)G.pt_obs[u];
+            if (P->image_camera[P->obs_image[G.kept[kb]]] != c2) continue;
+            for (int y = 0; y < K2; ++y)
+              for (int z = 0; z < 3; ++z) W2[y][z] += L.Jk[kb * 18 + y] * L.Jp[kb * 6 + z] + L.Jk[kb * 18 + 9 + y] * L.Jp[kb * 6 + 3 + z];
+          }
+          for (int x = 0; x < K; ++x)
+            for (int y = 0; y < K2; ++y) {
+              if (c2 == c && y > x) continue;
+              strip[(size_t)x * (n + 1) + G.col_intr[c2] + y] -= Tk[x][0] * W2[y][0] + Tk[x][1] * W2[y][1] + Tk[x][2] * W2[y][2];
+            }
+        }
+      }
+    }
+#pragma omp parallel for schedule(static)
+    for (int col = 0; col <= n; ++col)
+      for (int x = 0; x < K; ++x) {
+        double acc = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) acc += strips[((size_t)ch * K + x) * (n + 1) + col];
+        if (col == n) v[kc0 + x] += acc;
+        else if (col <= kc0 + x) S[(size_t)(kc0 + x) * n + col] += acc;
+      }
+  }
+}
+
+// Blocked Cholesky (lower, in place, row-major) that never leaves the row envelope: row i is structurally zero
+// left of first[i], and so is its row of the factor. Returns false if not SPD.
+bool envelope_cholesky(int n, double* A, const std::vector<int>& first) {
+  const int NB = 64;
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int kb = std::min(NB, n - k0);
+    for (int j = k0; j < k0 + kb; ++j) {
+      const int lo = std::max(k0, first[j]);
+      double d = A[(size_t)j * n + j];
+      for (int k = lo; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+      if (!(d > 0.0) || !std::isfinite(d)) return false;
+      d = std::sqrt(d);
+      A[(size_t)j * n + j] = d;
+      for (int i = j + 1; i < k0 + kb; ++i) {
+        if (first[i] > j) continue;
+        double s = A[(size_t)i * n + j];
+        for (int k = std::max(lo, first[i]); k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+        A[(size_t)i * n + j] = s / d;
+      }
+    }
+    const int r0 = k0 + kb;
+    // rows that reach into this panel
+    std::vector<int> act;
+    for (int i = r0; i < n; ++i) if (first[i] < r0) act.push_back(i);
+    const int na = (int)act.size();
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < na; ++t) {
+      const int i = act[t];
+      for (int j = std::max(k0, first[i]); j < k0 + kb; ++j) {
+        double s = A[(size_t)i * n + j];
+        for (int k = std::max(std::max(k0, first[i]), first[j]); k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+        A[(size_t)i * n + j] = s / A[(size_t)j * n + j];
+      }
+    }
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int t = 0; t < na; ++t) {
+      const int i = act[t];
+      const int ki = std::max(k0, first[i]);
+      const double* ai = &A[(size_t)i * n];
+      for (int u = 0; u <= t; ++u) {
+        const int j = act[u];
+        const double* aj = &A[(size_t)j * n];
+        double s = 0.0;
+        for (int k = std::max(ki, first[j]); k < k0 + kb; ++k) s += ai[k] * aj[k];
+        A[(size_t)i * n + j] -= s;
+      }
+    }
+  }
+  return true;
+}
+
+void envelope_solve(int n, const double* L, const std::vector<int>& first, double* b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = first[i]; k < i; ++k) s -= L[(size_t)i * n + k] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+  // backward, column-oriented so that only the envelope is read: x_i known -> subtract its column from the rows above
+  for (int i = n - 1; i >= 0; --i) {
+    b[i] /= L[(size_t)i * n + i];
+    const double xi = b[i];
+    for (int k = first[i]; k < i; ++k) b[k] -= L[(size_t)i * n + k] * xi;
+  }
+}
+
+
+// out[col] += sum over the rows of J of J[row][col] * (squares ? J[row][col] : r[row]), every column owned by one
+// thread (pose columns: the image; point columns: the point) or summed from fixed chunks in chunk order (intrinsics):
+// the result does not depend on the thread count. Mode-1 counterpart of the serial loops in evaluate / column_sq_norms.
+void accumulate_columns_parallel(const Program& G, const Lin& L, bool squares, std::vector<double>& out) {
+  const mavba_problem* P = G.P;
+  SparseIndex X(G);
+  build_sparse_index(G, X);
+  out.assign((size_t)G.n_cam + 3 * (size_t)G.n_fp, 0.0);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int i = 0; i < G.NI; ++i)
+    for (int64_t t = X.img_start[i]; t < X.img_start[i + 1]; ++t) {
+      const size_t k = (size_t)X.img_obs[t];
+      for (int row = 0; row < 2; ++row)
+        for (int e = 0; e < 6; ++e) {
+          const int col = G.col_pose[i * 6 + e];
+          if (col < 0) continue;
+          const double x = L.Jc[k * 12 + row * 6 + e];
+          out[col] += x * (squares ? x : L.r[k * 2 + row]);
+        }
+    }
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < G.NP; ++p) {
+    const int fp = G.idx_point[p];
+    if (fp < 0) continue;
+    for (int64_t t = G.pt_start[p]; t < G.pt_start[p + 1]; ++t) {
+      const size_t k = (size_t)G.pt_obs[t];
+      for (int row = 0; row < 2; ++row)
+        for (int e = 0; e < 3; ++e) {
+          const double x = L.Jp[k * 6 + row * 3 + e];
+          out[G.n_cam + 3 * fp + e] += x * (squares ? x : L.r[k * 2 + row]);
+        }
+    }
+  }
+  const int nchunk = 256;
+  const int64_t nk = (int64_t)G.kept.size();
+  std::vector<double> part((size_t)nchunk * G.NC * 9, 0.0);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int ch = 0; ch < nchunk; ++ch)
+    for (int64_t k = nk * ch / nchunk; k < nk * (ch + 1) / nchunk; ++k) {
+      const int c = P->image_camera[P->obs_image[G.kept[k]]];
+      if (G.col_intr[c] < 0) continue;
+      double* acc = &part[((size_t)ch * G.NC + c) * 9];
+      for (int row = 0; row < 2; ++row)
+        for (int e = 0; e < G.K[c]; ++e) {
+          const double x = L.Jk[k * 18 + row * 9 + e];
+          acc[e] += x * (squares ? x : L.r[k * 2 + row]);
+        }
+    }
+  for (int c = 0; c < G.NC; ++c)
+    if (G.col_intr[c] >= 0)
+      for (int e = 0; e < G.K[c]; ++e)
+        for (int ch = 0; ch < nchunk; ++ch) out[G.col_intr[c] + e] += part[((size_t)ch * G.NC + c) * 9 + e];
+  for (size_t q = 0; q < G.kept_prior.size(); ++q) {
+    const int i = P->rot_prior_image[G.kept_prior[q]];
+    for (int e = 0; e < 3; ++e) {
+      const int col = G.col_pose[i * 6 + e];
+      if (col >= 0) out[col] += L.pJ[q * 3 + e] * (squares ? L.pJ[q * 3 + e] : L.pr[q]);
+    }
+  }
+}
+
 // One LM linear solve (LevenbergMarquardtStrategy::ComputeStep + SchurComplementSolver).
 // Lsc is the *scaled* linearisation, diag the clamped squared column norms.
 // Returns false on linear-solver failure. step = -y over [cameras|points].
@@ -884,14 +1258,31 @@ bool compute_step(const Program& G, const Lin& Lsc, const std::vector<double>& d
   std::vector<double> D(np);
   for (size_t j = 0; j < np; ++j) D[j] = std::sqrt(diag[j] / radius);
   std::vector<double> S, v, ete_inv, gp;
-  schur_eliminate(G, Lsc, D, S, v, ete_inv, gp);
-  if (S_out) *S_out = S;
-  if (v_out) *v_out = v;
   step.assign(np, 0.0);
-  std::vector<double> y(v);
-  if (n > 0) {
-    if (!dense_cholesky(n, S.data())) return false;
-    cholesky_solve(n, S.data(), y.data());
+  std::vector<double> y;
+  if (g_linear_solver_mode == 1) {
+    SparseIndex X(G);
+    build_sparse_index(G, X);
+    schur_eliminate_sparse(G, Lsc, X, D, S, v, ete_inv, gp);
+    if (S_out) {
+      *S_out = S;
+      for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) (*S_out)[(size_t)a * n + b] = S[(size_t)b * n + a];
+    }
+    if (v_out) *v_out = v;
+    y = v;
+    if (n > 0) {
+      if (!envelope_cholesky(n, S.data(), X.first)) return false;
+      envelope_solve(n, S.data(), X.first, y.data());
+    }
+  } else {
+    schur_eliminate(G, Lsc, D, S, v, ete_inv, gp);
+    if (S_out) *S_out = S;
+    if (v_out) *v_out = v;
+    y = v;
+    if (n > 0) {
+      if (!dense_cholesky(n, S.data())) return false;
+      cholesky_solve(n, S.data(), y.data());
+    }
   }
   std::vector<double> yp(3 * (size_t)G.n_fp, 0.0);
   back_substitute(G, Lsc, ete_inv, gp, y.data(), yp.data());
@@ -906,7 +1297,7 @@ double model_cost_change(const Program& G, const Lin& Lsc, const std::vector<dou
   const mavba_problem* P = G.P;
   const int n = G.n_cam;
   double acc = 0.0;
-  for (size_t k = 0; k < G.kept.size(); ++k) {
+  auto one = [&](size_t k, double& a) {
     const int p = P->obs_point[G.kept[k]];
     const int fp = G.idx_point[p];
     for (int row = 0; row < 2; ++row) {
@@ -915,8 +1306,22 @@ double model_cost_change(const Program& G, const Lin& Lsc, const std::vector<dou
       double mr = 0.0;
       for (int x = 0; x < m; ++x) mr += vals[x] * step[cols[x]];
       if (fp >= 0) for (int x = 0; x < 3; ++x) mr += Lsc.Jp[k * 6 + row * 3 + x] * step[n + 3 * fp + x];
-      acc += mr * (Lsc.r[k * 2 + row] + mr / 2.0);
+      a += mr * (Lsc.r[k * 2 + row] + mr / 2.0);
     }
+  };
+  if (g_linear_solver_mode == 1) {
+    const int nchunk = 256;
+    const int64_t nk = (int64_t)G.kept.size();
+    double part[256];
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ch = 0; ch < nchunk; ++ch) {
+      double a = 0.0;
+      for (int64_t k = nk * ch / nchunk; k < nk * (ch + 1) / nchunk; ++k) one((size_t)k, a);
+      part[ch] = a;
+    }
+    for (int ch = 0; ch < nchunk; ++ch) acc += part[ch];
+  } else {
+    for (size_t k = 0; k < G.kept.size(); ++k) one(k, acc);
   }
   for (size_t q = 0; q < G.kept_prior.size(); ++q) {
     const int i = P->rot_prior_image[G.kept_prior[q]];
@@ -951,6 +1356,10 @@ void oracle_set_num_threads(int n) {
   (void)n;
 #endif
 }
+
+// 0 = dense Schur complement + dense Cholesky (default), 1 = block-sparse Schur complement + envelope Cholesky
+void oracle_set_linear_solver(int mode) { g_linear_solver_mode = mode == 1 ? 1 : 0; }
+int oracle_get_linear_solver(void) { return g_linear_solver_mode; }
 
 int oracle_max_threads(void) {
 #ifdef _OPENMP

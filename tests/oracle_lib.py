@@ -35,6 +35,8 @@ def lib():
         L.oracle_options_init.argtypes = [op]
         L.oracle_set_num_threads.argtypes = [C.c_int]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_set_linear_solver.argtypes = [C.c_int]
+        L.oracle_get_linear_solver.restype = C.c_int
         L.oracle_world2image.argtypes = [C.c_int, dp, C.c_double, C.c_double, C.c_double, dp, dp]
         L.oracle_image2world.argtypes = [C.c_int, dp, C.c_double, C.c_double, dp, dp, dp]
         L.oracle_rotate_point.argtypes = [dp, dp, dp]
@@ -72,6 +74,29 @@ def set_threads(n):
 
 def max_threads():
     return int(lib().oracle_max_threads())
+
+
+DENSE, SPARSE = 0, 1
+
+
+def set_linear_solver(mode):
+    """DENSE (default): dense Schur complement + dense Cholesky. SPARSE: block-sparse Schur complement with one owner
+    thread per row block + envelope Cholesky (what the cpu_baseline and the full-size C5 checks run)."""
+    lib().oracle_set_linear_solver(int(mode))
+
+
+class linear_solver:
+    """with oracle_lib.linear_solver(oracle_lib.SPARSE): ..."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = int(lib().oracle_get_linear_solver())
+        set_linear_solver(self.mode)
+
+    def __exit__(self, *a):
+        set_linear_solver(self.prev)
 
 
 def world2image(model, params, x, y, z):

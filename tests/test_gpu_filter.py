@@ -9,7 +9,7 @@ import pytest
 
 from mavmap_amd import _abi as A
 from mavmap_amd import synth
-from tests.conftest import global_opts, rel_err
+from tests.conftest import assert_params_close, global_opts, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -62,10 +62,9 @@ def test_filter_and_rebundle_matches_oracle(mavba, oracle, kind):
             assert rg[k] == ro[k], k
         assert abs(rg["initial_cost"] - ro["initial_cost"]) <= 1e-6 * ro["initial_cost"]
         assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
-    assert rel_err(g.poses, b.poses) < 1e-6
-    assert rel_err(g.intrinsics, b.intrinsics) < 1e-6
     live = removed_o == 0
-    assert rel_err(g.points[live], b.points[live]) < 1e-6
+    assert_params_close(dict(poses=g.poses, intrinsics=g.intrinsics, points=g.points[live]),
+                        dict(poses=b.poses, intrinsics=b.intrinsics, points=b.points[live]))
     # filtered points keep the coordinates of the first solve (nothing references them any more)
     assert rel_err(g.points[~live], a.points[~live]) < 1e-6
     m = ~np.isnan(e2o)
@@ -103,7 +102,8 @@ def test_filter_keep_set_constant_blocks_and_second_filter(mavba, oracle):
             assert abs(rg["fixed_cost"] - ro["fixed_cost"]) <= 1e-9 * max(ro["fixed_cost"], 1e-300)
             assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
             poses, intr, pts = s.get_params()
-            assert rel_err(poses, q.poses) < 1e-6 and rel_err(pts[removed == 0], q.points[removed == 0]) < 1e-6
+            assert_params_close(dict(poses=poses, intrinsics=intr, points=pts[removed == 0]),
+                                dict(poses=q.poses, intrinsics=q.intrinsics, points=q.points[removed == 0]))
             eg = s.point_errors()
             m = ~np.isnan(eo)
             assert np.array_equal(m, ~np.isnan(eg)) and rel_err(eg[m], eo[m]) < 1e-6

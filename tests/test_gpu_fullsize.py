@@ -15,7 +15,7 @@ import pytest
 
 from mavmap_amd import _abi as A
 from mavmap_amd import synth
-from tests.conftest import ROOT, global_opts, rel_err
+from tests.conftest import assert_params_close, ROOT, global_opts, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -76,9 +76,7 @@ def test_c3_full_size_solve_matches_oracle(mavba, fast_oracle, c3_full):
     rmse_g = np.sqrt(rg["final_cost"] / rg["num_residuals"])
     rmse_o = np.sqrt(ro["final_cost"] / ro["num_residuals"])
     assert abs(rmse_g - rmse_o) <= 1e-6 * rmse_o
-    assert rel_err(pg.poses, po.poses) < 1e-6
-    assert rel_err(pg.points, po.points) < 1e-6
-    assert rel_err(pg.intrinsics, po.intrinsics) < 1e-6
+    assert_params_close(pg, po)  # rvec, t, (fx fy cx cy), (k1 k2), (p1 p2), xi, points: each within 1e-6 of its own scale
     assert rel_err(eg, eo) < 1e-6
 
 
@@ -98,6 +96,99 @@ def test_c5_shaped_step_matches_oracle(mavba, fast_oracle):
             S, v = s.reduced_system(radius)
             st = s.linear_step(radius)
             _check_step(st, S, v, ref, ("C5x0.2", radius))
+
+
+@pytest.fixture(scope="module")
+def c5_full():
+    p = synth.make_config("C5")
+    assert (p.num_images, p.num_points) == (2000, 1000000) and p.num_obs > 10_000_000
+    assert len(p.rot_prior_image) > 1900
+    return p
+
+
+def test_c5_full_size_step_matches_oracle(mavba, fast_oracle, c5_full):
+    """BASELINE.json's largest configuration at FULL size on one GPU (2000 images / 1 M points / 10.3 M observations,
+    rotation priors, 5 % long loop-closure tracks): n = 12 018, the launch-per-panel factorisation, ~11 000 clusters AND
+    generic term lists. One linear step against the oracle (block-sparse Schur complement + envelope Cholesky on all host
+    cores - the same arithmetic as its dense path, tests/test_oracle.py)."""
+    p = c5_full
+    radius = 1e4
+    with fast_oracle.linear_solver(fast_oracle.SPARSE):
+        ref = fast_oracle.linear_step(p, radius, jac_mode=1)
+    with mavba.Session(p) as s:
+        info = s.info()
+        assert info["reduced_dim"] == 6 * 2000 + 18
+        assert 0 < info["clustered_points"] < p.num_points and info["schur_terms"][0] > 0
+        S, v = s.reduced_system(radius)
+        st = s.linear_step(radius)
+    _check_step(st, S, v, ref, ("C5", radius))
+
+
+def _solve_stepwise(s):
+    """One LM iteration per call; returns (final result, cost after every iteration)."""
+    costs = []
+    while True:
+        done, term = s.iterate(1)
+        costs.append(s.result()["final_cost"])
+        if term != A.TERM_RUNNING:
+            return s.result(), costs
+        assert len(costs) < 250
+
+
+def test_c5_full_size_solve_properties_and_two_rank_shards(mavba, c5_full):
+    """A complete full-size C5 solve: terminates by tolerance, the cost never rises, a repeat run is bit-identical, and the
+    same problem sharded by point over two in-process ranks (packed tile exchange of a 12 018-column system, union
+    envelope, max-reduced image graph) ends within 1e-8 of it."""
+    from tests.test_gpu_sharded import solve_sharded
+    p = c5_full
+    opts = global_opts()
+    with mavba.Session(p, opts) as s:
+        r1, costs = _solve_stepwise(s)
+        x1 = s.get_params()
+        s.reset()
+        r2 = s.solve()
+        x2 = s.get_params()
+    assert r1["termination"] in (A.TERM_FUNCTION_TOLERANCE, A.TERM_GRADIENT_TOLERANCE, A.TERM_PARAMETER_TOLERANCE), r1["termination_name"]
+    assert r1["final_cost"] < 0.2 * r1["initial_cost"]
+    assert all(b <= a for a, b in zip(costs, costs[1:])), costs
+    rmse = np.sqrt(r1["final_cost"] / r1["num_residuals"])
+    assert 0.2 < rmse < 0.6, rmse  # 0.5 px noise + 1 % gross outliers under the Cauchy loss
+    for k in ("termination", "num_successful_steps", "num_unsuccessful_steps", "final_cost", "initial_cost"):
+        assert r1[k] == r2[k], k
+    for a, b in zip(x1, x2):
+        assert np.array_equal(a, b)
+    out, _ = solve_sharded(mavba, p, 2, opts)
+    pts = np.zeros_like(p.points)
+    for res, poses, intr, q, owned in out:
+        assert res["termination"] == r1["termination"]
+        assert res["num_successful_steps"] == r1["num_successful_steps"] and res["num_unsuccessful_steps"] == r1["num_unsuccessful_steps"]
+        assert res["num_residuals"] == r1["num_residuals"] and res["num_parameters_reduced"] == r1["num_parameters_reduced"]
+        assert abs(res["final_cost"] - r1["final_cost"]) <= 1e-8 * r1["final_cost"]
+        assert np.array_equal(poses, out[0][1]) and np.array_equal(intr, out[0][2])
+        pts[owned] = q
+    assert_params_close(dict(poses=out[0][1], intrinsics=out[0][2], points=pts), dict(poses=x1[0], intrinsics=x1[1], points=x1[2]), tol=1e-8)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_c3_full_size_sharded_matches_single_rank(mavba, c3_full, world):
+    """Configuration C4's structure at real size: full-size C3 sharded by point over 2 and 8 in-process ranks (19 MB of
+    packed tiles per exchange, union envelope, rank-consistent dissection order) == the single-rank solve within 1e-8."""
+    from tests.test_gpu_sharded import solve_sharded
+    p = c3_full
+    opts = global_opts()
+    with mavba.Session(p, opts) as s:
+        r1 = s.solve()
+        x1 = s.get_params()
+    out, ar = solve_sharded(mavba, p, world, opts)
+    pts = np.zeros_like(p.points)
+    for res, poses, intr, q, owned in out:
+        assert res["termination"] == r1["termination"]
+        assert res["num_successful_steps"] == r1["num_successful_steps"] and res["num_unsuccessful_steps"] == r1["num_unsuccessful_steps"]
+        assert res["num_residuals"] == r1["num_residuals"] and res["num_parameters_reduced"] == r1["num_parameters_reduced"]
+        assert abs(res["final_cost"] - r1["final_cost"]) <= 1e-8 * r1["final_cost"]
+        assert np.array_equal(poses, out[0][1]) and np.array_equal(intr, out[0][2])
+        pts[owned] = q
+    assert_params_close(dict(poses=out[0][1], intrinsics=out[0][2], points=pts), dict(poses=x1[0], intrinsics=x1[1], points=x1[2]), tol=1e-8)
 
 
 def _spd(n, seed):

@@ -10,7 +10,7 @@ import pytest
 
 from mavmap_amd import _abi as A
 from mavmap_amd import synth
-from tests.conftest import global_opts, rel_err
+from tests.conftest import assert_params_close, global_opts, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -95,9 +95,7 @@ def test_full_solve_matches_oracle(mavba, oracle, kind):
     rmse_g = np.sqrt(rg["final_cost"] / rg["num_residuals"])
     rmse_o = np.sqrt(ro["final_cost"] / ro["num_residuals"])
     assert abs(rmse_g - rmse_o) <= 1e-6 * rmse_o
-    assert rel_err(pg.poses, po.poses) < 1e-6
-    assert rel_err(pg.points, po.points) < 1e-6
-    assert rel_err(pg.intrinsics, po.intrinsics) < 1e-6
+    assert_params_close(pg, po)  # rvec, t, (fx fy cx cy), (k1 k2), (p1 p2), xi, points: each within 1e-6 of its own scale
     m = ~np.isnan(eo)
     assert np.array_equal(m, ~np.isnan(eg))
     assert rel_err(eg[m], eo[m]) < 1e-6
@@ -119,7 +117,7 @@ def test_local_ba_windows_c1(mavba, oracle):
         po, ro, _, pg, rg, _ = _solve_both(mavba, oracle, p)  # BundleAdjustmentOptions defaults
         assert rg["termination"] == ro["termination"]
         assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
-        assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+        assert_params_close(pg, po)
         # images outside the window are not part of the problem and must not move
         out = np.setdiff1d(np.arange(g.num_images), np.arange(first, first + 8))
         assert np.array_equal(pg.poses[out], p.poses[out])
@@ -151,7 +149,7 @@ def test_small_system_paths_match_oracle(mavba, oracle, n_images, free):
     po, ro, _, pg, rg, _ = _solve_both(mavba, oracle, p)
     assert rg["termination"] == ro["termination"] and rg["num_successful_steps"] == ro["num_successful_steps"]
     assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
-    assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+    assert_params_close(pg, po)
 
 
 def test_pose_refinement_matches_oracle(mavba, oracle):
@@ -213,7 +211,7 @@ def test_edge_cases(mavba, oracle):
     po, ro, eo, pg, rg, eg = _solve_both(mavba, oracle, p, **global_opts())
     assert rg["termination"] == ro["termination"]
     assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
-    assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+    assert_params_close(pg, po)
     assert np.array_equal(pg.poses[4], p.poses[4])
     # bad inputs are rejected with the documented codes
     bad = p.copy(); bad.obs_image[0] = 99
@@ -354,7 +352,7 @@ def test_dissection_is_chosen_automatically_and_solves_like_the_oracle(mavba, or
     assert rg["termination"] == ro["termination"]
     assert rg["num_successful_steps"] == ro["num_successful_steps"]
     assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
-    assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+    assert_params_close(pg, po)
 
 
 def test_dissection_with_constant_blocks_and_unused_images(mavba, oracle):
@@ -427,7 +425,7 @@ def test_termination_kinds_match_oracle(mavba, oracle, optkw):
     assert rg["num_successful_steps"] == ro["num_successful_steps"]
     assert rg["num_unsuccessful_steps"] == ro["num_unsuccessful_steps"]
     assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"] + 1e-18
-    assert rel_err(pg.poses, po.poses) < 1e-6 and rel_err(pg.points, po.points) < 1e-6
+    assert_params_close(pg, po)
 
 
 def test_stepwise_iteration_equals_one_call(mavba):

@@ -12,7 +12,7 @@ import pytest
 
 from mavmap_amd import _abi as A
 from mavmap_amd import api, synth
-from tests.conftest import global_opts, rel_err
+from tests.conftest import assert_params_close, global_opts, rel_err
 from tests.test_shim import Scene as FmScene
 from tests.test_shim import expected_flat, mock, recorded, run, small_scene  # noqa: F401  (mock is a fixture)
 
@@ -245,7 +245,7 @@ def test_scene_local_ba_after_each_new_image_matches_fresh_problems_and_oracle(m
             ro, _ = oracle.solve(qo, oracle.options(**opts), jac_mode=1)
             assert res["termination"] == ro["termination"] and res["num_successful_steps"] == ro["num_successful_steps"]
             assert abs(res["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
-            assert rel_err(q.poses, qo.poses) < 1e-6 and rel_err(q.points, qo.points) < 1e-6
+            assert_params_close(q, qo)
         # the last call started from what the previous ones left behind
         assert not np.array_equal(sc.get_image(7)[0], fm.poses[6, :3])
 
