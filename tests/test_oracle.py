@@ -263,6 +263,44 @@ def test_point_errors_follow_reference_definition(oracle):
     assert rel_err(perr, expect) < 1e-12
 
 
+@pytest.mark.parametrize("kind", ["mixed_priors_long_tracks", "cata_constant_blocks"])
+def test_sparse_linear_solver_mode_equals_the_dense_one(oracle, kind):
+    """Linear-solver mode 1 (block-sparse Schur complement with one owner thread per row block + envelope Cholesky) is
+    the arithmetic of the dense checker path in another order: same S, v, step and the same complete solve. It is what
+    bench.py's cpu_baseline times and what checks the full-size C5 step, where the dense path would take minutes."""
+    from mavmap_amd import _abi as A, synth
+    if kind == "mixed_priors_long_tracks":
+        p = synth.make_scene(num_images=40, num_points=3000, track_len=5, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=3,
+                             rot_priors=True, long_track_frac=0.02, long_track_len=12)
+    else:
+        p = synth.make_scene(num_images=12, num_points=500, track_len=4, models=[A.MODEL_CATA], seed=5)
+        p.pose_const[3] = 15
+        p.point_const[::7] = 1
+    results = {}
+    for threads in (1, 3):
+        oracle.set_threads(threads)
+        dense = oracle.linear_step(p, 100.0, jac_mode=1)
+        with oracle.linear_solver(oracle.SPARSE):
+            sparse = oracle.linear_step(p, 100.0, jac_mode=1)
+            q = p.copy()
+            rs, _ = oracle.solve(q, oracle.options(**global_opts()), jac_mode=1)
+        for k in ("S", "v"):
+            assert rel_err(sparse[k], dense[k]) < 1e-13, k
+        for k in ("d_poses", "d_intr", "d_points"):
+            assert rel_err(sparse[k], dense[k]) < 1e-10, k
+        assert abs(sparse["model_cost_change"] - dense["model_cost_change"]) < 1e-10 * abs(dense["model_cost_change"])
+        results[threads] = (sparse, rs, q)
+    oracle.set_threads(1)
+    qd = p.copy()
+    rd, _ = oracle.solve(qd, oracle.options(**global_opts()), jac_mode=1)
+    for threads, (sparse, rs, q) in results.items():
+        assert rs["termination"] == rd["termination"] and rs["num_successful_steps"] == rd["num_successful_steps"]
+        assert abs(rs["final_cost"] - rd["final_cost"]) < 1e-9 * rd["final_cost"]
+        assert rel_err(q.poses, qd.poses) < 1e-7
+    # every row block has one owner and chunk partials are added in chunk order: no dependence on the thread count
+    assert np.array_equal(results[1][0]["S"], results[3][0]["S"]) and np.array_equal(results[1][0]["d_points"], results[3][0]["d_points"])
+
+
 def test_dense_cholesky_of_oracle(oracle):
     rng = np.random.default_rng(2)
     for n in (1, 7, 64, 130):
