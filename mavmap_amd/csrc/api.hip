@@ -172,7 +172,7 @@ int mavba_session_set_params(mavba_session* s, const double* poses, const double
       for (int e = 0; e < 3; ++e) hp[(size_t)q * 3 + e] = points[(size_t)s->h_pt_orig[q] * 3 + e];
     HIP_OK(hipMemcpyAsync(s->d_points.p, hp.data(), hp.size() * 8, hipMemcpyHostToDevice, s->st));
   }
-  s->camrec_current = false; s->evaluated = false;
+  s->camrec_current = false; s->evaluated = false; s->front_valid = false;
   s->sync();
   return MAVBA_OK;
   MAVBA_CATCH
@@ -262,6 +262,9 @@ int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, doubl
   MAVBA_SESSION_TRY(s)
   s->evaluate();
   if (cost) *cost = s->cost + s->fixed_cost;
+  // probe path: the Jacobian planes are not part of the solve any more (J-free front end); materialise them here
+  s->ensure_planes();
+  launch_jacobian_sweep(s->st, s->sweep_args(s->d_camrec.p, s->d_intr.p, s->d_points.p));
   const size_t S = s->Nstride, N = s->N;
   auto pull = [&](const double* dev, int planes, std::vector<double>& h) {
     h.resize((size_t)planes * S);
@@ -326,7 +329,7 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, 
   if (d_points && s->NP) { hdp.resize((size_t)s->NP * 3); HIP_OK(hipMemcpyAsync(hdp.data(), s->d_delta_pts.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st)); }
   s->sync();
   if (d_points) s->to_caller_points(hdp.data(), d_points, 3);
-  if (h[SC_FAIL] != 0.0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "linear solve failed (matrix not positive definite)");
+  if (h[SC_FAIL] != 0.0 || h[SC_FAIL_FRONT] != 0.0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "linear solve failed (matrix not positive definite)");
   return MAVBA_OK;
   MAVBA_CATCH
 }
@@ -334,6 +337,7 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, 
 int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   MAVBA_SESSION_TRY(s)
   if (reps < 1) reps = 1;
+  s->ensure_planes();  // (the materialising sweep is a probe: SURVEY 8(d) prices the Jacobian kernel with J written out)
   launch_cam_prepare(s->st, s->NI, s->d_poses.p, s->d_camrec.p);
   SweepArgs a = s->sweep_args(s->d_camrec.p, s->d_intr.p, s->d_points.p);
   launch_jacobian_sweep(s->st, a);  // warm-up

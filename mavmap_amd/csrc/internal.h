@@ -83,7 +83,8 @@ enum {
   SC_STEP_NORM2,      // |delta|^2
   SC_MODEL_CHANGE,    // model cost change
   SC_CAND_XNORM2,     // |x + delta|^2
-  SC_FAIL,            // > 0: linear solve failed (non-SPD point block or pivot)
+  SC_FAIL,            // > 0: the reduced solve failed (non-positive pivot; >= 1e30: the persistent launch gave up)
+  SC_FAIL_FRONT,      // > 0: a point's damped 3x3 block is not SPD (written by the front end, which may run once for several solves)
   SC_CAND_END,
   SC_EVAL_COUNT = SC_GRAD_MAX + 1,
   SC_CAND_BEGIN = SC_NEW_COST,
@@ -112,6 +113,32 @@ void launch_point_reduce(hipStream_t st, int NP, int NPs, int Nstride, int KMAX,
                          const int* q_start, const int* q_cam, const int* obs_img, const int* img_cam,
                          const double* R, const double* Jp, const double* Jk, double* Cu, double* gu,
                          double* Wk /*[Q][27]*/);
+
+// ---- J-free, point-major Schur front end (k_point_front) ------------------------------------------------------
+// One work-group per TILE of consecutive points (<= kFrontObs observations, <= kFrontPts points, <= kFrontQ (point,
+// camera) intrinsics entries; a point with more observations than a tile holds is a tile of its own and is walked in
+// windows). Residual and Jacobian of every observation are computed in registers, never stored: the per-point sums
+// Cu = sum Jp^T Jp, gu = sum Jp^T r and Wk = sum Jk^T Jp go through LDS, the point's damped 3x3 block is factorised and
+// the pose / intrinsics Schur entry records are written directly. The trust-region radius is a kernel argument: a
+// rejected step re-runs the kernel, no Jacobian is kept between linear solves.
+constexpr int kFrontObs = 256, kFrontPts = 64, kFrontQ = 96, kFrontMaxGrid = 65536;  // (one tile per work-group up to 65536 tiles, then contiguous runs)
+struct FrontTile { int p0, p1; };
+struct FrontArgs {
+  SweepArgs sw;                         // observations, cameras, points, loss, pt_active; cost_partial [grid]
+  int num_tiles, NPs;
+  const FrontTile* tiles;
+  const int* pt_start; const int* q_start; const int* q_cam; const int* q_pt;
+  const unsigned char* pt_free;
+  const double* scale_cam; const double* scale_pt;
+  double radius, dmin, dmax;
+  double* Cu; double* gu; double* Gi; double* h;   // per-point planes, stride NPs
+  double* Epose; double* Eintr;                     // entry records (kPoseRec / kIntrRec doubles)
+  double* fail;
+};
+int point_front_grid(int num_tiles);
+// kmax_intr: 0 when no intrinsics block is free (no Wk products), else the widest camera model (4, 8, 9).
+// entries false: only Cu, gu and the cost (the first evaluation of a solve, before the Jacobi scales exist).
+void launch_point_front(hipStream_t st, const FrontArgs& a, int kmax_intr, bool entries);
 
 struct CamSweepArgs {
   int NI, NC;

@@ -12,6 +12,7 @@
 // partial -> single-block final pass), so results are bit-reproducible run to run.
 #include "internal.h"
 #include <cstdlib>
+#include <type_traits>
 #include "ba_math.h"
 #include "dev_reduce.h"
 
@@ -390,6 +391,314 @@ void launch_point_reduce(hipStream_t st, int NP, int NPs, int Nstride, int KMAX,
                                        obs_img, img_cam, R, Jp, Jk, Cu, gu, Wk)
   if (KMAX <= 4) MAVBA_PR(4); else if (KMAX <= 8) MAVBA_PR(8); else MAVBA_PR(9);
 #undef MAVBA_PR
+}
+
+// ---------------------------------------------------------------------------
+// K2: the J-free, point-major Schur front end (layout in internal.h). Per tile of consecutive points:
+//   phase 1  one observation per lane: residual + Jacobian in registers (never stored), the 9 + 3 K products of the
+//            observation parked in LDS (two rounds share the buffer), then one lane per (point, value) / ((point, camera),
+//            value) adds the point's observations in order - a fixed sequential sum, independent of the tiling;
+//   owner    one lane per point: Cu, gu out; damped block C = S Cu S + D^2, Gi = chol(C)^-1, h = Gi S gu
+//            (the Schur eliminator's e-block step, D^2 = clamp(diag) / radius);
+//   phase 2  intrinsics entry records from the Wk sums (one lane per (record, parameter)), pose entry records from the
+//            Jacobians still in registers (staged through LDS, coalesced stores).
+// HBM traffic: 48 B read per observation; 192 B / observation + 288 B / (point, camera) + 144 B / point written.
+// The Jacobian planes (272 / 336 B per observation written, 400 - 500 B re-read by three kernels) are gone.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kFrPitch = kFrontObs + 1;  // park row pitch: rows v, v + 1 of one observation are one bank pair apart
+template <int KMAX>
+struct FrontShape {
+  static constexpr int K3 = 3 * KMAX, NROWS = 9 + K3;
+  static constexpr int ROUNDS = KMAX > 0 ? 2 : 1;
+  static constexpr int NR = (NROWS + ROUNDS - 1) / ROUNDS;  // park rows per round; >= 9: the point rows are all in round 0
+  static constexpr int PARK = NR * kFrPitch, SQ = kFrontQ * K3;
+  static constexpr int REC = 128 * 25;  // half a tile of pose records (pitch 25) is staged at a time
+  static constexpr int A = (PARK + SQ) > REC ? (PARK + SQ) : REC;
+  static constexpr int DOUBLES = A + kFrontPts * 9 + kFrontPts * 12 + 4;
+  static constexpr int INTS = (kFrontPts + 1) + kFrontObs + 2 * kFrontQ + 3;
+  static constexpr size_t BYTES = (size_t)DOUBLES * 8 + (size_t)INTS * 4;
+  static_assert(NR >= 9, "point rows must fit the first round");
+};
+}  // namespace
+
+template <int KMAX, bool ENTRIES, bool MASK>
+__global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
+  using SH = FrontShape<KMAX>;
+  extern __shared__ __attribute__((aligned(16))) double fr_smem[];
+  double* s_park = fr_smem;                         // [NR][kFrPitch] the window's products of this round
+  double* s_q = fr_smem + SH::PARK;                 // [kFrontQ][K3]  Wk sums
+  double* s_rec = fr_smem;                          // pose records of half a window (aliases park | s_q once they are consumed)
+  double* s_sum = fr_smem + SH::A;                  // [kFrontPts][9] Cu(6) gu(3) sums
+  double* s_g = s_sum + kFrontPts * 9;              // [kFrontPts][12] Gi(6) h(3) scale(3)
+  double* s_red = s_g + kFrontPts * 12;             // [4]
+  int* s_pb = reinterpret_cast<int*>(s_red + 4);    // [kFrontPts + 1] first observation of the tile's points
+  int* s_cam = s_pb + kFrontPts + 1;                // [kFrontObs] camera of the window's observations
+  int* s_qcam = s_cam + kFrontObs;                  // [kFrontQ] camera of the tile's intrinsics entries
+  int* s_qpt = s_qcam + kFrontQ;                    // [kFrontQ] their point (index within the tile)
+  const int tid = threadIdx.x;
+  const SweepArgs& w = a.sw;
+  const int NPs = a.NPs;
+  const int t_begin = (int)((long long)a.num_tiles * blockIdx.x / gridDim.x);
+  const int t_end = (int)((long long)a.num_tiles * (blockIdx.x + 1) / gridDim.x);
+  double cost = 0.0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const FrontTile T = a.tiles[tile];
+    const int np = T.p1 - T.p0;
+    const int o0 = a.pt_start[T.p0], o1 = a.pt_start[T.p1];
+    int q0 = 0, nq = 0;
+    if constexpr (KMAX > 0) { q0 = a.q_start[T.p0]; nq = a.q_start[T.p1] - q0; }
+    for (int j = tid; j <= np; j += 256) s_pb[j] = a.pt_start[T.p0 + j];
+    for (int i = tid; i < np * 9; i += 256) s_sum[i] = 0.0;
+    if constexpr (KMAX > 0) {
+      for (int q = tid; q < nq; q += 256) { s_qcam[q] = a.q_cam[q0 + q]; s_qpt[q] = a.q_pt[q0 + q] - T.p0; }
+      for (int i = tid; i < nq * SH::K3; i += 256) s_q[i] = 0.0;
+    }
+    __syncthreads();
+    const bool single = o1 - o0 <= kFrontObs;  // (all but tiles made of one very long track)
+    // the observation's weighted Jacobian blocks stay in registers from phase 1 to phase 2
+    double jc[12], jp[6];
+    int im = 0, lp = 0;
+    bool act = false;
+    // residual + Jacobian of observation o, rows weighted by sqrt(rho'); returns rho / 2
+    auto eval_obs = [&](int o, double (&rr)[2], double (&jk)[18], int& cam) -> double {
+      im = w.obs_img[o];
+      const int pt = w.obs_pt[o];
+      lp = pt - T.p0;
+      const double2 m = w.uv[o];
+      cam = w.img_cam[im];
+      const int model = w.cam_model[cam];
+      double rec[9], kin[9], X[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) rec[k] = w.camrec[9 * im + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) kin[k] = w.intr[9 * cam + k];
+      X[0] = w.points[3 * (long long)pt]; X[1] = w.points[3 * (long long)pt + 1]; X[2] = w.points[3 * (long long)pt + 2];
+      double r[2], Jc[12], Jp[6], Jk[18];
+      obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
+      double wgt, half_rho;
+      cauchy_weight(r[0] * r[0] + r[1] * r[1], w.loss_b, w.loss_inv_b, wgt, half_rho);
+      if constexpr (MASK) { if (!w.pt_active[pt]) { wgt = 0.0; half_rho = 0.0; } }  // filtered point: no residual block
+      rr[0] = wgt * r[0]; rr[1] = wgt * r[1];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) jc[e] = wgt * Jc[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) jp[e] = wgt * Jp[e];
+#pragma unroll
+      for (int e = 0; e < 18; ++e) jk[e] = wgt * Jk[e];
+      return half_rho;
+    };
+    // ---- phase 1: per-point sums ----
+    for (int base = o0; base < o1; base += kFrontObs) {
+      const int o = base + tid;
+      act = o < o1;
+      double prod[SH::NROWS];
+      if (act) {
+        double rr[2], jk[18];
+        int cam;
+        cost += eval_obs(o, rr, jk, cam);
+        s_cam[tid] = cam;
+        prod[0] = jp[0] * jp[0] + jp[3] * jp[3]; prod[1] = jp[0] * jp[1] + jp[3] * jp[4]; prod[2] = jp[0] * jp[2] + jp[3] * jp[5];
+        prod[3] = jp[1] * jp[1] + jp[4] * jp[4]; prod[4] = jp[1] * jp[2] + jp[4] * jp[5]; prod[5] = jp[2] * jp[2] + jp[5] * jp[5];
+        prod[6] = jp[0] * rr[0] + jp[3] * rr[1]; prod[7] = jp[1] * rr[0] + jp[4] * rr[1]; prod[8] = jp[2] * rr[0] + jp[5] * rr[1];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) prod[9 + 3 * k + t] = jk[k] * jp[t] + jk[9 + k] * jp[3 + t];
+      }
+      auto round = [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        constexpr int lo = R * SH::NR, hi = (lo + SH::NR < SH::NROWS) ? lo + SH::NR : SH::NROWS;
+        constexpr int PR = R == 0 ? 9 : 0;                       // point rows parked in this round
+        constexpr int wlo = (lo > 9 ? lo : 9) - 9, WR = hi - 9 - wlo;  // Wk values [wlo, wlo + WR) parked in this round
+        if (act) {
+#pragma unroll
+          for (int v = lo; v < hi; ++v) s_park[(v - lo) * kFrPitch + tid] = prod[v];
+        }
+        __syncthreads();
+        const int nit = np * PR + nq * WR;
+        for (int it = tid; it < nit; it += 256) {
+          if (it < np * PR) {
+            const int j = it / 9, v = it - 9 * j;
+            const int b = max(s_pb[j], base), e = min(s_pb[j + 1], base + kFrontObs);
+            const double* row = s_park + v * kFrPitch - base;
+            double acc = s_sum[it];
+            int i = b;
+            for (; i + 4 <= e; i += 4) {  // four loads in flight, the adds stay in observation order
+              const double x0 = row[i], x1 = row[i + 1], x2 = row[i + 2], x3 = row[i + 3];
+              acc += x0; acc += x1; acc += x2; acc += x3;
+            }
+            for (; i < e; ++i) acc += row[i];
+            s_sum[it] = acc;
+          } else if constexpr (WR > 0) {
+            const int t2 = it - np * PR;
+            const int q = t2 / WR, vv = wlo + (t2 - q * WR);
+            const int j = s_qpt[q], c = s_qcam[q];
+            const int b = max(s_pb[j], base), e = min(s_pb[j + 1], base + kFrontObs);
+            const double* row = s_park + (vv + 9 - lo) * kFrPitch - base;
+            const int* camv = s_cam - base;
+            double acc = s_q[q * SH::K3 + vv];
+            int i = b;
+            for (; i + 4 <= e; i += 4) {  // (adding 0.0 for another camera's observation leaves the sum as it is)
+              const double x0 = row[i], x1 = row[i + 1], x2 = row[i + 2], x3 = row[i + 3];
+              const int c0 = camv[i], c1 = camv[i + 1], c2 = camv[i + 2], c3 = camv[i + 3];
+              acc += c0 == c ? x0 : 0.0; acc += c1 == c ? x1 : 0.0; acc += c2 == c ? x2 : 0.0; acc += c3 == c ? x3 : 0.0;
+            }
+            for (; i < e; ++i) acc += camv[i] == c ? row[i] : 0.0;
+            s_q[q * SH::K3 + vv] = acc;
+          }
+        }
+        __syncthreads();
+      };
+      round(std::integral_constant<int, 0>{});
+      if constexpr (SH::ROUNDS > 1) round(std::integral_constant<int, 1>{});
+    }
+    // ---- owner lanes: the point's sums out, its damped block factorised ----
+    if (tid < np) {
+      const int p = T.p0 + tid;
+      double C6[6], g3[3];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) C6[k] = s_sum[tid * 9 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g3[k] = s_sum[tid * 9 + 6 + k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a.Cu[(size_t)k * NPs + p] = C6[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a.gu[(size_t)k * NPs + p] = g3[k];
+      if constexpr (ENTRIES) {
+        const bool fr = a.pt_free[p] != 0;
+        double G[6] = {0, 0, 0, 0, 0, 0}, hh[3] = {0, 0, 0}, sp[3] = {0, 0, 0};
+        if (fr) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) sp[k] = a.scale_pt[(size_t)k * NPs + p];
+          double C[6];
+          C[0] = sp[0] * sp[0] * C6[0]; C[1] = sp[0] * sp[1] * C6[1]; C[2] = sp[0] * sp[2] * C6[2];
+          C[3] = sp[1] * sp[1] * C6[3]; C[4] = sp[1] * sp[2] * C6[4]; C[5] = sp[2] * sp[2] * C6[5];
+          C[0] += clampd(C[0], a.dmin, a.dmax) / a.radius;
+          C[3] += clampd(C[3], a.dmin, a.dmax) / a.radius;
+          C[5] += clampd(C[5], a.dmin, a.dmax) / a.radius;
+          bool fin = chol3_inv(C, G);
+          const double gs[3] = {sp[0] * g3[0], sp[1] * g3[1], sp[2] * g3[2]};
+          gi_mul(G, gs, hh);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) fin = fin && isfinite(G[k]);
+          if (!fin) atomicAdd(a.fail, 1.0);
+        }
+        if (s_pb[tid + 1] > s_pb[tid]) {  // (points without observations keep the zeros of the set-up: nothing reads them)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) a.Gi[(size_t)k * NPs + p] = G[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a.h[(size_t)k * NPs + p] = hh[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_g[tid * 12 + k] = G[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_g[tid * 12 + 6 + k] = hh[k]; s_g[tid * 12 + 9 + k] = sp[k]; }
+      }
+    }
+    if constexpr (ENTRIES) {
+      __syncthreads();
+      // ---- intrinsics entry records: Uk = (s_k Wk s_p) Gi^T (9 x 3), ek = Uk h; one lane per (record, parameter) ----
+      if constexpr (KMAX > 0) {
+        for (int it = tid; it < nq * 9; it += 256) {
+          const int q = it / 9, k = it - 9 * q;
+          const double* g = s_g + s_qpt[q] * 12;
+          double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+          if (k < KMAX) {
+            const double sk = a.scale_cam[6 * w.NI + 9 * s_qcam[q] + k];
+            const double* W = s_q + q * SH::K3 + 3 * k;
+            w0 = W[0] * sk * g[9]; w1 = W[1] * sk * g[10]; w2 = W[2] * sk * g[11];
+          }
+          const double u0 = w0 * g[0];
+          const double u1 = w0 * g[1] + w1 * g[2];
+          const double u2 = w0 * g[3] + w1 * g[4] + w2 * g[5];
+          double* out = a.Eintr + (size_t)(q0 + q) * kIntrRec;
+          out[3 * k] = u0; out[3 * k + 1] = u1; out[3 * k + 2] = u2;
+          out[27 + k] = u0 * g[6] + u1 * g[7] + u2 * g[8];
+        }
+        __syncthreads();  // the Wk sums are consumed: their LDS becomes the record staging buffer
+      }
+      // ---- pose entry records: U_a = (Jc' ^T Jp') Gi^T (6 x 3), e_a = U_a h ----
+      for (int base = o0; base < o1; base += kFrontObs) {
+        const int o = base + tid;
+        if (!single) {
+          act = o < o1;
+          if (act) { double rr[2], jk[18]; int cam; (void)eval_obs(o, rr, jk, cam); }
+        }
+        double rec[kPoseRec];
+#pragma unroll
+        for (int k = 0; k < kPoseRec; ++k) rec[k] = 0.0;
+        if (act && a.pt_free[T.p0 + lp]) {
+          const double* g = s_g + lp * 12;
+          double jps[6];
+#pragma unroll
+          for (int row = 0; row < 2; ++row)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) jps[row * 3 + k] = jp[row * 3 + k] * g[9 + k];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            const double sc = a.scale_cam[6 * im + e];
+            const double j0 = jc[e] * sc, j1 = jc[6 + e] * sc;
+            const double w0 = j0 * jps[0] + j1 * jps[3], w1 = j0 * jps[1] + j1 * jps[4], w2 = j0 * jps[2] + j1 * jps[5];
+            const double u0 = w0 * g[0];
+            const double u1 = w0 * g[1] + w1 * g[2];
+            const double u2 = w0 * g[3] + w1 * g[4] + w2 * g[5];
+            rec[3 * e] = u0; rec[3 * e + 1] = u1; rec[3 * e + 2] = u2;
+            rec[18 + e] = u0 * g[6] + u1 * g[7] + u2 * g[8];
+          }
+        }
+        const long long lim = (long long)o1 * kPoseRec;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if ((tid >> 7) == half) {
+#pragma unroll
+            for (int k = 0; k < kPoseRec; ++k) s_rec[(tid & 127) * 25 + k] = rec[k];
+          }
+          __syncthreads();
+          const long long gbase = ((long long)base + half * 128) * kPoseRec;
+          for (int i = tid; i < 128 * kPoseRec; i += 256) {
+            const int t = i / kPoseRec, k = i - t * kPoseRec;
+            if (gbase + i < lim) a.Epose[gbase + i] = s_rec[t * 25 + k];
+          }
+          __syncthreads();
+        }
+      }
+    } else {
+      __syncthreads();  // (the next tile re-initialises the sums)
+    }
+  }
+  const double tot = block_sum_256(cost, s_red);
+  if (tid == 0) w.cost_partial[blockIdx.x] = tot;
+}
+
+int point_front_grid(int num_tiles) { return num_tiles < 1 ? 0 : (num_tiles > kFrontMaxGrid ? kFrontMaxGrid : num_tiles); }
+void launch_point_front(hipStream_t st, const FrontArgs& a, int kmax_intr, bool entries) {
+  const int grid = point_front_grid(a.num_tiles);
+  if (grid <= 0) return;
+  const bool mask = a.sw.pt_active != nullptr;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+#define MAVBA_FRONT_LAUNCH(K, E, M)                                                                                     \
+  {                                                                                                                     \
+    static bool configured[64] = {};  /* per device: more than 64 KiB of dynamic LDS has to be asked for */            \
+    if (dev >= 0 && dev < 64 && !configured[dev]) {                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_front<K, E, M>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)FrontShape<K>::BYTES);                                                             \
+      configured[dev] = true;                                                                                           \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((k_point_front<K, E, M>), dim3(grid), dim3(256), FrontShape<K>::BYTES, st, a);                   \
+  }
+#define MAVBA_FRONT_K(K)                                                                       \
+  {                                                                                            \
+    if (entries) { if (mask) MAVBA_FRONT_LAUNCH(K, true, true) else MAVBA_FRONT_LAUNCH(K, true, false) }   \
+    else { if (mask) MAVBA_FRONT_LAUNCH(K, false, true) else MAVBA_FRONT_LAUNCH(K, false, false) }         \
+  }
+  if (kmax_intr <= 0) MAVBA_FRONT_K(0)
+  else if (kmax_intr <= 4) MAVBA_FRONT_K(4)
+  else if (kmax_intr <= 8) MAVBA_FRONT_K(8)
+  else MAVBA_FRONT_K(9)
+#undef MAVBA_FRONT_K
+#undef MAVBA_FRONT_LAUNCH
 }
 
 // ---------------------------------------------------------------------------

@@ -251,6 +251,14 @@ struct mavba_session {
   DevBuf<double2> d_uv, d_im_uv;
   DevBuf<int> d_obs_img, d_obs_pt, d_pt_start, d_im_pt, d_img_cam, d_cam_model, d_img_chunk_start,
       d_cam_img_start, d_cam_imgs, d_prior_img, d_prior_start, d_q_pt, d_q_cam, d_q_start, d_pt_count;
+  // J-free front end (k_point_front): tiles of consecutive points; front_ok false = a point has more intrinsics entries
+  // than a tile holds (or MAVBA_FRONT_PLANES is set): the Jacobian-plane kernels are used instead
+  DevBuf<FrontTile> d_front_tiles;
+  int num_front_tiles = 0;
+  bool front_ok = false;
+  bool front_valid = false;     // Cu, gu, Gi, h and the entry records match the current x, scales and front_radius
+  double front_radius = 0.0;
+  bool planes_ready = false;    // the Jacobian planes exist (probe path / plane kernels only)
   DevBuf<SweepChunk> d_sweep_chunks;
   int num_sweep_chunks = 0;
   DevBuf<unsigned char> d_pose_free, d_intr_free, d_pt_free;
@@ -400,8 +408,14 @@ struct mavba_session {
   void finish_structure();
   void choose_elimination_order(const std::vector<SchurBlock>& blocks);
   void reset_state();
-  void evaluate();
-  void evaluate_enqueue();  // the launches of evaluate() without reading the scalars back
+  // next_radius > 0: the trust-region radius of the linear solve that follows (the front end then writes the Schur entry
+  // records in the same pass); <= 0: unknown
+  void evaluate(double next_radius = -1.0);
+  void evaluate_enqueue(double next_radius = -1.0);  // the launches of evaluate() without reading the scalars back
+  void launch_front(double r, bool entries);
+  void build_front_tiles(const std::vector<int>& q_start);
+  void ensure_planes();
+  int eval_cost_rows() const { return front_ok ? point_front_grid(num_front_tiles) : (N > 0 ? jacobian_sweep_grid(N) : 0); }
   void take_evaluation(const double* h) { cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]); }
   void assemble(double r);
   void solve_linear(double r);
@@ -416,7 +430,7 @@ struct mavba_session {
     HIP_OK(hipMemcpyAsync(d_poses.p, d_poses0.p, (size_t)NI * 6 * 8, hipMemcpyDeviceToDevice, st));
     HIP_OK(hipMemcpyAsync(d_intr.p, d_intr0.p, (size_t)NC * 9 * 8, hipMemcpyDeviceToDevice, st));
     HIP_OK(hipMemcpyAsync(d_points.p, d_points0.p, (size_t)NP * 3 * 8, hipMemcpyDeviceToDevice, st));
-    camrec_current = false; evaluated = false;
+    camrec_current = false; evaluated = false; front_valid = false;
   }
   void apply_filter_state();  // counts, used / free flags, fixed cost from h_pt_removed (empty = the problem as built)
   void to_caller_points(const double* internal, double* out, int width) const {

@@ -317,13 +317,12 @@ void mavba_session::build(const mavba_problem* P) {
   d_poses.alloc(nI * 6); d_intr.alloc(nC * 9); d_points.alloc(nP * 3);
   d_cposes.alloc(nI * 6); d_cintr.alloc(nC * 9); d_cpoints.alloc(nP * 3);
   d_camrec.alloc(nI * 9); d_ccamrec.alloc(nI * 9);
-  d_R.alloc((size_t)2 * Nstride); d_Jp.alloc((size_t)6 * Nstride); d_Jc.alloc((size_t)12 * Nstride);
-  d_Jk.alloc((size_t)2 * KMAX * Nstride);
+  // (the Jacobian planes R / Jp / Jc / Jk are allocated on demand: ensure_planes - the solve itself is J-free)
   d_Cu.alloc((size_t)6 * NPs); d_gu.alloc((size_t)3 * NPs); d_Gi.alloc((size_t)6 * NPs); d_h.alloc((size_t)3 * NPs);
   d_Gi.zero(st); d_h.zero(st);  // (written per linear solve for the points that have observations; the others stay 0)
   d_scale_cam.alloc((size_t)n_pad); d_scale_pt.alloc((size_t)3 * NPs);
   d_scale_cam.zero(st); d_scale_pt.zero(st);
-  d_sweep_partial.alloc((size_t)jacobian_sweep_grid(std::max(N, 1)) + 8);
+  d_sweep_partial.alloc((size_t)std::max(jacobian_sweep_grid(std::max(N, 1)), kFrontMaxGrid) + 8);
   d_camsum.alloc(nI * kImgRec + nC * kCamRec);
   d_camsum.zero(st);
   d_img_rec = d_camsum.p; d_cam_rec = d_camsum.p + (size_t)NI * kImgRec;
@@ -663,7 +662,8 @@ void mavba_session::finish_structure() {
   Q = (int)q_pt.size();
   d_q_start.upload(q_start, st); d_q_pt.upload(q_pt, st); d_q_cam.upload(q_cam, st);
   d_Eintr.alloc((size_t)std::max(Q, 1) * kIntrRec);
-  d_Wk.alloc((size_t)std::max(Q, 1) * 27);
+  if (planes_ready) d_Wk.alloc((size_t)std::max(Q, 1) * 27);
+  build_front_tiles(q_start);
 
   lap("flags + intr entries");
   // ---- point clusters (k_schur_clusters): consecutive points whose images / cameras fit one local list ----
@@ -1006,7 +1006,32 @@ void mavba_session::finish_structure() {
   lap("upload terms");
 }
 
+// Tiles of the J-free front end: consecutive points, at most kFrontObs observations / kFrontPts points / kFrontQ intrinsics
+// entries each; a point with more observations than that is a tile of its own (walked in windows by the kernel).
+void mavba_session::build_front_tiles(const std::vector<int>& q_start) {
+  std::vector<FrontTile> tiles;
+  static const bool planes_only = std::getenv("MAVBA_FRONT_PLANES") != nullptr;
+  front_ok = !planes_only;
+  int p0 = 0, obs = 0, qs = 0;
+  for (int p = 0; p < NP && front_ok; ++p) {
+    const int c = h_pt_start[p + 1] - h_pt_start[p], nq = q_start[p + 1] - q_start[p];
+    if (nq > kFrontQ) { front_ok = false; break; }  // a point seen by that many refined cameras: plane kernels
+    if (p > p0 && (obs + c > kFrontObs || p - p0 >= kFrontPts || qs + nq > kFrontQ)) {
+      tiles.push_back(FrontTile{p0, p});
+      p0 = p; obs = 0; qs = 0;
+    }
+    obs += c; qs += nq;
+  }
+  if (front_ok && NP > p0) tiles.push_back(FrontTile{p0, NP});
+  if (!front_ok) tiles.clear();
+  num_front_tiles = (int)tiles.size();
+  d_front_tiles.upload(tiles, st);
+  front_valid = false;
+  if (!front_ok) ensure_planes();
+}
+
 void mavba_session::reset_state() {
+  front_valid = false;
   // back to the problem as built: points filtered out of the resident problem return with their initial coordinates
   if (!h_pt_removed.empty()) {
     h_pt_removed.clear();

@@ -19,15 +19,47 @@ using namespace mavba;
 // Evaluation at the current x: residuals, Jacobian, cost, gradient norm (ceres
 // Evaluator::Evaluate with jacobian != NULL).
 // ===========================================================================
-void mavba_session::evaluate_enqueue() {
+void mavba_session::ensure_planes() {
+  if (planes_ready) return;
+  d_R.alloc((size_t)2 * Nstride); d_Jp.alloc((size_t)6 * Nstride); d_Jc.alloc((size_t)12 * Nstride);
+  d_Jk.alloc((size_t)2 * KMAX * Nstride);
+  d_Wk.alloc((size_t)std::max(Q, 1) * 27);
+  planes_ready = true;
+}
+
+// The J-free front end at the current x: cost partials, Cu, gu and - with `entries` - the points' factors and the Schur
+// entry records for trust-region radius r.
+void mavba_session::launch_front(double r, bool entries) {
+  FrontArgs f;
+  f.sw = sweep_args(d_camrec.p, d_intr.p, d_points.p);
+  f.num_tiles = num_front_tiles; f.NPs = NPs; f.tiles = d_front_tiles.p;
+  f.pt_start = d_pt_start.p; f.q_start = d_q_start.p; f.q_cam = d_q_cam.p; f.q_pt = d_q_pt.p;
+  f.pt_free = d_pt_free.p; f.scale_cam = d_scale_cam.p; f.scale_pt = d_scale_pt.p;
+  f.radius = r; f.dmin = opt.min_lm_diagonal; f.dmax = opt.max_lm_diagonal;
+  f.Cu = d_Cu.p; f.gu = d_gu.p; f.Gi = d_Gi.p; f.h = d_h.p; f.Epose = d_Epose.p; f.Eintr = d_Eintr.p;
+  f.fail = d_scal.p + SC_FAIL_FRONT;
+  if (entries) HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL_FRONT, 0, sizeof(double), st));
+  timed(entries ? "point_front" : "point_front_sums", [&] { launch_point_front(st, f, Q > 0 ? KMAX : 0, entries); });
+  front_valid = entries;
+  front_radius = r;
+}
+
+void mavba_session::evaluate_enqueue(double next_radius) {
   if (!camrec_current) timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
   camrec_current = true;
   SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
-  timed("jacobian_sweep", [&] { launch_jacobian_sweep(st, a); });
-  timed("point_reduce", [&] {
-    launch_point_reduce(st, NP, NPs, Nstride, KMAX, d_pt_start.p, d_q_start.p, d_q_cam.p, d_obs_img.p, d_img_cam.p,
-                        d_R.p, d_Jp.p, d_Jk.p, d_Cu.p, d_gu.p, d_Wk.p);
-  });
+  if (front_ok) {
+    // one pass: the evaluation's sums and (once the Jacobi scales exist and the next radius is known) the entries
+    launch_front(next_radius, scales_ready && next_radius > 0.0);
+  } else {
+    ensure_planes();
+    front_valid = false;
+    timed("jacobian_sweep", [&] { launch_jacobian_sweep(st, a); });
+    timed("point_reduce", [&] {
+      launch_point_reduce(st, NP, NPs, Nstride, KMAX, d_pt_start.p, d_q_start.p, d_q_cam.p, d_obs_img.p, d_img_cam.p,
+                          d_R.p, d_Jp.p, d_Jk.p, d_Cu.p, d_gu.p, d_Wk.p);
+    });
+  }
   CamSweepArgs c;
   c.NI = NI; c.NC = NC; c.chunks = d_sweep_chunks.p; c.num_chunks = num_sweep_chunks;
   c.im_uv = d_im_uv.p; c.im_pt = d_im_pt.p; c.camrec = d_camrec.p; c.intr = d_intr.p;
@@ -59,18 +91,17 @@ void mavba_session::evaluate_enqueue() {
                        d_intr.p, d_points.p, d_img_rec, d_cam_rec, d_gu.p, d_norm_partial.p, &rows);
   });
   timed("reduce", [&] {
-    const int nsweep = N > 0 ? jacobian_sweep_grid(N) : 0;
     ReduceTasks T;
     T.t[0] = ReduceTask{d_norm_partial.p, rows, 2, 1, nullptr, 0, d_scal.p + SC_GRAD_MAX};
     T.t[1] = ReduceTask{d_norm_partial.p + 1, rows, 2, 0, nullptr, 0, d_scal.p + SC_XNORM2};
-    T.t[2] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
+    T.t[2] = ReduceTask{d_sweep_partial.p, eval_cost_rows(), 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
     launch_reduce_tasks(st, T, 3);
   });
   if (sharded()) allreduce(d_scal.p + SC_COST, SC_EVAL_COUNT, 2);  // the evaluation's two sums, then max|g| (never the candidate's slots)
   evaluated = true; assembled = false;
 }
-void mavba_session::evaluate() {
-  evaluate_enqueue();
+void mavba_session::evaluate(double next_radius) {
+  evaluate_enqueue(next_radius);
   double h[SC_COUNT];
   read_scalars(h);
   take_evaluation(h);
@@ -81,16 +112,23 @@ void mavba_session::evaluate() {
 void mavba_session::assemble(double r) {
   const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
   HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, sizeof(double), st));
-  // (the points' 3x3 factors are computed inside the entries kernel: one launch; points without observations are not free)
-  timed("entries_pose", [&] {
-    launch_factor_entries_pose(st, N, Nstride, NPs, d_obs_img.p, d_obs_pt.p, d_pt_free.p, d_Jc.p, d_Jp.p, d_scale_cam.p,
-                               d_scale_pt.p, d_Gi.p, d_h.p, d_Epose.p, d_pt_start.p, d_Cu.p, d_gu.p, r, dmin, dmax,
-                               d_scal.p + SC_FAIL);
-  });
-  timed("entries_intr", [&] {
-    launch_entries_intr(st, Q, NI, NPs, d_q_pt.p, d_q_cam.p, d_Wk.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p,
-                        d_Eintr.p);
-  });
+  if (front_ok) {
+    // the entry records of this (x, radius) may already be there (written together with the evaluation); a rejected
+    // step comes back with a smaller radius: the front end runs again, Jacobians recomputed, nothing was stored
+    if (!(front_valid && front_radius == r)) launch_front(r, true);
+  } else {
+    HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL_FRONT, 0, sizeof(double), st));
+    // (the points' 3x3 factors are computed inside the entries kernel: one launch; points without observations are not free)
+    timed("entries_pose", [&] {
+      launch_factor_entries_pose(st, N, Nstride, NPs, d_obs_img.p, d_obs_pt.p, d_pt_free.p, d_Jc.p, d_Jp.p, d_scale_cam.p,
+                                 d_scale_pt.p, d_Gi.p, d_h.p, d_Epose.p, d_pt_start.p, d_Cu.p, d_gu.p, r, dmin, dmax,
+                                 d_scal.p + SC_FAIL);
+    });
+    timed("entries_intr", [&] {
+      launch_entries_intr(st, Q, NI, NPs, d_q_pt.p, d_q_cam.p, d_Wk.p, d_scale_cam.p, d_scale_pt.p, d_Gi.p, d_h.p,
+                          d_Eintr.p);
+    });
+  }
   // The assembly writes the same (structural) entries every time and the persistent factorisation only reads the
   // matrix: its zeros survive from one linear solve to the next. Only the launch-per-panel schedule, which factorises
   // in place, makes a fresh clear necessary.
@@ -240,7 +278,7 @@ int mavba_session::iterate(int max_iters, int* done) {
       }
     }
     const double mcc = h[SC_MODEL_CHANGE];
-    const bool solved = h[SC_FAIL] == 0.0 && std::isfinite(mcc) && std::isfinite(h[SC_STEP_NORM2]);
+    const bool solved = h[SC_FAIL] == 0.0 && h[SC_FAIL_FRONT] == 0.0 && std::isfinite(mcc) && std::isfinite(h[SC_STEP_NORM2]);
     const bool valid = solved && !(mcc < 0.0);
     bool successful = false;
     double rel = 0.0, step_norm = 0.0, cost_change = 0.0;
@@ -264,10 +302,10 @@ int mavba_session::iterate(int max_iters, int* done) {
       std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
       std::swap(d_camrec.p, d_ccamrec.p);  // the candidate's camera records are the new point's (camrec_current stays true)
       if (defer) {
-        evaluate_enqueue();
+        evaluate_enqueue(radius);
         pending_eval = true;
       } else {
-        evaluate();
+        evaluate(radius);
         if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
       }
     } else {
@@ -315,6 +353,7 @@ void mavba_session::point_errors(double* out) {
 // starts with a fresh trust region and re-estimates the Jacobi scaling), without any of the set-up.
 void mavba_session::restart() {
   evaluated = scales_ready = started = assembled = false;
+  front_valid = false;
   // The Jacobi scales are re-estimated: which columns are constant (unit diagonal) may differ from the previous solve
   // (filter_points), so the matrix is cleared and its constant / padding diagonal rewritten once (k_fix_diag).
   M_is_clean = false;
