@@ -376,6 +376,15 @@ int mavba_session_set_rccl(mavba_session* s, const void* unique_id128, int32_t r
 int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r,
                                 double* Jc, double* Jp, double* Jk);
 
+/* Test / debugging aid, needs no device: the elimination tree (nested-dissection order of the reduced camera system,
+ * what replaces CHOLMOD's fill-reducing ordering behind ceres SPARSE_SCHUR, bundle_adjustment.cc:555) the session
+ * set-up chooses for an image graph given as `npairs` coupled image pairs (images that share a 3-D point).
+ * node_of_image [NI]: tree node of every image; node_parent [cap]: parent of every node, -1 for the root; nodes are
+ * numbered in elimination order (children before parents). Returns the number of nodes, 0 = no dissection. */
+int mavba_debug_elimination_tree(int32_t num_images, int32_t num_cameras, int64_t npairs, const int32_t* pair_a,
+                                 const int32_t* pair_b, int32_t max_depth, int32_t* node_of_image, int32_t* node_parent,
+                                 int32_t cap);
+
 /* Build the reduced camera system for the current Jacobian and trust-region
  * radius and download it: S [n][n] row-major (both triangles), v [n], with
  * n = mavba_session_reduced_dim(). Column j of image i's pose is 6*i+j,

@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "mavba_scene_add_points2d", "mavba_scene_set_point3d", "mavba_scene_link", "mavba_scene_delete_point3d", "mavba_scene_get_image", "mavba_scene_get_point3d",
     "mavba_scene_get_camera", "mavba_scene_flatten", "mavba_scene_bundle_adjust",
     "mavba_rccl_unique_id", "mavba_session_set_rccl", "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
+    "mavba_debug_elimination_tree",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -110,6 +111,7 @@ def load():
     L.mavba_session_restart.argtypes = [sp]
     L.mavba_session_filter_points.argtypes = [sp, C.c_double, bp, bp, dp, C.POINTER(C.c_int64)]
     L.mavba_solve_filter_solve.argtypes = [pp, op, C.c_double, bp, rp, rp, dp, bp, C.POINTER(C.c_int64)]
+    L.mavba_debug_elimination_tree.argtypes = [C.c_int32, C.c_int32, C.c_int64, ip, ip, C.c_int32, ip, ip, C.c_int32]
     for f in EXPORTED_SYMBOLS:
         if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy", "mavba_scene_destroy"):
             getattr(L, f).restype = C.c_int
@@ -523,6 +525,20 @@ class Session:
         n = load().mavba_session_kernel_stats(self._h, buf, 64)
         return {buf[i].name.decode(): dict(launches=int(buf[i].launches), total_ms=float(buf[i].total_ms))
                 for i in range(min(n, 64))}
+
+
+def elimination_tree(num_images, num_cameras, pairs, max_depth=3):
+    """The elimination tree of the reduced camera system for an image graph (`pairs`: [n, 2] coupled images); no GPU
+    needed. Returns (node_of_image [num_images], node_parent [num_nodes]); no nodes = no dissection."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    a, b = np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
+    node = np.zeros(max(num_images, 1), np.int32)
+    parent = np.zeros(4096, np.int32)
+    n = load().mavba_debug_elimination_tree(int(num_images), int(num_cameras), len(a), A.ptr(a, C.c_int32), A.ptr(b, C.c_int32),
+                                           int(max_depth), A.ptr(node, C.c_int32), A.ptr(parent, C.c_int32), len(parent))
+    if n < 0:
+        _check(n)
+    return node[:num_images], parent[:n]
 
 
 def rccl_unique_id():

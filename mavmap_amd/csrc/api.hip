@@ -293,6 +293,31 @@ int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, doubl
 
 int mavba_session_reduced_dim(mavba_session* s) { return s ? s->n_full : 0; }
 
+// Debug / test entry (no device needed): the elimination tree the session set-up would choose for an image graph given
+// as `npairs` coupled image pairs. node_of_image [NI] receives every image's tree node, node_parent [cap] the parents
+// (-1: root); returns the number of nodes (0: no dissection) or a negative error code.
+int mavba_debug_elimination_tree(int32_t NI, int32_t NC, int64_t npairs, const int32_t* pair_a, const int32_t* pair_b, int32_t max_depth,
+                                 int32_t* node_of_image, int32_t* node_parent, int32_t cap) {
+  MAVBA_TRY
+  if (NI < 0 || NC < 0 || npairs < 0 || (npairs > 0 && (!pair_a || !pair_b)) || !node_of_image || !node_parent)
+    throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "bad argument");
+  std::vector<std::vector<int>> lower(NI);
+  for (int64_t k = 0; k < npairs; ++k) {
+    const int a = pair_a[k], b = pair_b[k];
+    if (a < 0 || a >= NI || b < 0 || b >= NI) throw Failure(MAVBA_ERR_BAD_INDEX, "image pair out of range");
+    if (a != b) lower[std::max(a, b)].push_back(std::min(a, b));
+  }
+  const std::vector<ElimNode> tn = elimination_tree(NI, NC, lower, -1, max_depth);
+  if ((int)tn.size() > cap) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "node_parent too small");
+  for (int i = 0; i < NI; ++i) node_of_image[i] = -1;
+  for (size_t t = 0; t < tn.size(); ++t) {
+    node_parent[t] = tn[t].parent;
+    for (int i : tn[t].imgs) node_of_image[i] = (int)t;
+  }
+  return (int)tn.size();
+  MAVBA_CATCH
+}
+
 int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, double* vout) {
   MAVBA_SESSION_TRY(s)
   if (!s->evaluated) s->evaluate();

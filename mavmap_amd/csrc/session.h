@@ -65,6 +65,10 @@ struct DevBuf {
   void zero(hipStream_t st) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
 };
 
+// session_build.hip: elimination tree of the reduced camera system (host only)
+struct ElimNode { std::vector<int> imgs; int parent; };
+std::vector<ElimNode> elimination_tree(int NI, int NC, const std::vector<std::vector<int>>& lower, int forced, int max_depth);
+
 // pose_refine.hip
 void pose_refine_batch(int count, mavba_pose_refine_item* items, const mavba_options& opt, mavba_result* results);
 

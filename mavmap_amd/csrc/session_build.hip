@@ -359,38 +359,14 @@ void mavba_session::build(const mavba_problem* P) {
 // separator S, and the remaining parts A_1..A_P are mutually uncoupled. Ordered [A_1 | .. | A_P | S |
 // intrinsics] their panels are factorised concurrently and the chain is max|A_p| + |S| instead of the sum.
 // P (and for P = 2 the cut position) is chosen to minimise that chain, P = 1 (no dissection) included.
-void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& blocks) {
-  const int tiles0 = std::max(1, round_up(n_full, 64) / 64);
-  // Tree of image sets in elimination order (children before parents, root last); the root also carries the
-  // intrinsics blocks. One node = no dissection.
-  struct TNode { std::vector<int> imgs; int parent; };
-  std::vector<TNode> tn;
-  int forced = -1, max_depth = 2;
-  if (const char* e = std::getenv("MAVBA_ND_PARTS")) forced = std::atoi(e);  // 0/1 = off, n = force n flat parts
-  // Depth of the recursive bisection. The persistent factorisation has no barrier between tree levels, so what counts is
-  // the longest root-to-leaf path and a third level pays (C3: 0.44 -> 0.41 ms); large systems run the launch-per-panel
-  // schedule, whose per-level launches make depth 3 slightly slower (C5: 3.46 -> 3.58 ms).
-  if (tiles0 <= 96) max_depth = 3;
-  if (const char* e = std::getenv("MAVBA_ND_DEPTH")) max_depth = std::atoi(e);
-  const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && max_depth > 0 && (world == 1 || NI <= 4096);
-  if (can_dissect) {
-    // image adjacency (lower: col < row) from the pose-pose blocks; with shards, the union over ranks
-    std::vector<std::vector<int>> lower(NI);
-    if (sharded()) {
-      std::vector<double> a((size_t)NI * NI, 0.0);
-      for (const SchurBlock& B : blocks)
-        if (B.kind == BLK_PP && B.row_ent != B.col_ent) a[(size_t)std::max(B.row_ent, B.col_ent) * NI + std::min(B.row_ent, B.col_ent)] = 1.0;
-      DevBuf<double> d;
-      d.upload(a, st);
-      allreduce(d.p, (long long)NI * NI, 1);
-      HIP_OK(hipMemcpyAsync(a.data(), d.p, a.size() * 8, hipMemcpyDeviceToHost, st));
-      sync();
-      for (int r = 0; r < NI; ++r)
-        for (int c = 0; c < r; ++c) if (a[(size_t)r * NI + c] != 0.0) lower[r].push_back(c);
-    } else {
-      for (const SchurBlock& B : blocks)
-        if (B.kind == BLK_PP && B.row_ent != B.col_ent) lower[std::max(B.row_ent, B.col_ent)].push_back(std::min(B.row_ent, B.col_ent));
-    }
+// Elimination tree of the reduced camera system over the image graph (lower[r] = images c < r that share a point with
+// r): nodes in elimination order, children before parents, the root last; empty = no dissection. Pure host code (no
+// device): also exported for tests as mavba_debug_elimination_tree.
+namespace mavba {
+std::vector<ElimNode> elimination_tree(int NI, int NC, const std::vector<std::vector<int>>& lower, int forced, int max_depth) {
+  std::vector<ElimNode> tn;
+  typedef ElimNode TNode;
+  {
     const int tail = 9 * NC;
     auto tiles_of = [](int cols) { return (cols + 63) / 64; };
     if (forced > 1) {
@@ -537,6 +513,43 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
       rec(std::move(all), 0, tail);
       if (tn.size() < 3) tn.clear();
     }
+  }
+  return tn;
+}
+}  // namespace mavba
+
+void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& blocks) {
+  const int tiles0 = std::max(1, round_up(n_full, 64) / 64);
+  // Tree of image sets in elimination order (children before parents, root last); the root also carries the
+  // intrinsics blocks. One node = no dissection.
+  std::vector<ElimNode> tn;
+  int forced = -1, max_depth = 2;
+  if (const char* e = std::getenv("MAVBA_ND_PARTS")) forced = std::atoi(e);  // 0/1 = off, n = force n flat parts
+  // Depth of the recursive bisection. The persistent factorisation has no barrier between tree levels, so what counts is
+  // the longest root-to-leaf path and a third level pays (C3: 0.44 -> 0.41 ms); large systems run the launch-per-panel
+  // schedule, whose per-level launches make depth 3 slightly slower (C5: 3.46 -> 3.58 ms).
+  if (tiles0 <= 96) max_depth = 3;
+  if (const char* e = std::getenv("MAVBA_ND_DEPTH")) max_depth = std::atoi(e);
+  const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && max_depth > 0 && (world == 1 || NI <= 4096);
+  if (can_dissect) {
+    // image adjacency (lower: col < row) from the pose-pose blocks; with shards, the union over ranks
+    std::vector<std::vector<int>> lower(NI);
+    if (sharded()) {
+      std::vector<double> a((size_t)NI * NI, 0.0);
+      for (const SchurBlock& B : blocks)
+        if (B.kind == BLK_PP && B.row_ent != B.col_ent) a[(size_t)std::max(B.row_ent, B.col_ent) * NI + std::min(B.row_ent, B.col_ent)] = 1.0;
+      DevBuf<double> d;
+      d.upload(a, st);
+      allreduce(d.p, (long long)NI * NI, 1);
+      HIP_OK(hipMemcpyAsync(a.data(), d.p, a.size() * 8, hipMemcpyDeviceToHost, st));
+      sync();
+      for (int r = 0; r < NI; ++r)
+        for (int c = 0; c < r; ++c) if (a[(size_t)r * NI + c] != 0.0) lower[r].push_back(c);
+    } else {
+      for (const SchurBlock& B : blocks)
+        if (B.kind == BLK_PP && B.row_ent != B.col_ent) lower[std::max(B.row_ent, B.col_ent)].push_back(std::min(B.row_ent, B.col_ent));
+    }
+    tn = elimination_tree(NI, NC, lower, forced, max_depth);
   }
   // column offsets in tree order (every node padded to whole tiles), intrinsics at the end of the root
   h_off_img.assign(NI, 0); h_off_cam.assign(NC, 0);
