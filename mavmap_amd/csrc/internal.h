@@ -134,6 +134,7 @@ struct FrontArgs {
   double* Cu; double* gu; double* Gi; double* h;   // per-point planes, stride NPs
   double* Epose; double* Eintr;                     // entry records (kPoseRec / kIntrRec doubles)
   double* fail;
+  long long* trace;  // MAVBA_FRONT_TRACE (debugging): s_memtime stamps per work-group, else null
 };
 int point_front_grid(int num_tiles);
 // kmax_intr: 0 when no intrinsics block is free (no Wk products), else the widest camera model (4, 8, 9).

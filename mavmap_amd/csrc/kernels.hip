@@ -422,9 +422,13 @@ struct FrontShape {
 };
 }  // namespace
 
-template <int KMAX, bool ENTRIES, bool MASK>
+template <int KMAX, bool ENTRIES, bool MASK, bool TRACE = false>
 __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
   using SH = FrontShape<KMAX>;
+  long long stamp[TRACE ? 12 : 1];
+  int nstamp = 0;
+  auto mark = [&]() { if constexpr (TRACE) { if (nstamp < 12) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
+  mark();
   extern __shared__ __attribute__((aligned(16))) double fr_smem[];
   double* s_park = fr_smem;                         // [NR][kFrPitch] the window's products of this round
   double* s_q = fr_smem + SH::PARK;                 // [kFrontQ][K3]  Wk sums
@@ -455,6 +459,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
       for (int i = tid; i < nq * SH::K3; i += 256) s_q[i] = 0.0;
     }
     __syncthreads();
+    mark();  // 1: tile bounds loaded
     const bool single = o1 - o0 <= kFrontObs;  // (all but tiles made of one very long track)
     // the observation's weighted Jacobian blocks stay in registers from phase 1 to phase 2
     double jc[12], jp[6];
@@ -506,6 +511,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
 #pragma unroll
           for (int t = 0; t < 3; ++t) prod[9 + 3 * k + t] = jk[k] * jp[t] + jk[9 + k] * jp[3 + t];
       }
+      mark();  // 2: Jacobian + products in registers
       auto round = [&](auto rc) {
         constexpr int R = decltype(rc)::value;
         constexpr int lo = R * SH::NR, hi = (lo + SH::NR < SH::NROWS) ? lo + SH::NR : SH::NROWS;
@@ -551,7 +557,9 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
         __syncthreads();
       };
       round(std::integral_constant<int, 0>{});
+      mark();  // 3: round 0
       if constexpr (SH::ROUNDS > 1) round(std::integral_constant<int, 1>{});
+      mark();  // 4: round 1
     }
     // ---- owner lanes: the point's sums out, its damped block factorised ----
     if (tid < np) {
@@ -598,6 +606,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
     }
     if constexpr (ENTRIES) {
       __syncthreads();
+      mark();  // 5: owner lanes done
       // ---- intrinsics entry records: Uk = (s_k Wk s_p) Gi^T (9 x 3), ek = Uk h; one lane per (record, parameter) ----
       if constexpr (KMAX > 0) {
         for (int it = tid; it < nq * 9; it += 256) {
@@ -618,6 +627,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
         }
         __syncthreads();  // the Wk sums are consumed: their LDS becomes the record staging buffer
       }
+      mark();  // 6: intrinsics records
       // ---- pose entry records: U_a = (Jc' ^T Jp') Gi^T (6 x 3), e_a = U_a h ----
       for (int base = o0; base < o1; base += kFrontObs) {
         const int o = base + tid;
@@ -647,6 +657,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
             rec[18 + e] = u0 * g[6] + u1 * g[7] + u2 * g[8];
           }
         }
+        mark();  // 7: pose records in registers
         const long long lim = (long long)o1 * kPoseRec;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -667,17 +678,57 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
       __syncthreads();  // (the next tile re-initialises the sums)
     }
   }
+  mark();  // 8: records stored
+  if constexpr (TRACE) {
+    if (a.trace && (tid & 63) == 0 && blockIdx.x < 16384) {  // one line per wave: [n, stamps...] (single-tile work-groups)
+      long long* out = a.trace + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 16;
+      out[0] = nstamp;
+      for (int i = 0; i < nstamp; ++i) out[1 + i] = stamp[i];
+    }
+  }
   const double tot = block_sum_256(cost, s_red);
   if (tid == 0) w.cost_partial[blockIdx.x] = tot;
 }
 
-int point_front_grid(int num_tiles) { return num_tiles < 1 ? 0 : (num_tiles > kFrontMaxGrid ? kFrontMaxGrid : num_tiles); }
+int point_front_grid(int num_tiles) {
+  static const int cap = [] { const char* e = std::getenv("MAVBA_FRONT_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 && v < kFrontMaxGrid ? v : kFrontMaxGrid; }();  // tuning knob
+  return num_tiles < 1 ? 0 : (num_tiles > cap ? cap : num_tiles);
+}
 void launch_point_front(hipStream_t st, const FrontArgs& a, int kmax_intr, bool entries) {
   const int grid = point_front_grid(a.num_tiles);
   if (grid <= 0) return;
   const bool mask = a.sw.pt_active != nullptr;
   int dev = 0;
   (void)hipGetDevice(&dev);
+  // MAVBA_FRONT_TRACE=<file>: the 5th entries launch (widest model, unmasked) records s_memtime stamps per wave
+  static const char* trace_file = std::getenv("MAVBA_FRONT_TRACE");
+  static int trace_calls = 0;
+  if (trace_file && entries && !mask && kmax_intr > 4 && kmax_intr <= 8 && ++trace_calls == 5) {
+    const size_t n = (size_t)16384 * 4 * 16;
+    long long* tr = nullptr;
+    (void)hipMalloc(reinterpret_cast<void**>(&tr), n * 8);
+    (void)hipMemsetAsync(tr, 0, n * 8, st);
+    FrontArgs b = a;
+    b.trace = tr;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_front<8, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)FrontShape<8>::BYTES);
+    hipLaunchKernelGGL((k_point_front<8, true, false, true>), dim3(grid), dim3(256), FrontShape<8>::BYTES, st, b);
+    std::vector<long long> h(n);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), tr, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(tr);
+    if (FILE* fp = std::fopen(trace_file, "w")) {
+      for (int b2 = 0; b2 < std::min(grid, 16384); ++b2)
+        for (int wv = 0; wv < 4; ++wv) {
+          const long long* r = &h[((size_t)b2 * 4 + wv) * 16];
+          std::fprintf(fp, "%d %d", b2, wv);
+          for (int i = 0; i < (int)r[0]; ++i) std::fprintf(fp, " %lld", r[1 + i]);
+          std::fprintf(fp, "\n");
+        }
+      std::fclose(fp);
+    }
+    return;
+  }
 #define MAVBA_FRONT_LAUNCH(K, E, M)                                                                                     \
   {                                                                                                                     \
     static bool configured[64] = {};  /* per device: more than 64 KiB of dynamic LDS has to be asked for */            \

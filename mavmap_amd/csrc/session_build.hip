@@ -508,10 +508,28 @@ std::vector<ElimNode> elimination_tree(int NI, int NC, const std::vector<std::ve
         tn[ra.first].parent = me; tn[rb.first].parent = me;
         return std::make_pair(me, std::max(ra.second, rb.second) + sep_tiles);
       };
-      std::vector<int> all(NI);
-      for (int i = 0; i < NI; ++i) all[i] = i;
+      // Images without a neighbour (entirely constant poses: the datum image of a global BA) couple to nothing. As a
+      // component of their own they would distort the level structures (C3: one branch stayed unsplit, 24 instead of 19
+      // dependent panel steps), so they stay out of the bisection and join the leaf with the most padding to spare.
+      std::vector<int> all, isolated;
+      for (int i = 0; i < NI; ++i) (adj[i].empty() ? isolated : all).push_back(i);
       rec(std::move(all), 0, tail);
       if (tn.size() < 3) tn.clear();
+      if (!tn.empty()) {
+        std::vector<char> is_leaf(tn.size(), 1);
+        for (const TNode& t : tn) if (t.parent >= 0) is_leaf[t.parent] = 0;
+        for (int i : isolated) {
+          int best = -1, best_slack = -1;
+          for (size_t t = 0; t < tn.size(); ++t) {
+            if (!is_leaf[t]) continue;
+            const int cols = 6 * (int)tn[t].imgs.size();
+            const int slack = std::max(64, (cols + 63) / 64 * 64) - cols;
+            if (slack > best_slack) { best_slack = slack; best = (int)t; }
+          }
+          tn[best].imgs.push_back(i);
+        }
+        for (TNode& t : tn) std::sort(t.imgs.begin(), t.imgs.end());
+      }
     }
   }
   return tn;

@@ -38,6 +38,7 @@ void mavba_session::launch_front(double r, bool entries) {
   f.radius = r; f.dmin = opt.min_lm_diagonal; f.dmax = opt.max_lm_diagonal;
   f.Cu = d_Cu.p; f.gu = d_gu.p; f.Gi = d_Gi.p; f.h = d_h.p; f.Epose = d_Epose.p; f.Eintr = d_Eintr.p;
   f.fail = d_scal.p + SC_FAIL_FRONT;
+  f.trace = nullptr;
   if (entries) HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL_FRONT, 0, sizeof(double), st));
   timed(entries ? "point_front" : "point_front_sums", [&] { launch_point_front(st, f, Q > 0 ? KMAX : 0, entries); });
   front_valid = entries;
