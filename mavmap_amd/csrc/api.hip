@@ -420,6 +420,17 @@ int mavba_session_kernel_stats(mavba_session* s, mavba_kernel_stat* out, int32_t
 }
 
 int mavba_solve(const mavba_problem* problem, const mavba_options* options, mavba_result* result, double* point_error) {
+  // MAVBA_GPUS=N: this one call - the one an unchanged mapper.cc makes (sequential_mapper.cc:1074-1080) - shards the points
+  // over N devices of this process (multi_gpu.hip). Small problems stay on one GPU: the exchange would cost more than it saves.
+  const char* min_obs_env = std::getenv("MAVBA_GPUS_MIN_OBS");
+  if (problem && options && options->device < 0 && problem->num_obs >= (min_obs_env ? std::atoll(min_obs_env) : 200000ll)) {
+    const int world = multi_gpu_ranks();
+    if (world > 1) {
+      MAVBA_TRY
+      return solve_multi_gpu(problem, options, result, point_error, world);
+      MAVBA_CATCH
+    }
+  }
   const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
   double t0 = now_s();
   auto lap = [&](const char* what) { if (tt) { const double t = now_s(); std::fprintf(stderr, "[solve] %-28s %8.2f ms\n", what, 1e3 * (t - t0)); t0 = t; } };

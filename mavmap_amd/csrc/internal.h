@@ -122,7 +122,7 @@ void launch_point_reduce(hipStream_t st, int NP, int NPs, int Nstride, int KMAX,
 // the pose / intrinsics Schur entry records are written directly. The trust-region radius is a kernel argument: a
 // rejected step re-runs the kernel, no Jacobian is kept between linear solves.
 constexpr int kFrontObs = 256, kFrontPts = 64, kFrontQ = 96, kFrontMaxGrid = 65536;  // (one tile per work-group up to 65536 tiles, then contiguous runs)
-struct FrontTile { int p0, p1; };
+struct FrontTile { int p0, p1, o0, o1, q0, q1; };  // points [p0, p1), their observations [o0, o1) and intrinsics entries [q0, q1)
 struct FrontArgs {
   SweepArgs sw;                         // observations, cameras, points, loss, pt_active; cost_partial [grid]
   int num_tiles, NPs;

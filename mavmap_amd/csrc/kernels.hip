@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) double fr_smem[];
   double* s_park = fr_smem;                         // [NR][kFrPitch] the window's products of this round
   double* s_q = fr_smem + SH::PARK;                 // [kFrontQ][K3]  Wk sums
-  double* s_rec = fr_smem;                          // pose records of half a window (aliases park | s_q once they are consumed)
+  double* s_rec = fr_smem;                          // pose records being staged (aliases park | s_q once they are consumed)
   double* s_sum = fr_smem + SH::A;                  // [kFrontPts][9] Cu(6) gu(3) sums
   double* s_g = s_sum + kFrontPts * 9;              // [kFrontPts][12] Gi(6) h(3) scale(3)
   double* s_red = s_g + kFrontPts * 12;             // [4]
@@ -447,35 +447,43 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
   const int t_end = (int)((long long)a.num_tiles * (blockIdx.x + 1) / gridDim.x);
   double cost = 0.0;
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const FrontTile T = a.tiles[tile];
+    const FrontTile T = a.tiles[tile];  // (one 24-byte record: nothing else has to arrive before the loads below go out)
     const int np = T.p1 - T.p0;
-    const int o0 = a.pt_start[T.p0], o1 = a.pt_start[T.p1];
-    int q0 = 0, nq = 0;
-    if constexpr (KMAX > 0) { q0 = a.q_start[T.p0]; nq = a.q_start[T.p1] - q0; }
+    const int o0 = T.o0, o1 = T.o1;
+    const int q0 = T.q0, nq = KMAX > 0 ? T.q1 - T.q0 : 0;
+    // The first window's observation and the owner lanes' per-point inputs are requested FIRST: their latency (and that
+    // of the gathers that depend on them) runs under the tile's bookkeeping below instead of after it.
+    int im = 0, lp = 0, pt0 = 0;
+    double2 m0 = make_double2(0.0, 0.0);
+    bool act = o0 + tid < o1;
+    if (act) { im = w.obs_img[o0 + tid]; pt0 = w.obs_pt[o0 + tid]; m0 = w.uv[o0 + tid]; }
+    bool own_free = false;
+    double own_sp[3] = {0.0, 0.0, 0.0};
+    if constexpr (ENTRIES) {
+      if (tid < np) {
+        own_free = a.pt_free[T.p0 + tid] != 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) own_sp[k] = a.scale_pt[(size_t)k * NPs + T.p0 + tid];
+      }
+    }
     for (int j = tid; j <= np; j += 256) s_pb[j] = a.pt_start[T.p0 + j];
     for (int i = tid; i < np * 9; i += 256) s_sum[i] = 0.0;
     if constexpr (KMAX > 0) {
       for (int q = tid; q < nq; q += 256) { s_qcam[q] = a.q_cam[q0 + q]; s_qpt[q] = a.q_pt[q0 + q] - T.p0; }
       for (int i = tid; i < nq * SH::K3; i += 256) s_q[i] = 0.0;
     }
-    __syncthreads();
-    mark();  // 1: tile bounds loaded
     const bool single = o1 - o0 <= kFrontObs;  // (all but tiles made of one very long track)
     // the observation's weighted Jacobian blocks stay in registers from phase 1 to phase 2
     double jc[12], jp[6];
-    int im = 0, lp = 0;
-    bool act = false;
-    // residual + Jacobian of observation o, rows weighted by sqrt(rho'); returns rho / 2
-    auto eval_obs = [&](int o, double (&rr)[2], double (&jk)[18], int& cam) -> double {
-      im = w.obs_img[o];
-      const int pt = w.obs_pt[o];
+    // residual + Jacobian of an observation (image imv, point pt, pixel m), rows weighted by sqrt(rho'); returns rho / 2
+    auto eval_obs = [&](int imv, int pt, double2 m, double (&rr)[2], double (&jk)[18], int& cam) -> double {
+      im = imv;
       lp = pt - T.p0;
-      const double2 m = w.uv[o];
-      cam = w.img_cam[im];
+      cam = w.img_cam[imv];
       const int model = w.cam_model[cam];
       double rec[9], kin[9], X[3];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) rec[k] = w.camrec[9 * im + k];
+      for (int k = 0; k < 9; ++k) rec[k] = w.camrec[9 * imv + k];
 #pragma unroll
       for (int k = 0; k < 9; ++k) kin[k] = w.intr[9 * cam + k];
       X[0] = w.points[3 * (long long)pt]; X[1] = w.points[3 * (long long)pt + 1]; X[2] = w.points[3 * (long long)pt + 2];
@@ -493,16 +501,19 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
       for (int e = 0; e < 18; ++e) jk[e] = wgt * Jk[e];
       return half_rho;
     };
+    mark();  // 1: first loads out, tile bookkeeping written
     // ---- phase 1: per-point sums ----
     for (int base = o0; base < o1; base += kFrontObs) {
       const int o = base + tid;
-      act = o < o1;
+      if (base != o0) {
+        act = o < o1;
+        if (act) { im = w.obs_img[o]; pt0 = w.obs_pt[o]; m0 = w.uv[o]; }
+      }
       double prod[SH::NROWS];
+      int cam = -1;
       if (act) {
         double rr[2], jk[18];
-        int cam;
-        cost += eval_obs(o, rr, jk, cam);
-        s_cam[tid] = cam;
+        cost += eval_obs(im, pt0, m0, rr, jk, cam);
         prod[0] = jp[0] * jp[0] + jp[3] * jp[3]; prod[1] = jp[0] * jp[1] + jp[3] * jp[4]; prod[2] = jp[0] * jp[2] + jp[3] * jp[5];
         prod[3] = jp[1] * jp[1] + jp[4] * jp[4]; prod[4] = jp[1] * jp[2] + jp[4] * jp[5]; prod[5] = jp[2] * jp[2] + jp[5] * jp[5];
         prod[6] = jp[0] * rr[0] + jp[3] * rr[1]; prod[7] = jp[1] * rr[0] + jp[4] * rr[1]; prod[8] = jp[2] * rr[0] + jp[5] * rr[1];
@@ -515,51 +526,60 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
       auto round = [&](auto rc) {
         constexpr int R = decltype(rc)::value;
         constexpr int lo = R * SH::NR, hi = (lo + SH::NR < SH::NROWS) ? lo + SH::NR : SH::NROWS;
-        constexpr int PR = R == 0 ? 9 : 0;                       // point rows parked in this round
+        constexpr int PR = R == 0 ? 9 : 0;                             // point rows parked in this round
         constexpr int wlo = (lo > 9 ? lo : 9) - 9, WR = hi - 9 - wlo;  // Wk values [wlo, wlo + WR) parked in this round
+        if (R > 0) __syncthreads();  // (the previous round's sums have been read)
         if (act) {
+          if (R == 0) s_cam[tid] = cam;
 #pragma unroll
           for (int v = lo; v < hi; ++v) s_park[(v - lo) * kFrPitch + tid] = prod[v];
         }
         __syncthreads();
+        // One lane per sum. A point's observations are a run of at most 16 in almost every tile: SIXTEEN (clamped, masked)
+        // reads go out together and the adds follow in observation order - one LDS round trip per 16 observations
+        // instead of one per element; longer tracks loop.
         const int nit = np * PR + nq * WR;
         for (int it = tid; it < nit; it += 256) {
-          if (it < np * PR) {
-            const int j = it / 9, v = it - 9 * j;
-            const int b = max(s_pb[j], base), e = min(s_pb[j + 1], base + kFrontObs);
-            const double* row = s_park + v * kFrPitch - base;
-            double acc = s_sum[it];
-            int i = b;
-            for (; i + 4 <= e; i += 4) {  // four loads in flight, the adds stay in observation order
-              const double x0 = row[i], x1 = row[i + 1], x2 = row[i + 2], x3 = row[i + 3];
-              acc += x0; acc += x1; acc += x2; acc += x3;
-            }
-            for (; i < e; ++i) acc += row[i];
-            s_sum[it] = acc;
-          } else if constexpr (WR > 0) {
+          const bool is_pt = it < np * PR;
+          int j, slot, c = -1;
+          const double* row;
+          double* dst;
+          if (is_pt) {
+            j = it / 9;
+            slot = it - 9 * j;
+            row = s_park + slot * kFrPitch - base;
+            dst = s_sum + it;
+          } else {
             const int t2 = it - np * PR;
-            const int q = t2 / WR, vv = wlo + (t2 - q * WR);
-            const int j = s_qpt[q], c = s_qcam[q];
-            const int b = max(s_pb[j], base), e = min(s_pb[j + 1], base + kFrontObs);
-            const double* row = s_park + (vv + 9 - lo) * kFrPitch - base;
-            const int* camv = s_cam - base;
-            double acc = s_q[q * SH::K3 + vv];
-            int i = b;
-            for (; i + 4 <= e; i += 4) {  // (adding 0.0 for another camera's observation leaves the sum as it is)
-              const double x0 = row[i], x1 = row[i + 1], x2 = row[i + 2], x3 = row[i + 3];
-              const int c0 = camv[i], c1 = camv[i + 1], c2 = camv[i + 2], c3 = camv[i + 3];
-              acc += c0 == c ? x0 : 0.0; acc += c1 == c ? x1 : 0.0; acc += c2 == c ? x2 : 0.0; acc += c3 == c ? x3 : 0.0;
-            }
-            for (; i < e; ++i) acc += camv[i] == c ? row[i] : 0.0;
-            s_q[q * SH::K3 + vv] = acc;
+            const int wr = WR > 0 ? WR : 1;
+            const int q = t2 / wr, vv = wlo + (t2 - q * wr);
+            j = s_qpt[q]; c = s_qcam[q];
+            row = s_park + (vv + 9 - lo) * kFrPitch - base;
+            dst = s_q + q * SH::K3 + vv;
           }
+          const int b = max(s_pb[j], base), e = min(s_pb[j + 1], base + kFrontObs);
+          const int* camv = s_cam - base;
+          double acc = *dst;
+          for (int i0 = b; i0 < e; i0 += 16) {
+            double x[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              const int i = min(i0 + k, e - 1);
+              double v = row[i];
+              if (WR > 0 && !is_pt) v = camv[i] == c ? v : 0.0;
+              x[k] = i0 + k < e ? v : 0.0;   // (adding 0.0 leaves the sum as it is: the order of the real terms is the observations')
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += x[k];
+          }
+          *dst = acc;
         }
-        __syncthreads();
       };
       round(std::integral_constant<int, 0>{});
       mark();  // 3: round 0
       if constexpr (SH::ROUNDS > 1) round(std::integral_constant<int, 1>{});
       mark();  // 4: round 1
+      __syncthreads();  // sums complete; the park buffer is free for the next window
     }
     // ---- owner lanes: the point's sums out, its damped block factorised ----
     if (tid < np) {
@@ -574,11 +594,10 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) a.gu[(size_t)k * NPs + p] = g3[k];
       if constexpr (ENTRIES) {
-        const bool fr = a.pt_free[p] != 0;
         double G[6] = {0, 0, 0, 0, 0, 0}, hh[3] = {0, 0, 0}, sp[3] = {0, 0, 0};
-        if (fr) {
+        if (own_free) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) sp[k] = a.scale_pt[(size_t)k * NPs + p];
+          for (int k = 0; k < 3; ++k) sp[k] = own_sp[k];
           double C[6];
           C[0] = sp[0] * sp[0] * C6[0]; C[1] = sp[0] * sp[1] * C6[1]; C[2] = sp[0] * sp[2] * C6[2];
           C[3] = sp[1] * sp[1] * C6[3]; C[4] = sp[1] * sp[2] * C6[4]; C[5] = sp[2] * sp[2] * C6[5];
@@ -633,7 +652,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
         const int o = base + tid;
         if (!single) {
           act = o < o1;
-          if (act) { double rr[2], jk[18]; int cam; (void)eval_obs(o, rr, jk, cam); }
+          if (act) { double rr[2], jk[18]; int cam; (void)eval_obs(w.obs_img[o], w.obs_pt[o], w.uv[o], rr, jk, cam); }
         }
         double rec[kPoseRec];
 #pragma unroll
@@ -659,15 +678,18 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
         }
         mark();  // 7: pose records in registers
         const long long lim = (long long)o1 * kPoseRec;
+        // staged through LDS (pitch 25), coalesced stores: the whole window at once where the buffer holds 256 records,
+        // else in two halves
+        constexpr int kStage = SH::A >= 256 * 25 ? 256 : 128;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          if ((tid >> 7) == half) {
+        for (int part = 0; part < 256 / kStage; ++part) {
+          if (tid / kStage == part) {
 #pragma unroll
-            for (int k = 0; k < kPoseRec; ++k) s_rec[(tid & 127) * 25 + k] = rec[k];
+            for (int k = 0; k < kPoseRec; ++k) s_rec[(tid % kStage) * 25 + k] = rec[k];
           }
           __syncthreads();
-          const long long gbase = ((long long)base + half * 128) * kPoseRec;
-          for (int i = tid; i < 128 * kPoseRec; i += 256) {
+          const long long gbase = ((long long)base + part * kStage) * kPoseRec;
+          for (int i = tid; i < kStage * kPoseRec; i += 256) {
             const int t = i / kPoseRec, k = i - t * kPoseRec;
             if (gbase + i < lim) a.Epose[gbase + i] = s_rec[t * 25 + k];
           }

@@ -1,0 +1,274 @@
+// multi_gpu.hip - ONE process driving several GPUs: what an unchanged mapper.cc reaches through bundle_adjustment()
+// -> mavba_solve when MAVBA_GPUS=N is set (reference call site: src/sfm/sequential_mapper.cc:1074-1080, one call from
+// one thread of one process).
+//
+// The 3-D points (with all their observations) are sharded over N ranks exactly as the one-process-per-GPU path does
+// (SURVEY.md 8(e)): contiguous point ranges balanced by observation count, cameras replicated, rotation priors on rank 0.
+// Every rank is a host thread with its own session on its own device; the exchange of the reduced camera system is an
+// in-process all-reduce over xGMI peer access:
+//
+//   one-shot, owner-computes-slice: rank r reduces slice r of the vector by reading that slice from every rank's buffer
+//   (direct peer loads, fixed rank order: every rank ends with bit-identical sums) and writes the result back into every
+//   rank's buffer (direct peer stores). Every link of the full mesh carries 1/N of the vector in each direction - the
+//   point-to-point topology of the MI355X node is used as what it is, no ring.
+//
+// Where peer access is not available the slices travel by hipMemcpyPeer through a staging buffer. Host threads meet at
+// a barrier before and after the kernel (the sessions' hook protocol is host-synchronised anyway).
+#include "session.h"
+
+namespace mavba {
+namespace {
+
+constexpr int kMaxRanks = 16;
+
+struct PeerTable { double* p[kMaxRanks]; };
+
+// out = op over ranks (fixed order 0..world-1) of bufs[r][i] for i in [begin, end), written back to every rank.
+// op 0 = sum, 1 = max, 2 = sum for all but the LAST element of the whole vector (index count - 1), max for that one.
+__global__ void __launch_bounds__(256) k_inproc_allreduce(PeerTable T, int world, long long begin, long long end, long long count,
+                                                          int op) {
+  for (long long i = begin + (long long)blockIdx.x * 256 + threadIdx.x; i < end; i += (long long)gridDim.x * 256) {
+    const bool mx = op == 1 || (op == 2 && i == count - 1);
+    double acc = T.p[0][i];
+    for (int r = 1; r < world; ++r) {
+      const double x = T.p[r][i];
+      acc = mx ? fmax(acc, x) : acc + x;
+    }
+    for (int r = 0; r < world; ++r) T.p[r][i] = acc;
+  }
+}
+
+struct InProcGroup {
+  int world = 1;
+  std::vector<int> device;            // device of every rank
+  bool direct = true;                 // every pair of devices can map each other's memory
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned long long generation = 0;
+  bool failed = false;
+  std::vector<double*> ptr;           // this exchange: every rank's buffer
+  std::vector<long long> count;
+  std::vector<hipStream_t> stream;    // one per rank, on its device
+  std::vector<double*> stage;         // memcpy path: staging block on every rank's device (world slices of the largest exchange)
+  std::vector<size_t> stage_doubles;
+
+  // false: another rank failed - give up (nobody may wait for a rank that is gone)
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    if (failed) return false;
+    const unsigned long long g = generation;
+    if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); return true; }
+    cv.wait(lk, [&] { return generation != g || failed; });
+    return !failed;
+  }
+  void fail() {
+    std::lock_guard<std::mutex> lk(m);
+    failed = true;
+    cv.notify_all();
+  }
+};
+
+struct RankCtx { InProcGroup* g; int rank; };
+
+int inproc_allreduce(void* vctx, void* device_ptr, int64_t count, int32_t op) {
+  RankCtx* c = static_cast<RankCtx*>(vctx);
+  InProcGroup& G = *c->g;
+  const int r = c->rank, W = G.world;
+  G.ptr[r] = static_cast<double*>(device_ptr);
+  G.count[r] = count;
+  if (!G.barrier()) return 1;  // every rank's buffer is complete (its stream is idle) and published
+  for (int q = 0; q < W; ++q) if (G.count[q] != count) { G.fail(); return 1; }
+  const long long b = count * r / W, e = count * (r + 1) / W;
+  hipStream_t st = G.stream[r];
+  bool ok = true;
+  if (G.direct) {
+    if (e > b) {
+      PeerTable T;
+      for (int q = 0; q < W; ++q) T.p[q] = G.ptr[q];
+      const int grid = (int)std::min<long long>(1024, (e - b + 255) / 256);
+      hipLaunchKernelGGL(k_inproc_allreduce, dim3(grid), dim3(256), 0, st, T, W, b, e, (long long)count, (int)op);
+    }
+    ok = hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+  } else {
+    // staged: gather the peers' copies of my slice, reduce locally, scatter the result
+    const size_t n = (size_t)(e - b);
+    if (n > 0) {
+      if (G.stage_doubles[r] < n * W) {
+        if (G.stage[r]) device_free(G.stage[r]);
+        G.stage[r] = nullptr;
+        ok = device_alloc(reinterpret_cast<void**>(&G.stage[r]), n * W * sizeof(double)) == hipSuccess;
+        G.stage_doubles[r] = ok ? n * W : 0;
+      }
+      PeerTable T;
+      for (int q = 0; q < W && ok; ++q) {
+        T.p[q] = G.stage[r] + (size_t)q * n - b;  // (indexed with the global element number)
+        ok = hipMemcpyPeerAsync(G.stage[r] + (size_t)q * n, G.device[r], G.ptr[q] + b, G.device[q], n * sizeof(double), st) == hipSuccess;
+      }
+      if (ok) {
+        const int grid = (int)std::min<long long>(1024, (e - b + 255) / 256);
+        hipLaunchKernelGGL(k_inproc_allreduce, dim3(grid), dim3(256), 0, st, T, W, b, e, (long long)count, (int)op);
+        for (int q = 0; q < W && ok; ++q)
+          ok = hipMemcpyPeerAsync(G.ptr[q] + b, G.device[q], G.stage[r], G.device[r], n * sizeof(double), st) == hipSuccess;
+      }
+    }
+    ok = hipStreamSynchronize(st) == hipSuccess && ok;
+  }
+  if (!ok) { G.fail(); return 1; }
+  if (!G.barrier()) return 1;  // every slice is written everywhere
+  return 0;
+}
+
+// contiguous point ranges balanced by observation count (the rule of BAProblem.shard_by_point / bench.py)
+std::vector<int> shard_bounds(const mavba_problem* P, int world) {
+  std::vector<long long> csum((size_t)P->num_points + 1, 0);
+  for (long long o = 0; o < P->num_obs; ++o) csum[P->obs_point[o] + 1]++;
+  for (int p = 0; p < P->num_points; ++p) csum[p + 1] += csum[p];
+  const long long total = csum[P->num_points];
+  std::vector<int> bounds(world + 1, P->num_points);
+  bounds[0] = 0;
+  for (int r = 1; r < world; ++r) {
+    const double target = (double)total * r / world;
+    // first p with csum(obs of points 0..p) >= target
+    int lo = 0, hi = P->num_points;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if ((double)csum[mid + 1] >= target) hi = mid; else lo = mid + 1; }
+    bounds[r] = std::max(bounds[r - 1], std::min(lo, P->num_points));
+  }
+  return bounds;
+}
+
+}  // namespace
+
+int multi_gpu_ranks() {
+  const char* e = std::getenv("MAVBA_GPUS");
+  if (!e) return 1;
+  int n = std::atoi(e);
+  if (n <= 1) return 1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  if (std::getenv("MAVBA_GPUS_SAME_DEVICE")) return std::min(n, kMaxRanks);  // tests: every rank on the current device
+  return std::max(1, std::min(std::min(n, ndev), kMaxRanks));
+}
+
+// mavba_solve over `world` devices of this process. Same contract: parameters written back in place (unless the solve
+// ends in NUMERICAL_FAILURE), `result` summarises the (global) solve, `point_error` as mavba_solve.
+int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_result* result, double* point_error, int world) {
+  const bool same_device = std::getenv("MAVBA_GPUS_SAME_DEVICE") != nullptr;
+  int cur = 0;
+  HIP_OK(hipGetDevice(&cur));
+  InProcGroup G;
+  G.world = world;
+  G.device.resize(world);
+  for (int r = 0; r < world; ++r) G.device[r] = same_device ? cur : r;
+  G.ptr.assign(world, nullptr); G.count.assign(world, 0); G.stream.assign(world, nullptr);
+  G.stage.assign(world, nullptr); G.stage_doubles.assign(world, 0);
+  G.direct = std::getenv("MAVBA_GPUS_STAGED") == nullptr;
+  for (int a = 0; a < world && G.direct; ++a)
+    for (int b = 0; b < world && G.direct; ++b) {
+      if (G.device[a] == G.device[b]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, G.device[a], G.device[b]) != hipSuccess || !can) { (void)hipGetLastError(); G.direct = false; }
+    }
+  for (int a = 0; a < world; ++a) {
+    HIP_OK(hipSetDevice(G.device[a]));
+    HIP_OK(hipStreamCreate(&G.stream[a]));
+    if (G.direct)
+      for (int b = 0; b < world; ++b)
+        if (G.device[a] != G.device[b]) {
+          const hipError_t e = hipDeviceEnablePeerAccess(G.device[b], 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) G.direct = false;
+          (void)hipGetLastError();
+        }
+  }
+  HIP_OK(hipSetDevice(cur));
+
+  const std::vector<int> bounds = shard_bounds(P, world);
+  struct Shard {
+    std::vector<double> points, uv, perr;
+    std::vector<uint8_t> pconst;
+    std::vector<int32_t> oimg, opt;
+    std::vector<double> poses, intr;
+    mavba_problem prob;
+    mavba_result res;
+    int rc = MAVBA_OK, term = MAVBA_TERM_RUNNING;
+    std::string error;
+  };
+  std::vector<Shard> sh(world);
+  // observations to their rank, input order kept
+  std::vector<int> rank_of_point((size_t)std::max(P->num_points, 1), 0);
+  for (int r = 0; r < world; ++r) for (int p = bounds[r]; p < bounds[r + 1]; ++p) rank_of_point[p] = r;
+  for (long long o = 0; o < P->num_obs; ++o) {
+    const int p = P->obs_point[o];
+    if (p < 0 || p >= P->num_points) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
+    Shard& S = sh[rank_of_point[p]];
+    S.uv.push_back(P->obs_uv[2 * o]); S.uv.push_back(P->obs_uv[2 * o + 1]);
+    S.oimg.push_back(P->obs_image[o]); S.opt.push_back(p - bounds[rank_of_point[p]]);
+  }
+  for (int r = 0; r < world; ++r) {
+    Shard& S = sh[r];
+    const int lo = bounds[r], hi = bounds[r + 1];
+    S.points.assign(P->points + 3 * (size_t)lo, P->points + 3 * (size_t)hi);
+    if (P->point_const) S.pconst.assign(P->point_const + lo, P->point_const + hi);
+    S.poses.assign(P->poses, P->poses + 6 * (size_t)P->num_images);
+    S.intr.assign(P->intrinsics, P->intrinsics + 9 * (size_t)P->num_cameras);
+    S.perr.assign((size_t)std::max(hi - lo, 1), std::numeric_limits<double>::quiet_NaN());
+    S.prob = *P;
+    S.prob.num_points = hi - lo; S.prob.num_obs = (int64_t)S.oimg.size();
+    S.prob.points = S.points.data(); S.prob.point_const = P->point_const ? S.pconst.data() : nullptr;
+    S.prob.obs_uv = S.uv.data(); S.prob.obs_image = S.oimg.data(); S.prob.obs_point = S.opt.data();
+    S.prob.poses = S.poses.data(); S.prob.intrinsics = S.intr.data();
+    if (r != 0) { S.prob.num_rot_priors = 0; S.prob.rot_prior_image = nullptr; S.prob.rot_prior_rvec = nullptr; }  // camera-only residuals: counted once
+    std::memset(&S.res, 0, sizeof(S.res));
+  }
+
+  std::vector<RankCtx> ctx(world);
+  auto worker = [&](int r) {
+    Shard& S = sh[r];
+    mavba_session* s = nullptr;
+    mavba_options o = *options;
+    o.device = G.device[r];
+    ctx[r] = RankCtx{&G, r};
+    S.rc = mavba_session_create(&S.prob, &o, &s);
+    if (S.rc == MAVBA_OK) S.rc = mavba_session_set_allreduce(s, inproc_allreduce, &ctx[r], r, world);
+    int done = 0;
+    if (S.rc == MAVBA_OK) S.rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &S.term);
+    if (S.rc == MAVBA_OK) S.rc = mavba_session_result(s, &S.res);
+    // ceres leaves the user's parameter blocks untouched after NUMERICAL_FAILURE
+    if (S.rc == MAVBA_OK && S.term != MAVBA_TERM_NUMERICAL_FAILURE)
+      S.rc = mavba_session_get_params(s, S.poses.data(), S.intr.data(), S.points.data());
+    if (S.rc == MAVBA_OK && point_error && options->update_point_errors) S.rc = mavba_session_point_errors(s, S.perr.data());
+    if (S.rc != MAVBA_OK) { S.error = g_last_error; G.fail(); }
+    if (s) mavba_session_destroy(s);
+  };
+  std::vector<std::thread> threads;
+  for (int r = 1; r < world; ++r) threads.emplace_back(worker, r);
+  worker(0);
+  for (auto& t : threads) t.join();
+  for (int r = 0; r < world; ++r) {
+    (void)hipSetDevice(G.device[r]);
+    if (G.stream[r]) (void)hipStreamDestroy(G.stream[r]);
+    if (G.stage[r]) device_free(G.stage[r]);
+  }
+  (void)hipSetDevice(cur);
+  for (int r = 0; r < world; ++r)
+    if (sh[r].rc != MAVBA_OK && !sh[r].error.empty()) throw Failure(sh[r].rc, "rank " + std::to_string(r) + ": " + sh[r].error);
+  for (int r = 0; r < world; ++r)
+    if (sh[r].rc != MAVBA_OK) throw Failure(sh[r].rc, "rank " + std::to_string(r) + " failed");
+  // every rank holds the same cameras and the same (global) summary
+  if (result) *result = sh[0].res;
+  if (sh[0].term != MAVBA_TERM_NUMERICAL_FAILURE) {
+    std::memcpy(P->poses, sh[0].poses.data(), sizeof(double) * 6 * (size_t)P->num_images);
+    std::memcpy(P->intrinsics, sh[0].intr.data(), sizeof(double) * 9 * (size_t)P->num_cameras);
+    for (int r = 0; r < world; ++r)
+      std::memcpy(P->points + 3 * (size_t)bounds[r], sh[r].points.data(), sizeof(double) * 3 * (size_t)(bounds[r + 1] - bounds[r]));
+  }
+  if (point_error && options->update_point_errors)
+    for (int r = 0; r < world; ++r)
+      for (int p = bounds[r]; p < bounds[r + 1]; ++p) {
+        const double e = sh[r].perr[p - bounds[r]];
+        if (!std::isnan(e)) point_error[p] = e;  // (points without observations are left untouched, as mavba_solve leaves them)
+      }
+  return MAVBA_OK;
+}
+
+}  // namespace mavba

@@ -69,6 +69,10 @@ struct DevBuf {
 struct ElimNode { std::vector<int> imgs; int parent; };
 std::vector<ElimNode> elimination_tree(int NI, int NC, const std::vector<std::vector<int>>& lower, int forced, int max_depth);
 
+// multi_gpu.hip: one process, several devices (MAVBA_GPUS)
+int multi_gpu_ranks();
+int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_result* result, double* point_error, int world);
+
 // pose_refine.hip
 void pose_refine_batch(int count, mavba_pose_refine_item* items, const mavba_options& opt, mavba_result* results);
 

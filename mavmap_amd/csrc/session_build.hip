@@ -1048,12 +1048,12 @@ void mavba_session::build_front_tiles(const std::vector<int>& q_start) {
     const int c = h_pt_start[p + 1] - h_pt_start[p], nq = q_start[p + 1] - q_start[p];
     if (nq > kFrontQ) { front_ok = false; break; }  // a point seen by that many refined cameras: plane kernels
     if (p > p0 && (obs + c > kFrontObs || p - p0 >= kFrontPts || qs + nq > kFrontQ)) {
-      tiles.push_back(FrontTile{p0, p});
+      tiles.push_back(FrontTile{p0, p, h_pt_start[p0], h_pt_start[p], q_start[p0], q_start[p]});
       p0 = p; obs = 0; qs = 0;
     }
     obs += c; qs += nq;
   }
-  if (front_ok && NP > p0) tiles.push_back(FrontTile{p0, NP});
+  if (front_ok && NP > p0) tiles.push_back(FrontTile{p0, NP, h_pt_start[p0], h_pt_start[NP], q_start[p0], q_start[NP]});
   if (!front_ok) tiles.clear();
   num_front_tiles = (int)tiles.size();
   d_front_tiles.upload(tiles, st);

@@ -293,3 +293,49 @@ def test_native_rccl_two_or_more_ranks(mavba, tmp_path):
         assert np.array_equal(d["poses"], ranks[0]["poses"]) and np.array_equal(d["intr"], ranks[0]["intr"])
         pts[d["owned"]] = d["pts"]
     assert_params_close(dict(poses=ranks[0]["poses"], intrinsics=ranks[0]["intr"], points=pts), single, tol=1e-8)
+
+
+@pytest.mark.parametrize("world,staged", [(2, False), (4, False), (3, True)])
+def test_one_process_several_ranks_through_mavba_solve(mavba, oracle, monkeypatch, world, staged):
+    """MAVBA_GPUS=N: ONE mavba_solve call - what an unchanged mapper.cc issues through the shim - shards the points over N
+    ranks (host threads, one session each) inside the process and all-reduces the reduced camera system through the
+    in-process exchange (owner-computes-slice kernel over peer pointers; MAVBA_GPUS_STAGED: the hipMemcpyPeer path).
+    MAVBA_GPUS_SAME_DEVICE lets the ranks share this box's only GPU: same code, same result as the single-rank call."""
+    p = synth.make_config("C3", scale=0.03, seed=23)
+    p.point_const[::11] = 1
+    opts = global_opts()
+    single, e1 = p.copy(), np.full(p.num_points, np.nan)
+    _, r1 = mavba.bundle_adjustment(single, opts, point3D_errors=e1)
+    monkeypatch.setenv("MAVBA_GPUS", str(world))
+    monkeypatch.setenv("MAVBA_GPUS_SAME_DEVICE", "1")
+    monkeypatch.setenv("MAVBA_GPUS_MIN_OBS", "0")
+    if staged:
+        monkeypatch.setenv("MAVBA_GPUS_STAGED", "1")
+    multi, e2 = p.copy(), np.full(p.num_points, np.nan)
+    cost, r2 = mavba.bundle_adjustment(multi, opts, point3D_errors=e2)
+    assert r2["termination"] == r1["termination"]
+    assert r2["num_successful_steps"] == r1["num_successful_steps"] and r2["num_unsuccessful_steps"] == r1["num_unsuccessful_steps"]
+    for k in ("num_residuals", "num_residuals_reduced", "num_parameters_reduced"):
+        assert r2[k] == r1[k], k
+    assert abs(r2["initial_cost"] - r1["initial_cost"]) <= 1e-10 * r1["initial_cost"]
+    assert abs(r2["final_cost"] - r1["final_cost"]) <= 1e-9 * r1["final_cost"]
+    assert_params_close(multi, single, tol=1e-8)
+    m = ~np.isnan(e1)
+    assert np.array_equal(m, ~np.isnan(e2)) and rel_err(e2[m], e1[m]) < 1e-8
+    assert np.array_equal(multi.points[::11], p.points[::11])  # constant points stay put on every rank
+    q = p.copy()
+    ro, _ = oracle.solve(q, oracle.options(**opts))
+    assert abs(r2["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+    assert_params_close(multi, q)
+
+
+def test_one_process_several_ranks_a_failing_rank_does_not_hang(mavba, monkeypatch):
+    """A rank that cannot build its session (bad camera model) must take the others down with an error, not leave them
+    waiting at the exchange's barrier."""
+    p = synth.make_config("C3", scale=0.02, seed=29)
+    p.camera_model[1] = 7
+    monkeypatch.setenv("MAVBA_GPUS", "3")
+    monkeypatch.setenv("MAVBA_GPUS_SAME_DEVICE", "1")
+    monkeypatch.setenv("MAVBA_GPUS_MIN_OBS", "0")
+    with pytest.raises(mavba.MavbaError):
+        mavba.bundle_adjustment(p.copy(), global_opts())

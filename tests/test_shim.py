@@ -336,6 +336,31 @@ def test_shim_end_to_end_on_gpu(mavba, oracle):
     assert np.abs(np.concatenate([rvec, tvec]) - q.poses[3]).max() < 5e-2   # single-image robust refit stays at the BA pose
 
 
+@pytest.mark.gpu
+def test_shim_reaches_several_ranks_with_mavba_gpus(mavba, oracle, monkeypatch):
+    """The reference-signature bundle_adjustment() with MAVBA_GPUS set: the unchanged call site (sequential_mapper.cc:1074)
+    ends up in the in-process multi-rank solve. (One GPU here: the ranks share it.)"""
+    L = _build(real=True)
+    L.shim_last_exception.restype = C.c_char_p
+    p = synth.make_scene(num_images=10, num_points=900, track_len=4, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=67)
+    free, fixed, fixed_x = list(range(2, 10)), [0], [1]
+    opts = dict(max_num_iterations=200, function_tolerance=1e-6, gradient_tolerance=1e-10)
+    rc, ret1, cam1, poses1, points1, perr1 = run(L, Scene(p, extra_unmatched=10), free, fixed, fixed_x, refine_camera_params=1,
+                                                  update_point3D_errors=1, **opts)
+    assert rc == 0, L.shim_last_exception()
+    monkeypatch.setenv("MAVBA_GPUS", "2")
+    monkeypatch.setenv("MAVBA_GPUS_SAME_DEVICE", "1")
+    monkeypatch.setenv("MAVBA_GPUS_MIN_OBS", "0")
+    rc, ret2, cam2, poses2, points2, perr2 = run(L, Scene(p, extra_unmatched=10), free, fixed, fixed_x, refine_camera_params=1,
+                                                  update_point3D_errors=1, **opts)
+    assert rc == 0, L.shim_last_exception()
+    assert abs(ret2 - ret1) < 1e-9 * ret1
+    assert np.abs(poses2 - poses1).max() < 1e-8 * np.abs(poses1).max()
+    assert np.abs(points2 - points1).max() < 1e-8 * np.abs(points1).max()
+    assert np.abs(cam2 - cam1).max() < 1e-8 * np.abs(cam1).max()
+    assert np.abs(perr2 - perr1).max() < 1e-8 * np.abs(perr1).max()
+
+
 def test_print_report_matches_the_reference_layout(mock, capfd):
     """_print_report (reference src/base3d/bundle_adjustment.cc:114-136) + the header of :604-607, character for
     character: labels right-aligned in 18 columns, counts left-aligned, costs sqrt(cost / num_residuals) at 6
