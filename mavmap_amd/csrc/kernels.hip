@@ -423,12 +423,11 @@ struct FrontShape {
 }  // namespace
 
 template <int KMAX, bool ENTRIES, bool MASK, bool TRACE = false>
-__global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
+__global__ void __launch_bounds__(256, 2) k_point_front(FrontArgs a) {  // two work-groups per CU (LDS and registers)
   using SH = FrontShape<KMAX>;
   long long stamp[TRACE ? 12 : 1];
   int nstamp = 0;
   auto mark = [&]() { if constexpr (TRACE) { if (nstamp < 12) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
-  mark();
   extern __shared__ __attribute__((aligned(16))) double fr_smem[];
   double* s_park = fr_smem;                         // [NR][kFrPitch] the window's products of this round
   double* s_q = fr_smem + SH::PARK;                 // [kFrontQ][K3]  Wk sums
@@ -446,26 +445,40 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
   const int t_begin = (int)((long long)a.num_tiles * blockIdx.x / gridDim.x);
   const int t_end = (int)((long long)a.num_tiles * (blockIdx.x + 1) / gridDim.x);
   double cost = 0.0;
+  // A work-group walks a contiguous run of tiles. What a tile needs FIRST - its record, every lane's observation (image,
+  // point, pixel) and the owner lanes' per-point inputs - is requested while the PREVIOUS tile is still in its second
+  // phase, so the only latency left at the top of a tile is that of the gathers (camera record, point) behind them.
+  FrontTile Tn{0, 0, 0, 0, 0, 0};
+  int im_n = 0, pt_n = 0;
+  double2 m_n = make_double2(0.0, 0.0);
+  bool act_n = false, own_free_n = false;
+  double own_sp_n[3] = {0.0, 0.0, 0.0};
+  auto request_tile = [&](int t) {
+    Tn = a.tiles[t];
+    act_n = Tn.o0 + tid < Tn.o1;
+    if (act_n) { im_n = w.obs_img[Tn.o0 + tid]; pt_n = w.obs_pt[Tn.o0 + tid]; m_n = w.uv[Tn.o0 + tid]; }
+    if constexpr (ENTRIES) {
+      own_free_n = false;
+      if (tid < Tn.p1 - Tn.p0) {
+        own_free_n = a.pt_free[Tn.p0 + tid] != 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) own_sp_n[k] = a.scale_pt[(size_t)k * NPs + Tn.p0 + tid];
+      }
+    }
+  };
+  if (t_begin < t_end) request_tile(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const FrontTile T = a.tiles[tile];  // (one 24-byte record: nothing else has to arrive before the loads below go out)
+    nstamp = 0;
+    mark();  // 0: top of the tile (the trace keeps the work-group's LAST tile: steady state, prefetched)
+    const FrontTile T = Tn;
     const int np = T.p1 - T.p0;
     const int o0 = T.o0, o1 = T.o1;
     const int q0 = T.q0, nq = KMAX > 0 ? T.q1 - T.q0 : 0;
-    // The first window's observation and the owner lanes' per-point inputs are requested FIRST: their latency (and that
-    // of the gathers that depend on them) runs under the tile's bookkeeping below instead of after it.
-    int im = 0, lp = 0, pt0 = 0;
-    double2 m0 = make_double2(0.0, 0.0);
-    bool act = o0 + tid < o1;
-    if (act) { im = w.obs_img[o0 + tid]; pt0 = w.obs_pt[o0 + tid]; m0 = w.uv[o0 + tid]; }
-    bool own_free = false;
-    double own_sp[3] = {0.0, 0.0, 0.0};
-    if constexpr (ENTRIES) {
-      if (tid < np) {
-        own_free = a.pt_free[T.p0 + tid] != 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) own_sp[k] = a.scale_pt[(size_t)k * NPs + T.p0 + tid];
-      }
-    }
+    int im = im_n, lp = 0, pt0 = pt_n;
+    double2 m0 = m_n;
+    bool act = act_n;
+    const bool own_free = own_free_n;
+    const double own_sp[3] = {own_sp_n[0], own_sp_n[1], own_sp_n[2]};
     for (int j = tid; j <= np; j += 256) s_pb[j] = a.pt_start[T.p0 + j];
     for (int i = tid; i < np * 9; i += 256) s_sum[i] = 0.0;
     if constexpr (KMAX > 0) {
@@ -528,16 +541,14 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
         constexpr int lo = R * SH::NR, hi = (lo + SH::NR < SH::NROWS) ? lo + SH::NR : SH::NROWS;
         constexpr int PR = R == 0 ? 9 : 0;                             // point rows parked in this round
         constexpr int wlo = (lo > 9 ? lo : 9) - 9, WR = hi - 9 - wlo;  // Wk values [wlo, wlo + WR) parked in this round
-        if (R > 0) __syncthreads();  // (the previous round's sums have been read)
+        if (R > 0) lds_barrier();  // (the previous round's sums have been read)
         if (act) {
           if (R == 0) s_cam[tid] = cam;
 #pragma unroll
           for (int v = lo; v < hi; ++v) s_park[(v - lo) * kFrPitch + tid] = prod[v];
         }
-        __syncthreads();
-        // One lane per sum. A point's observations are a run of at most 16 in almost every tile: SIXTEEN (clamped, masked)
-        // reads go out together and the adds follow in observation order - one LDS round trip per 16 observations
-        // instead of one per element; longer tracks loop.
+        lds_barrier();
+        // One lane per sum, a point's observations added in order (a fixed sequential sum, independent of the tiling).
         const int nit = np * PR + nq * WR;
         for (int it = tid; it < nit; it += 256) {
           const bool is_pt = it < np * PR;
@@ -560,17 +571,16 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
           const int b = max(s_pb[j], base), e = min(s_pb[j + 1], base + kFrontObs);
           const int* camv = s_cam - base;
           double acc = *dst;
-          for (int i0 = b; i0 < e; i0 += 16) {
-            double x[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-              const int i = min(i0 + k, e - 1);
-              double v = row[i];
-              if (WR > 0 && !is_pt) v = camv[i] == c ? v : 0.0;
-              x[k] = i0 + k < e ? v : 0.0;   // (adding 0.0 leaves the sum as it is: the order of the real terms is the observations')
+          for (int i0 = b; i0 < e; i0 += 4) {  // four (clamped, masked) reads in flight, the adds stay in observation order
+            const int i1 = min(i0 + 1, e - 1), i2 = min(i0 + 2, e - 1), i3 = min(i0 + 3, e - 1);
+            double x0 = row[i0], x1 = row[i1], x2 = row[i2], x3 = row[i3];
+            if (WR > 0 && !is_pt) {
+              x0 = camv[i0] == c ? x0 : 0.0; x1 = camv[i1] == c ? x1 : 0.0; x2 = camv[i2] == c ? x2 : 0.0; x3 = camv[i3] == c ? x3 : 0.0;
             }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc += x[k];
+            acc += x0;
+            acc += i0 + 1 < e ? x1 : 0.0;   // (adding 0.0 leaves the sum as it is)
+            acc += i0 + 2 < e ? x2 : 0.0;
+            acc += i0 + 3 < e ? x3 : 0.0;
           }
           *dst = acc;
         }
@@ -579,8 +589,9 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
       mark();  // 3: round 0
       if constexpr (SH::ROUNDS > 1) round(std::integral_constant<int, 1>{});
       mark();  // 4: round 1
-      __syncthreads();  // sums complete; the park buffer is free for the next window
+      lds_barrier();  // sums complete; the park buffer is free for the next window
     }
+    if (tile + 1 < t_end) request_tile(tile + 1);  // (arrives under the rest of this tile)
     // ---- owner lanes: the point's sums out, its damped block factorised ----
     if (tid < np) {
       const int p = T.p0 + tid;
@@ -624,7 +635,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
       }
     }
     if constexpr (ENTRIES) {
-      __syncthreads();
+      lds_barrier();
       mark();  // 5: owner lanes done
       // ---- intrinsics entry records: Uk = (s_k Wk s_p) Gi^T (9 x 3), ek = Uk h; one lane per (record, parameter) ----
       if constexpr (KMAX > 0) {
@@ -644,7 +655,7 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
           out[3 * k] = u0; out[3 * k + 1] = u1; out[3 * k + 2] = u2;
           out[27 + k] = u0 * g[6] + u1 * g[7] + u2 * g[8];
         }
-        __syncthreads();  // the Wk sums are consumed: their LDS becomes the record staging buffer
+        lds_barrier();  // the Wk sums are consumed: their LDS becomes the record staging buffer
       }
       mark();  // 6: intrinsics records
       // ---- pose entry records: U_a = (Jc' ^T Jp') Gi^T (6 x 3), e_a = U_a h ----
@@ -687,20 +698,20 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
 #pragma unroll
             for (int k = 0; k < kPoseRec; ++k) s_rec[(tid % kStage) * 25 + k] = rec[k];
           }
-          __syncthreads();
+          lds_barrier();
           const long long gbase = ((long long)base + part * kStage) * kPoseRec;
           for (int i = tid; i < kStage * kPoseRec; i += 256) {
             const int t = i / kPoseRec, k = i - t * kPoseRec;
             if (gbase + i < lim) a.Epose[gbase + i] = s_rec[t * 25 + k];
           }
-          __syncthreads();
+          lds_barrier();
         }
       }
     } else {
-      __syncthreads();  // (the next tile re-initialises the sums)
+      lds_barrier();  // (the next tile re-initialises the sums)
     }
+    mark();  // 8: records stored
   }
-  mark();  // 8: records stored
   if constexpr (TRACE) {
     if (a.trace && (tid & 63) == 0 && blockIdx.x < 16384) {  // one line per wave: [n, stamps...] (single-tile work-groups)
       long long* out = a.trace + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 16;
@@ -712,8 +723,23 @@ __global__ void __launch_bounds__(256) k_point_front(FrontArgs a) {
   if (tid == 0) w.cost_partial[blockIdx.x] = tot;
 }
 
+// Grid: as many work-groups as are resident at once (two per CU: LDS and registers) - each walks a contiguous run of
+// tiles and prefetches the next one; MAVBA_FRONT_GRID overrides (tuning).
 int point_front_grid(int num_tiles) {
-  static const int cap = [] { const char* e = std::getenv("MAVBA_FRONT_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 && v < kFrontMaxGrid ? v : kFrontMaxGrid; }();  // tuning knob
+  static const int cap_env = [] { const char* e = std::getenv("MAVBA_FRONT_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 && v < kFrontMaxGrid ? v : 0; }();
+  static int resident[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int cap = cap_env;
+  if (cap <= 0) {
+    if (dev >= 0 && dev < 64 && resident[dev] == 0) {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+      resident[dev] = 2 * cus;
+    }
+    cap = dev >= 0 && dev < 64 ? resident[dev] : 512;
+  }
+  if (cap > kFrontMaxGrid) cap = kFrontMaxGrid;
   return num_tiles < 1 ? 0 : (num_tiles > cap ? cap : num_tiles);
 }
 void launch_point_front(hipStream_t st, const FrontArgs& a, int kmax_intr, bool entries) {

@@ -10,4 +10,4 @@ for w in range(4):
     d = np.diff(a[wv == w], axis=1)
     print(f"wave {w}: total {d.sum(1).mean():9.0f} cycles  " + "  ".join(f"{n} {x:7.0f}" for n, x in zip(names, d.mean(0))))
 t0, t1 = a[:, 0].min(), a[:, -1].max()
-print("kernel span (cycles):", t1 - t0, " tiles:", len(a) // 4, " per-tile mean:", np.diff(a[wv == 0][:, [0, -1]], axis=1).mean())
+print("kernel span (cycles):", t1 - t0, " work-groups:", len(a) // 4, " per-tile mean:", np.diff(a[wv == 0][:, [0, -1]], axis=1).mean())
