@@ -700,6 +700,7 @@ __global__ void __launch_bounds__(256, 2) k_point_front(FrontArgs a) {  // two w
           }
           lds_barrier();
           const long long gbase = ((long long)base + part * kStage) * kPoseRec;
+#pragma unroll 4
           for (int i = tid; i < kStage * kPoseRec; i += 256) {
             const int t = i / kPoseRec, k = i - t * kPoseRec;
             if (gbase + i < lim) a.Epose[gbase + i] = s_rec[t * 25 + k];
@@ -723,23 +724,10 @@ __global__ void __launch_bounds__(256, 2) k_point_front(FrontArgs a) {  // two w
   if (tid == 0) w.cost_partial[blockIdx.x] = tot;
 }
 
-// Grid: as many work-groups as are resident at once (two per CU: LDS and registers) - each walks a contiguous run of
-// tiles and prefetches the next one; MAVBA_FRONT_GRID overrides (tuning).
+// Grid: one tile per work-group (dynamic balance beat a resident grid walking runs of tiles with prefetch: 0.275 vs 0.291 ms
+// at C3); beyond kFrontMaxGrid tiles a work-group walks a contiguous run. MAVBA_FRONT_GRID overrides (tuning).
 int point_front_grid(int num_tiles) {
-  static const int cap_env = [] { const char* e = std::getenv("MAVBA_FRONT_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 && v < kFrontMaxGrid ? v : 0; }();
-  static int resident[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  int cap = cap_env;
-  if (cap <= 0) {
-    if (dev >= 0 && dev < 64 && resident[dev] == 0) {
-      int cus = 0;
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
-      resident[dev] = 2 * cus;
-    }
-    cap = dev >= 0 && dev < 64 ? resident[dev] : 512;
-  }
-  if (cap > kFrontMaxGrid) cap = kFrontMaxGrid;
+  static const int cap = [] { const char* e = std::getenv("MAVBA_FRONT_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 && v < kFrontMaxGrid ? v : kFrontMaxGrid; }();
   return num_tiles < 1 ? 0 : (num_tiles > cap ? cap : num_tiles);
 }
 void launch_point_front(hipStream_t st, const FrontArgs& a, int kmax_intr, bool entries) {
