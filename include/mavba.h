@@ -385,6 +385,10 @@ int mavba_debug_elimination_tree(int32_t num_images, int32_t num_cameras, int64_
                                  const int32_t* pair_b, int32_t max_depth, int32_t* node_of_image, int32_t* node_parent,
                                  int32_t cap);
 
+/* Test entry of the set-up's device sort (device_setup.hip): order_out [n] = the stable ascending order of 0..n-1 by
+ * keys[i] (the low `key_bytes` bytes are significant). */
+int mavba_debug_radix_sort(int32_t n, const uint32_t* keys, int32_t key_bytes, int32_t* order_out, int32_t device);
+
 /* Build the reduced camera system for the current Jacobian and trust-region
  * radius and download it: S [n][n] row-major (both triangles), v [n], with
  * n = mavba_session_reduced_dim(). Column j of image i's pose is 6*i+j,

@@ -273,6 +273,7 @@ int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, doubl
   std::vector<double> hR, hJp, hJc, hJk;
   pull(s->d_R.p, 2, hR); pull(s->d_Jp.p, 6, hJp); pull(s->d_Jc.p, 12, hJc); pull(s->d_Jk.p, 2 * s->KMAX, hJk);
   s->sync();
+  s->ensure_perm_host();
   const size_t NO = (size_t)s->NO_all;
   if (r) std::memset(r, 0, NO * 2 * 8);
   if (Jc) std::memset(Jc, 0, NO * 12 * 8);

@@ -298,6 +298,7 @@ struct mavba_session {
   DevBuf<double> d_M, d_L, d_y, d_diag_ws, d_delta_cam, d_delta_pts, d_norm_partial, d_step_partial, d_scal;
   DevBuf<double> d_rnorm, d_perr;
   DevBuf<int> d_pt_orig;      // internal point -> caller's index (read-backs are permuted on the device)
+  DevBuf<int> d_perm32;       // device set-up: point-major position -> caller's observation index (`perm` on demand)
   DevBuf<double> d_pts_out;   // [NP][3] staging in the caller's order
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
@@ -412,6 +413,11 @@ struct mavba_session {
   }
 
   void build(const mavba_problem* P);
+  void order_on_device(const mavba_problem* P, std::vector<int>& img_start);  // device_setup.hip
+  void order_on_host(const mavba_problem* P, const long long* keptp, std::vector<int>& img_start,
+                     std::unique_ptr<PinnedBuf<double2>>& uv_h, std::unique_ptr<PinnedBuf<int>>& opt_h,
+                     std::unique_ptr<PinnedBuf<double2>>& im_uv_h, std::unique_ptr<PinnedBuf<int>>& im_pt_h);
+  void ensure_perm_host();
   void derive_free_flags();
   void finish_structure();
   void choose_elimination_order(const std::vector<SchurBlock>& blocks);

@@ -38,6 +38,121 @@ void mavba_session::derive_free_flags() {
   num_parameters_reduced = np;
 }
 
+// The ordering block of build() on the host (problems with dropped all-constant blocks, small problems): the same
+// definitions as order_on_device - point order = the 8 smallest images that see the point, then the caller's index.
+void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp, std::vector<int>& img_start,
+                                  std::unique_ptr<PinnedBuf<double2>>& uv_h, std::unique_ptr<PinnedBuf<int>>& opt_h,
+                                  std::unique_ptr<PinnedBuf<double2>>& im_uv_h, std::unique_ptr<PinnedBuf<int>>& im_pt_h) {
+  const bool all_kept = keptp == nullptr;
+  auto kept_at = [keptp](long long k) { return keptp ? keptp[k] : k; };
+  // ---- internal point order ----
+  // One stable counting sort of the kept observations by (caller's) point gives every point's bucket; the
+  // point-major order is the buckets concatenated in the new point order.
+  std::vector<int> pt_new(NP);
+  std::vector<int> cstart;
+  HostBuf<long long> bucket(N);  // kept observation ids, grouped by caller's point, input order inside
+  // (pixel and image travel with it: the caller's arrays are read once, in order, instead of being gathered again)
+  HostBuf<double2> buv(N);
+  HostBuf<int> bimg(N);
+  {
+    HostBuf<int> simg(N);
+    counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept_at(k)]; }, cstart,
+                           [&](long long k, int at) {
+                             const long long o = kept_at(k);
+                             bucket[at] = o; simg[at] = bimg[at] = P->obs_image[o];
+                             buv[at] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
+                           });
+      if (all_kept)
+      for (int p = 0; p < NP; ++p) { h_pt_count_all[p] = cstart[p + 1] - cstart[p]; h_pt_used[p] = h_pt_count_all[p] > 0; }
+    // Order: the 8 smallest DISTINCT images that see the point, 16 bits each in one 128-bit key (0xFFFF padded: a point
+    // nobody sees sorts last), ties by the caller's point index - a strict total order, so the result does not depend on
+    // the number of threads, and the same definition as k_point_keys + the radix sort of the device path.
+    struct KeyId { unsigned long long hi, lo; int id; };
+    HostBuf<KeyId> keyed(NP);
+    parallel_ranges(NP, [&](long long b0, long long b1) {
+      for (long long p = b0; p < b1; ++p) {
+        unsigned k[8] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+        for (int a2 = cstart[p]; a2 < cstart[p + 1]; ++a2) {
+          unsigned x = (unsigned)simg[a2];
+          bool dup = false;
+          for (int t = 0; t < 8; ++t) dup = dup || k[t] == x;
+          if (dup) continue;
+          for (int t = 0; t < 8; ++t) if (x < k[t]) std::swap(x, k[t]);
+        }
+        KeyId kk;
+        kk.hi = (unsigned long long)k[0] << 48 | (unsigned long long)k[1] << 32 | (unsigned long long)k[2] << 16 | k[3];
+        kk.lo = (unsigned long long)k[4] << 48 | (unsigned long long)k[5] << 32 | (unsigned long long)k[6] << 16 | k[7];
+        kk.id = (int)p;
+        keyed[p] = kk;
+      }
+    });
+    auto before = [&](const KeyId& x, const KeyId& y) {
+      if (x.hi != y.hi) return x.hi < y.hi;
+      if (x.lo != y.lo) return x.lo < y.lo;
+      return x.id < y.id;
+    };
+    // Points are first dealt into buckets by their FIRST image (the key's leading 16 bits; a stable counting sort),
+    // then every bucket is sorted on its own - no merge passes.
+    if (NP >= 20000) {
+      std::vector<int> fstart;
+      HostBuf<KeyId> dealt(NP);
+      // (bucket NI: points without observations, whose key starts with 0xFFFF)
+      counting_sort_parallel(NP, NI + 1, [&](long long p) { return std::min((int)(keyed[p].hi >> 48), NI); }, fstart,
+                             [&](long long p, int at) { dealt[at] = keyed[p]; });
+      std::vector<int> nonempty;
+      for (int k = 0; k <= NI; ++k) if (fstart[k + 1] > fstart[k]) nonempty.push_back(k);
+      parallel_ranges((long long)nonempty.size(), [&](long long k0, long long k1) {
+        for (long long k = k0; k < k1; ++k) std::sort(dealt.data() + fstart[nonempty[k]], dealt.data() + fstart[nonempty[k] + 1], before);
+      }, 2);
+      parallel_ranges(NP, [&](long long b0, long long b1) { for (long long q = b0; q < b1; ++q) keyed[q] = dealt[q]; }, 20000);
+    } else {
+      std::sort(keyed.data(), keyed.data() + NP, before);
+    }
+    h_pt_orig.resize(NP);
+    for (int q = 0; q < NP; ++q) h_pt_orig[q] = keyed[q].id;
+    for (int q = 0; q < NP; ++q) pt_new[h_pt_orig[q]] = q;
+    auto permute = [&](auto& v, int width) {
+      auto old = v;
+      parallel_ranges(NP, [&](long long b0, long long b1) {
+        for (long long q = b0; q < b1; ++q)
+          for (int e = 0; e < width; ++e) v[(size_t)q * width + e] = old[(size_t)h_pt_orig[q] * width + e];
+      });
+    };
+    permute(h_points0, 3); permute(h_pt_const_in, 1); permute(h_pt_count_all, 1); permute(h_pt_used, 1);
+  }
+
+  // ---- point-major order: the buckets in the new point order ----
+  h_pt_start.assign(NP + 1, 0);
+  for (int q = 0; q < NP; ++q) h_pt_start[q + 1] = h_pt_start[q] + (cstart[h_pt_orig[q] + 1] - cstart[h_pt_orig[q]]);
+  HostSpare<long long>::take(perm, (size_t)N);
+  HostSpare<int>::take(h_oimg, (size_t)N);
+  perm.resize(N);    // (every element is written by the pass below)
+  uv_h.reset(new PinnedBuf<double2>(N));   // (uploaded by build(), asynchronously: they live until its final sync)
+  opt_h.reset(new PinnedBuf<int>(N));
+  PinnedBuf<double2>& uv = *uv_h;
+  PinnedBuf<int>& opt_ = *opt_h;
+  h_oimg.resize(N);
+  parallel_ranges(NP, [&](long long q0, long long q1) {
+    for (long long q = q0; q < q1; ++q) {
+      const int src = cstart[h_pt_orig[q]], cnt = h_pt_start[q + 1] - h_pt_start[q];
+      for (int j = 0; j < cnt; ++j) {
+        const int a = h_pt_start[q] + j;
+        perm[a] = bucket[src + j];
+        uv[a] = buv[src + j];
+        h_oimg[a] = bimg[src + j]; opt_[a] = (int)q;
+      }
+    }
+  });
+
+  // ---- image-major view for the camera sweep ----
+  im_uv_h.reset(new PinnedBuf<double2>(N));
+  im_pt_h.reset(new PinnedBuf<int>(N));
+  PinnedBuf<double2>& im_uv = *im_uv_h;
+  PinnedBuf<int>& im_pt = *im_pt_h;
+  counting_sort_parallel(N, NI, [&](long long a) { return h_oimg[a]; }, img_start,
+                         [&](long long a, int at) { im_uv[at] = uv[a]; im_pt[at] = opt_[a]; });
+}
+
 void mavba_session::build(const mavba_problem* P) {
   const double t0 = now_s();
   const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
@@ -62,16 +177,7 @@ void mavba_session::build(const mavba_problem* P) {
   KMAX = kmax;  // 4, 8 or 9: number of intrinsics columns the Jacobian planes carry
   for (int i = 0; i < NI; ++i)
     if (h_img_cam[i] < 0 || h_img_cam[i] >= NC) throw Failure(MAVBA_ERR_BAD_INDEX, "image_camera out of range");
-  {
-    int bad = 0;
-    parallel_ranges(NO_all, [&](long long b0, long long b1) {
-      int local = 0;
-      for (long long o = b0; o < b1; ++o)
-        local |= (P->obs_image[o] < 0) | (P->obs_image[o] >= NI) | (P->obs_point[o] < 0) | (P->obs_point[o] >= NP);
-      if (local) __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
-    });
-    if (bad) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
-  }
+  // (the observation indices are checked below: on the host, or by the device set-up's counting kernel)
   if (P->num_rot_priors < 0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "negative num_rot_priors");
   if (P->num_rot_priors > 0 && (!P->rot_prior_image || !P->rot_prior_rvec)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null rotation-prior arrays");
   for (int q = 0; q < P->num_rot_priors; ++q)
@@ -101,6 +207,21 @@ void mavba_session::build(const mavba_problem* P) {
   for (int i = 0; i < NI; ++i) any_const_img |= (h_pose_const[i] & 15u) == 15u && h_intr_const_in[h_img_cam[i]];
   for (int p = 0; p < NP; ++p) any_const_pt |= h_pt_const_in[p] != 0;
   const bool all_kept = !(any_const_img && any_const_pt);
+  // where the ordering block will run (device_setup.hip unless all-constant residual blocks are dropped - the host walks
+  // the kept list then - or the problem is small); MAVBA_SETUP=device | host forces one implementation (tests, timing)
+  const char* setup_env = std::getenv("MAVBA_SETUP");
+  const int setup_mode = !setup_env ? 0 : (std::string(setup_env) == "device" ? 1 : (std::string(setup_env) == "host" ? 2 : 0));
+  const bool device_order = all_kept && NO_all > 0 && NP > 0 && setup_mode != 2 && (setup_mode == 1 || NO_all >= 50000);
+  if (!device_order) {
+    int bad = 0;
+    parallel_ranges(NO_all, [&](long long b0, long long b1) {
+      int local = 0;
+      for (long long o = b0; o < b1; ++o)
+        local |= (P->obs_image[o] < 0) | (P->obs_image[o] >= NI) | (P->obs_point[o] < 0) | (P->obs_point[o] >= NP);
+      if (local) __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+    });
+    if (bad) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
+  }
   if (all_kept) {
     // (the per-point counts and the used flags then fall out of the counting sorts below; `kept` stays empty = identity)
   } else {
@@ -157,117 +278,18 @@ void mavba_session::build(const mavba_problem* P) {
   num_residuals = 2 * NO_all + P->num_rot_priors;
   num_residuals_reduced = 2ll * N + num_priors;
 
-  // ---- internal point order: lexicographic by the sorted list of images that see the point ----
-  // One stable counting sort of the kept observations by (caller's) point gives every point's bucket; the
-  // point-major order is the buckets concatenated in the new point order.
-  std::vector<int> pt_new(NP);
-  std::vector<int> cstart;
-  HostBuf<long long> bucket(N);  // kept observation ids, grouped by caller's point, input order inside
-  // (pixel and image travel with it: the caller's arrays are read once, in order, instead of being gathered again)
-  HostBuf<double2> buv(N);
-  HostBuf<int> bimg(N);
-  {
-    HostBuf<int> simg(N);
-    counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept_at(k)]; }, cstart,
-                           [&](long long k, int at) {
-                             const long long o = kept_at(k);
-                             bucket[at] = o; simg[at] = bimg[at] = P->obs_image[o];
-                             buv[at] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
-                           });
-    lap("  buckets by point");
-    if (all_kept)
-      for (int p = 0; p < NP; ++p) { h_pt_count_all[p] = cstart[p + 1] - cstart[p]; h_pt_used[p] = h_pt_count_all[p] > 0; }
-    parallel_ranges(NP, [&](long long b0, long long b1) {
-      for (long long p = b0; p < b1; ++p) std::sort(simg.data() + cstart[p], simg.data() + cstart[p + 1]);
-    });
-    // Order: by the first four images packed into one 64-bit key (cache-friendly sort of (key, point) pairs),
-    // ties by the full list, then by point id - a strict total order, so the result does not depend on the
-    // number of threads.
-    auto before_full = [&](int a, int b) {
-      const int* xa = simg.data() + cstart[a]; const int* xb = simg.data() + cstart[b];
-      const int na = cstart[a + 1] - cstart[a], nb = cstart[b + 1] - cstart[b];
-      const int n = std::min(na, nb);
-      for (int i = 0; i < n; ++i) if (xa[i] != xb[i]) return xa[i] < xb[i];
-      if (na != nb) return na < nb;
-      return a < b;
-    };
-    lap("  per-point image lists");
-    typedef std::pair<unsigned long long, int> KeyId;
-    HostBuf<KeyId> keyed(NP);
-    const bool packable = NI < 65535;
-    parallel_ranges(NP, [&](long long b0, long long b1) {
-      for (long long p = b0; p < b1; ++p) {
-        unsigned long long key = 0;
-        const int n = cstart[p + 1] - cstart[p];
-        for (int i = 0; i < 4; ++i) key = key << 16 | (unsigned long long)(packable && i < n ? simg[cstart[p] + i] : 0xFFFF);
-        keyed[p] = KeyId(packable ? key : 0ull, (int)p);
-      }
-    });
-    auto before = [&](const KeyId& a, const KeyId& b) {
-      if (a.first != b.first) return a.first < b.first;
-      return before_full(a.second, b.second);
-    };
-    // Points are first dealt into buckets by their FIRST image (the key's leading 16 bits; a stable counting sort),
-    // then every bucket is sorted on its own - no merge passes, and the result still does not depend on the number of
-    // threads (`before` is a strict total order).
-    if (packable && NP >= 20000) {
-      std::vector<int> fstart;
-      HostBuf<KeyId> dealt(NP);
-      // (bucket NI: points without observations, whose key starts with 0xFFFF)
-      counting_sort_parallel(NP, NI + 1, [&](long long p) { return std::min((int)(keyed[p].first >> 48), NI); }, fstart,
-                             [&](long long p, int at) { dealt[at] = keyed[p]; });
-      std::vector<int> nonempty;
-      for (int k = 0; k <= NI; ++k) if (fstart[k + 1] > fstart[k]) nonempty.push_back(k);
-      parallel_ranges((long long)nonempty.size(), [&](long long k0, long long k1) {
-        for (long long k = k0; k < k1; ++k) std::sort(dealt.data() + fstart[nonempty[k]], dealt.data() + fstart[nonempty[k] + 1], before);
-      }, 2);
-      parallel_ranges(NP, [&](long long b0, long long b1) { for (long long q = b0; q < b1; ++q) keyed[q] = dealt[q]; }, 20000);
-    } else {
-      std::sort(keyed.data(), keyed.data() + NP, before);
-    }
-    lap("  sort points");
-    h_pt_orig.resize(NP);
-    for (int q = 0; q < NP; ++q) h_pt_orig[q] = keyed[q].second;
-    for (int q = 0; q < NP; ++q) pt_new[h_pt_orig[q]] = q;
-    auto permute = [&](auto& v, int width) {
-      auto old = v;
-      parallel_ranges(NP, [&](long long b0, long long b1) {
-        for (long long q = b0; q < b1; ++q)
-          for (int e = 0; e < width; ++e) v[(size_t)q * width + e] = old[(size_t)h_pt_orig[q] * width + e];
-      });
-    };
-    permute(h_points0, 3); permute(h_pt_const_in, 1); permute(h_pt_count_all, 1); permute(h_pt_used, 1);
-  }
-  lap("point order");
-
-  // ---- point-major order: the buckets in the new point order ----
-  h_pt_start.assign(NP + 1, 0);
-  for (int q = 0; q < NP; ++q) h_pt_start[q + 1] = h_pt_start[q] + (cstart[h_pt_orig[q] + 1] - cstart[h_pt_orig[q]]);
-  HostSpare<long long>::take(perm, (size_t)N);
-  HostSpare<int>::take(h_oimg, (size_t)N);
-  perm.resize(N);    // (every element is written by the pass below)
-  PinnedBuf<double2> uv(N);   // (uploaded below, asynchronously: they live until the sync at the end of build)
-  PinnedBuf<int> opt_(N);
-  h_oimg.resize(N);
-  parallel_ranges(NP, [&](long long q0, long long q1) {
-    for (long long q = q0; q < q1; ++q) {
-      const int src = cstart[h_pt_orig[q]], cnt = h_pt_start[q + 1] - h_pt_start[q];
-      for (int j = 0; j < cnt; ++j) {
-        const int a = h_pt_start[q] + j;
-        perm[a] = bucket[src + j];
-        uv[a] = buv[src + j];
-        h_oimg[a] = bimg[src + j]; opt_[a] = (int)q;
-      }
-    }
-  });
-
-  lap("point-major sort");
-  // ---- image-major view for the camera sweep ----
+  // ---- internal point order and the two observation orders: on the device (device_setup.hip) unless all-constant
+  // residual blocks were dropped (the host walks the kept list then) or the problem is small ----
   std::vector<int> img_start;
-  PinnedBuf<double2> im_uv(N);
-  PinnedBuf<int> im_pt(N);
-  counting_sort_parallel(N, NI, [&](long long a) { return h_oimg[a]; }, img_start,
-                         [&](long long a, int at) { im_uv[at] = uv[a]; im_pt[at] = opt_[a]; });
+  std::unique_ptr<PinnedBuf<double2>> uv_h, im_uv_h;   // host path: page-locked staging of the arrays uploaded below
+  std::unique_ptr<PinnedBuf<int>> opt_h, im_pt_h;
+  if (device_order) {
+    order_on_device(P, img_start);
+    lap("order on device");
+  } else {
+    order_on_host(P, keptp, img_start, uv_h, opt_h, im_uv_h, im_pt_h);
+    lap("order on host");
+  }
   if (all_kept)
     for (int i = 0; i < NI; ++i)
       if (img_start[i + 1] > img_start[i]) { h_img_used[i] = 1; h_cam_used[h_img_cam[i]] = 1; }
@@ -304,15 +326,18 @@ void mavba_session::build(const mavba_problem* P) {
 
   lap("image-major view");
   // ---- uploads of the static data ----
-  d_uv.upload(uv.data(), (size_t)N, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload(opt_.data(), (size_t)N, st); d_pt_start.upload(h_pt_start, st);
-  d_im_uv.upload(im_uv.data(), (size_t)N, st); d_im_pt.upload(im_pt.data(), (size_t)N, st);
+  if (!device_order) {
+    d_uv.upload(uv_h->data(), (size_t)N, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload(opt_h->data(), (size_t)N, st); d_pt_start.upload(h_pt_start, st);
+    d_im_uv.upload(im_uv_h->data(), (size_t)N, st); d_im_pt.upload(im_pt_h->data(), (size_t)N, st);
+  }
   d_img_cam.upload(h_img_cam, st); d_cam_model.upload(h_cam_model, st);
   d_sweep_chunks.upload(sweep_chunks, st); d_img_chunk_start.upload(img_chunk_start, st);
   d_cam_img_start.upload(cam_img_start, st); d_cam_imgs.upload(cam_imgs, st);
   d_prior_img.upload(prior_img, st); d_prior_start.upload(prior_start, st); d_prior_R0.upload(prior_R0, st);
   d_pt_count.upload(h_pt_count_all, st);
-  d_pt_orig.upload(h_pt_orig, st); d_pts_out.alloc((size_t)std::max(NP, 1) * 3);
-  d_poses0.upload(h_poses0, st); d_intr0.upload(h_intr0, st); d_points0.upload(h_points0, st);
+  if (!device_order) { d_pt_orig.upload(h_pt_orig, st); d_points0.upload(h_points0, st); }
+  d_pts_out.alloc((size_t)std::max(NP, 1) * 3);
+  d_poses0.upload(h_poses0, st); d_intr0.upload(h_intr0, st);
   const size_t nI = std::max(NI, 1), nC = std::max(NC, 1), nP = std::max(NP, 1);
   d_poses.alloc(nI * 6); d_intr.alloc(nC * 9); d_points.alloc(nP * 3);
   d_cposes.alloc(nI * 6); d_cintr.alloc(nC * 9); d_cpoints.alloc(nP * 3);
