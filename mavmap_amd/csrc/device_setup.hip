@@ -230,6 +230,15 @@ using namespace mavba;
 void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& img_start) {
   const int n = N;
   RadixScratch S;
+  const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
+  double tl = now_s();
+  auto lap = [&](const char* what) {  // (timing mode synchronises the stream at every lap)
+    if (!tt) return;
+    (void)hipStreamSynchronize(st);
+    const double t = now_s();
+    std::fprintf(stderr, "[setup]   dev: %-22s %8.2f ms\n", what, 1e3 * (t - tl));
+    tl = t;
+  };
   // raw problem -> device (page-locked staging blocks filled by a few host threads: the copies are asynchronous)
   PinnedBuf<double> s_uv((size_t)2 * n);
   PinnedBuf<int> s_img(n), s_pt(n);
@@ -240,6 +249,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
     std::memcpy(s_pt.data() + b0, P->obs_point + b0, (size_t)(b1 - b0) * 4);
   });
   std::memcpy(s_pts.data(), P->points, (size_t)NP * 24);
+  lap("stage (host memcpy)");
   DevBuf<double> r_uv, r_pts;
   DevBuf<int> r_img, r_pt;
   DevBuf<unsigned char> r_pconst;
@@ -259,6 +269,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   HIP_OK(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
   sync();
   if (h_bad) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
+  lap("upload + counts");
   // observations grouped by (caller's) point, caller order inside a point
   DevBuf<int> byp;
   byp.alloc((size_t)n);
@@ -267,6 +278,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
     for (int b = 0; b < bytes_for(std::max(NP - 1, 0)); ++b) passes.push_back({reinterpret_cast<const unsigned*>(r_pt.p), 8 * b});
     radix_sort_indices(st, n, nullptr, byp.p, S, passes);
   }
+  lap("sort obs by point");
   // point order: 128-bit key of the 8 smallest images, ties by the caller's index
   for (int k = 0; k < 4; ++k) w[k].alloc((size_t)std::max(NP, 1));
   hipLaunchKernelGGL(k_point_keys, dim3((NP + 255) / 256), dim3(256), 0, st, NP, cstart.p, byp.p, r_img.p, w[0].p, w[1].p, w[2].p, w[3].p);
@@ -277,6 +289,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
       for (int b = 0; b < 4; ++b) passes.push_back({w[k].p, 8 * b});
     radix_sort_indices(st, NP, nullptr, d_pt_orig.p, S, passes);
   }
+  lap("point keys + sort");
   // point-major arrays in the new order
   hipLaunchKernelGGL(k_new_counts, dim3((NP + 255) / 256), dim3(256), 0, st, NP, d_pt_orig.p, cstart.p, pstart.p);
   HIP_OK(hipMemsetAsync(pstart.p + NP, 0, 4, st));
@@ -288,6 +301,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   hipLaunchKernelGGL(k_gather_point_major, dim3((NP + 1 + 255) / 256), dim3(256), 0, st, NP, d_pt_orig.p, cstart.p, pstart.p, byp.p,
                      r_uv.p, r_img.p, r_pts.p, P->point_const ? r_pconst.p : nullptr, d_uv.p, d_obs_img.p, d_obs_pt.p, d_perm32.p,
                      d_points0.p, pconst_new.p, d_pt_start.p);
+  lap("gather point-major");
   // image-major view: positions sorted by image, point-major order inside an image
   DevBuf<int> im_order;
   im_order.alloc((size_t)std::max(n, 1));
@@ -298,6 +312,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   }
   d_im_uv.alloc((size_t)std::max(n, 1)); d_im_pt.alloc((size_t)std::max(n, 1));
   hipLaunchKernelGGL(k_gather_image_major, dim3((n + 255) / 256), dim3(256), 0, st, n, im_order.p, d_uv.p, d_obs_pt.p, d_im_uv.p, d_im_pt.p);
+  lap("image-major view");
   // what the host's structure pass needs: 4 B per point and per observation
   h_pt_orig.resize(NP); h_pt_start.resize((size_t)NP + 1); img_start.resize((size_t)NI + 1);
   HostSpare<int>::take(h_oimg, (size_t)n);
@@ -312,6 +327,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   h_pt_const_in.assign(pc.begin(), pc.begin() + NP);
   h_pt_count_all.resize(NP); h_pt_used.resize(NP);
   for (int q = 0; q < NP; ++q) { h_pt_count_all[q] = h_pt_start[q + 1] - h_pt_start[q]; h_pt_used[q] = h_pt_count_all[q] > 0; }
+  lap("downloads");
   h_points0.clear();  // (the device holds the initial points; nothing on the host reads them on this path)
   perm.clear();
 }
