@@ -39,8 +39,8 @@ __global__ void __launch_bounds__(kRsThreads) k_radix_hist(const int* __restrict
   hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
 }
 
-// exclusive prefix sum of `total` unsigned values in place; ONE work-group of 1024 threads. out_total (may be null)
-// receives the grand total.
+// exclusive prefix sum of `total` unsigned values in place; ONE work-group of 1024 threads (short arrays: per-point /
+// per-image counts). out_total (may be null) receives the grand total.
 __global__ void __launch_bounds__(1024) k_scan_exclusive(unsigned* __restrict__ data, long long total, unsigned* __restrict__ out_total) {
   __shared__ unsigned s_part[1024];
   const int t = threadIdx.x;
@@ -60,6 +60,48 @@ __global__ void __launch_bounds__(1024) k_scan_exclusive(unsigned* __restrict__ 
   unsigned run = t > 0 ? s_part[t - 1] : 0u;
   for (long long i = b; i < e; ++i) { const unsigned x = data[i]; data[i] = run; run += x; }
   if (out_total && t == 1023) *out_total = s_part[1023];
+}
+
+// The radix histogram hist[bin][block] is scanned in two parallel steps instead of by one work-group: row totals (one
+// work-group per bin, coalesced over the blocks), then every row scans itself starting from the total of the bins before it.
+__device__ __forceinline__ unsigned block_sum_u256(unsigned v, unsigned* s4) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s4[0] + s4[1] + s4[2] + s4[3];
+}
+__global__ void __launch_bounds__(256) k_hist_row_totals(const unsigned* __restrict__ hist, int nblocks, unsigned* __restrict__ totals) {
+  __shared__ unsigned s4[4];
+  const unsigned* row = hist + (size_t)blockIdx.x * nblocks;
+  unsigned sum = 0u;
+  for (int i = threadIdx.x; i < nblocks; i += 256) sum += row[i];
+  const unsigned tot = block_sum_u256(sum, s4);
+  if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) k_hist_row_scan(unsigned* __restrict__ hist, int nblocks, const unsigned* __restrict__ totals) {
+  __shared__ unsigned s4[4];
+  __shared__ unsigned s_scan[256];
+  unsigned* row = hist + (size_t)blockIdx.x * nblocks;
+  // base = total of the bins before this one
+  const unsigned before = (int)threadIdx.x < (int)blockIdx.x ? totals[threadIdx.x] : 0u;
+  unsigned run = block_sum_u256(before, s4);
+  for (int b0 = 0; b0 < nblocks; b0 += 256) {
+    const int i = b0 + threadIdx.x;
+    const unsigned x = i < nblocks ? row[i] : 0u;
+    s_scan[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const unsigned add = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
+      __syncthreads();
+      s_scan[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nblocks) row[i] = run + s_scan[threadIdx.x] - x;  // exclusive
+    run += s_scan[255];
+    __syncthreads();
+  }
 }
 
 // Stable scatter: element i of the input goes to  hist[digit][block] (scanned) + its rank among the block's earlier
@@ -109,8 +151,35 @@ __global__ void __launch_bounds__(kRsThreads) k_radix_scatter(const int* __restr
   }
 }
 
+// ---- exclusive scan of any length: work-group chunks of 2048 (local scan + chunk total), scan of the totals, add ----
+__global__ void __launch_bounds__(256) k_scan_chunks(unsigned* __restrict__ data, long long n, unsigned* __restrict__ totals) {
+  __shared__ unsigned s_scan[256];
+  const long long base = (long long)blockIdx.x * 2048 + (long long)threadIdx.x * 8;
+  unsigned x[8], sum = 0u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { x[k] = base + k < n ? data[base + k] : 0u; sum += x[k]; }
+  s_scan[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const unsigned add = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s_scan[threadIdx.x] += add;
+    __syncthreads();
+  }
+  unsigned run = s_scan[threadIdx.x] - sum;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { if (base + k < n) data[base + k] = run; run += x[k]; }
+  if (threadIdx.x == 255) totals[blockIdx.x] = s_scan[255];
+}
+__global__ void __launch_bounds__(256) k_scan_add(unsigned* __restrict__ data, long long n, const unsigned* __restrict__ offsets) {
+  const unsigned off = offsets[blockIdx.x];
+  const long long base = (long long)blockIdx.x * 2048 + (long long)threadIdx.x * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (base + k < n) data[base + k] += off;
+}
+
 struct RadixScratch {
-  DevBuf<unsigned> hist;
+  DevBuf<unsigned> hist, totals;
   DevBuf<int> tmp;
 };
 
@@ -122,13 +191,15 @@ void radix_sort_indices(hipStream_t st, int n, const int* idx, int* out, RadixSc
   const int nblocks = (n + kRsChunk - 1) / kRsChunk;
   if (S.hist.n < (size_t)256 * nblocks) S.hist.alloc((size_t)256 * nblocks);
   if (S.tmp.n < (size_t)n) S.tmp.alloc((size_t)n);
+  if (S.totals.n < 256) S.totals.alloc(256);
   // ping-pong so that the LAST pass writes `out`
   const int np = (int)passes.size();
   const int* src = idx;
   for (int k = 0; k < np; ++k) {
     int* dst = ((np - 1 - k) % 2 == 0) ? out : S.tmp.p;
     hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kRsThreads), 0, st, src, n, passes[k].first, passes[k].second, S.hist.p, nblocks);
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, S.hist.p, (long long)256 * nblocks, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k_hist_row_totals, dim3(256), dim3(256), 0, st, S.hist.p, nblocks, S.totals.p);
+    hipLaunchKernelGGL(k_hist_row_scan, dim3(256), dim3(256), 0, st, S.hist.p, nblocks, S.totals.p);
     hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(kRsThreads), 0, st, src, dst, n, passes[k].first, passes[k].second, S.hist.p, nblocks);
     src = dst;
   }
@@ -138,6 +209,21 @@ void radix_sort_indices(hipStream_t st, int n, const int* idx, int* out, RadixSc
   }
 }
 
+}  // namespace
+// scratch: at least device_scan_scratch(n) unsigned values, alive until the stream has run the scan
+long long device_scan_scratch(long long n) {
+  const long long n1 = (n + 2047) / 2048;
+  return n <= 4096 ? 1 : n1 + (n1 + 2047) / 2048 + 1;
+}
+void device_scan_exclusive(hipStream_t st, unsigned* data, long long n, unsigned* scratch) {
+  if (n <= 0) return;
+  if (n <= 4096) { hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, data, n, (unsigned*)nullptr); return; }
+  const long long nchunks = (n + 2047) / 2048;
+  hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)nchunks), dim3(256), 0, st, data, n, scratch);
+  device_scan_exclusive(st, scratch, nchunks, scratch + nchunks);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nchunks), dim3(256), 0, st, data, n, scratch);
+}
+namespace {
 int bytes_for(long long max_value) {  // key bytes needed for values in [0, max_value]
   int b = 1;
   while (b < 4 && (max_value >> (8 * b)) != 0) ++b;
@@ -145,14 +231,30 @@ int bytes_for(long long max_value) {  // key bytes needed for values in [0, max_
 }
 
 // ---- set-up kernels ----------------------------------------------------------------------------------------------
-__global__ void k_count_obs(int n, int NI, int NP, const int* __restrict__ oimg, const int* __restrict__ opt,
-                            unsigned* __restrict__ cnt_pt, unsigned* __restrict__ cnt_img, int* __restrict__ bad) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n) return;
-  const int i = oimg[o], p = opt[o];
-  if (i < 0 || i >= NI || p < 0 || p >= NP) { *bad = 1; return; }
-  atomicAdd(&cnt_pt[p], 1u);
-  atomicAdd(&cnt_img[i], 1u);
+// Observations per point (global atomics: ~10 increments per address) and per image (thousands per address: first an LDS
+// histogram per work-group of 4096 observations, then one global increment per image the group saw); index check.
+constexpr int kCountImgLds = 8192;
+__global__ void __launch_bounds__(256) k_count_obs(int n, int NI, int NP, const int* __restrict__ oimg, const int* __restrict__ opt,
+                                                   unsigned* __restrict__ cnt_pt, unsigned* __restrict__ cnt_img, int* __restrict__ bad) {
+  extern __shared__ unsigned s_img[];  // [min(NI, kCountImgLds)] or nothing
+  const bool lds = NI <= kCountImgLds;
+  if (lds) {
+    for (int i = threadIdx.x; i < NI; i += 256) s_img[i] = 0u;
+    __syncthreads();
+  }
+  const int base = blockIdx.x * 4096;
+  for (int k = 0; k < 16; ++k) {
+    const int o = base + k * 256 + threadIdx.x;
+    if (o >= n) break;
+    const int i = oimg[o], p = opt[o];
+    if (i < 0 || i >= NI || p < 0 || p >= NP) { *bad = 1; continue; }
+    atomicAdd(&cnt_pt[p], 1u);
+    if (lds) atomicAdd(&s_img[i], 1u); else atomicAdd(&cnt_img[i], 1u);
+  }
+  if (lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < NI; i += 256) { const unsigned c = s_img[i]; if (c) atomicAdd(&cnt_img[i], c); }
+  }
 }
 
 // Per caller point: the 8 smallest images that see it (repeats count once), packed 16 bits each into four key words,
@@ -227,7 +329,7 @@ using namespace mavba;
 // The ordering block of build() on the device. Fills: d_uv, d_obs_img, d_obs_pt, d_pt_start, d_im_uv, d_im_pt, d_pt_orig,
 // d_points0, d_perm32; host: h_pt_orig, h_pt_start, h_oimg, h_pt_const_in (internal order), h_pt_count_all, h_pt_used,
 // img_start. Throws MAVBA_ERR_BAD_INDEX for an observation index out of range.
-void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& img_start) {
+void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& img_start, const DeviceRaw* raw) {
   const int n = N;
   RadixScratch S;
   const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
@@ -239,37 +341,48 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
     std::fprintf(stderr, "[setup]   dev: %-22s %8.2f ms\n", what, 1e3 * (t - tl));
     tl = t;
   };
-  // raw problem -> device (page-locked staging blocks filled by a few host threads: the copies are asynchronous)
-  PinnedBuf<double> s_uv((size_t)2 * n);
-  PinnedBuf<int> s_img(n), s_pt(n);
-  PinnedBuf<double> s_pts((size_t)3 * std::max(NP, 1));
-  parallel_ranges(n, [&](long long b0, long long b1) {
-    std::memcpy(s_uv.data() + 2 * b0, P->obs_uv + 2 * b0, (size_t)(b1 - b0) * 16);
-    std::memcpy(s_img.data() + b0, P->obs_image + b0, (size_t)(b1 - b0) * 4);
-    std::memcpy(s_pt.data() + b0, P->obs_point + b0, (size_t)(b1 - b0) * 4);
-  });
-  std::memcpy(s_pts.data(), P->points, (size_t)NP * 24);
-  lap("stage (host memcpy)");
-  DevBuf<double> r_uv, r_pts;
-  DevBuf<int> r_img, r_pt;
+  // raw problem -> device (page-locked staging blocks filled by a few host threads: the copies are asynchronous) - unless
+  // it is there already (device-resident scene)
+  DevBuf<double> r_uv_own, r_pts_own;
+  DevBuf<int> r_img_own, r_pt_own;
   DevBuf<unsigned char> r_pconst;
-  r_uv.upload(s_uv.data(), (size_t)2 * n, st); r_img.upload(s_img.data(), (size_t)n, st); r_pt.upload(s_pt.data(), (size_t)n, st);
-  r_pts.upload(s_pts.data(), (size_t)3 * NP, st);
+  std::unique_ptr<PinnedBuf<double>> s_uv, s_pts;
+  std::unique_ptr<PinnedBuf<int>> s_img, s_pt;
+  struct { const double* p; } r_uv, r_pts;
+  struct { const int* p; } r_img, r_pt;
+  if (raw) {
+    r_uv.p = raw->uv; r_img.p = raw->img; r_pt.p = raw->pt; r_pts.p = raw->points;
+  } else {
+    s_uv.reset(new PinnedBuf<double>((size_t)2 * n)); s_img.reset(new PinnedBuf<int>(n)); s_pt.reset(new PinnedBuf<int>(n));
+    s_pts.reset(new PinnedBuf<double>((size_t)3 * std::max(NP, 1)));
+    parallel_ranges(n, [&](long long b0, long long b1) {
+      std::memcpy(s_uv->data() + 2 * b0, P->obs_uv + 2 * b0, (size_t)(b1 - b0) * 16);
+      std::memcpy(s_img->data() + b0, P->obs_image + b0, (size_t)(b1 - b0) * 4);
+      std::memcpy(s_pt->data() + b0, P->obs_point + b0, (size_t)(b1 - b0) * 4);
+    });
+    std::memcpy(s_pts->data(), P->points, (size_t)NP * 24);
+    lap("stage (host memcpy)");
+    r_uv_own.upload(s_uv->data(), (size_t)2 * n, st); r_img_own.upload(s_img->data(), (size_t)n, st); r_pt_own.upload(s_pt->data(), (size_t)n, st);
+    r_pts_own.upload(s_pts->data(), (size_t)3 * NP, st);
+    r_uv.p = r_uv_own.p; r_img.p = r_img_own.p; r_pt.p = r_pt_own.p; r_pts.p = r_pts_own.p;
+  }
   if (P->point_const) r_pconst.upload(h_pt_const_in, st);  // (still in the caller's order here)
+  lap("upload");
   // counts per point / per image, index check
   DevBuf<unsigned> cstart, pstart, istart, w[4];
   DevBuf<int> bad;
   cstart.alloc((size_t)NP + 1); pstart.alloc((size_t)NP + 1); istart.alloc((size_t)NI + 1);
   bad.alloc(1);
   cstart.zero(st); istart.zero(st); bad.zero(st);
-  hipLaunchKernelGGL(k_count_obs, dim3((n + 255) / 256), dim3(256), 0, st, n, NI, NP, r_img.p, r_pt.p, cstart.p, istart.p, bad.p);
+  hipLaunchKernelGGL(k_count_obs, dim3((n + 4095) / 4096), dim3(256), NI <= kCountImgLds ? (size_t)NI * 4 : 0, st, n, NI, NP, r_img.p, r_pt.p,
+                     cstart.p, istart.p, bad.p);
   hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, cstart.p, (long long)NP + 1, (unsigned*)nullptr);
   hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, istart.p, (long long)NI + 1, (unsigned*)nullptr);
   int h_bad = 0;
   HIP_OK(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
   sync();
   if (h_bad) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
-  lap("upload + counts");
+  lap("counts");
   // observations grouped by (caller's) point, caller order inside a point
   DevBuf<int> byp;
   byp.alloc((size_t)n);

@@ -69,6 +69,11 @@ struct DevBuf {
 struct ElimNode { std::vector<int> imgs; int parent; };
 std::vector<ElimNode> elimination_tree(int NI, int NC, const std::vector<std::vector<int>>& lower, int forced, int max_depth);
 
+// device_setup.hip: a problem whose observations and points ALREADY live in HBM (the device-resident scene hands these over)
+struct DeviceRaw { const double* uv; const int* img; const int* pt; const double* points; };
+long long device_scan_scratch(long long n);
+void device_scan_exclusive(hipStream_t st, unsigned* data, long long n, unsigned* scratch);  // in place, any length; scratch >= device_scan_scratch(n) values
+
 // multi_gpu.hip: one process, several devices (MAVBA_GPUS)
 int multi_gpu_ranks();
 int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_result* result, double* point_error, int world);
@@ -412,8 +417,10 @@ struct mavba_session {
     sync();
   }
 
-  void build(const mavba_problem* P);
-  void order_on_device(const mavba_problem* P, std::vector<int>& img_start);  // device_setup.hip
+  // raw != null: obs_uv / obs_image / obs_point / points of the problem are DEVICE arrays given by `raw` (P's own pointers to
+  // them are not read); needs a problem without dropped all-constant blocks
+  void build(const mavba_problem* P, const DeviceRaw* raw = nullptr);
+  void order_on_device(const mavba_problem* P, std::vector<int>& img_start, const DeviceRaw* raw);  // device_setup.hip
   void order_on_host(const mavba_problem* P, const long long* keptp, std::vector<int>& img_start,
                      std::unique_ptr<PinnedBuf<double2>>& uv_h, std::unique_ptr<PinnedBuf<int>>& opt_h,
                      std::unique_ptr<PinnedBuf<double2>>& im_uv_h, std::unique_ptr<PinnedBuf<int>>& im_pt_h);

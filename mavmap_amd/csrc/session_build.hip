@@ -153,7 +153,7 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
                          [&](long long a, int at) { im_uv[at] = uv[a]; im_pt[at] = opt_[a]; });
 }
 
-void mavba_session::build(const mavba_problem* P) {
+void mavba_session::build(const mavba_problem* P, const DeviceRaw* raw) {
   const double t0 = now_s();
   const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
   double tl = t0;
@@ -165,8 +165,8 @@ void mavba_session::build(const mavba_problem* P) {
   if (!(opt.loss_scale_factor > 0.0)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "loss_scale_factor must be > 0");
   if (NI > 0 && (!P->poses || !P->image_camera)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null pose arrays");
   if (NC > 0 && (!P->intrinsics || !P->camera_model)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null camera arrays");
-  if (NP > 0 && !P->points) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null point array");
-  if (NO_all > 0 && (!P->obs_uv || !P->obs_image || !P->obs_point)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null observation arrays");
+  if (!raw && NP > 0 && !P->points) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null point array");
+  if (!raw && NO_all > 0 && (!P->obs_uv || !P->obs_image || !P->obs_point)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null observation arrays");
   h_cam_model.assign(P->camera_model, P->camera_model + NC);
   h_img_cam.assign(P->image_camera, P->image_camera + NI);
   int kmax = 4;
@@ -185,8 +185,10 @@ void mavba_session::build(const mavba_problem* P) {
 
   h_poses0.assign(P->poses, P->poses + (size_t)NI * 6);
   h_intr0.assign(P->intrinsics, P->intrinsics + (size_t)NC * 9);
-  HostSpare<double>::take(h_points0, (size_t)NP * 3);
-  h_points0.assign(P->points, P->points + (size_t)NP * 3);
+  if (!raw) {
+    HostSpare<double>::take(h_points0, (size_t)NP * 3);
+    h_points0.assign(P->points, P->points + (size_t)NP * 3);
+  }
   h_pose_const.assign(NI, 0); h_intr_const_in.assign(NC, 0); h_pt_const_in.assign(NP, 0);
   if (P->pose_const) h_pose_const.assign(P->pose_const, P->pose_const + NI);
   if (P->intr_const) h_intr_const_in.assign(P->intr_const, P->intr_const + NC);
@@ -211,7 +213,8 @@ void mavba_session::build(const mavba_problem* P) {
   // the kept list then - or the problem is small); MAVBA_SETUP=device | host forces one implementation (tests, timing)
   const char* setup_env = std::getenv("MAVBA_SETUP");
   const int setup_mode = !setup_env ? 0 : (std::string(setup_env) == "device" ? 1 : (std::string(setup_env) == "host" ? 2 : 0));
-  const bool device_order = all_kept && NO_all > 0 && NP > 0 && setup_mode != 2 && (setup_mode == 1 || NO_all >= 50000);
+  const bool device_order = raw || (all_kept && NO_all > 0 && NP > 0 && setup_mode != 2 && (setup_mode == 1 || NO_all >= 50000));
+  if (raw && !(all_kept && NO_all > 0 && NP > 0)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "device-resident problem with dropped residual blocks (or none at all)");
   if (!device_order) {
     int bad = 0;
     parallel_ranges(NO_all, [&](long long b0, long long b1) {
@@ -284,7 +287,7 @@ void mavba_session::build(const mavba_problem* P) {
   std::unique_ptr<PinnedBuf<double2>> uv_h, im_uv_h;   // host path: page-locked staging of the arrays uploaded below
   std::unique_ptr<PinnedBuf<int>> opt_h, im_pt_h;
   if (device_order) {
-    order_on_device(P, img_start);
+    order_on_device(P, img_start, raw);
     lap("order on device");
   } else {
     order_on_host(P, keptp, img_start, uv_h, opt_h, im_uv_h, im_pt_h);

@@ -33,3 +33,18 @@ for rep in range(5):
     rc = L.mavba_scene_flatten(sc._h, *args, C.byref(so), C.byref(P), None, None, None)
     t1 = time.perf_counter()
     print("flatten %.2f ms rc=%d NI=%d NP=%d NO=%d" % ((t1 - t0) * 1e3, rc, P.num_images, P.num_points, P.num_obs))
+
+# host route vs device-resident route of mavba_scene_bundle_adjust (same scene, fresh copy of the parameters each time)
+for route in ("host", "device"):
+    os.environ["MAVBA_SCENE"] = route
+    for i in range(ni):
+        sc.set_image(i + 1, -1, p.poses[i, :3], p.poses[i, 3:])
+    t = time.time()
+    for q in range(p.num_points):
+        pass
+    for rep in range(3):
+        t = time.time()
+        cost, res = sc.bundle_adjustment(free, fixed, fixed_x, opts, refine_camera_params=1)
+        dt = time.time() - t
+        print("route %-6s call %d: %.1f ms end to end (setup %.1f ms, solve %.1f ms, %d iterations, cost %.6f)" % (
+            route, rep, 1e3 * dt, 1e3 * res["setup_seconds"], 1e3 * res["solve_seconds"], res["num_successful_steps"] + res["num_unsuccessful_steps"], cost), file=sys.stderr)

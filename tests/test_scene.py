@@ -268,3 +268,57 @@ def test_scene_global_ba_with_gcps_and_camera_refinement(mavba, oracle):
         assert model == A.MODEL_OPENCV and rel_err(params, qo.intrinsics[0, :len(params)]) < 1e-6
         for g in gcp:
             assert np.array_equal(sc.get_point3D(g), fm.points[g - 1])       # GCPs did not move
+
+
+@pytest.mark.gpu
+def test_device_resident_scene_equals_the_host_route_bit_for_bit(mavba, oracle, monkeypatch):
+    """The device-resident route (2-D / 3-D points in HBM, selection + first-appearance numbering in kernels, session built
+    from the arrays where they are, refined points scattered back) against the host route (flatten + mavba_solve) on
+    twin scenes: a global call, then growth by new images, a deleted 3-D point, re-linked 2-D points, and two more calls
+    (dirty-range uploads, the resident points of the first call feeding the second). Same costs, same step counts, the
+    same poses / points / point errors to the last bit; and the oracle on the first call's flat problem."""
+    p = synth.make_scene(num_images=26, num_points=2500, track_len=5, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=41, spacing=5.0)
+    fm = FmScene(p, extra_unmatched=40)
+    first = list(range(20))
+    opts = global_opts()
+    out = {}
+    for route in ("host", "device"):
+        monkeypatch.setenv("MAVBA_SCENE", route)
+        log = []
+        with mirror(fm, images=first) as sc:
+            free, fixed, fixed_x = ids(first[2:]), ids([first[0]]), ids([first[1]])
+            f0 = sc.flatten(free, fixed, fixed_x, refine_camera_params=1)
+            errs = {}
+            cost, res = sc.bundle_adjustment(free, fixed, fixed_x, opts, point3D_errors=errs, refine_camera_params=1)
+            log.append((cost, res, dict(errs), [np.r_[sc.get_image(i)] for i in ids(first)], [sc.get_point3D(int(q)) for q in f0["point_ids"]]))
+            # growth: six more images, one 3-D point deleted, two 2-D points re-linked / unlinked
+            add_images(sc, fm, range(20, 26), bulk=True)
+            dead = int(f0["point_ids"][5])
+            sc.delete_point3D(dead)
+            oo = np.nonzero(fm.obs_pt >= 0)[0]
+            sc.link(int(oo[10]) + 1, -1)
+            sc.link(int(oo[11]) + 1, int(fm.obs_pt[oo[12]]) + 1)
+            allimg = list(range(26))
+            free, fixed, fixed_x = ids(allimg[2:]), ids([0]), ids([1])
+            for rep in range(2):
+                f1 = sc.flatten(free, fixed, fixed_x, min_track_len=3)
+                errs = {}
+                cost, res = sc.bundle_adjustment(free, fixed, fixed_x, opts, point3D_errors=errs, min_track_len=3)
+                log.append((cost, res, dict(errs), [np.r_[sc.get_image(i)] for i in ids(allimg)], [sc.get_point3D(int(q)) for q in f1["point_ids"]]))
+                assert dead not in f1["point_ids"]
+        out[route] = (log, f0)
+    (lh, f0h), (ld, f0d) = out["host"], out["device"]
+    assert len(lh) == len(ld) == 3
+    for (ch, rh, eh, ph, xh), (cd, rd, ed, pd, xd) in zip(lh, ld):
+        assert ch == cd
+        for k in ("termination", "num_successful_steps", "num_unsuccessful_steps", "final_cost", "initial_cost", "num_residuals",
+                  "num_residuals_reduced", "num_parameters_reduced"):
+            assert rh[k] == rd[k], k
+        assert rh["num_successful_steps"] > 0
+        assert sorted(eh) == sorted(ed) and all(eh[k] == ed[k] for k in eh)
+        assert all(np.array_equal(a, b) for a, b in zip(ph, pd)) and all(np.array_equal(a, b) for a, b in zip(xh, xd))
+    # the first call against the oracle on its flat problem
+    qo = _fresh_problem(f0h)
+    ro, _ = oracle.solve(qo, oracle.options(**opts), jac_mode=1)
+    assert ld[0][1]["termination"] == ro["termination"] and ld[0][1]["num_successful_steps"] == ro["num_successful_steps"]
+    assert abs(ld[0][1]["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
