@@ -1,5 +1,5 @@
 """Host time of mavba_scene_flatten for a global BA (no GPU needed). Usage: scene_timing.py [C2|C3]"""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 from mavmap_amd import api, synth
@@ -37,14 +37,9 @@ for rep in range(5):
 # host route vs device-resident route of mavba_scene_bundle_adjust (same scene, fresh copy of the parameters each time)
 for route in ("host", "device"):
     os.environ["MAVBA_SCENE"] = route
-    for i in range(ni):
-        sc.set_image(i + 1, -1, p.poses[i, :3], p.poses[i, 3:])
-    t = time.time()
-    for q in range(p.num_points):
-        pass
     for rep in range(3):
         t = time.time()
-        cost, res = sc.bundle_adjustment(free, fixed, fixed_x, opts, refine_camera_params=1)
+        cost, res = sc.bundle_adjustment(free, fixed, fx, dict(max_num_iterations=200, function_tolerance=1e-6, gradient_tolerance=1e-10), refine_camera_params=1)
         dt = time.time() - t
         print("route %-6s call %d: %.1f ms end to end (setup %.1f ms, solve %.1f ms, %d iterations, cost %.6f)" % (
             route, rep, 1e3 * dt, 1e3 * res["setup_seconds"], 1e3 * res["solve_seconds"], res["num_successful_steps"] + res["num_unsuccessful_steps"], cost), file=sys.stderr)

@@ -309,12 +309,12 @@ def test_device_resident_scene_equals_the_host_route_bit_for_bit(mavba, oracle, 
         out[route] = (log, f0)
     (lh, f0h), (ld, f0d) = out["host"], out["device"]
     assert len(lh) == len(ld) == 3
-    for (ch, rh, eh, ph, xh), (cd, rd, ed, pd, xd) in zip(lh, ld):
+    for call, ((ch, rh, eh, ph, xh), (cd, rd, ed, pd, xd)) in enumerate(zip(lh, ld)):
         assert ch == cd
         for k in ("termination", "num_successful_steps", "num_unsuccessful_steps", "final_cost", "initial_cost", "num_residuals",
                   "num_residuals_reduced", "num_parameters_reduced"):
             assert rh[k] == rd[k], k
-        assert rh["num_successful_steps"] > 0
+        assert rh["num_successful_steps"] > 0 or call == 2   # (the repeat call starts at the previous call's minimum)
         assert sorted(eh) == sorted(ed) and all(eh[k] == ed[k] for k in eh)
         assert all(np.array_equal(a, b) for a, b in zip(ph, pd)) and all(np.array_equal(a, b) for a, b in zip(xh, xd))
     # the first call against the oracle on its flat problem
