@@ -367,14 +367,23 @@ int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   launch_cam_prepare(s->st, s->NI, s->d_poses.p, s->d_camrec.p);
   SweepArgs a = s->sweep_args(s->d_camrec.p, s->d_intr.p, s->d_points.p);
   launch_jacobian_sweep(s->st, a);  // warm-up
+  HIP_OK(hipStreamSynchronize(s->st));
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-  HIP_OK(hipEventRecord(e0, s->st));
-  for (int i = 0; i < reps; ++i) launch_jacobian_sweep(s->st, a);
-  HIP_OK(hipEventRecord(e1, s->st));
-  HIP_OK(hipEventSynchronize(e1));
+  // Every launch is bracketed on its own and the stream drained in between: back to back, a launch shares HBM with the
+  // write-back of the 576 MB the previous one left in the caches (133 instead of 111 us at C3) - inside a solve the sweep
+  // never followed itself.
   float ms = 0.f;
-  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  for (int i = 0; i < reps; ++i) {
+    HIP_OK(hipEventRecord(e0, s->st));
+    launch_jacobian_sweep(s->st, a);
+    HIP_OK(hipEventRecord(e1, s->st));
+    HIP_OK(hipEventSynchronize(e1));
+    float one = 0.f;
+    HIP_OK(hipEventElapsedTime(&one, e0, e1));
+    ms += one;
+    HIP_OK(hipStreamSynchronize(s->st));
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (ms_avg) *ms_avg = ms / reps;
   s->sync();

@@ -376,8 +376,10 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   cstart.zero(st); istart.zero(st); bad.zero(st);
   hipLaunchKernelGGL(k_count_obs, dim3((n + 4095) / 4096), dim3(256), NI <= kCountImgLds ? (size_t)NI * 4 : 0, st, n, NI, NP, r_img.p, r_pt.p,
                      cstart.p, istart.p, bad.p);
-  hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, cstart.p, (long long)NP + 1, (unsigned*)nullptr);
-  hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, istart.p, (long long)NI + 1, (unsigned*)nullptr);
+  DevBuf<unsigned> scan_scratch;  // (alive until this function's final synchronisation)
+  scan_scratch.alloc((size_t)device_scan_scratch((long long)std::max(NP, NI) + 1) + 8);
+  device_scan_exclusive(st, cstart.p, (long long)NP + 1, scan_scratch.p);
+  device_scan_exclusive(st, istart.p, (long long)NI + 1, scan_scratch.p);
   int h_bad = 0;
   HIP_OK(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
   sync();
@@ -406,7 +408,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   // point-major arrays in the new order
   hipLaunchKernelGGL(k_new_counts, dim3((NP + 255) / 256), dim3(256), 0, st, NP, d_pt_orig.p, cstart.p, pstart.p);
   HIP_OK(hipMemsetAsync(pstart.p + NP, 0, 4, st));
-  hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, pstart.p, (long long)NP + 1, (unsigned*)nullptr);
+  device_scan_exclusive(st, pstart.p, (long long)NP + 1, scan_scratch.p);
   d_uv.alloc((size_t)std::max(n, 1)); d_obs_img.alloc((size_t)std::max(n, 1)); d_obs_pt.alloc((size_t)std::max(n, 1));
   d_perm32.alloc((size_t)std::max(n, 1)); d_pt_start.alloc((size_t)NP + 1); d_points0.alloc((size_t)std::max(NP, 1) * 3);
   DevBuf<unsigned char> pconst_new;
