@@ -1763,6 +1763,288 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
     }
   }
 }
+// ---------------------------------------------------------------------------
+// The cluster kernel with the front end inside (k_schur_fused): for problems whose every observed point sits in a
+// cluster (global BA of short tracks: C2, C3) the Schur entry records never exist in HBM. Per batch of 32 points the
+// work-group (512 lanes, one observation each) evaluates residual + Jacobian in registers, sums Cu / gu / Wk per point
+// through LDS (the park buffer aliases E, which is only built afterwards), factorises the points' damped 3x3 blocks,
+// writes U_a = (Jc'^T Jp') Gi^T, Uk = (s_k Wk s_p) Gi^T and h straight into the stacked entry matrix E and runs
+// S_cl += E E^T on the matrix cores. Out: cost partial per cluster, Cu, gu, Gi, h per point (the back-substitution and
+// the gradient norm read them) and the cluster's block partials. Gone against k_point_front + k_schur_clusters: the
+// 192 B / observation + 288 B / (point, camera) of records written and read again, one launch.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kFuPitch = kClThreads + 1;  // park row pitch
+template <int KMAX>
+struct FusedShape {
+  static constexpr int K3 = 3 * KMAX, NROWS = 9 + K3;
+  static constexpr int ESIZE = ClShape<16, 3>::rows * kClPitch;
+  static constexpr int ROUNDS = NROWS * kFuPitch <= ESIZE ? 1 : 2;
+  static constexpr int NR = (NROWS + ROUNDS - 1) / ROUNDS;
+  static_assert(NR * kFuPitch <= ESIZE, "the park buffer must fit the entry matrix it aliases");
+  static_assert(NR >= 9, "point rows must fit the first round");
+};
+}  // namespace
+
+template <int KMAX>
+__global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
+    FrontArgs a, const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const unsigned short* __restrict__ obs_meta,
+    const unsigned short* __restrict__ q_meta, double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
+  using SH = ClShape<16, 3>;
+  using FS = FusedShape<KMAX>;
+  __shared__ __attribute__((aligned(16))) double E[SH::rows * kClPitch];  // park buffer of the sums, then the entry matrix
+  __shared__ double s_q[kClBatch * kClCamsMax * (FS::K3 > 0 ? FS::K3 : 1)];  // Wk sums of the batch's (point, camera) entries
+  __shared__ double s_sum[kClBatch * 9];
+  __shared__ double s_g[kClBatch * 12];                                      // Gi(6) h(3) scale(3)
+  __shared__ double s_red[8];
+  __shared__ int s_bounds[2][kClMaxBatches + 1];
+  __shared__ int s_tab[SH::tab];
+  __shared__ int s_pb[kClBatch + 1];
+  __shared__ int s_cam[kClThreads];
+  __shared__ int s_qcam[kClBatch * kClCamsMax], s_qpt[kClBatch * kClCamsMax], s_qm[kClBatch * kClCamsMax];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const SweepArgs& w = a.sw;
+  const int NPs = a.NPs;
+  const SchurCluster cl = clusters[blockIdx.x];
+  const int nbatch = (cl.p1 - cl.p0 + kClBatch - 1) / kClBatch;
+  for (int i = tid; i <= nbatch; i += kClThreads) {
+    const int p = min(cl.p0 + i * kClBatch, cl.p1);
+    s_bounds[0][i] = a.pt_start[p];
+    s_bounds[1][i] = a.q_start[p];
+  }
+  for (int i = tid; i < SH::tab; i += kClThreads) s_tab[i] = tabs[(size_t)blockIdx.x * SH::tab + i];
+  cl_d4 acc[SH::acc];
+#pragma unroll
+  for (int i = 0; i < SH::acc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
+  double cost = 0.0;
+  __syncthreads();
+  for (int bi = 0; bi < nbatch; ++bi) {
+    const int b0 = cl.p0 + bi * kClBatch, b1 = min(b0 + kClBatch, cl.p1), np = b1 - b0;
+    const int o0 = s_bounds[0][bi], o1 = s_bounds[0][bi + 1];   // <= 16 observations per clustered point: o1 - o0 <= 512
+    const int q0 = s_bounds[1][bi], nq = KMAX > 0 ? s_bounds[1][bi + 1] - q0 : 0;
+    // ---- this lane's observation: loads first, bookkeeping under their latency ----
+    const bool act = o0 + tid < o1;
+    int im = 0, pt = 0;
+    double2 m = make_double2(0.0, 0.0);
+    unsigned meta = 0xFFFFu;
+    if (act) { im = w.obs_img[o0 + tid]; pt = w.obs_pt[o0 + tid]; m = w.uv[o0 + tid]; meta = obs_meta[o0 + tid]; }
+    bool own_free = false;
+    double own_sp[3] = {0.0, 0.0, 0.0};
+    if (tid < np) {
+      own_free = a.pt_free[b0 + tid] != 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) own_sp[k] = a.scale_pt[(size_t)k * NPs + b0 + tid];
+    }
+    for (int j = tid; j <= np; j += kClThreads) s_pb[j] = a.pt_start[b0 + j];
+    for (int i = tid; i < np * 9; i += kClThreads) s_sum[i] = 0.0;
+    if constexpr (KMAX > 0) {
+      for (int q = tid; q < nq; q += kClThreads) { s_qcam[q] = a.q_cam[q0 + q]; s_qpt[q] = a.q_pt[q0 + q] - b0; s_qm[q] = q_meta[q0 + q]; }
+      for (int i = tid; i < nq * FS::K3; i += kClThreads) s_q[i] = 0.0;
+    }
+    double jc[12], jp[6];
+    double prod[FS::NROWS];
+    int cam = -1;
+    if (act) {
+      cam = w.img_cam[im];
+      const int model = w.cam_model[cam];
+      double rec[9], kin[9], X[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) rec[k] = w.camrec[9 * im + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) kin[k] = w.intr[9 * cam + k];
+      X[0] = w.points[3 * (long long)pt]; X[1] = w.points[3 * (long long)pt + 1]; X[2] = w.points[3 * (long long)pt + 2];
+      double r[2], Jc[12], Jp[6], Jk[18];
+      obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
+      double wgt, half_rho;
+      cauchy_weight(r[0] * r[0] + r[1] * r[1], w.loss_b, w.loss_inv_b, wgt, half_rho);
+      cost += half_rho;
+      const double rr0 = wgt * r[0], rr1 = wgt * r[1];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) jc[e] = wgt * Jc[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) jp[e] = wgt * Jp[e];
+      prod[0] = jp[0] * jp[0] + jp[3] * jp[3]; prod[1] = jp[0] * jp[1] + jp[3] * jp[4]; prod[2] = jp[0] * jp[2] + jp[3] * jp[5];
+      prod[3] = jp[1] * jp[1] + jp[4] * jp[4]; prod[4] = jp[1] * jp[2] + jp[4] * jp[5]; prod[5] = jp[2] * jp[2] + jp[5] * jp[5];
+      prod[6] = jp[0] * rr0 + jp[3] * rr1; prod[7] = jp[1] * rr0 + jp[4] * rr1; prod[8] = jp[2] * rr0 + jp[5] * rr1;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const double k0 = wgt * Jk[k], k1 = wgt * Jk[9 + k];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) prod[9 + 3 * k + t] = k0 * jp[t] + k1 * jp[3 + t];
+      }
+    }
+    // ---- per-point sums: products parked in LDS (over the not yet built entry matrix), one lane per sum, a point's
+    // observations added in order (the same fixed sequential sums as k_point_front) ----
+    auto round = [&](auto rc) {
+      constexpr int R = decltype(rc)::value;
+      constexpr int lo = R * FS::NR, hi = (lo + FS::NR < FS::NROWS) ? lo + FS::NR : FS::NROWS;
+      constexpr int PR = R == 0 ? 9 : 0;
+      constexpr int wlo = (lo > 9 ? lo : 9) - 9, WR = hi - 9 - wlo;
+      lds_barrier();  // (R == 0: the previous batch's matrix instructions have read E, the batch's tables are written)
+      if (act) {
+        if (R == 0) s_cam[tid] = cam;
+#pragma unroll
+        for (int v = lo; v < hi; ++v) E[(v - lo) * kFuPitch + tid] = prod[v];
+      }
+      lds_barrier();
+      const int nit = np * PR + nq * WR;
+      for (int it = tid; it < nit; it += kClThreads) {
+        const bool is_pt = it < np * PR;
+        int j, c = -1;
+        const double* row;
+        double* dst;
+        if (is_pt) {
+          j = it / 9;
+          row = E + (it - 9 * j) * kFuPitch - o0;
+          dst = s_sum + it;
+        } else {
+          const int t2 = it - np * PR;
+          const int wr = WR > 0 ? WR : 1;
+          const int q = t2 / wr, vv = wlo + (t2 - q * wr);
+          j = s_qpt[q]; c = s_qcam[q];
+          row = E + (vv + 9 - lo) * kFuPitch - o0;
+          dst = s_q + q * FS::K3 + vv;
+        }
+        const int b = s_pb[j], e = s_pb[j + 1];
+        const int* camv = s_cam - o0;
+        double acc1 = *dst;
+        for (int i0 = b; i0 < e; i0 += 4) {
+          const int i1 = min(i0 + 1, e - 1), i2 = min(i0 + 2, e - 1), i3 = min(i0 + 3, e - 1);
+          double x0 = row[i0], x1 = row[i1], x2 = row[i2], x3 = row[i3];
+          if (WR > 0 && !is_pt) {
+            x0 = camv[i0] == c ? x0 : 0.0; x1 = camv[i1] == c ? x1 : 0.0; x2 = camv[i2] == c ? x2 : 0.0; x3 = camv[i3] == c ? x3 : 0.0;
+          }
+          acc1 += x0;
+          acc1 += i0 + 1 < e ? x1 : 0.0;
+          acc1 += i0 + 2 < e ? x2 : 0.0;
+          acc1 += i0 + 3 < e ? x3 : 0.0;
+        }
+        *dst = acc1;
+      }
+    };
+    round(std::integral_constant<int, 0>{});
+    if constexpr (FS::ROUNDS > 1) round(std::integral_constant<int, 1>{});
+    lds_barrier();  // sums complete, the park buffer is free
+    // ---- owner lanes: Cu, gu out, damped 3x3 block factorised; everybody clears E ----
+    if (tid < np) {
+      const int p = b0 + tid;
+      double C6[6], g3[3];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) C6[k] = s_sum[tid * 9 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g3[k] = s_sum[tid * 9 + 6 + k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a.Cu[(size_t)k * NPs + p] = C6[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a.gu[(size_t)k * NPs + p] = g3[k];
+      double G[6] = {0, 0, 0, 0, 0, 0}, hh[3] = {0, 0, 0}, sp[3] = {0, 0, 0};
+      if (own_free) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sp[k] = own_sp[k];
+        double C[6];
+        C[0] = sp[0] * sp[0] * C6[0]; C[1] = sp[0] * sp[1] * C6[1]; C[2] = sp[0] * sp[2] * C6[2];
+        C[3] = sp[1] * sp[1] * C6[3]; C[4] = sp[1] * sp[2] * C6[4]; C[5] = sp[2] * sp[2] * C6[5];
+        C[0] += clampd(C[0], a.dmin, a.dmax) / a.radius;
+        C[3] += clampd(C[3], a.dmin, a.dmax) / a.radius;
+        C[5] += clampd(C[5], a.dmin, a.dmax) / a.radius;
+        bool fin = chol3_inv(C, G);
+        const double gs[3] = {sp[0] * g3[0], sp[1] * g3[1], sp[2] * g3[2]};
+        gi_mul(G, gs, hh);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fin = fin && isfinite(G[k]);
+        if (!fin) atomicAdd(a.fail, 1.0);
+      }
+      if (s_pb[tid + 1] > s_pb[tid]) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.Gi[(size_t)k * NPs + p] = G[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.h[(size_t)k * NPs + p] = hh[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s_g[tid * 12 + k] = G[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { s_g[tid * 12 + 6 + k] = hh[k]; s_g[tid * 12 + 9 + k] = sp[k]; }
+    }
+    for (int i = tid; i < SH::rows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
+    lds_barrier();
+    // ---- the stacked entry matrix of the batch, straight from registers ----
+    if (act && meta != 0xFFFFu) {  // (0xFFFF: the image's pose is constant - it has no rows; the sums above included it)
+      const int lp = pt - b0;
+      const double* g = s_g + lp * 12;
+      double* Eo = E + 6 * (int)(meta >> 8) * kClPitch + 3 * (int)(meta & 255u);
+      double jps[6];
+#pragma unroll
+      for (int row = 0; row < 2; ++row)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) jps[row * 3 + k] = jp[row * 3 + k] * g[9 + k];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const double sc = a.scale_cam[6 * im + e];
+        const double j0 = jc[e] * sc, j1 = jc[6 + e] * sc;
+        const double w0 = j0 * jps[0] + j1 * jps[3], w1 = j0 * jps[1] + j1 * jps[4], w2 = j0 * jps[2] + j1 * jps[5];
+        Eo[e * kClPitch] = w0 * g[0];
+        Eo[e * kClPitch + 1] = w0 * g[1] + w1 * g[2];
+        Eo[e * kClPitch + 2] = w0 * g[3] + w1 * g[4] + w2 * g[5];
+      }
+    }
+    if constexpr (KMAX > 0) {
+      for (int it = tid; it < nq * KMAX; it += kClThreads) {
+        const int q = it / KMAX, k = it - KMAX * q;
+        const unsigned qm = (unsigned)s_qm[q];
+        if (qm == 0xFFFFu) continue;
+        const double* g = s_g + s_qpt[q] * 12;
+        const double sk = a.scale_cam[6 * w.NI + 9 * s_qcam[q] + k];
+        const double* W = s_q + q * FS::K3 + 3 * k;
+        const double w0 = W[0] * sk * g[9], w1 = W[1] * sk * g[10], w2 = W[2] * sk * g[11];
+        double* Eo = E + (SH::cam_row0 + 9 * (int)(qm >> 8) + k) * kClPitch + 3 * (int)(qm & 255u);
+        Eo[0] = w0 * g[0];
+        Eo[1] = w0 * g[1] + w1 * g[2];
+        Eo[2] = w0 * g[3] + w1 * g[4] + w2 * g[5];
+      }
+    }
+    if (tid < np * 3) {
+      const int pp = tid / 3, t = tid - 3 * pp;
+      if (a.pt_free[b0 + pp] && s_pb[pp + 1] > s_pb[pp]) E[SH::hrow * kClPitch + tid] = s_g[pp * 12 + 6 + t];
+    }
+    lds_barrier();
+    switch (wv) {
+      case 0: cluster_mfma<SH, 0>(E, lane, acc); break;
+      case 1: cluster_mfma<SH, 1>(E, lane, acc); break;
+      case 2: cluster_mfma<SH, 2>(E, lane, acc); break;
+      case 3: cluster_mfma<SH, 3>(E, lane, acc); break;
+      case 4: cluster_mfma<SH, 4>(E, lane, acc); break;
+      case 5: cluster_mfma<SH, 5>(E, lane, acc); break;
+      case 6: cluster_mfma<SH, 6>(E, lane, acc); break;
+      default: cluster_mfma<SH, 7>(E, lane, acc); break;
+    }
+    // (the next batch's first lds_barrier comes after its loads and bookkeeping)
+  }
+  const int* tab = s_tab;
+  switch (wv) {
+    case 0: cluster_emit<SH, 0>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 1: cluster_emit<SH, 1>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 2: cluster_emit<SH, 2>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 3: cluster_emit<SH, 3>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 4: cluster_emit<SH, 4>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 5: cluster_emit<SH, 5>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    case 6: cluster_emit<SH, 6>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+    default: cluster_emit<SH, 7>(lane, acc, tab, part_pp, part_ip, part_ii); break;
+  }
+  // cost partial of the cluster (fixed tree: lanes -> waves -> work-group)
+  const double wsum = wave_sum(cost);
+  __syncthreads();
+  if (lane == 0) s_red[wv] = wsum;
+  __syncthreads();
+  if (tid == 0) w.cost_partial[blockIdx.x] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+}
+void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int num_clusters, const SchurCluster* clusters, const int* tab,
+                        const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii) {
+  if (num_clusters <= 0) return;
+#define MAVBA_FUSED(K) hipLaunchKernelGGL((k_schur_fused<K>), dim3(num_clusters), dim3(kClThreads), 0, st, a, clusters, tab, obs_meta, q_meta, part_pp, part_ip, part_ii)
+  if (kmax_intr <= 0) MAVBA_FUSED(0); else if (kmax_intr <= 4) MAVBA_FUSED(4); else if (kmax_intr <= 8) MAVBA_FUSED(8); else MAVBA_FUSED(9);
+#undef MAVBA_FUSED
+}
+
 #define MAVBA_CL_S12 ClShape<12, 2>
 #define MAVBA_CL_S16 ClShape<16, 3>
 void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters, const SchurCluster* clusters, const int* tab,

@@ -269,6 +269,8 @@ struct mavba_session {
   DevBuf<FrontTile> d_front_tiles;
   int num_front_tiles = 0;
   bool front_ok = false;
+  bool fused_ok = false;        // every observed point is clustered: the front end runs inside the cluster kernel (k_schur_fused)
+  int eval_rows = 0;            // cost partials the last evaluation pass wrote
   bool front_valid = false;     // Cu, gu, Gi, h and the entry records match the current x, scales and front_radius
   double front_radius = 0.0;
   bool planes_ready = false;    // the Jacobian planes exist (probe path / plane kernels only)
@@ -436,7 +438,8 @@ struct mavba_session {
   void launch_front(double r, bool entries);
   void build_front_tiles(const std::vector<int>& q_start);
   void ensure_planes();
-  int eval_cost_rows() const { return front_ok ? point_front_grid(num_front_tiles) : (N > 0 ? jacobian_sweep_grid(N) : 0); }
+  bool fused_now() const { return fused_ok && h_pt_removed.empty(); }
+  int eval_cost_rows() const { return front_ok ? eval_rows : (N > 0 ? jacobian_sweep_grid(N) : 0); }
   void take_evaluation(const double* h) { cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]); }
   void assemble(double r);
   void solve_linear(double r);

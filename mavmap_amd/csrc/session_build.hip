@@ -1061,6 +1061,15 @@ void mavba_session::finish_structure() {
     d_clusters.upload(cl_sorted, st); d_cl_tab.upload(tab_sorted, st);
     d_obs_meta.upload(obs_meta, st); d_q_meta.upload(q_meta, st); d_pt_clustered.upload(ptc, st);
   }
+  // the front end can run inside the cluster kernel when every observed point is clustered (no generic term lists, no
+  // constant points with observations) and the clusters have the 16 x 3 shape
+  {
+    long long observed = 0;
+    for (int p = 0; p < NP; ++p) observed += h_pt_start[p + 1] > h_pt_start[p];
+    static const bool no_fuse = std::getenv("MAVBA_NO_FUSE") != nullptr;
+    fused_ok = front_ok && !no_fuse && cl_shape.images == 16 && num_clusters > 0 && clustered_points == observed &&
+               tot[0] == 0 && tot[1] == 0 && tot[2] == 0 && num_clusters <= kFrontMaxGrid;
+  }
   sync();
   lap("upload terms");
 }

@@ -40,7 +40,18 @@ void mavba_session::launch_front(double r, bool entries) {
   f.fail = d_scal.p + SC_FAIL_FRONT;
   f.trace = nullptr;
   if (entries) HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL_FRONT, 0, sizeof(double), st));
-  timed(entries ? "point_front" : "point_front_sums", [&] { launch_point_front(st, f, Q > 0 ? KMAX : 0, entries); });
+  if (entries && fused_now()) {
+    // every observed point sits in a cluster: the cluster kernel evaluates the Jacobians itself and leaves the block
+    // partials of S for this radius (no entry records in HBM)
+    timed("schur_fused", [&] {
+      launch_schur_fused(st, f, Q > 0 ? KMAX : 0, num_clusters, d_clusters.p, d_cl_tab.p, d_obs_meta.p, d_q_meta.p, d_part[0].p, d_part[1].p,
+                         d_part[2].p);
+    });
+    eval_rows = num_clusters;
+  } else {
+    timed(entries ? "point_front" : "point_front_sums", [&] { launch_point_front(st, f, Q > 0 ? KMAX : 0, entries); });
+    eval_rows = point_front_grid(num_front_tiles);
+  }
   front_valid = entries;
   front_radius = r;
 }
@@ -142,7 +153,7 @@ void mavba_session::assemble(double r) {
     });
     M_is_clean = true;
   }
-  timed("schur_clusters", [&] {
+  if (!(front_ok && fused_now())) timed("schur_clusters", [&] {
     launch_schur_clusters(st, cl_shape, num_clusters, d_clusters.p, d_cl_tab.p, d_pt_start.p, d_q_start.p, d_obs_meta.p,
                           d_q_meta.p, d_pt_clustered.p, d_Epose.p, d_Eintr.p, d_h.p, NPs, d_part[0].p, d_part[1].p,
                           d_part[2].p);
