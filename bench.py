@@ -57,7 +57,7 @@ def algorithmic_work(stats_name, prob, sess_info):
         # r, Jp and the Jk planes (padded to the widest model) in; Cu, gu per point and Wk per (point, camera) out
         kmax = int(K.max())
         return "hbm", (64.0 + 16.0 * kmax) * n_obs + 72.0 * n_pts + 216.0 * sess_info["intr_entries"], "B"
-    if stats_name == "schur_clusters":
+    if stats_name in ("schur_clusters", "schur_fused"):
         # Schur formation = sum_p (6 L_p + K_p)^2 * 3 * 2 flops (L_p observations of point p,
         # K_p refined intrinsics of the cameras that see it). The matrix-instruction flops the kernel really
         # executes (structural zeros of the stacked entry matrix included) are reported beside it as executed_flops.
@@ -88,7 +88,8 @@ PMC_KERNEL = {  # bench timer name -> rocprofv3 kernel-name prefix in profiles/*
     "camera_sweep": "k_camera_sweep", "entries_pose": "k_entries_pose", "entries_intr": "k_entries_intr",
     "backsub_points": "k_backsub_points", "schur_chunks_pp": "k_schur_chunks<6, 6", "schur_chunks_ip": "k_schur_chunks<9, 6",
     "schur_chunks_ii": "k_schur_chunks<9, 9", "schur_clusters": "k_schur_clusters", "schur_finalize": "k_schur_finalize",
-    "chol_factor": "k_chol_persist", "chol_backsolve": "k_chol_backsolve_all", "point_front": "k_point_front",
+    "chol_factor": "k_chol_persist", "chol_backsolve": "k_chol_backsolve_all", "point_front": "k_point_front<8, true",
+    "point_front_sums": "k_point_front<8, false", "schur_fused": "k_schur_fused",
 }
 
 
@@ -354,6 +355,19 @@ def main():
                                     "SURVEY 8(d) algorithmic flops sum_p (6 L_p + K_p)^2 * 6 / kernel time; executed_* = the matrix-"
                                     "instruction flops really issued (structural zeros of the stacked entry matrix included); traffic "
                                     "= HBM bytes per launch")
+            if dominant["kernel"] == "schur_fused":
+                sweep_bytes = algorithmic_work("jacobian_sweep", prob, info)[1]
+                ex = info["cluster_flops"] / (dominant["avg_ms"] * 1e-3) / 1e12
+                roofline.update(executed_flops=info["cluster_flops"], executed_tflops=round(ex, 3),
+                                executed_frac=round(ex / FP64_MFMA_PEAK_TFLOPS, 4),
+                                sweep_equivalent_gbs=round(sweep_bytes / (dominant["avg_ms"] * 1e-3) / 1e9, 1),
+                                sweep_equivalent_frac=round(sweep_bytes / (dominant["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                roofline["note"] = ("k_schur_fused: Jacobian evaluation, per-point sums, 3x3 factors AND the Schur complement of the point "
+                                    "clusters (E E^T on v_mfma_f64_16x16x4_f64) in one kernel, no Jacobian and no entry records in HBM. "
+                                    "FP64 vector and matrix instructions share the SIMD's pipe, so the kernel is bound by their SUM; "
+                                    "achieved / frac price only SURVEY 8(d)'s Schur-formation flops sum_p (6 L_p + K_p)^2 * 6 over the "
+                                    "kernel's time; executed_* = matrix-instruction flops really issued; sweep_equivalent_* = SURVEY "
+                                    "8(d)'s Jacobian-sweep bytes (J counted as if written) over the same time")
             if dominant["kernel"] == "chol_factor":
                 de = info["dense_factor_flops"] / (dominant["avg_ms"] * 1e-3) / 1e12
                 roofline.update(executed_flops=info["factor_flops"], dense_equivalent_tflops=round(de, 3),
@@ -384,6 +398,11 @@ def main():
                                        f"64-column panel steps"))
         sweep = next((r for r in table if r["kernel"] == "jacobian_sweep"), None)
         front = next((r for r in table if r["kernel"] == "point_front"), None)
+        fused = next((r for r in table if r["kernel"] == "schur_fused"), None)
+        if front is None and fused is not None:  # the front end runs inside the cluster kernel: its share of that kernel is not separable
+            sb = algorithmic_work("jacobian_sweep", prob, info)[1]
+            front = dict(kernel="schur_fused", avg_ms=fused["avg_ms"], achieved=round(sb / (fused["avg_ms"] * 1e-3) / 1e9, 1),
+                         frac=round(sb / (fused["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
         front_own_bytes = float(48 * prob.num_obs + 192 * prob.num_obs + 288 * info["intr_entries"] + 144 * prob.num_points)
         cpu_baseline = None
@@ -444,11 +463,11 @@ def main():
             "reduced_solve": reduced_solve,
             "jacobian_sweep": jacobian_probe,
             "front_end": None if not front else {
-                "kernel": "k_point_front", "avg_ms": front["avg_ms"], "obs_per_sec": round(prob.num_obs / (front["avg_ms"] * 1e-3), 1),
+                "kernel": "k_point_front" if front["kernel"] == "point_front" else "k_schur_fused (front end + cluster Schur complement in one kernel: the time is the WHOLE kernel's)", "avg_ms": front["avg_ms"], "obs_per_sec": round(prob.num_obs / (front["avg_ms"] * 1e-3), 1),
                 "bound": "hbm", "achieved": front["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": front["frac"],
-                "front_own_bytes": front_own_bytes,
-                "own_achieved": round(front_own_bytes / (front["avg_ms"] * 1e-3) / 1e9, 1),
-                "traffic": pmc_traffic("point_front", args.config, args.scale, world),
+                "front_own_bytes": front_own_bytes if front["kernel"] == "point_front" else None,
+                "own_achieved": round(front_own_bytes / (front["avg_ms"] * 1e-3) / 1e9, 1) if front["kernel"] == "point_front" else None,
+                "traffic": pmc_traffic(front["kernel"], args.config, args.scale, world),
                 "note": "the J-free Schur front end inside the LM loop: residual + Jacobian per observation in registers, per-point "
                         "sums, 3x3 factors and entry records in one pass. achieved / frac price SURVEY 8(d)'s Jacobian-sweep bytes "
                         "(J counted as if written, 272 / 336 B per observation) over this kernel's time although it does the work of "

@@ -1818,23 +1818,36 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
   for (int i = 0; i < SH::acc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
   __syncthreads();
+  // A batch's first loads - every lane's observation, the owner lanes' per-point inputs - are requested before the
+  // PREVIOUS batch's matrix instructions start, so they travel under those (~15 k cycles) instead of stalling the batch.
+  bool act_n = false, own_free_n = false;
+  int im_n = 0, pt_n = 0;
+  double2 m_n = make_double2(0.0, 0.0);
+  unsigned meta_n = 0xFFFFu;
+  double own_sp_n[3] = {0.0, 0.0, 0.0};
+  auto request_batch = [&](int bj) {
+    const int c0 = cl.p0 + bj * kClBatch, c1 = min(c0 + kClBatch, cl.p1);
+    const int oo0 = s_bounds[0][bj], oo1 = s_bounds[0][bj + 1];
+    act_n = oo0 + tid < oo1;
+    if (act_n) { im_n = w.obs_img[oo0 + tid]; pt_n = w.obs_pt[oo0 + tid]; m_n = w.uv[oo0 + tid]; meta_n = obs_meta[oo0 + tid]; }
+    own_free_n = false;
+    if (tid < c1 - c0) {
+      own_free_n = a.pt_free[c0 + tid] != 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) own_sp_n[k] = a.scale_pt[(size_t)k * NPs + c0 + tid];
+    }
+  };
+  if (nbatch > 0) request_batch(0);
   for (int bi = 0; bi < nbatch; ++bi) {
     const int b0 = cl.p0 + bi * kClBatch, b1 = min(b0 + kClBatch, cl.p1), np = b1 - b0;
     const int o0 = s_bounds[0][bi], o1 = s_bounds[0][bi + 1];   // <= 16 observations per clustered point: o1 - o0 <= 512
     const int q0 = s_bounds[1][bi], nq = KMAX > 0 ? s_bounds[1][bi + 1] - q0 : 0;
-    // ---- this lane's observation: loads first, bookkeeping under their latency ----
-    const bool act = o0 + tid < o1;
-    int im = 0, pt = 0;
-    double2 m = make_double2(0.0, 0.0);
-    unsigned meta = 0xFFFFu;
-    if (act) { im = w.obs_img[o0 + tid]; pt = w.obs_pt[o0 + tid]; m = w.uv[o0 + tid]; meta = obs_meta[o0 + tid]; }
-    bool own_free = false;
-    double own_sp[3] = {0.0, 0.0, 0.0};
-    if (tid < np) {
-      own_free = a.pt_free[b0 + tid] != 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) own_sp[k] = a.scale_pt[(size_t)k * NPs + b0 + tid];
-    }
+    const bool act = act_n, own_free = own_free_n;
+    const int im = im_n, pt = pt_n;
+    const double2 m = m_n;
+    const unsigned meta = act ? meta_n : 0xFFFFu;
+    const double own_sp[3] = {own_sp_n[0], own_sp_n[1], own_sp_n[2]};
+    (void)o1;
     for (int j = tid; j <= np; j += kClThreads) s_pb[j] = a.pt_start[b0 + j];
     for (int i = tid; i < np * 9; i += kClThreads) s_sum[i] = 0.0;
     if constexpr (KMAX > 0) {
@@ -2007,6 +2020,10 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
       if (a.pt_free[b0 + pp] && s_pb[pp + 1] > s_pb[pp]) E[SH::hrow * kClPitch + tid] = s_g[pp * 12 + 6 + t];
     }
     lds_barrier();
+    if (bi + 1 < nbatch) {
+      request_batch(bi + 1);
+      __builtin_amdgcn_sched_barrier(0);  // (keep the loads here: the scheduler would sink them to their use)
+    }
     switch (wv) {
       case 0: cluster_mfma<SH, 0>(E, lane, acc); break;
       case 1: cluster_mfma<SH, 1>(E, lane, acc); break;
