@@ -366,25 +366,25 @@ int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   s->ensure_planes();  // (the materialising sweep is a probe: SURVEY 8(d) prices the Jacobian kernel with J written out)
   launch_cam_prepare(s->st, s->NI, s->d_poses.p, s->d_camrec.p);
   SweepArgs a = s->sweep_args(s->d_camrec.p, s->d_intr.p, s->d_points.p);
-  launch_jacobian_sweep(s->st, a);  // warm-up
+  // warm-up: ~25 ms of the same kernel, so that the timed launches run at the clocks of a busy device (a cold burst of 20
+  // launches measured 134 us at C3 where the same kernel took 111 us inside a running solve)
+  for (int i = 0; i < 200; ++i) launch_jacobian_sweep(s->st, a);
+  std::vector<hipEvent_t> ev((size_t)reps + 1);
+  for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+  // one event between consecutive launches, everything enqueued at once: the device stays busy, every launch has its own bracket
+  HIP_OK(hipEventRecord(ev[0], s->st));
+  for (int i = 0; i < reps; ++i) {
+    launch_jacobian_sweep(s->st, a);
+    HIP_OK(hipEventRecord(ev[(size_t)i + 1], s->st));
+  }
   HIP_OK(hipStreamSynchronize(s->st));
-  hipEvent_t e0, e1;
-  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-  // Every launch is bracketed on its own and the stream drained in between: back to back, a launch shares HBM with the
-  // write-back of the 576 MB the previous one left in the caches (133 instead of 111 us at C3) - inside a solve the sweep
-  // never followed itself.
   float ms = 0.f;
   for (int i = 0; i < reps; ++i) {
-    HIP_OK(hipEventRecord(e0, s->st));
-    launch_jacobian_sweep(s->st, a);
-    HIP_OK(hipEventRecord(e1, s->st));
-    HIP_OK(hipEventSynchronize(e1));
     float one = 0.f;
-    HIP_OK(hipEventElapsedTime(&one, e0, e1));
+    HIP_OK(hipEventElapsedTime(&one, ev[(size_t)i], ev[(size_t)i + 1]));
     ms += one;
-    HIP_OK(hipStreamSynchronize(s->st));
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  for (auto& e : ev) (void)hipEventDestroy(e);
   if (ms_avg) *ms_avg = ms / reps;
   s->sync();
   return MAVBA_OK;
