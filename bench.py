@@ -426,7 +426,9 @@ def main():
             # the reference's own solver, where the box has it; otherwise said explicitly
             from tests import ceres_harness
             ceres = "unavailable"
-            if ceres_harness.build() is not None:
+            if ceres_harness.build() is None and "IS installed" in ceres_harness.why_unavailable():
+                ceres = "failed: " + ceres_harness.why_unavailable()   # a box with Ceres on which the harness does not compile says so
+            elif ceres_harness.build() is not None:
                 try:
                     rc = ceres_harness.solve(full, dict(max_num_iterations=args.cpu_iters, function_tolerance=1e-6, gradient_tolerance=1e-10,
                                                         loss_scale_factor=1.0), threads=cores)

@@ -16,23 +16,40 @@ _BUILD = os.path.join(_ROOT, "oracle", "_build", "ceres_check")
 _state = {}
 
 
+def why_unavailable():
+    """Why build() returned None: "no cmake", "Ceres not found by CMake" - or, on a box that HAS Ceres, the tail of the
+    compiler output (the harness has never met a real Ceres installation: a box that has one must say why it failed
+    instead of silently reporting "unavailable")."""
+    build()
+    return _state.get("why", "")
+
+
 def build():
-    """Path of the mavba_ceres_check binary, or None when Ceres (or cmake) is unavailable."""
+    """Path of the mavba_ceres_check binary, or None when Ceres (or cmake) is unavailable (see why_unavailable())."""
     if "exe" in _state:
         return _state["exe"]
     exe = None
     cmake = shutil.which("cmake")
-    if cmake:
+    if not cmake:
+        _state["why"] = "no cmake"
+    else:
         try:
             os.makedirs(_BUILD, exist_ok=True)
             cfg = subprocess.run([cmake, "-S", _SRC, "-B", _BUILD], capture_output=True, text=True, timeout=300)
-            if cfg.returncode == 0 and "harness not built" not in cfg.stdout:
+            if cfg.returncode != 0:
+                _state["why"] = "cmake configure failed: " + (cfg.stderr or cfg.stdout)[-1500:]
+            elif "harness not built" in cfg.stdout:
+                _state["why"] = "Ceres not found by CMake (find_package(Ceres QUIET))"
+            else:
                 mk = subprocess.run([cmake, "--build", _BUILD, "-j", "8"], capture_output=True, text=True, timeout=1200)
                 cand = os.path.join(_BUILD, "mavba_ceres_check")
                 if mk.returncode == 0 and os.path.exists(cand):
                     exe = cand
-        except (OSError, subprocess.SubprocessError):
+                else:
+                    _state["why"] = "Ceres IS installed but oracle/ceres_check did not compile:\n" + (mk.stderr or mk.stdout)[-3000:]
+        except (OSError, subprocess.SubprocessError) as e:
             exe = None
+            _state["why"] = repr(e)
     _state["exe"] = exe
     return exe
 

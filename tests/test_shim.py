@@ -19,11 +19,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 
 
-def _build(real):
+REFERENCE_SRC = "/root/reference/src"   # build container only (never present on the GPU box)
+
+
+def _build(real, reference_fm=False):
+    """reference_fm: compile against the REFERENCE's own src/fm/feature_management.{h,cc} (the real FeatureManager class,
+    its sources used where they lie, only the Eigen vector types come from the test double) instead of the 26-line
+    FeatureManager double in tests/stubs."""
     out = os.path.join(ROOT, "tests", "shim", "_shim_real.so" if real else "_shim_mock.so")
+    if reference_fm:  # anything compiled from the reference's sources lives under oracle/_ref (git-ignored)
+        os.makedirs(os.path.join(ROOT, "oracle", "_ref"), exist_ok=True)
+        out = os.path.join(ROOT, "oracle", "_ref", "_shim_mock_reffm.so")
     srcs = [os.path.join(ROOT, "tests", "shim", "shim_driver.cpp"), os.path.join(ROOT, "shim", "base3d", "bundle_adjustment.cc")]
-    cmd = ["g++", "-std=c++11", "-O1", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "tests", "stubs"),
-           "-I" + os.path.join(ROOT, "shim"), "-I" + os.path.join(ROOT, "include")] + srcs
+    inc = ["-I" + os.path.join(ROOT, "shim")]
+    if reference_fm:  # shim/ first (its base3d/bundle_adjustment.h replaces the reference's), then the reference tree for fm/
+        inc.append("-I" + REFERENCE_SRC)
+        srcs.append(os.path.join(REFERENCE_SRC, "fm", "feature_management.cc"))
+    cmd = ["g++", "-std=c++11", "-O1", "-pthread", "-fPIC", "-shared"] + inc + ["-I" + os.path.join(ROOT, "tests", "stubs"),
+           "-I" + os.path.join(ROOT, "include")] + srcs
     if real:
         libdir = os.path.join(ROOT, "mavmap_amd", "lib")
         cmd += ["-L" + libdir, "-lmavba", "-Wl,-rpath," + libdir]
@@ -33,9 +46,8 @@ def _build(real):
     return C.CDLL(out)
 
 
-@pytest.fixture(scope="module")
-def mock():
-    L = _build(real=False)
+def _mock_library(reference_fm):
+    L = _build(real=False, reference_fm=reference_fm)
     for name, rt in (("mock_poses", dp), ("mock_intr", dp), ("mock_points", dp), ("mock_uv", dp), ("mock_prior_rvec", dp),
                      ("mock_pose_const", bp), ("mock_intr_const", bp), ("mock_point_const", bp),
                      ("mock_image_camera", ip), ("mock_camera_model", ip), ("mock_obs_image", ip),
@@ -45,6 +57,19 @@ def mock():
     L.mock_prior_weight.restype = C.c_double
     L.shim_last_exception.restype = C.c_char_p
     return L
+
+
+@pytest.fixture(scope="module")
+def mock():
+    return _mock_library(False)
+
+
+@pytest.fixture(scope="module")
+def mock_reference_fm():
+    """The shim compiled against the reference's real FeatureManager (header AND feature_management.cc)."""
+    if not os.path.isdir(os.path.join(REFERENCE_SRC, "fm")):
+        pytest.skip("needs /root/reference (build container only)")
+    return _mock_library(True)
 
 
 class Scene:
@@ -431,3 +456,22 @@ def test_shim_rotation_constraints_end_to_end_on_gpu(mavba, oracle):
     assert np.abs(poses - q.poses).max() < 1e-6 * np.abs(q.poses).max()
     assert np.abs(points - q.points).max() < 1e-6 * np.abs(q.points).max()
     assert np.abs(perr - eo).max() < 1e-6 * np.abs(eo).max()
+
+
+def test_shim_is_source_compatible_with_the_reference_feature_manager(mock_reference_fm):
+    """Build-container-only: shim/base3d/bundle_adjustment.{h,cc} compiled against the REFERENCE's
+    src/fm/feature_management.h and linked with its feature_management.cc (sources used where they lie; only
+    Eigen::Vector2d/3d come from the test double, there is no Eigen here) hands the same flat problem to the C ABI as the
+    independent restatement of bundle_adjustment.cc:228-549 expects: global call with camera refinement, local window with
+    min_track_len 3, GCPs, rotation constraints."""
+    L = mock_reference_fm
+    sc = Scene(small_scene(seed=4), extra_unmatched=7)
+    for free, fixed, fixed_x, gcp, mtl, refine in (([2, 3, 4, 5], [0], [1], (), 2, 1), ([2, 3], [0, 1], [], (), 3, 0),
+                                                   ([0, 1, 2, 3, 4, 5], [], [], (0, 5, 9), 2, 1)):
+        rc, *_ = run(L, sc, free, fixed, fixed_x, gcp=gcp, min_track_len=mtl, refine_camera_params=refine)
+        assert rc == 0, L.shim_last_exception()
+        r = check_against_expected(L, sc, expected_flat(sc, free, fixed, fixed_x, gcp, mtl, refine))
+        assert r["no"] > 0
+    # the two std::invalid_argument conditions of the reference (:459-471) through the real class as well
+    rc, *_ = run(L, sc, [1, 2, 3], [], [0])
+    assert rc == 1 and b"7 parameters" in L.shim_last_exception()
