@@ -361,7 +361,9 @@ def main():
                 roofline.update(executed_flops=info["cluster_flops"], executed_tflops=round(ex, 3),
                                 executed_frac=round(ex / FP64_MFMA_PEAK_TFLOPS, 4),
                                 sweep_equivalent_gbs=round(sweep_bytes / (dominant["avg_ms"] * 1e-3) / 1e9, 1),
-                                sweep_equivalent_frac=round(sweep_bytes / (dominant["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                                sweep_equivalent_frac=round(sweep_bytes / (dominant["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                mfma_util=None if not mfma else (mfma.get("schur_fused") or {}).get("mfma_util"),
+                                mfma_counters=None if not mfma else mfma.get("schur_fused"))
                 roofline["note"] = ("k_schur_fused: Jacobian evaluation, per-point sums, 3x3 factors AND the Schur complement of the point "
                                     "clusters (E E^T on v_mfma_f64_16x16x4_f64) in one kernel, no Jacobian and no entry records in HBM. "
                                     "FP64 vector and matrix instructions share the SIMD's pipe, so the kernel is bound by their SUM; "

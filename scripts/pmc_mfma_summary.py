@@ -57,7 +57,8 @@ def group(pred):
                 mfma_flops=mops * 512.0, cycles_per_mfma=(busy / (mops / 4.0) if mops else None))
 
 
-summary = dict(reduced_solve=group(lambda k: k.startswith("k_chol_")), schur_clusters=group(lambda k: k.startswith("k_schur_clusters")))
+summary = dict(reduced_solve=group(lambda k: k.startswith("k_chol_")), schur_clusters=group(lambda k: k.startswith("k_schur_clusters")),
+               schur_fused=group(lambda k: k.startswith("k_schur_fused")))
 json.dump(dict(note=__doc__, summary=summary, kernels=kernels), open(out, "w"), indent=1)
 for name, g in summary.items():
     print(name, "mfma_util", g["mfma_util"], "busy", g["mfma_busy_cycles"], "gui", g["gui_active_cycles"])
