@@ -122,13 +122,19 @@ __device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, 
   const int li = lane & 15, lk = lane >> 4;
   constexpr int c0 = 4 * B;
   // D4[a][b], a >= b: register B of lane (a << 4 | c0 + b)
+  // The first pivot goes first and its reciprocal square root is started before the other nine values are fetched: the
+  // wave issues in order, so the 18 v_readlane that follow fill the latency of v_rsq_f64 and of the correction's
+  // dependent operations (the empty asm only pins that order: the compiler would fetch all ten values first).
   const double d00 = readlane_d(acc[B], 0 * 16 + c0 + 0);
-  const double d10 = readlane_d(acc[B], 1 * 16 + c0 + 0), d11 = readlane_d(acc[B], 1 * 16 + c0 + 1);
-  const double d20 = readlane_d(acc[B], 2 * 16 + c0 + 0), d21 = readlane_d(acc[B], 2 * 16 + c0 + 1), d22 = readlane_d(acc[B], 2 * 16 + c0 + 2);
-  const double d30 = readlane_d(acc[B], 3 * 16 + c0 + 0), d31 = readlane_d(acc[B], 3 * 16 + c0 + 1), d32 = readlane_d(acc[B], 3 * 16 + c0 + 2),
-               d33 = readlane_d(acc[B], 3 * 16 + c0 + 3);
+  const double y00 = __builtin_amdgcn_rsq(d00);
+  int alo = __double2loint(acc[B]), ahi = __double2hiint(acc[B]);
+  asm volatile("" : "+v"(alo), "+v"(ahi) : "v"(y00));
+  auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(ahi, l), __builtin_amdgcn_readlane(alo, l)); };
+  const double d10 = rl(1 * 16 + c0 + 0), d11 = rl(1 * 16 + c0 + 1);
+  const double d20 = rl(2 * 16 + c0 + 0), d21 = rl(2 * 16 + c0 + 1), d22 = rl(2 * 16 + c0 + 2);
+  const double d30 = rl(3 * 16 + c0 + 0), d31 = rl(3 * 16 + c0 + 1), d32 = rl(3 * 16 + c0 + 2), d33 = rl(3 * 16 + c0 + 3);
   // 4x4 Cholesky, reciprocal diagonal r_k = 1 / l_kk
-  const double r0 = rsqrt_halley(d00);
+  const double r0 = rsqrt_finish(y00, __builtin_fma(-(d00 * y00), y00, 1.0));
   const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
   const double t11 = __builtin_fma(-l10, l10, d11);
   const double r1 = rsqrt_halley(t11);
@@ -147,15 +153,17 @@ __device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, 
   const double x31 = -__builtin_fma(l32, x21, l31 * r1) * r3;
   const double x30 = -__builtin_fma(l32, x20, __builtin_fma(l31, x10, l30 * r0)) * r3;
   // A operand: lane (k = lk, i = li) supplies X4[i][k] for i < 4, k <= i
-  double xa = 0.0;
-  if (li == 0) xa = lk == 0 ? r0 : 0.0;
-  else if (li == 1) xa = lk == 0 ? x10 : (lk == 1 ? r1 : 0.0);
-  else if (li == 2) xa = lk == 0 ? x20 : (lk == 1 ? x21 : (lk == 2 ? r2 : 0.0));
-  else if (li == 3) xa = lk == 0 ? x30 : (lk == 1 ? x31 : (lk == 2 ? x32 : r3));
+  // (selects, not branches: with an if-ladder the compiler sinks the pivot chain into divergent blocks)
+  const double c0v = li == 0 ? r0 : (li == 1 ? x10 : (li == 2 ? x20 : x30));
+  const double c1v = li == 1 ? r1 : (li == 2 ? x21 : x31);
+  const double c2v = li == 2 ? r2 : x32;
+  double xa = lk == 0 ? c0v : (lk == 1 ? c1v : (lk == 2 ? c2v : r3));
+  xa = (li < 4 && lk <= li) ? xa : 0.0;
   const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
   const double ba = li >= c0 ? acc[B] : 0.0;  // columns left of the block are stale (never needed again)
   const d4 U = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, ba, zero, 0, 0, 0);
   const d4 Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xacc[B], zero, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);  // (both issued back to back: the second one runs in the first one's result latency)
   const double u = li >= c0 + lk ? U[0] : 0.0;  // row m of L^T is zero left of column c0 + m (rounding residue otherwise)
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, u, acc, 0, 0, 0);
   xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, Xn[0], xacc, 0, 0, 0);
@@ -231,8 +239,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 struct NoPhaseHook { __device__ __forceinline__ void operator()(int) const {} };
 // `hook(ph)`: called by every thread right after the barrier that ends phase ph (1..4): lets the caller slip a flag poll /
 // a prefetch into the factorisation (the persistent chain asks for its next tiles there).
-template <class Hook = NoPhaseHook>
-__device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid, Hook hook = Hook()) {
+// `mark(id)`: wave 0's way points for the cycle harness (scripts/_dbg/tile_bench.hip); nothing in the product.
+struct NoMark { __device__ __forceinline__ void operator()(int) const {} };
+template <class Hook = NoPhaseHook, class Mark = NoMark>
+__device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid, Hook hook = Hook(), Mark mark = Mark()) {
   const int wv = tid >> 6, lane = tid & 63;
   const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
   auto Tb = [&](int i, int j) { return T + (16 * i) * GLD + 16 * j; };
@@ -253,7 +263,23 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
   auto chain = [&](double* C, const double* P, int c) -> bool {
     d4 a = load_d16(C, GLD, lane), x;
     if (P) a = gemm16(P, GLD, P, GLD, true, -1.0, a, lane);
+    mark(4 * c + 1);
+    // Padding (every front of the elimination tree ends on a tile boundary: unit diagonal, zero elsewhere - and stays so
+    // under the updates, whose panel rows are exact zeros): a block that IS the identity is its own factor and inverse.
+    // One wave-wide compare instead of 16 dependent pivots (3 500 cycles); C3: ~6 such blocks on the critical path.
+    {
+      const int li = lane & 15, lk = lane >> 4;
+      bool ident = true;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ident = ident && a[r] == ((lk + 4 * r == li) ? 1.0 : 0.0);
+      if (__builtin_amdgcn_ballot_w64(!ident) == 0) {
+        store_d16(Xb(c, c), GLD, a, lane);
+        mark(4 * c + 2);
+        return true;
+      }
+    }
     const bool ok = kPivot4 ? potrf_inv16_b4(a, x, lane) : potrf_inv16(a, x, lane);
+    mark(4 * c + 2);
     store_d16(Xb(c, c), GLD, x, lane);
     return ok;
   };
@@ -263,8 +289,10 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
   __syncthreads();
   // ---- phase 1: panel 0; wave 0 goes on to D_1
   if (wv == 0) {
+    mark(3);
     panel(Tb(1, 0), Xb(0, 0), Lb(1, 0));
     wave_lds_sync();
+    mark(4);
     ok = chain(Tb(1, 1), Lb(1, 0), 1) && ok;
   } else if (wv == 1) {
     panel(Tb(2, 0), Xb(0, 0), Lb(2, 0));
@@ -288,8 +316,10 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
   hook(1);
   // ---- phase 2: panel 1; wave 0 goes on to D_2; wave 3 starts on the inverse
   if (wv == 0) {
+    mark(7);
     panel(Tb(2, 1), Xb(1, 1), Lb(2, 1));
     wave_lds_sync();
+    mark(8);
     ok = chain(Tb(2, 2), Lb(2, 1), 2) && ok;
   } else if (wv == 1) {
     panel(Tb(3, 1), Xb(1, 1), Lb(3, 1));
@@ -312,8 +342,10 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
   hook(2);
   // ---- phase 3: panel 2; wave 0 goes on to D_3
   if (wv == 0) {
+    mark(11);
     panel(Tb(3, 2), Xb(2, 2), Lb(3, 2));
     wave_lds_sync();
+    mark(12);
     ok = chain(Tb(3, 3), Lb(3, 2), 3) && ok;
   } else if (wv == 1) {
     // X_21 = -Dinv_2 (L_21 Dinv_1)
@@ -330,21 +362,30 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
     wave_lds_sync();
     m = gemm16(Xb(2, 2), GLD, Tb(0, 2), GLD, false, -1.0, zero, lane);
     store_d16(Xb(2, 0), GLD, m, lane);
+  } else {
+    // (idle otherwise) the parts of the last block row's sums that do not need X_2j: L_30 X_00 + L_31 X_10, L_31 X_11
+    d4 m = gemm16(Lb(3, 0), GLD, Xb(0, 0), GLD, false, 1.0, zero, lane);
+    m = gemm16(Lb(3, 1), GLD, Xb(1, 0), GLD, false, 1.0, m, lane);
+    store_d16(Tb(0, 3), GLD, m, lane);
+    m = gemm16(Lb(3, 1), GLD, Xb(1, 1), GLD, false, 1.0, zero, lane);
+    store_d16(Tb(1, 3), GLD, m, lane);
   }
   __syncthreads();
   hook(3);
   // ---- phase 4: last block row of the inverse, X_3j = -Dinv_3 sum_{k=j}^{2} L_3k X_kj
+  mark(15);
   if (wv < 3) {
     const int j = 2 - wv;  // wave 0: X_32, wave 1: X_31, wave 2: X_30
     double* scr = wv == 0 ? Tb(1, 2) : (wv == 1 ? Tb(0, 1) : Tb(0, 2));
-    d4 m = zero;
-    for (int k = j; k < 3; ++k) m = gemm16(Lb(3, k), GLD, Xb(k, j), GLD, false, 1.0, m, lane);
+    d4 m = j == 2 ? zero : load_d16(j == 1 ? Tb(1, 3) : Tb(0, 3), GLD, lane);  // (wave 3's phase-3 partial sums)
+    m = gemm16(Lb(3, 2), GLD, Xb(2, j), GLD, false, 1.0, m, lane);
     store_d16(scr, GLD, m, lane);
     wave_lds_sync();
     m = gemm16(Xb(3, 3), GLD, scr, GLD, false, -1.0, zero, lane);
     store_d16(Xb(3, j), GLD, m, lane);
   }
   __syncthreads();
+  mark(16);
   // ---- the parked factor blocks leave the upper triangle of Ti
   for (int e = tid; e < 6 * 256; e += 256) {
     const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;

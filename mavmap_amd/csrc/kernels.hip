@@ -1786,7 +1786,7 @@ struct FusedShape {
 };
 }  // namespace
 
-template <int KMAX>
+template <int KMAX, bool TRACE = false>
 __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
     FrontArgs a, const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const unsigned short* __restrict__ obs_meta,
     const unsigned short* __restrict__ q_meta, double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
@@ -1817,6 +1817,11 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
 #pragma unroll
   for (int i = 0; i < SH::acc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
+  // (TRACE: s_memtime stamps of the cluster's SECOND batch - steady state - per wave; a separate instantiation)
+  long long stamp[TRACE ? 10 : 1];
+  int nstamp = 0;
+  bool tracing = false;
+  auto mark = [&]() { if constexpr (TRACE) { if (tracing && nstamp < 10) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
   __syncthreads();
   // A batch's first loads - every lane's observation, the owner lanes' per-point inputs - are requested before the
   // PREVIOUS batch's matrix instructions start, so they travel under those (~15 k cycles) instead of stalling the batch.
@@ -1848,6 +1853,8 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
     const unsigned meta = act ? meta_n : 0xFFFFu;
     const double own_sp[3] = {own_sp_n[0], own_sp_n[1], own_sp_n[2]};
     (void)o1;
+    if constexpr (TRACE) tracing = bi == 1;
+    mark();  // 0: top of the batch
     for (int j = tid; j <= np; j += kClThreads) s_pb[j] = a.pt_start[b0 + j];
     for (int i = tid; i < np * 9; i += kClThreads) s_sum[i] = 0.0;
     if constexpr (KMAX > 0) {
@@ -1935,9 +1942,12 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
         *dst = acc1;
       }
     };
+    mark();  // 1: Jacobian + products done
     round(std::integral_constant<int, 0>{});
+    mark();  // 2
     if constexpr (FS::ROUNDS > 1) round(std::integral_constant<int, 1>{});
     lds_barrier();  // sums complete, the park buffer is free
+    mark();  // 3
     // ---- owner lanes: Cu, gu out, damped 3x3 block factorised; everybody clears E ----
     if (tid < np) {
       const int p = b0 + tid;
@@ -1980,6 +1990,7 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
     }
     for (int i = tid; i < SH::rows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
     lds_barrier();
+    mark();  // 4: owners + clear
     // ---- the stacked entry matrix of the batch, straight from registers ----
     if (act && meta != 0xFFFFu) {  // (0xFFFF: the image's pose is constant - it has no rows; the sums above included it)
       const int lp = pt - b0;
@@ -2020,6 +2031,7 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
       if (a.pt_free[b0 + pp] && s_pb[pp + 1] > s_pb[pp]) E[SH::hrow * kClPitch + tid] = s_g[pp * 12 + 6 + t];
     }
     lds_barrier();
+    mark();  // 5: entry matrix written
     if (bi + 1 < nbatch) {
       request_batch(bi + 1);
       __builtin_amdgcn_sched_barrier(0);  // (keep the loads here: the scheduler would sink them to their use)
@@ -2034,7 +2046,15 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
       case 6: cluster_mfma<SH, 6>(E, lane, acc); break;
       default: cluster_mfma<SH, 7>(E, lane, acc); break;
     }
+    mark();  // 6: matrix instructions issued
     // (the next batch's first lds_barrier comes after its loads and bookkeeping)
+  }
+  if constexpr (TRACE) {
+    if (a.trace && lane == 0 && blockIdx.x < 4096) {
+      long long* out = a.trace + ((size_t)blockIdx.x * 8 + wv) * 16;
+      out[0] = nstamp;
+      for (int i = 0; i < nstamp; ++i) out[1 + i] = stamp[i];
+    }
   }
   const int* tab = s_tab;
   switch (wv) {
@@ -2057,6 +2077,34 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
 void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int num_clusters, const SchurCluster* clusters, const int* tab,
                         const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii) {
   if (num_clusters <= 0) return;
+  // MAVBA_FUSED_TRACE=<file>: the 5th launch of the process (widest model <= 8) records s_memtime stamps per wave (debugging aid)
+  static const char* trace_file = std::getenv("MAVBA_FUSED_TRACE");
+  static int trace_calls = 0;
+  if (trace_file && kmax_intr > 4 && kmax_intr <= 8 && ++trace_calls == 5) {
+    const size_t trace_n = (size_t)4096 * 8 * 16;
+    long long* tr = nullptr;
+    (void)hipMalloc(reinterpret_cast<void**>(&tr), trace_n * 8);
+    (void)hipMemsetAsync(tr, 0, trace_n * 8, st);
+    FrontArgs b = a;
+    b.trace = tr;
+    hipLaunchKernelGGL((k_schur_fused<8, true>), dim3(num_clusters), dim3(kClThreads), 0, st, b, clusters, tab, obs_meta, q_meta, part_pp, part_ip, part_ii);
+    std::vector<long long> hst(trace_n);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hst.data(), tr, trace_n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(tr);
+    if (FILE* fp = std::fopen(trace_file, "w")) {
+      for (int g = 0; g < std::min(num_clusters, 4096); ++g)
+        for (int wv = 0; wv < 8; ++wv) {
+          const long long* r = hst.data() + ((size_t)g * 8 + wv) * 16;
+          if (r[0] <= 0) continue;
+          std::fprintf(fp, "%d %d", g, wv);
+          for (int i = 0; i < (int)r[0]; ++i) std::fprintf(fp, " %lld", r[1 + i]);
+          std::fprintf(fp, "\n");
+        }
+      std::fclose(fp);
+    }
+    return;
+  }
 #define MAVBA_FUSED(K) hipLaunchKernelGGL((k_schur_fused<K>), dim3(num_clusters), dim3(kClThreads), 0, st, a, clusters, tab, obs_meta, q_meta, part_pp, part_ip, part_ii)
   if (kmax_intr <= 0) MAVBA_FUSED(0); else if (kmax_intr <= 4) MAVBA_FUSED(4); else if (kmax_intr <= 8) MAVBA_FUSED(8); else MAVBA_FUSED(9);
 #undef MAVBA_FUSED

@@ -846,6 +846,27 @@ void mavba_session::finish_structure() {
   }, 64);
   clustered_points = 0;
   for (int p = 0; p < NP; ++p) clustered_points += pt_mode[p] == 1;
+  if (std::getenv("MAVBA_CLUSTER_STATS")) {  // debugging aid: how many 16-row blocks of the pose rows a 32-point batch really touches
+    long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tiles_needed = 0, tiles_all = 0, obs_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int cl = 0; cl < num_clusters; ++cl)
+      for (int b0 = clusters[cl].p0; b0 < clusters[cl].p1; b0 += kClBatch) {
+        unsigned mask = 0;
+        const int b1 = std::min(b0 + kClBatch, clusters[cl].p1);
+        for (int p = b0; p < b1; ++p)
+          for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a)
+            if (obs_meta[a] != 0xFFFFu) { const int l = obs_meta[a] >> 8; mask |= 1u << (6 * l / 16); mask |= 1u << ((6 * l + 5) / 16); }
+        const int nb = __builtin_popcount(mask);
+        hist[std::min(nb, 7)]++;
+        const int nt = nb + 2;  // + the two row blocks of the camera / h rows
+        tiles_needed += nt * (nt + 1) / 2; tiles_all += 36;
+        obs_hist[std::min(8, (h_pt_start[b1] - h_pt_start[b0]) / 64)]++;
+      }
+    std::fprintf(stderr, "[cluster stats] batches by touched pose row blocks:");
+    for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %d:%lld", i, hist[i]);
+    std::fprintf(stderr, "  tiles needed %lld of %lld; batches by observations/64:", tiles_needed, tiles_all);
+    for (int i = 0; i < 9; ++i) std::fprintf(stderr, " %d:%lld", i, obs_hist[i]);
+    std::fprintf(stderr, "\n");
+  }
   lap("point clusters");
   // term enumeration over a range of points: f(kind, row_ent, col_ent, x, y)
   auto enumerate = [&](int p_begin, int p_end, auto&& f) {

@@ -81,6 +81,8 @@ __global__ void __launch_bounds__(256) k_bench(const double* A, double* Xout, lo
   __shared__ __attribute__((aligned(16))) double rd[4 * 16 * MLD];
   const int tid = threadIdx.x;
   long long total = 0;
+  long long marks[20];
+  for (int i = 0; i < 20; ++i) marks[i] = 0;
   for (int rep = 0; rep < reps; ++rep) {
     load_tile(A, NB, T, tid);
     for (int i = tid; i < NB * GLD; i += 256) Ti[i] = 0.0;
@@ -88,6 +90,16 @@ __global__ void __launch_bounds__(256) k_bench(const double* A, double* Xout, lo
     const long long t0 = clock64();
     if (variant == 0) tile_potrf_inv(T, Ti, rd, tid);
     else if (variant == 1) tile_potrf_inv_la(T, Ti, tid);
+    else if (variant == 3) {  // 4 x potrf_inv16_b4 alone (timing only)
+      if (tid < 64) for (int cb = 0; cb < 4; ++cb) {
+        d4 a = load_d16(T + 16 * cb * GLD + 16 * cb, GLD, tid), x;
+        potrf_inv16_b4(a, x, tid);
+        store_d16(Ti + 16 * cb * GLD + 16 * cb, GLD, x, tid);
+      }
+    } else if (variant == 4) {  // look-ahead variant with wave 0's way points
+      auto mark = [&](int id) { if (tid == 0) marks[id] += clock64() - t0; };
+      tile_potrf_inv_la(T, Ti, tid, NoPhaseHook(), mark);
+    }
     else if (variant == 2) {  // 4 x potrf_inv16 alone (timing only)
       if (tid < 64) for (int cb = 0; cb < 4; ++cb) {
         d4 a = load_d16(T + 16 * cb * GLD + 16 * cb, GLD, tid), x;
@@ -98,7 +110,7 @@ __global__ void __launch_bounds__(256) k_bench(const double* A, double* Xout, lo
     __syncthreads();
     total += clock64() - t0;
   }
-  if (tid == 0) cyc[0] = total / reps;
+  if (tid == 0) { cyc[0] = total / reps; for (int i = 0; i < 20; ++i) cyc[1 + i] = marks[i] / reps; }
   store_tile(Xout, NB, Ti, tid);
 }
 __global__ void k_rsq(const double* d, double* out_nr, double* out_h, double* out_seed, int n) {
@@ -120,16 +132,26 @@ int main() {
   for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) L[i * n + j] = 0.0;
   for (int c = 0; c < n; ++c) for (int i = c; i < n; ++i) { double v = (i == c) ? 1.0 : 0.0; for (int k = c; k < i; ++k) v -= L[i * n + k] * X[k * n + c]; X[i * n + c] = v / L[i * n + i]; }
   double *dA, *dX; long long* dc;
-  hipMalloc(&dA, n * n * 8); hipMalloc(&dX, n * n * 8); hipMalloc(&dc, 8);
+  hipMalloc(&dA, n * n * 8); hipMalloc(&dX, n * n * 8); hipMalloc(&dc, 8 * 32);
   hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
-  for (int v = 0; v < 3; ++v) {
-    hipLaunchKernelGGL(k_bench, dim3(1), dim3(256), 0, 0, dA, dX, dc, v, 20);
+  for (int v = 0; v < 6; ++v) {
+    if (v == 5) {  // the last 32 columns are padding (identity): the look-ahead variant skips their pivots
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (i >= 32 || j >= 32) A[i * n + j] = i == j ? 1.0 : 0.0;
+      hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+      L = A; X.assign(n * n, 0.0);
+      for (int j = 0; j < n; ++j) { for (int k = 0; k < j; ++k) for (int i = j; i < n; ++i) L[i * n + j] -= L[i * n + k] * L[j * n + k];
+        const double d = std::sqrt(L[j * n + j]); for (int i = j; i < n; ++i) L[i * n + j] /= d; }
+      for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) L[i * n + j] = 0.0;
+      for (int c = 0; c < n; ++c) for (int i = c; i < n; ++i) { double vv = (i == c) ? 1.0 : 0.0; for (int k = c; k < i; ++k) vv -= L[i * n + k] * X[k * n + c]; X[i * n + c] = vv / L[i * n + i]; }
+    }
+    hipLaunchKernelGGL(k_bench, dim3(1), dim3(256), 0, 0, dA, dX, dc, v == 5 ? 1 : v, 20);
     hipDeviceSynchronize();
     std::vector<double> Xd(n * n); long long c;
     hipMemcpy(Xd.data(), dX, n * n * 8, hipMemcpyDeviceToHost); hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
     double err = 0, mx = 0, up = 0;
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { if (v == 2 && (i / 16 != j / 16)) continue; mx = std::fmax(mx, std::fabs(X[i * n + j])); if (j <= i) err = std::fmax(err, std::fabs(Xd[i * n + j] - X[i * n + j])); else up = std::fmax(up, std::fabs(Xd[i * n + j])); }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { if ((v == 2 || v == 3) && (i / 16 != j / 16)) continue; mx = std::fmax(mx, std::fabs(X[i * n + j])); if (j <= i) err = std::fmax(err, std::fabs(Xd[i * n + j] - X[i * n + j])); else up = std::fmax(up, std::fabs(Xd[i * n + j])); }
     printf("variant %d: %lld cycles/tile, inverse max err %.2e (scale %.2e), upper max %.2e\n", v, c, err, mx, up);
+    if (v == 4) { long long m[21]; hipMemcpy(m, dc, 8 * 21, hipMemcpyDeviceToHost); printf("  way points of wave 0 (cycles from start):"); for (int i = 1; i <= 16; ++i) printf(" %d:%lld", i, m[1 + i]); printf("\n"); }
   }
   {
     const int m = 1 << 20; std::vector<double> d(m), o1(m), o2(m), o3(m);
