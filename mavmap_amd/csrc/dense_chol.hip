@@ -241,8 +241,15 @@ struct NoPhaseHook { __device__ __forceinline__ void operator()(int) const {} };
 // a prefetch into the factorisation (the persistent chain asks for its next tiles there).
 // `mark(id)`: wave 0's way points for the cycle harness (scripts/_dbg/tile_bench.hip); nothing in the product.
 struct NoMark { __device__ __forceinline__ void operator()(int) const {} };
-template <class Hook = NoPhaseHook, class Mark = NoMark>
-__device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid, Hook hook = Hook(), Mark mark = Mark()) {
+// `phase0(stage)`: the caller's work inside phase 0, where only wave 0 is busy (the persistent chain finishes the panel
+// solve and the diagonal update of the column there): stage 0 - wave 0, before it factorises D_0 (its own part of the
+// update); stage 1 - wave 0, right before the first block of the new inverse is written into Ti (Ti may still be read
+// as the PREVIOUS column's inverse by the other waves: wait for them); stage 2 - waves 1..3, instead of idling; stage 3 -
+// waves 1..3 at the start of phase 1 (their own panel work there is short: more of the caller's update fits).
+struct NoPhase0 { __device__ __forceinline__ void operator()(int) const {} };
+template <class Hook = NoPhaseHook, class Mark = NoMark, class Phase0 = NoPhase0>
+__device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid, Hook hook = Hook(), Mark mark = Mark(),
+                                                  Phase0 phase0 = Phase0()) {
   const int wv = tid >> 6, lane = tid & 63;
   const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
   auto Tb = [&](int i, int j) { return T + (16 * i) * GLD + 16 * j; };
@@ -273,6 +280,7 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
 #pragma unroll
       for (int r = 0; r < 4; ++r) ident = ident && a[r] == ((lk + 4 * r == li) ? 1.0 : 0.0);
       if (__builtin_amdgcn_ballot_w64(!ident) == 0) {
+        if (c == 0) phase0(1);
         store_d16(Xb(c, c), GLD, a, lane);
         mark(4 * c + 2);
         return true;
@@ -280,14 +288,18 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
     }
     const bool ok = kPivot4 ? potrf_inv16_b4(a, x, lane) : potrf_inv16(a, x, lane);
     mark(4 * c + 2);
+    if (c == 0) phase0(1);
     store_d16(Xb(c, c), GLD, x, lane);
     return ok;
   };
   bool ok = true;
   // ---- phase 0: D_0
-  if (wv == 0) ok = chain(Tb(0, 0), nullptr, 0);
+  if (wv == 0) { phase0(0); ok = chain(Tb(0, 0), nullptr, 0); }
+  else phase0(2);
   __syncthreads();
+  hook(0);
   // ---- phase 1: panel 0; wave 0 goes on to D_1
+  if (wv != 0) phase0(3);
   if (wv == 0) {
     mark(3);
     panel(Tb(1, 0), Xb(0, 0), Lb(1, 0));
@@ -897,6 +909,93 @@ __device__ __forceinline__ void syrk_lower_blocks(double* Ds, const double* Ps, 
   }
 }
 
+// ---- the same two products cut so that they fit AROUND the tile factorisation (persistent chain) ----
+// One 16x16 block of P = As Li^T: rows [16 rb, +16), column block N (Li lower triangular: 4 (N + 1) k-steps).
+template <int N>
+__device__ __forceinline__ d4 trsm_block16(const double* As, const double* Li, int rb, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int K = 4 * (N + 1);
+  const double* pa = As + (16 * rb + li) * GLD + lk;
+  const double* pb = Li + (16 * N + li) * GLD + lk;
+  double a[K], b[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { a[s] = pa[4 * s]; b[s] = pb[4 * s]; }
+  d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < K; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+  return c;
+}
+// A whole 16-row block of P: the four column blocks on four independent accumulators (40 matrix instructions).
+__device__ __forceinline__ void trsm_row16(const double* As, const double* Li, int rb, int lane, d4 (&c)[4]) {
+  const int li = lane & 15, lk = lane >> 4;
+  const double* pa = As + (16 * rb + li) * GLD + lk;
+  double a[16], b0[4], b1[8], b2[12], b3[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) { a[s] = pa[4 * s]; b3[s] = Li[(48 + li) * GLD + lk + 4 * s]; }
+#pragma unroll
+  for (int s = 0; s < 12; ++s) b2[s] = Li[(32 + li) * GLD + lk + 4 * s];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) b1[s] = Li[(16 + li) * GLD + lk + 4 * s];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) b0[s] = Li[li * GLD + lk + 4 * s];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c[q] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    if (s < 4) c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b0[s], c[0], 0, 0, 0);
+    if (s < 8) c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b1[s], c[1], 0, 0, 0);
+    if (s < 12) c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b2[s], c[2], 0, 0, 0);
+    c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b3[s], c[3], 0, 0, 0);
+  }
+}
+// D(bi, bj) -= P_bi P_bj^T for one or two 16x16 blocks of the diagonal tile (K = 64)
+__device__ __forceinline__ void syrk16(double* Ds, const double* Ps, int bi, int bj, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  double pi[16], pj[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) { pi[s] = Ps[(16 * bi + li) * GLD + 4 * s + lk]; pj[s] = Ps[(16 * bj + li) * GLD + 4 * s + lk]; }
+  d4 acc = load_d16(Ds + 16 * bi * GLD + 16 * bj, GLD, lane);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[s], pj[s], acc, 0, 0, 0);
+  store_d16(Ds + 16 * bi * GLD + 16 * bj, GLD, acc, lane);
+}
+__device__ __forceinline__ void syrk16_own(double* Ds, const double* Ps, int w, int lane) {  // (w, 0) and (w, w)
+  const int li = lane & 15, lk = lane >> 4;
+  double pw[16], p0[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) { pw[s] = Ps[(16 * w + li) * GLD + 4 * s + lk]; p0[s] = Ps[li * GLD + 4 * s + lk]; }
+  d4 a0 = load_d16(Ds + 16 * w * GLD, GLD, lane), aw = load_d16(Ds + 16 * w * GLD + 16 * w, GLD, lane);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pw[s], p0[s], a0, 0, 0, 0);
+    aw = __builtin_amdgcn_mfma_f64_16x16x4f64(-pw[s], pw[s], aw, 0, 0, 0);
+  }
+  store_d16(Ds + 16 * w * GLD, GLD, a0, lane);
+  store_d16(Ds + 16 * w * GLD + 16 * w, GLD, aw, lane);
+}
+// one 16x16 block of a tile from the accumulator layout straight to memory (system scope, like store_tile_coh)
+typedef int i2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_block_coh(double* G, size_t ld, int rb, int cb, d4 v, int lane) {
+  const __amdgpu_buffer_rsrc_t r = tile_rsrc(G);
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double x = v[q];
+    i2v w;
+    w[0] = __double2loint(x); w[1] = __double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)(((size_t)(16 * rb + lk + 4 * q) * ld + 16 * cb + li) * 8), 0, kCoherent);
+  }
+}
+// flags between the waves of one work-group, in LDS (the LDS unit executes a wave's accesses in order)
+__device__ __forceinline__ void lds_flag_set(volatile int* f, int v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  *f = v;
+}
+__device__ __forceinline__ void lds_flag_wait(const volatile int* f, int v) {
+  while (*f != v) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ void publish(unsigned* f, unsigned epoch) {
   __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -944,10 +1043,14 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
   __shared__ __attribute__((aligned(16))) double As[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * GLD];
   __shared__ __attribute__((aligned(16))) double Cs[NB * GLD];
-  __shared__ int s_ok;
+  __shared__ __attribute__((aligned(16))) double Ds[NB * GLD];  // the chain's diagonal tile (As still holds the sub-diagonal one)
+  __shared__ int s_ok, s_ok2;
+  __shared__ int s_rows[4];  // per wave: the chain column (+ 1) whose row block of the panel tile is complete in Cs
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
   const int nb = A.nb;
+  if (tid < 4) s_rows[tid] = 0;
+  __syncthreads();
   const size_t ld = (size_t)A.ld;
   const unsigned ep = A.epoch;
   // waits: lane 0 polls, everyone learns the outcome behind a barrier (which also orders the LDS reuse)
@@ -1048,65 +1151,104 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       }
       have_next = false;
       stamp((size_t)8 * j + 1);
+      // Column j with a sub-diagonal tile: P = A_{j,j-1} L_{j-1,j-1}^-T and D_j -= P P^T are cut so that only what the FIRST
+      // 16 pivots need precedes them: all four waves solve the first 16 rows of P (one column block each, <= 16 matrix
+      // instructions), wave 0 updates block (0, 0) of D_j and starts factorising; the other 48 rows of P (40 instructions
+      // per wave) and the other nine blocks of D_j (48 per wave) are done by waves 1..3 in phase 0 of the tile
+      // factorisation, where they used to idle. The panel tile goes to memory block by block, straight from the
+      // accumulators; it is drained after phase 0 and published after phase 1.
+      const bool more = j + 1 < T.j;
+      const int seq = j + 1;
       if (sub) {
         tile_regs_to_lds(Rsub, As, tid);
+        tile_regs_to_lds(Rdiag, Ds, tid);
         __syncthreads();
-        trsm_lower_tri(As, Bs, Cs, wv, lane);  // P = A_{j,j-1} L_{j-1,j-1}^-T
-        __syncthreads();
-        store_tile_coh(A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, Cs, tid);
-        stamp((size_t)8 * j + 2);
-      }
-      tile_regs_to_lds(Rdiag, As, tid);
-      __syncthreads();
-      stamp((size_t)8 * j + 3);
-      if (sub) syrk_lower_blocks(As, Cs, wv, lane);
-      stamp((size_t)8 * j + 4);
-      // next column's tiles: ask for them now if the helpers are done (one poll, no waiting)
-      const bool more = j + 1 < T.j;
-      if (tid == 0) {
-        int ready = 0;
-        if (more) {
-          const int ni = A.chain_info[j + 1];
-          ready = 1;
-          if ((ni & 2) && __hip_atomic_load(A.pflag + 2 * (j + 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
-          if ((ni & 1) && __hip_atomic_load(A.pflag + 2 * (j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
+        double* Pg = A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB;
+        // rows 0..31 of P now, 20 matrix instructions per wave: blocks (0,0)+(1,3) | (0,1)+(1,2) | (0,2)+(1,1) | (0,3)+(1,0)
+        d4 p0, p1;
+        switch (wv) {
+          case 0: p0 = trsm_block16<0>(As, Bs, 0, lane); p1 = trsm_block16<3>(As, Bs, 1, lane); break;
+          case 1: p0 = trsm_block16<1>(As, Bs, 0, lane); p1 = trsm_block16<2>(As, Bs, 1, lane); break;
+          case 2: p0 = trsm_block16<2>(As, Bs, 0, lane); p1 = trsm_block16<1>(As, Bs, 1, lane); break;
+          default: p0 = trsm_block16<3>(As, Bs, 0, lane); p1 = trsm_block16<0>(As, Bs, 1, lane); break;
         }
-        s_ok = ready;
+        store_d16(Cs + 16 * wv, GLD, p0, lane);
+        store_d16(Cs + 16 * GLD + 16 * (3 - wv), GLD, p1, lane);
+        store_block_coh(Pg, ld, 0, wv, p0, lane);
+        store_block_coh(Pg, ld, 1, 3 - wv, p1, lane);
+        __syncthreads();
+      } else {
+        tile_regs_to_lds(Rdiag, Ds, tid);
+        __syncthreads();
       }
-      if (sub) drain_stores();  // the panel tile's stores
-      __syncthreads();          // (also: the diagonal tile is complete in As)
-      if (sub && tid == 0) publish(A.lflag + A.tile_id[(size_t)j * nb + (j - 1)], ep);
-      if (s_ok) {
+      stamp((size_t)8 * j + 2);
+      stamp((size_t)8 * j + 3);
+      stamp((size_t)8 * j + 4);
+      stamp((size_t)8 * j + 5);
+      auto next_ready = [&]() {
+        const int ni = A.chain_info[j + 1];
+        int ready = 1;
+        if ((ni & 2) && __hip_atomic_load(A.pflag + 2 * (j + 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
+        if ((ni & 1) && __hip_atomic_load(A.pflag + 2 * (j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
+        return ready;
+      };
+      auto request_next = [&]() {
         const int ni = A.chain_info[j + 1];
         if (ni & 2) load_tile_regs(A.pre + (size_t)(2 * (j + 1) + 1) * NB * NB, NB, Rsub, tid, true);
         else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)j * NB, ld, Rsub, tid, false);
         if (ni & 1) load_tile_regs(A.pre + (size_t)(2 * (j + 1)) * NB * NB, NB, Rdiag, tid, true);
         else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB, ld, Rdiag, tid, false);
         have_next = true;
-      }
-      stamp((size_t)8 * j + 5);
-      // The helpers usually finish the next column's tiles while this factorisation runs: wave 3 (idle in phase 3)
-      // polls once more after phase 2, the loads go out after phase 3 and land during the last phase.
-      auto late_prefetch = [&](int ph) {
-        if (!more || have_next) return;
-        if (ph == 2) {
-          if (tid == 192) {
-            const int ni = A.chain_info[j + 1];
-            int ready = 1;
-            if ((ni & 2) && __hip_atomic_load(A.pflag + 2 * (j + 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
-            if ((ni & 1) && __hip_atomic_load(A.pflag + 2 * (j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) ready = 0;
-            s_ok = ready;
-          }
-        } else if (ph == 3 && s_ok) {
-          const int ni = A.chain_info[j + 1];
-          if (ni & 2) load_tile_regs(A.pre + (size_t)(2 * (j + 1) + 1) * NB * NB, NB, Rsub, tid, true);
-          else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)j * NB, ld, Rsub, tid, false);
-          if (ni & 1) load_tile_regs(A.pre + (size_t)(2 * (j + 1)) * NB * NB, NB, Rdiag, tid, true);
-          else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB, ld, Rdiag, tid, false);
-          have_next = true;
+      };
+      // hook(ph): every thread, right after the barrier that ends phase ph of the factorisation
+      //   0: the panel tile's stores are drained; wave 3 polls the flags of the next column's two tiles
+      //   1: the panel tile is published; the next column's loads go out if the helpers were done, else ...
+      //   2: ... wave 3 polls again and   3: the loads go out now (they land during the last phase)
+      // (measured and dropped: publishing after phase 0 behind one more barrier - 0.4 us per column for nothing)
+      auto in_factor = [&](int ph) {
+        if (ph == 0) {
+          if (sub) drain_stores();
+          if (more && tid == 192) s_ok = next_ready();
+        } else if (ph == 1) {
+          if (sub && tid == 0) publish(A.lflag + A.tile_id[(size_t)j * nb + (j - 1)], ep);
+          if (more && s_ok) request_next();
+        } else if (ph == 2) {
+          if (more && !have_next && tid == 192) s_ok2 = next_ready();
+        } else if (ph == 3) {
+          if (more && !have_next && s_ok2) request_next();
         }
       };
-      const bool ok = tile_potrf_inv_la(As, Bs, tid, late_prefetch);  // (ends with a barrier: s_ok is free again)
+      auto phase0 = [&](int stage) {
+        if (!sub) return;
+        if (stage == 0) {
+          syrk16(Ds, Cs, 0, 0, lane);  // wave 0: block (0, 0) of the diagonal update (row block 0 of P is complete)
+          wave_lds_sync();
+        } else if (stage == 1) {
+          // the first block of the new inverse overwrites Bs: the other waves must be done reading the old one
+          lds_flag_wait(&s_rows[1], seq); lds_flag_wait(&s_rows[2], seq); lds_flag_wait(&s_rows[3], seq);
+        } else if (stage == 2) {
+          if (wv == 1) {
+            syrk16_own(Ds, Cs, 1, lane);  // (1, 0), (1, 1): rows 0..31 of P are complete
+            if (lane == 0) lds_flag_set(&s_rows[1], seq);  // (this wave does not read Bs in phase 0)
+          } else {
+            double* Pg = A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB;
+            d4 c[4];
+            trsm_row16(As, Bs, wv, lane, c);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { store_d16(Cs + 16 * wv * GLD + 16 * n, GLD, c[n], lane); store_block_coh(Pg, ld, wv, n, c[n], lane); }
+            if (lane == 0) lds_flag_set(&s_rows[wv], seq);  // (Bs is no longer read by this wave)
+            wave_lds_sync();
+            syrk16(Ds, Cs, wv, 0, lane);  // (wv, 0): what phase 1 reads
+          }
+        } else {
+          // start of phase 1 (all of P is complete): the blocks this wave itself updates further in phases 1..3
+          if (wv == 1) { syrk16(Ds, Cs, 2, 1, lane); syrk16(Ds, Cs, 2, 2, lane); }
+          else if (wv == 2) { syrk16(Ds, Cs, 3, 1, lane); syrk16(Ds, Cs, 3, 3, lane); }
+          else syrk16(Ds, Cs, 3, 2, lane);
+          wave_lds_sync();
+        }
+      };
+      const bool ok = tile_potrf_inv_la(Ds, Bs, tid, in_factor, NoMark(), phase0);
       if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
       stamp((size_t)8 * j + 6);
       store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);

@@ -4,8 +4,9 @@
   MAVBA_CHOL_TRACE=/tmp/trace.txt python scripts/chol_trace.py [C3|C2|C5] [scale]
 
 Runs a few LM iterations so that the last solve's stamps (100 MHz wall clock) are dumped when the session closes,
-then prints per chain column: wait for the helpers' sub-diagonal tile, panel solve, wait for the diagonal tile,
-load, update, tile factor + inverse, publish; and how late the helpers' PRE tasks were."""
+then prints per chain column: wait for the helpers' two tiles (+ their loads when they were not prefetched), the first 32
+rows of the panel solve, the tile factor + inverse (which now contains the rest of the panel solve and the diagonal update),
+publish; and how late the helpers' PRE tasks were."""
 import os
 import sys
 
@@ -33,13 +34,13 @@ C = np.array(C, dtype=np.int64)
 T = np.array(T, dtype=np.int64)
 t0 = min(C[:, 2][C[:, 2] > 0].min(), T[:, 5][T[:, 5] > 0].min())
 us = lambda x: (x - t0) / 100.0
-print("col node |  start  wait_sub  trsm  wait_diag  load  syrk  potrf  publish | end   (us; durations)")
+print("col node |  start  wait+load  trsm(rows 0-31)  factor(+rest of trsm, update)  publish | end   (us; durations)")
 for r in C:
     j, n, t = r[0], r[1], r[2:]
     if t[0] == 0:
         continue
     sub = t[1] > 0
-    seq = [t[0], t[1] if sub else t[0], t[2] if sub else t[0], t[3], t[4], t[5], t[6], t[7]]
+    seq = [t[0], t[1], t[2], t[6], t[7]]
     d = np.diff(seq) / 100.0
     print(f"{j:3d} {n:3d} | {us(t[0]):7.1f} " + " ".join(f"{x:7.1f}" for x in d) + f" | {us(t[7]):7.1f}")
 print("total forward us:", us(max(C[:, 9].max(), T[:, 8].max())))
