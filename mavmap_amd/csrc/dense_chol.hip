@@ -1204,7 +1204,9 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       //   0: the panel tile's stores are drained; wave 3 polls the flags of the next column's two tiles
       //   1: the panel tile is published; the next column's loads go out if the helpers were done, else ...
       //   2: ... wave 3 polls again and   3: the loads go out now (they land during the last phase)
-      // (measured and dropped: publishing after phase 0 behind one more barrier - 0.4 us per column for nothing)
+      // (measured and dropped, A/B on one box: publishing after phase 0 behind one more barrier - 0.4 us per column for
+      // nothing; a third prefetch attempt, polled after phase 1 - 3 % slower; moving update blocks (2,2) into phase 0 and
+      // (3,2), (3,3) into phase 2 - no difference)
       auto in_factor = [&](int ph) {
         if (ph == 0) {
           if (sub) drain_stores();
