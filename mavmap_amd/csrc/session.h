@@ -273,6 +273,7 @@ struct mavba_session {
   int eval_rows = 0;            // cost partials the last evaluation pass wrote
   bool front_valid = false;     // Cu, gu, Gi, h and the entry records match the current x, scales and front_radius
   double front_radius = 0.0;
+  bool fail_slot_clean = false; // SC_FAIL was cleared (with SC_FAIL_FRONT, by the front end) and no solve has run since
   bool planes_ready = false;    // the Jacobian planes exist (probe path / plane kernels only)
   DevBuf<SweepChunk> d_sweep_chunks;
   int num_sweep_chunks = 0;

@@ -39,7 +39,9 @@ void mavba_session::launch_front(double r, bool entries) {
   f.Cu = d_Cu.p; f.gu = d_gu.p; f.Gi = d_Gi.p; f.h = d_h.p; f.Epose = d_Epose.p; f.Eintr = d_Eintr.p;
   f.fail = d_scal.p + SC_FAIL_FRONT;
   f.trace = nullptr;
-  if (entries) HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL_FRONT, 0, sizeof(double), st));
+  // (one fill for the two failure slots - they are neighbours: the solve that follows this front end finds SC_FAIL clean)
+  static_assert(SC_FAIL_FRONT == SC_FAIL + 1, "the two failure slots are cleared together");
+  if (entries) { HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, 2 * sizeof(double), st)); fail_slot_clean = true; }
   if (entries && fused_now()) {
     // every observed point sits in a cluster: the cluster kernel evaluates the Jacobians itself and leaves the block
     // partials of S for this radius (no entry records in HBM)
@@ -123,12 +125,13 @@ void mavba_session::evaluate(double next_radius) {
 // rows [0, n_pad) of d_M <- S, row n_pad <- v   (SchurEliminator::Eliminate).
 void mavba_session::assemble(double r) {
   const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
-  HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, sizeof(double), st));
   if (front_ok) {
     // the entry records of this (x, radius) may already be there (written together with the evaluation); a rejected
     // step comes back with a smaller radius: the front end runs again, Jacobians recomputed, nothing was stored
     if (!(front_valid && front_radius == r)) launch_front(r, true);
+    else if (!fail_slot_clean) HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, sizeof(double), st));  // (a repeated solve of the same system)
   } else {
+    HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, sizeof(double), st));
     HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL_FRONT, 0, sizeof(double), st));
     // (the points' 3x3 factors are computed inside the entries kernel: one launch; points without observations are not free)
     timed("entries_pose", [&] {
@@ -186,6 +189,7 @@ void mavba_session::solve_linear(double r) {
     dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p, allow_persistent, mid);
   });
   assembled = false;  // the factorisation overwrote S
+  fail_slot_clean = false;
   // (in place; and with shards the exchange leaves the SUM over ranks in tiles this rank's assembly does not rewrite)
   if (!(allow_persistent && chol_struct.persist_ok) || sharded()) M_is_clean = false;
 }
