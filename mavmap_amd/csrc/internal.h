@@ -162,6 +162,7 @@ void launch_scales(hipStream_t st, int NI, int NC, int NP, int NPs, int jacobi,
                    const unsigned char* pt_free, const double* img_rec, const double* cam_rec,
                    const double* Cu, double* scale_cam, double* scale_pt);
 
+constexpr int kStateNormsCamBlocks = 64;  // partial[] holds 2 x (512 + this) values
 void launch_state_norms(hipStream_t st, int NI, int NC, int NP, int NPs, bool cam_part,
                         const unsigned char* pose_free, const unsigned char* intr_free,
                         const unsigned char* pt_free, const double* poses, const double* intr,

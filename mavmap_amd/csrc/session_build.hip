@@ -361,7 +361,7 @@ void mavba_session::build(const mavba_problem* P, const DeviceRaw* raw) {
   d_Epose.alloc((size_t)std::max(N, 1) * kPoseRec);
   d_y.alloc(n_pad); d_y.zero(st);  // the matrix-sized buffers follow the elimination order chosen in finish_structure
   d_delta_cam.alloc(n_pad); d_delta_pts.alloc(nP * 3);
-  d_norm_partial.alloc((size_t)(512 + 2) * 2); d_step_partial.alloc((size_t)(1024 + update_cameras_groups(NI) + 2) * 3);
+  d_norm_partial.alloc((size_t)(512 + kStateNormsCamBlocks) * 2); d_step_partial.alloc((size_t)(1024 + update_cameras_groups(NI) + 2) * 3);
   d_scal.alloc(SC_COUNT); d_scal.zero(st);
   d_rnorm.alloc(std::max(N, 1)); d_perr.alloc(nP);
 
