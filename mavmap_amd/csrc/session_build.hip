@@ -1087,7 +1087,7 @@ void mavba_session::finish_structure() {
   {
     long long observed = 0;
     for (int p = 0; p < NP; ++p) observed += h_pt_start[p + 1] > h_pt_start[p];
-    static const bool no_fuse = std::getenv("MAVBA_NO_FUSE") != nullptr;
+    const bool no_fuse = std::getenv("MAVBA_NO_FUSE") != nullptr;  // (read per session: the tests switch paths)
     fused_ok = front_ok && !no_fuse && cl_shape.images == 16 && num_clusters > 0 && clustered_points == observed &&
                tot[0] == 0 && tot[1] == 0 && tot[2] == 0 && num_clusters <= kFrontMaxGrid;
   }
@@ -1099,7 +1099,7 @@ void mavba_session::finish_structure() {
 // entries each; a point with more observations than that is a tile of its own (walked in windows by the kernel).
 void mavba_session::build_front_tiles(const std::vector<int>& q_start) {
   std::vector<FrontTile> tiles;
-  static const bool planes_only = std::getenv("MAVBA_FRONT_PLANES") != nullptr;
+  const bool planes_only = std::getenv("MAVBA_FRONT_PLANES") != nullptr;
   front_ok = !planes_only;
   int p0 = 0, obs = 0, qs = 0;
   for (int p = 0; p < NP && front_ok; ++p) {

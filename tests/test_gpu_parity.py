@@ -410,6 +410,33 @@ def test_clusters_off_gives_the_same_system(mavba, monkeypatch):
     assert rel_err(S1, S0) < 1e-12 and rel_err(v1, v0) < 1e-12
 
 
+@pytest.mark.parametrize("kind", ["mixed", "fixed_intr"])
+def test_the_three_front_ends_give_the_same_system_and_solve(mavba, oracle, kind, monkeypatch):
+    """k_schur_fused (every point clustered), k_point_front + k_schur_clusters (MAVBA_NO_FUSE) and the plane kernels of
+    rounds 1-2 (MAVBA_FRONT_PLANES: still the route of a point seen by more than 96 refined cameras) are three routes to the
+    same reduced system: identical up to summation order, and each solves like the oracle."""
+    p = _scene(kind)
+    po = p.copy()
+    ro, _ = oracle.solve(po, oracle.options(**global_opts()), want_point_errors=True)
+    systems, timers = [], []
+    for env in (None, "MAVBA_NO_FUSE", "MAVBA_FRONT_PLANES"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        with mavba.Session(p, dict(profile_kernels=1)) as s:
+            systems.append(s.reduced_system(1e4))
+            timers.append(set(s.kernel_stats()))
+        q = p.copy()
+        _, res = mavba.bundle_adjustment(q, global_opts())
+        assert res["termination"] == ro["termination"] and res["num_successful_steps"] == ro["num_successful_steps"], env
+        assert_params_close(q, po, what=str(env))
+    # the routes really differ
+    assert "schur_fused" in timers[0] and "schur_fused" not in timers[1] and "point_front" in timers[1]
+    assert "point_front" not in timers[2] and "entries_pose" in timers[2]
+    S0, v0 = systems[0]
+    for S, v in systems[1:]:
+        assert rel_err(S, S0) < 1e-11 and rel_err(v, v0) < 1e-11
+
+
 # ---- LM control flow around the deferred read-back of the evaluation ------------------------------------
 
 @pytest.mark.parametrize("optkw", [dict(gradient_tolerance=1e-3), dict(gradient_tolerance=1e-2, function_tolerance=1e-12),
