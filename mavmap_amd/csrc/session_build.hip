@@ -702,6 +702,9 @@ void mavba_session::finish_structure() {
       return n;
     };
     if (any_cam_active) {
+      // (two passes that both walk the observations. Keeping the first pass's cameras in a 16 B / point side buffer saved
+      // 0.3 ms here - and made the NEXT call's 48 MB upload from page-locked memory take 15-25 ms instead of 1 ms every
+      // other time, reproducibly, A/B on one box; cause not understood, so the buffer is gone)
       parallel_ranges(NP, [&](long long p0, long long p1) {
         std::vector<int> tmp(std::max(NC, 1));
         for (long long p = p0; p < p1; ++p) q_start[p + 1] = h_pt_free[p] ? cams_of((int)p, tmp.data()) : 0;
@@ -756,49 +759,67 @@ void mavba_session::finish_structure() {
     // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
     // thread": the clusters - and with them the order in which partials are added - must not depend on the
     // machine's core count).
-    const int kRange = 4096;
+    const int kRange = 2048;
     const int nranges = (NP + kRange - 1) / kRange;
     std::vector<std::vector<SchurCluster>> r_clusters(nranges);
     std::vector<std::vector<int>> r_imgs(nranges), r_cams(nranges);
-    auto do_range = [&](int rg) {
+    // Membership of an image in the open cluster / in the current point is an epoch tag per image (one table per host
+    // thread's range, reused): a point costs its observations, not a set union (2.6 -> ~1 ms at C3). Same greedy rule as
+    // before - the cluster closes when the UNION of its images and the point's would not fit - so the clusters are the same.
+    auto do_range = [&](int rg, std::vector<int>& in_cluster, std::vector<int>& in_point) {
       const int r0 = rg * kRange, r1 = std::min(NP, r0 + kRange);
-      std::vector<int> cur_i, cur_c, mi, mc, pi;
+      std::vector<int> cur_i, cur_c, pi;
+      // (epoch tags, never reset: cluster serials are unique over all ranges - a range closes at most kRange + 1 clusters -
+      // and so are point indices)
+      int cl_serial = rg * (kRange + 1);
       int cur_p0 = r0, cur_n = 0;
       auto close = [&](int p_end) {
         if (cur_n > 0) {
+          std::sort(cur_i.begin(), cur_i.end());
+          std::sort(cur_c.begin(), cur_c.end());
           r_clusters[rg].push_back(SchurCluster{cur_p0, p_end});
           for (int k = 0; k < kClImages; ++k) r_imgs[rg].push_back(k < (int)cur_i.size() ? cur_i[k] : -1);
           for (int k = 0; k < kClCams; ++k) r_cams[rg].push_back(k < (int)cur_c.size() ? cur_c[k] : -1);
         }
-        cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end;
+        cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end; ++cl_serial;
       };
       for (int p = r0; p < r1; ++p) {
         if (!h_pt_free[p]) continue;
         pi.clear();
-        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) if (img_active[h_oimg[a]]) pi.push_back(h_oimg[a]);
+        bool dup = false;
+        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
+          const int i = h_oimg[a];
+          if (!img_active[i]) continue;
+          if (in_point[i] == p) dup = true;
+          in_point[i] = p;
+          pi.push_back(i);
+        }
         const int nq = q_start[p + 1] - q_start[p];
         if (pi.empty() && nq == 0) continue;
-        std::sort(pi.begin(), pi.end());
-        const bool dup = std::adjacent_find(pi.begin(), pi.end()) != pi.end();
         if (!use_clusters || dup || (int)pi.size() > kClImages || nq > kClCams) { pt_mode[p] = 2; continue; }
-        auto merged_sizes = [&]() {
-          mi.clear(); mc.clear();
-          std::set_union(cur_i.begin(), cur_i.end(), pi.begin(), pi.end(), std::back_inserter(mi));
-          std::set_union(cur_c.begin(), cur_c.end(), q_cam.begin() + q_start[p], q_cam.begin() + q_start[p + 1], std::back_inserter(mc));
+        auto grown = [&](int& ni, int& nc) {  // sizes of the unions with the open cluster
+          ni = (int)cur_i.size(); nc = (int)cur_c.size();
+          for (int i : pi) ni += in_cluster[i] != cl_serial;
+          for (int q = q_start[p]; q < q_start[p + 1]; ++q) nc += std::find(cur_c.begin(), cur_c.end(), q_cam[q]) == cur_c.end();
         };
-        merged_sizes();
-        if ((int)mi.size() > kClImages || (int)mc.size() > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1) {
+        int ni, nc;
+        grown(ni, nc);
+        if (ni > kClImages || nc > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1) {
           close(p);
-          merged_sizes();
+          grown(ni, nc);
         }
         if (cur_n == 0) cur_p0 = p;
-        cur_i.swap(mi); cur_c.swap(mc);
+        for (int i : pi) if (in_cluster[i] != cl_serial) { in_cluster[i] = cl_serial; cur_i.push_back(i); }
+        for (int q = q_start[p]; q < q_start[p + 1]; ++q) if (std::find(cur_c.begin(), cur_c.end(), q_cam[q]) == cur_c.end()) cur_c.push_back(q_cam[q]);
         ++cur_n;
         pt_mode[p] = 1;
       }
       close(r1);
     };
-    parallel_ranges(nranges, [&](long long g0, long long g1) { for (long long g = g0; g < g1; ++g) do_range((int)g); }, 2);
+    parallel_ranges(nranges, [&](long long g0, long long g1) {
+      std::vector<int> in_cluster(NI, -1), in_point(NI, -1);
+      for (long long g = g0; g < g1; ++g) do_range((int)g, in_cluster, in_point);
+    }, 2);
     for (int rg = 0; rg < nranges; ++rg) {
       clusters.insert(clusters.end(), r_clusters[rg].begin(), r_clusters[rg].end());
       cl_imgs.insert(cl_imgs.end(), r_imgs[rg].begin(), r_imgs[rg].end());
@@ -812,26 +833,34 @@ void mavba_session::finish_structure() {
   // local indices of every clustered observation / intrinsics entry, and which blocks a cluster touches
   std::vector<unsigned char> cl_present((size_t)std::max(num_clusters, 1) * kClTab, 0);
   parallel_ranges(num_clusters, [&](long long c0, long long c1) {
-    int loc[kClImagesMax];
+    int loc[kClImagesMax], prev_loc[kClImagesMax];
+    std::vector<int> slot_of(NI, 0);  // image -> its place in the cluster's list (only read for the cluster's own images)
     for (long long cl = c0; cl < c1; ++cl) {
       const int* imgs = &cl_imgs[(size_t)cl * kClImages];
       const int* cams = &cl_cams[(size_t)cl * kClCams];
       int ni = 0, nc = 0;
-      while (ni < kClImages && imgs[ni] >= 0) ++ni;
+      while (ni < kClImages && imgs[ni] >= 0) { slot_of[imgs[ni]] = ni; ++ni; }
       while (nc < kClCams && cams[nc] >= 0) ++nc;
       unsigned char* pres = &cl_present[(size_t)cl * kClTab];
+      int prev_n = -1;
       for (int p = clusters[cl].p0; p < clusters[cl].p1; ++p) {
         if (pt_mode[p] != 1) continue;
         int n = 0;
         for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
           if (!img_active[h_oimg[a]]) continue;
-          const int l = (int)(std::lower_bound(imgs, imgs + ni, h_oimg[a]) - imgs);
+          const int l = slot_of[h_oimg[a]];
           obs_meta[a] = (unsigned short)(l << 8 | ((p - clusters[cl].p0) % kClBatch));
           loc[n++] = l;
         }
-        for (int x = 0; x < n; ++x)
-          for (int y = 0; y < n; ++y)
-            if (loc[x] >= loc[y]) pres[kClTabPP + loc[x] * (loc[x] + 1) / 2 + loc[y]] = 1;
+        // (neighbours in the point order usually see the same images: their block pairs are already marked)
+        const bool same = n == prev_n && std::equal(loc, loc + n, prev_loc);
+        if (!same) {
+          for (int x = 0; x < n; ++x)
+            for (int y = 0; y < n; ++y)
+              if (loc[x] >= loc[y]) pres[kClTabPP + loc[x] * (loc[x] + 1) / 2 + loc[y]] = 1;
+          std::copy(loc, loc + n, prev_loc);
+          prev_n = n;
+        }
         for (int q = q_start[p]; q < q_start[p + 1]; ++q) {
           const int lc = (int)(std::lower_bound(cams, cams + nc, q_cam[q]) - cams);
           q_meta[q] = (unsigned short)(lc << 8 | ((p - clusters[cl].p0) % kClBatch));
@@ -937,26 +966,18 @@ void mavba_session::finish_structure() {
   // blocks a cluster touches get one partial slot per cluster
   std::vector<int> cref[3];
   for (int k = 0; k < 3; ++k) cref[k].assign(nkeys[k], 0);
+  // slot of a cluster's table -> the local pair it stands for (looked up ~300 000 times per set-up at C3)
+  std::vector<unsigned char> slot_a(kClTab), slot_b(kClTab);
+  for (int la = 0, sl = kClTabPP; la < kClImages; ++la) for (int lb = 0; lb <= la; ++lb, ++sl) { slot_a[sl] = (unsigned char)la; slot_b[sl] = (unsigned char)lb; }
+  for (int sl = kClTabIP; sl < kClTabII; ++sl) { slot_a[sl] = (unsigned char)((sl - kClTabIP) / kClImages); slot_b[sl] = (unsigned char)((sl - kClTabIP) % kClImages); }
+  for (int lc = 0, sl = kClTabII; lc < kClCams; ++lc) for (int ld = 0; ld <= lc; ++ld, ++sl) { slot_a[sl] = (unsigned char)lc; slot_b[sl] = (unsigned char)ld; }
   auto cluster_key = [&](long long cl, int slot, int& kind) -> size_t {
     const int* imgs = &cl_imgs[(size_t)cl * kClImages];
     const int* cams = &cl_cams[(size_t)cl * kClCams];
-    if (slot < kClTabIP) {
-      int la = 0;
-      while ((la + 1) * (la + 2) / 2 <= slot) ++la;
-      const int lb = slot - la * (la + 1) / 2;
-      kind = BLK_PP;
-      return (size_t)imgs[la] * NI + imgs[lb];
-    }
-    if (slot < kClTabII) {
-      const int lc = (slot - kClTabIP) / kClImages, la = (slot - kClTabIP) % kClImages;
-      kind = BLK_IP;
-      return (size_t)cams[lc] * NI + imgs[la];
-    }
-    int lc = 0;
-    const int sl = slot - kClTabII;
-    while ((lc + 1) * (lc + 2) / 2 <= sl) ++lc;
+    if (slot < kClTabIP) { kind = BLK_PP; return (size_t)imgs[slot_a[slot]] * NI + imgs[slot_b[slot]]; }
+    if (slot < kClTabII) { kind = BLK_IP; return (size_t)cams[slot_a[slot]] * NI + imgs[slot_b[slot]]; }
     kind = BLK_II;
-    return (size_t)cams[lc] * NC + cams[sl - lc * (lc + 1) / 2];
+    return (size_t)cams[slot_a[slot]] * NC + cams[slot_b[slot]];
   };
   cluster_partials = 0;
   for (long long cl = 0; cl < num_clusters; ++cl)
@@ -986,17 +1007,19 @@ void mavba_session::finish_structure() {
     std::vector<size_t> keys;
     for (size_t key = 0; key < count[k].size(); ++key)
       if (count[k][key] != 0 || mandatory[k][key] || cref[k][key] != 0) keys.push_back(key);
-    if (k == BLK_PP) {
-      const long long nc = ncols[k];
-      std::stable_sort(keys.begin(), keys.end(), [&](size_t a, size_t b) {
-        const long long ia = a / nc, ja = a % nc, ib = b / nc, jb = b % nc;
-        if (ia / kTile != ib / kTile) return ia / kTile < ib / kTile;
-        if (ja / kTile != jb / kTile) return ja / kTile < jb / kTile;
-        return a < b;
-      });
-    } else if (k == BLK_IP) {
-      const long long nc = ncols[k];
-      std::stable_sort(keys.begin(), keys.end(), [&](size_t a, size_t b) { return a % nc < b % nc; });
+    if (k == BLK_PP || k == BLK_IP) {
+      // (the order as one precomputed integer per block: the comparator with its divisions was 1 ms of the C3 set-up)
+      const unsigned long long nc = (unsigned long long)ncols[k];
+      std::vector<std::pair<unsigned long long, size_t>> ranked(keys.size());
+      for (size_t q = 0; q < keys.size(); ++q) {
+        const unsigned long long a = keys[q], ia = a / nc, ja = a % nc;
+        // pose-pose: (row tile, column tile, key); intrinsics-pose: (image, position in the ascending key list)
+        ranked[q] = {k == BLK_PP ? ((ia / kTile) << 42 | (ja / kTile) << 21 | 0) : ja, q};
+      }
+      std::stable_sort(ranked.begin(), ranked.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+      std::vector<size_t> sorted(keys.size());
+      for (size_t q = 0; q < keys.size(); ++q) sorted[q] = keys[ranked[q].second];
+      keys.swap(sorted);
     }
     int off = 0, slot = 0;
     for (size_t key : keys) {
