@@ -163,14 +163,14 @@ int mavba_session_point_errors(mavba_session* s, double* point_error) {
 
 int mavba_session_set_params(mavba_session* s, const double* poses, const double* intrinsics, const double* points) {
   MAVBA_SESSION_TRY(s)
-  if (poses && s->NI) HIP_OK(hipMemcpyAsync(s->d_poses.p, poses, (size_t)s->NI * 48, hipMemcpyHostToDevice, s->st));
-  if (intrinsics && s->NC) HIP_OK(hipMemcpyAsync(s->d_intr.p, intrinsics, (size_t)s->NC * 72, hipMemcpyHostToDevice, s->st));
+  if (poses && s->NI) HIP_OK(copy_h2d_staged(s->d_poses.p, poses, (size_t)s->NI * 48, s->st));
+  if (intrinsics && s->NC) HIP_OK(copy_h2d_staged(s->d_intr.p, intrinsics, (size_t)s->NC * 72, s->st));
   std::vector<double> hp;
   if (points && s->NP) {
     hp.resize((size_t)s->NP * 3);
     for (int q = 0; q < s->NP; ++q)
       for (int e = 0; e < 3; ++e) hp[(size_t)q * 3 + e] = points[(size_t)s->h_pt_orig[q] * 3 + e];
-    HIP_OK(hipMemcpyAsync(s->d_points.p, hp.data(), hp.size() * 8, hipMemcpyHostToDevice, s->st));
+    HIP_OK(copy_h2d_staged(s->d_points.p, hp.data(), hp.size() * 8, s->st));
   }
   s->camrec_current = false; s->evaluated = false; s->front_valid = false;
   s->sync();
@@ -212,8 +212,7 @@ static void join_ranks(mavba_session* s) {
   g[0] = s->fixed_cost; g[1] = (double)s->num_residuals; g[2] = (double)s->num_residuals_reduced; g[3] = (double)free_pts;
   HIP_OK(hipMemcpyAsync(d.p + s->NI + s->NC, g.data(), 32, hipMemcpyHostToDevice, s->st));
   s->allreduce(d.p + s->NI + s->NC, 4, 0);
-  HIP_OK(hipMemcpyAsync(h.data(), d.p, n * 8, hipMemcpyDeviceToHost, s->st));
-  s->sync();
+  s->download(h.data(), d.p, n * 8);
   for (int i = 0; i < s->NI; ++i) s->h_img_used[i] = h[i] != 0.0;
   for (int c = 0; c < s->NC; ++c) s->h_cam_used[c] = h[s->NI + c] != 0.0;
   s->derive_free_flags();
@@ -268,7 +267,7 @@ int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, doubl
   const size_t S = s->Nstride, N = s->N;
   auto pull = [&](const double* dev, int planes, std::vector<double>& h) {
     h.resize((size_t)planes * S);
-    HIP_OK(hipMemcpyAsync(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost, s->st));
+    s->download(h.data(), dev, h.size() * 8);
   };
   std::vector<double> hR, hJp, hJc, hJk;
   pull(s->d_R.p, 2, hR); pull(s->d_Jp.p, 6, hJp); pull(s->d_Jc.p, 12, hJc); pull(s->d_Jk.p, 2 * s->KMAX, hJk);
@@ -326,7 +325,7 @@ int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, 
   // the device matrix is in elimination order; hand it out in the variables' order
   const int n = s->n_full, m = s->n_mat;
   std::vector<double> h((size_t)(m + 1) * m);
-  HIP_OK(hipMemcpyAsync(h.data(), s->d_M.p, h.size() * 8, hipMemcpyDeviceToHost, s->st));
+  s->download(h.data(), s->d_M.p, h.size() * 8);
   s->sync();
   std::vector<int> var_col(n, 0);
   for (int t = 0; t < m; ++t) if (s->h_col_var[t] >= 0) var_col[s->h_col_var[t]] = t;
@@ -349,10 +348,10 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses, 
   double h[SC_COUNT];
   s->linear_step(radius, h);
   if (model_cost_change) *model_cost_change = h[SC_MODEL_CHANGE];
-  if (d_poses && s->NI) HIP_OK(hipMemcpyAsync(d_poses, s->d_delta_cam.p, (size_t)s->NI * 48, hipMemcpyDeviceToHost, s->st));
-  if (d_intr && s->NC) HIP_OK(hipMemcpyAsync(d_intr, s->d_delta_cam.p + 6 * (size_t)s->NI, (size_t)s->NC * 72, hipMemcpyDeviceToHost, s->st));
+  if (d_poses && s->NI) s->download(d_poses, s->d_delta_cam.p, (size_t)s->NI * 48);
+  if (d_intr && s->NC) s->download(d_intr, s->d_delta_cam.p + 6 * (size_t)s->NI, (size_t)s->NC * 72);
   std::vector<double> hdp;
-  if (d_points && s->NP) { hdp.resize((size_t)s->NP * 3); HIP_OK(hipMemcpyAsync(hdp.data(), s->d_delta_pts.p, (size_t)s->NP * 24, hipMemcpyDeviceToHost, s->st)); }
+  if (d_points && s->NP) { hdp.resize((size_t)s->NP * 3); s->download(hdp.data(), s->d_delta_pts.p, (size_t)s->NP * 24); }
   s->sync();
   if (d_points) s->to_caller_points(hdp.data(), d_points, 3);
   if (h[SC_FAIL] != 0.0 || h[SC_FAIL_FRONT] != 0.0) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "linear solve failed (matrix not positive definite)");
@@ -624,9 +623,9 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
     double fail = 0.0;
     for (int attempt = 0; attempt < 2; ++attempt) {
       dense_spd_solve_device(st, dM.p, n_pad, dy.p, dfail.p, dws.p, dL.p, cs, nullptr, nullptr, attempt == 0);
-      HIP_OK(hipMemcpyAsync(y.data(), dy.p, (size_t)n_pad * 8, hipMemcpyDeviceToHost, st));
       HIP_OK(hipMemcpyAsync(&fail, dfail.p, 8, hipMemcpyDeviceToHost, st));
-      HIP_OK(hipStreamSynchronize(st));
+      HIP_OK(copy_d2h_staged_sync(y.data(), dy.p, (size_t)n_pad * 8, st));
+      release_staged(st);
       if (fail < 1e29) break;
       // the persistent launch gave up (it leaves M untouched): once more with the launch-per-panel schedule
       dfail.zero(st);

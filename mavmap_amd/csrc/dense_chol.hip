@@ -1451,16 +1451,17 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   const size_t o_flags = pack.size();
   pack.resize(pack.size() + nb, 0);
   hipError_t e = device_alloc(reinterpret_cast<void**>(&d_ints), pack.size() * sizeof(int));
-  if (e == hipSuccess) e = hipMemcpyAsync(d_ints, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = copy_h2d_staged(d_ints, pack.data(), pack.size() * sizeof(int), st);
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_fronts), std::max<size_t>(fronts.size(), 1) * sizeof(CholFront));
   if (e == hipSuccess && !fronts.empty())
-    e = hipMemcpyAsync(d_fronts, fronts.data(), fronts.size() * sizeof(CholFront), hipMemcpyHostToDevice, st);
+    e = copy_h2d_staged(d_fronts, fronts.data(), fronts.size() * sizeof(CholFront), st);
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_merges), std::max<size_t>(merges.size(), 1) * sizeof(CholMerge));
   if (e == hipSuccess && !merges.empty())
-    e = hipMemcpyAsync(d_merges, merges.data(), merges.size() * sizeof(CholMerge), hipMemcpyHostToDevice, st);
+    e = copy_h2d_staged(d_merges, merges.data(), merges.size() * sizeof(CholMerge), st);
   if (e == hipSuccess && shadow_doubles)
     e = device_alloc(reinterpret_cast<void**>(&d_shadow), shadow_doubles * sizeof(double));
   if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging vectors go out of scope
+  release_staged(st);
   if (e != hipSuccess) { release(); return e; }
   d_rows = d_ints;
   d_seg_of_tile = d_ints + o_seg;
@@ -1641,13 +1642,14 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   pack.insert(pack.end(), chain_info.begin(), chain_info.end());
   const size_t nflags = (size_t)nt + 3 * (size_t)nb + 1;
   hipError_t e = device_alloc(reinterpret_cast<void**>(&d_pints), pack.size() * sizeof(int));
-  if (e == hipSuccess) e = hipMemcpyAsync(d_pints, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = copy_h2d_staged(d_pints, pack.data(), pack.size() * sizeof(int), st);
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_tasks), tasks.size() * sizeof(CholTask));
-  if (e == hipSuccess) e = hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(CholTask), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = copy_h2d_staged(d_tasks, tasks.data(), tasks.size() * sizeof(CholTask), st);
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_pflags), nflags * sizeof(unsigned));
   if (e == hipSuccess) e = hipMemsetAsync(d_pflags, 0, nflags * sizeof(unsigned), st);
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_pre), (size_t)2 * nb * NB * NB * sizeof(double));
   if (e == hipSuccess) e = hipStreamSynchronize(st);
+  release_staged(st);
   if (e != hipSuccess) return e;
   if (std::getenv("MAVBA_CHOL_TRACE")) {
     h_tasks = tasks; h_wg_begin = wg_begin;

@@ -322,9 +322,66 @@ __global__ void k_gather_image_major(int n, const int* __restrict__ order, const
 }
 
 }  // namespace
+// ---- intrinsics entries: one per (free point, free camera that sees it), cameras ascending (finish_structure) ----
+// Distinct cameras by repeated minimum: k rounds over the point's observations (k = its number of refined cameras, 1-3
+// in practice), no scratch. COUNT: q_count[p]; else fills q_pt / q_cam at q_start[p].
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_intr_entries(int NP, const int* __restrict__ pt_start, const int* __restrict__ obs_img,
+                                                      const int* __restrict__ img_cam, const unsigned char* __restrict__ cam_active,
+                                                      const unsigned char* __restrict__ pt_free, unsigned* __restrict__ q_count,
+                                                      const unsigned* __restrict__ q_start, int* __restrict__ q_pt, int* __restrict__ q_cam) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= NP) return;
+  int n = 0;
+  if (pt_free[p]) {
+    const int a0 = pt_start[p], a1 = pt_start[p + 1];
+    int last = -1;
+    for (;;) {
+      int best = 0x7fffffff;
+      for (int a = a0; a < a1; ++a) {
+        const int c = img_cam[obs_img[a]];
+        if (c > last && c < best && cam_active[c]) best = c;
+      }
+      if (best == 0x7fffffff) break;
+      if (!COUNT) { q_pt[q_start[p] + n] = p; q_cam[q_start[p] + n] = best; }
+      last = best;
+      ++n;
+    }
+  }
+  if (COUNT) q_count[p] = (unsigned)n;
+}
+
 }  // namespace mavba
 
 using namespace mavba;
+
+// finish_structure's intrinsics entries on the device (large problems: the host version walks the observations twice on 16
+// threads, 1.1 ms at C3). d_q_start / d_q_pt / d_q_cam stay where the kernels want them; the host gets q_start and q_cam for
+// the cluster construction. Same definition as the host version: cameras ascending inside a point.
+void mavba_session::intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::vector<int>& q_start, std::vector<int>& q_cam) {
+  DevBuf<unsigned char> d_active;
+  d_active.upload(cam_active, st);
+  DevBuf<unsigned> cnt, scratch;
+  cnt.alloc((size_t)NP + 1);
+  scratch.alloc((size_t)device_scan_scratch((long long)NP + 1) + 8);
+  HIP_OK(hipMemsetAsync(cnt.p + NP, 0, 4, st));
+  hipLaunchKernelGGL((k_intr_entries<true>), dim3((NP + 255) / 256), dim3(256), 0, st, NP, d_pt_start.p, d_obs_img.p, d_img_cam.p, d_active.p,
+                     d_pt_free.p, cnt.p, (const unsigned*)nullptr, (int*)nullptr, (int*)nullptr);
+  device_scan_exclusive(st, cnt.p, (long long)NP + 1, scratch.p);
+  q_start.resize((size_t)NP + 1);
+  download(q_start.data(), cnt.p, ((size_t)NP + 1) * 4);
+  const int total = q_start[NP];
+  d_q_start.alloc((size_t)NP + 1);
+  HIP_OK(hipMemcpyAsync(d_q_start.p, cnt.p, ((size_t)NP + 1) * 4, hipMemcpyDeviceToDevice, st));
+  d_q_pt.alloc((size_t)std::max(total, 1)); d_q_cam.alloc((size_t)std::max(total, 1));
+  q_cam.resize((size_t)total);
+  if (total > 0) {
+    hipLaunchKernelGGL((k_intr_entries<false>), dim3((NP + 255) / 256), dim3(256), 0, st, NP, d_pt_start.p, d_obs_img.p, d_img_cam.p, d_active.p,
+                       d_pt_free.p, (unsigned*)nullptr, cnt.p, d_q_pt.p, d_q_cam.p);
+    download(q_cam.data(), d_q_cam.p, (size_t)total * 4);
+  }
+  sync();  // (cnt, scratch and d_active are freed behind this)
+}
 
 // The ordering block of build() on the device. Fills: d_uv, d_obs_img, d_obs_pt, d_pt_start, d_im_uv, d_im_pt, d_pt_orig,
 // d_points0, d_perm32; host: h_pt_orig, h_pt_start, h_oimg, h_pt_const_in (internal order), h_pt_count_all, h_pt_used,
@@ -362,8 +419,8 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
     });
     std::memcpy(s_pts->data(), P->points, (size_t)NP * 24);
     lap("stage (host memcpy)");
-    r_uv_own.upload(s_uv->data(), (size_t)2 * n, st); r_img_own.upload(s_img->data(), (size_t)n, st); r_pt_own.upload(s_pt->data(), (size_t)n, st);
-    r_pts_own.upload(s_pts->data(), (size_t)3 * NP, st);
+    r_uv_own.upload_pinned(s_uv->data(), (size_t)2 * n, st); r_img_own.upload_pinned(s_img->data(), (size_t)n, st); r_pt_own.upload_pinned(s_pt->data(), (size_t)n, st);
+    r_pts_own.upload_pinned(s_pts->data(), (size_t)3 * NP, st);
     r_uv.p = r_uv_own.p; r_img.p = r_img_own.p; r_pt.p = r_pt_own.p; r_pts.p = r_pts_own.p;
   }
   if (P->point_const) r_pconst.upload(h_pt_const_in, st);  // (still in the caller's order here)
@@ -433,11 +490,12 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   HostSpare<int>::take(h_oimg, (size_t)n);
   h_oimg.resize(n);
   std::vector<unsigned char> pc((size_t)std::max(NP, 1));
-  if (NP) HIP_OK(hipMemcpyAsync(h_pt_orig.data(), d_pt_orig.p, (size_t)NP * 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(h_pt_start.data(), d_pt_start.p, ((size_t)NP + 1) * 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(img_start.data(), istart.p, ((size_t)NI + 1) * 4, hipMemcpyDeviceToHost, st));
-  if (n) HIP_OK(hipMemcpyAsync(h_oimg.data(), d_obs_img.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-  if (NP) HIP_OK(hipMemcpyAsync(pc.data(), pconst_new.p, (size_t)NP, hipMemcpyDeviceToHost, st));
+  // (through page-locked staging blocks, never into the vectors directly: see copy_h2d_staged in host_util.hip)
+  if (NP) download(h_pt_orig.data(), d_pt_orig.p, (size_t)NP * 4);
+  download(h_pt_start.data(), d_pt_start.p, ((size_t)NP + 1) * 4);
+  download(img_start.data(), istart.p, ((size_t)NI + 1) * 4);
+  if (n) download(h_oimg.data(), d_obs_img.p, (size_t)n * 4);
+  if (NP) download(pc.data(), pconst_new.p, (size_t)NP);
   sync();
   h_pt_const_in.assign(pc.begin(), pc.begin() + NP);
   h_pt_count_all.resize(NP); h_pt_used.resize(NP);
@@ -451,8 +509,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
 void mavba_session::ensure_perm_host() {
   if (!perm.empty() || N == 0 || !d_perm32.p) return;
   std::vector<int> p32((size_t)N);
-  HIP_OK(hipMemcpyAsync(p32.data(), d_perm32.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
-  sync();
+  download(p32.data(), d_perm32.p, (size_t)N * 4);
   perm.assign(p32.begin(), p32.end());
 }
 
@@ -476,8 +533,8 @@ extern "C" int mavba_debug_radix_sort(int32_t n, const uint32_t* keys, int32_t k
       std::vector<std::pair<const unsigned*, int>> passes;
       for (int b = 0; b < key_bytes; ++b) passes.push_back({k.p, 8 * b});
       radix_sort_indices(st, n, nullptr, out.p, S, passes);
-      HIP_OK(hipMemcpyAsync(order_out, out.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-      HIP_OK(hipStreamSynchronize(st));
+      HIP_OK(copy_d2h_staged_sync(order_out, out.p, (size_t)n * 4, st));
+      release_staged(st);
     }
     (void)hipStreamDestroy(st);
     return rc;

@@ -1,5 +1,6 @@
 // host_util.hip - process-wide helpers of the host side: caching device allocator, stream cache, worker threads.
 #include "session.h"
+#include <cstring>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -186,6 +187,72 @@ void pinned_free(void* p) {
   (void)hipHostFree(p);
 }
 
+// Copies between PAGEABLE host memory and the device. Handed a pageable buffer of a megabyte or more, the HIP runtime
+// page-locks it in place (a userptr registration with the kernel driver); when that memory is later freed or trimmed by
+// the allocator, the driver's MMU notifier quiesces ALL queues of the process until a worker has revalidated them -
+// measured here as a 15-25 ms stall of the NEXT call's first transfer, every few calls, depending on what malloc did with
+// the set-up's temporaries. So nothing pageable ever reaches hipMemcpy: transfers of kStagedCopyMin bytes or more go through
+// page-locked blocks of the pool above (smaller ones use the runtime's own staging buffers, which pin nothing).
+namespace {
+constexpr size_t kStagedCopyMin = (size_t)128 << 10, kStagedChunk = (size_t)32 << 20;
+struct Parked { std::mutex m; std::unordered_map<hipStream_t, std::vector<void*>> by_stream; };
+Parked& parked() { static Parked* p = new Parked; return *p; }
+}  // namespace
+hipError_t copy_h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (bytes < kStagedCopyMin) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  for (size_t off = 0; off < bytes; off += kStagedChunk) {
+    const size_t len = std::min(kStagedChunk, bytes - off);
+    void* stage = nullptr;
+    hipError_t e = pinned_alloc(&stage, len);
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipMemcpyAsync((char*)dst + off, (const char*)src + off, bytes - off, hipMemcpyHostToDevice, st); }
+    std::memcpy(stage, (const char*)src + off, len);
+    e = hipMemcpyAsync((char*)dst + off, stage, len, hipMemcpyHostToDevice, st);
+    { std::lock_guard<std::mutex> g(parked().m); parked().by_stream[st].push_back(stage); }  // (freed by release_staged, behind a synchronisation)
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+void release_staged(hipStream_t st) {
+  std::vector<void*> blocks;
+  {
+    std::lock_guard<std::mutex> g(parked().m);
+    auto it = parked().by_stream.find(st);
+    if (it == parked().by_stream.end()) return;
+    blocks.swap(it->second);
+  }
+  for (void* b : blocks) pinned_free(b);
+}
+hipError_t copy_d2h_staged_sync(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (bytes < kStagedCopyMin) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  }
+  // all chunks in flight, one synchronisation, then the host copies
+  std::vector<std::pair<void*, size_t>> stages;
+  hipError_t e = hipSuccess;
+  for (size_t off = 0; off < bytes && e == hipSuccess; off += kStagedChunk) {
+    const size_t len = std::min(kStagedChunk, bytes - off);
+    void* stage = nullptr;
+    e = pinned_alloc(&stage, len);
+    if (e != hipSuccess) break;
+    stages.push_back({stage, len});
+    e = hipMemcpyAsync(stage, (const char*)src + off, len, hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  size_t off = 0;
+  for (auto& sg : stages) {
+    if (e == hipSuccess) std::memcpy((char*)dst + off, sg.first, sg.second);
+    off += sg.second;
+    pinned_free(sg.first);
+  }
+  if (e != hipSuccess && stages.empty()) {  // no page-locked memory to be had: the plain copy
+    (void)hipGetLastError();
+    e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  return e;
+}
+
 // Big host scratch blocks (the set-up's per-observation temporaries) are cached as well: at most kScratchCacheBytes
 // stay parked, blocks under 256 KiB go straight to malloc (its own free lists handle those without page faults).
 namespace {
@@ -248,6 +315,7 @@ hipError_t stream_acquire(hipStream_t* st) {
   return hipStreamCreate(st);
 }
 void stream_release(hipStream_t st, int dev) {  // the caller has synchronised it
+  release_staged(st);
   if (!st) return;
   DevicePool& P = pool();
   std::lock_guard<std::mutex> g(P.m);

@@ -251,6 +251,10 @@ void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const doub
 // class) and handed out again; contents are NOT cleared. MAVBA_POOL_MB caps the cache (default 16384, 0 = off).
 hipError_t device_alloc(void** p, size_t bytes);
 void device_free(void* p);
+// host_util.hip: pageable host memory <-> device through pooled page-locked blocks (never page-locked in place)
+hipError_t copy_h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t st);       // asynchronous; staging released by release_staged
+hipError_t copy_d2h_staged_sync(void* dst, const void* src, size_t bytes, hipStream_t st);  // returns with the data in dst
+void release_staged(hipStream_t st);  // call behind a synchronisation of st
 
 // ---- dense SPD solve (dense_chol.hip) --------------------------------------
 // M: (n_pad + 64) x n_pad row-major, n_pad % 64 == 0. Rows [0, n_pad) hold the

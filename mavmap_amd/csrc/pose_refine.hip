@@ -264,16 +264,16 @@ void pose_refine_batch(int count, mavba_pose_refine_item* items, const mavba_opt
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   HIP_OK(stream_acquire(&st));
-  struct Release { hipStream_t st; int dev; ~Release() { (void)hipStreamSynchronize(st); stream_release(st, dev); } } rel{st, dev};
+  struct Release { hipStream_t st; int dev; ~Release() { (void)hipStreamSynchronize(st); release_staged(st); stream_release(st, dev); } } rel{st, dev};
   DevBuf<PoseItemDev> d_items; DevBuf<double> d_poses, d_intr, d_xyz; DevBuf<double2> d_uv; DevBuf<mavba_result> d_res;
   d_items.upload(hd, st); d_poses.upload(poses, st); d_intr.upload(intr, st); d_uv.upload(uv, st); d_xyz.upload(xyz, st);
   d_res.alloc((size_t)count);
   const double t1 = now_s();
   hipLaunchKernelGGL(k_pose_refine_batch, dim3(count), dim3(256), 0, st, d_items.p, d_poses.p, d_intr.p, d_uv.p, d_xyz.p, opt, d_res.p);
   std::vector<mavba_result> hres((size_t)count);
-  HIP_OK(hipMemcpyAsync(poses.data(), d_poses.p, poses.size() * 8, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(hres.data(), d_res.p, hres.size() * sizeof(mavba_result), hipMemcpyDeviceToHost, st));
-  HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(copy_d2h_staged_sync(poses.data(), d_poses.p, poses.size() * 8, st));
+  HIP_OK(copy_d2h_staged_sync(hres.data(), d_res.p, hres.size() * sizeof(mavba_result), st));
+  release_staged(st);
   HIP_OK(hipGetLastError());
   const double t2 = now_s();
   for (int q = 0; q < count; ++q) {

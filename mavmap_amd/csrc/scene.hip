@@ -333,16 +333,17 @@ void mavba_scene::sync_device() {
   std::vector<int> l32;
   auto push2 = [&](size_t lo, size_t hi) {
     if (hi <= lo) return;
-    HIP_OK(hipMemcpyAsync(dev.xy.p + lo, xy.data() + 2 * lo, (hi - lo) * 16, hipMemcpyHostToDevice, st));
+    HIP_OK(copy_h2d_staged(dev.xy.p + lo, xy.data() + 2 * lo, (hi - lo) * 16, st));  // (the scene's vectors are pageable and grow)
     l32.resize(hi - lo);
     for (size_t i = lo; i < hi; ++i) l32[i - lo] = link[i] < 0 || link[i] >= ((long long)1 << 31) ? -1 : (int)link[i];
-    HIP_OK(hipMemcpyAsync(dev.link.p + lo, l32.data(), (hi - lo) * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(copy_h2d_staged(dev.link.p + lo, l32.data(), (hi - lo) * 4, st));
     HIP_OK(hipStreamSynchronize(st));  // (l32 is a temporary)
+    release_staged(st);
   };
   auto push3 = [&](size_t lo, size_t hi) {
     if (hi <= lo) return;
-    HIP_OK(hipMemcpyAsync(dev.xyz.p + 3 * lo, xyz.data() + 3 * lo, (hi - lo) * 24, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(dev.alive.p + lo, p3d_alive.data() + lo, hi - lo, hipMemcpyHostToDevice, st));
+    HIP_OK(copy_h2d_staged(dev.xyz.p + 3 * lo, xyz.data() + 3 * lo, (hi - lo) * 24, st));
+    HIP_OK(copy_h2d_staged(dev.alive.p + lo, p3d_alive.data() + lo, hi - lo, st));
   };
   if (n2 > dev.cap2) {
     dev.cap2 = n2 + n2 / 2 + 1024;
@@ -360,6 +361,7 @@ void mavba_scene::sync_device() {
   }
   dirty2_any = dirty3_any = false;
   HIP_OK(hipStreamSynchronize(st));
+  release_staged(st);
 }
 
 // One bundle_adjustment() call on the device-resident scene (no GCPs: the caller takes the host route for those).
@@ -411,7 +413,7 @@ int mavba_scene::device_bundle_adjust(const long long* const lists[3], const int
   DevBuf<unsigned> count, first_pos, keep, isfirst, scratch, gathered;
   DevBuf<double2> o_uv;
   DevBuf<double> pts;
-  d_cand.upload(cand.data(), (size_t)T, st);
+  d_cand.upload_pinned(cand.data(), (size_t)T, st);
   d_cand_off.upload(cand_off, st);
   count.alloc((size_t)std::max(n3, 1)); first_pos.alloc((size_t)std::max(n3, 1));
   count.zero(st);
@@ -427,8 +429,8 @@ int mavba_scene::device_bundle_adjust(const long long* const lists[3], const int
   gathered.alloc((size_t)S + 1);
   hipLaunchKernelGGL(k_sel_gather, dim3((S + 1 + 255) / 256), dim3(256), 0, st, S + 1, keep.p, d_cand_off.p, gathered.p);
   std::vector<unsigned> slot_start((size_t)S + 1);
-  HIP_OK(hipMemcpyAsync(slot_start.data(), gathered.p, ((size_t)S + 1) * 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(copy_d2h_staged_sync(slot_start.data(), gathered.p, ((size_t)S + 1) * 4, st));
+  release_staged(st);
   const int NO = (int)slot_start[S];
   if (NO == 0) return MAVBA_ERR_NEEDS_REBUILD;  // (nothing to optimise: the host route produces the reference's NaN / warnings)
   o_uv.alloc((size_t)NO); o_slot.alloc((size_t)NO); o_id3.alloc((size_t)NO); o_pt.alloc((size_t)NO); o_img.alloc((size_t)NO);
@@ -497,8 +499,9 @@ int mavba_scene::device_bundle_adjust(const long long* const lists[3], const int
   hipLaunchKernelGGL(k_sel_points, dim3((NO + 255) / 256), dim3(256), 0, st, NO, o_id3.p, first_pos.p, isfirst.p, dev.xyz.p, o_pt.p, point_id3.p, pts.p);
   hipLaunchKernelGGL(k_sel_images, dim3((NO + 255) / 256), dim3(256), 0, st, NO, o_slot.p, d_slot_img.p, o_img.p);
   std::vector<int> h_point_id3((size_t)NPf);
-  if (NPf) HIP_OK(hipMemcpyAsync(h_point_id3.data(), point_id3.p, (size_t)NPf * 4, hipMemcpyDeviceToHost, st));
+  if (NPf) HIP_OK(copy_d2h_staged_sync(h_point_id3.data(), point_id3.p, (size_t)NPf * 4, st));
   HIP_OK(hipStreamSynchronize(st));
+  release_staged(st);
   point_ids.assign(h_point_id3.begin(), h_point_id3.end());
   // ---- the session, built from the arrays where they are ----
   mavba_problem P;

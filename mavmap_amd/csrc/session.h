@@ -54,11 +54,17 @@ struct DevBuf {
     n = count;
     if (count) HIP_OK(device_alloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
   }
+  // from PAGEABLE host memory (std::vector, caller arrays): staged, see copy_h2d_staged
   void upload(const std::vector<T>& h, hipStream_t st) {
     alloc(std::max<size_t>(h.size(), 1));
-    if (!h.empty()) HIP_OK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    if (!h.empty()) HIP_OK(copy_h2d_staged(p, h.data(), h.size() * sizeof(T), st));
   }
   void upload(const T* h, size_t count, hipStream_t st) {
+    alloc(std::max<size_t>(count, 1));
+    if (count) HIP_OK(copy_h2d_staged(p, h, count * sizeof(T), st));
+  }
+  // from a page-locked block (PinnedBuf): the plain asynchronous copy
+  void upload_pinned(const T* h, size_t count, hipStream_t st) {
     alloc(std::max<size_t>(count, 1));
     if (count) HIP_OK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));
   }
@@ -395,7 +401,9 @@ struct mavba_session {
     }
     pending.clear();
   }
-  void sync() { HIP_OK(hipStreamSynchronize(st)); HIP_OK(hipGetLastError()); flush_timers(); }
+  void sync() { HIP_OK(hipStreamSynchronize(st)); HIP_OK(hipGetLastError()); release_staged(st); flush_timers(); }
+  // device -> pageable host memory (synchronises the stream)
+  void download(void* dst, const void* src, size_t bytes) { HIP_OK(copy_d2h_staged_sync(dst, src, bytes, st)); release_staged(st); }
 
   void allreduce(double* dptr, long long count, int op) {
     if (!sharded()) return;
@@ -423,7 +431,8 @@ struct mavba_session {
   // raw != null: obs_uv / obs_image / obs_point / points of the problem are DEVICE arrays given by `raw` (P's own pointers to
   // them are not read); needs a problem without dropped all-constant blocks
   void build(const mavba_problem* P, const DeviceRaw* raw = nullptr);
-  void order_on_device(const mavba_problem* P, std::vector<int>& img_start, const DeviceRaw* raw);  // device_setup.hip
+void intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::vector<int>& q_start, std::vector<int>& q_cam);
+    void order_on_device(const mavba_problem* P, std::vector<int>& img_start, const DeviceRaw* raw);  // device_setup.hip
   void order_on_host(const mavba_problem* P, const long long* keptp, std::vector<int>& img_start,
                      std::unique_ptr<PinnedBuf<double2>>& uv_h, std::unique_ptr<PinnedBuf<int>>& opt_h,
                      std::unique_ptr<PinnedBuf<double2>>& im_uv_h, std::unique_ptr<PinnedBuf<int>>& im_pt_h);

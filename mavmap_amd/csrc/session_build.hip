@@ -330,8 +330,8 @@ void mavba_session::build(const mavba_problem* P, const DeviceRaw* raw) {
   lap("image-major view");
   // ---- uploads of the static data ----
   if (!device_order) {
-    d_uv.upload(uv_h->data(), (size_t)N, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload(opt_h->data(), (size_t)N, st); d_pt_start.upload(h_pt_start, st);
-    d_im_uv.upload(im_uv_h->data(), (size_t)N, st); d_im_pt.upload(im_pt_h->data(), (size_t)N, st);
+    d_uv.upload_pinned(uv_h->data(), (size_t)N, st); d_obs_img.upload(h_oimg, st); d_obs_pt.upload_pinned(opt_h->data(), (size_t)N, st); d_pt_start.upload(h_pt_start, st);
+    d_im_uv.upload_pinned(im_uv_h->data(), (size_t)N, st); d_im_pt.upload_pinned(im_pt_h->data(), (size_t)N, st);
   }
   d_img_cam.upload(h_img_cam, st); d_cam_model.upload(h_cam_model, st);
   d_sweep_chunks.upload(sweep_chunks, st); d_img_chunk_start.upload(img_chunk_start, st);
@@ -587,8 +587,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
       DevBuf<double> d;
       d.upload(a, st);
       allreduce(d.p, (long long)NI * NI, 1);
-      HIP_OK(hipMemcpyAsync(a.data(), d.p, a.size() * 8, hipMemcpyDeviceToHost, st));
-      sync();
+      download(a.data(), d.p, a.size() * 8);
       for (int r = 0; r < NI; ++r)
         for (int c = 0; c < r; ++c) if (a[(size_t)r * NI + c] != 0.0) lower[r].push_back(c);
     } else {
@@ -649,8 +648,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
     DevBuf<double> d;
     d.upload(h, st);
     allreduce(d.p, (long long)h.size(), 1);
-    HIP_OK(hipMemcpyAsync(h.data(), d.p, h.size() * 8, hipMemcpyDeviceToHost, st));
-    sync();
+    download(h.data(), d.p, h.size() * 8);
     for (size_t t = 0; t < h.size(); ++t) mark[t] = h[t] != 0.0;
   }
   std::vector<std::pair<int, int>> tile_pairs;
@@ -686,6 +684,7 @@ void mavba_session::finish_structure() {
   // intrinsics entries: one per (free point, free camera that sees it), cameras ascending; two parallel passes
   // over the points (count, then fill at the scanned offsets)
   std::vector<int> q_start(NP + 1, 0), q_pt, q_cam;
+  bool q_on_device = false;
   {
     bool any_cam_active = false;
     for (int c = 0; c < NC; ++c) any_cam_active |= cam_active[c] != 0;
@@ -701,7 +700,12 @@ void mavba_session::finish_structure() {
       std::sort(out, out + n);
       return n;
     };
-    if (any_cam_active) {
+    // large problems: on the device, from the point-major arrays that are already there (MAVBA_SETUP=host keeps it here)
+    static const bool q_host = [] { const char* e = std::getenv("MAVBA_SETUP"); return e && std::string(e) == "host"; }();
+    q_on_device = any_cam_active && N >= 50000 && !q_host;
+    if (q_on_device) {
+      intr_entries_on_device(cam_active, q_start, q_cam);
+    } else if (any_cam_active) {
       // (two passes that both walk the observations. Keeping the first pass's cameras in a 16 B / point side buffer saved
       // 0.3 ms here - and made the NEXT call's 48 MB upload from page-locked memory take 15-25 ms instead of 1 ms every
       // other time, reproducibly, A/B on one box; cause not understood, so the buffer is gone)
@@ -721,8 +725,8 @@ void mavba_session::finish_structure() {
       }, 20000);
     }
   }
-  Q = (int)q_pt.size();
-  d_q_start.upload(q_start, st); d_q_pt.upload(q_pt, st); d_q_cam.upload(q_cam, st);
+  Q = (int)q_cam.size();
+  if (!q_on_device) { d_q_start.upload(q_start, st); d_q_pt.upload(q_pt, st); d_q_cam.upload(q_cam, st); }
   d_Eintr.alloc((size_t)std::max(Q, 1) * kIntrRec);
   if (planes_ready) d_Wk.alloc((size_t)std::max(Q, 1) * 27);
   build_front_tiles(q_start);
@@ -1084,7 +1088,7 @@ void mavba_session::finish_structure() {
     num_terms[k] = tot[k];
     d_chunks[k].upload(chunks[k], st);
     d_terms[k].alloc(std::max<size_t>((size_t)tot[k], 1));
-    if (tot[k]) HIP_OK(hipMemcpyAsync(d_terms[k].p, terms[k].get(), (size_t)tot[k] * sizeof(int2), hipMemcpyHostToDevice, st));
+    if (tot[k]) HIP_OK(copy_h2d_staged(d_terms[k].p, terms[k].get(), (size_t)tot[k] * sizeof(int2), st));
     d_part[k].alloc((size_t)std::max(num_slots[k], 1) * schur_partial_stride(k));
   }
   {

@@ -353,7 +353,7 @@ void mavba_session::point_errors(double* out) {
   launch_raw_residual_norm(st, a, d_rnorm.p);
   launch_point_errors(st, NP, d_pt_start.p, d_rnorm.p, d_pt_count.p, d_perr.p);
   std::vector<double> h(NP);
-  if (NP) HIP_OK(hipMemcpyAsync(h.data(), d_perr.p, (size_t)NP * 8, hipMemcpyDeviceToHost, st));
+  if (NP) download(h.data(), d_perr.p, (size_t)NP * 8);
   sync();
   evaluated = false;  // camrec still matches x, but keep the contract simple
   // Only points that have observations in the problem are touched (bundle_adjustment.cc:578-581);
