@@ -1,5 +1,6 @@
 """Host time of the drop-in shim's FeatureManager walk at a bench configuration, against the recording mock
-(no GPU needed). Usage: shim_timing.py [C2|C3]"""
+(no GPU needed), or - second argument `real` - the whole drop-in call on the GPU: walk + mavba_solve + write-back into the maps.
+Usage: shim_timing.py [C2|C3] [real]"""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 os.environ["MAVBA_SETUP_TIMING"] = "1"
@@ -8,7 +9,7 @@ from mavmap_amd import synth
 from tests import test_shim as T
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 p = synth.make_config(cfg)
-L = T._build(real=False)
+L = T._build(real=len(sys.argv) > 2 and sys.argv[2] == "real")
 L.shim_last_ba_seconds.restype = __import__("ctypes").c_double
 fm = T.Scene(p)
 free = list(range(2, p.num_images)); fixed = [0]; fixed_x = [1]

@@ -32,7 +32,11 @@ namespace {
 
 // ---- a few host threads for the read-only walks over the FeatureManager's hash maps ----------------------------------
 int host_threads() {
-  static const int n = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  // (MAVBA_SHIM_THREADS overrides; the default is a measurement: see INTEGRATION.md)
+  static const int n = [] {
+    if (const char* e = std::getenv("MAVBA_SHIM_THREADS")) return std::max(1, std::atoi(e));
+    return (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  }();
   return n;
 }
 // body(begin, end, thread) over [0, n) in contiguous ranges; small jobs stay on the calling thread
