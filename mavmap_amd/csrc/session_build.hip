@@ -701,7 +701,8 @@ void mavba_session::finish_structure() {
       return n;
     };
     // large problems: on the device, from the point-major arrays that are already there (MAVBA_SETUP=host keeps it here)
-    static const bool q_host = [] { const char* e = std::getenv("MAVBA_SETUP"); return e && std::string(e) == "host"; }();
+    const char* setup_env = std::getenv("MAVBA_SETUP");  // (read per session: the tests switch it)
+    const bool q_host = setup_env && std::string(setup_env) == "host";
     q_on_device = any_cam_active && N >= 50000 && !q_host;
     if (q_on_device) {
       intr_entries_on_device(cam_active, q_start, q_cam);
