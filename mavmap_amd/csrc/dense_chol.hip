@@ -33,7 +33,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // 1/sqrt(d) to full FP64 precision: v_rsq_f64 seed + two Newton steps (no divide, no sqrt
 // expansion on the factorisation's critical path).
-__device__ __forceinline__ double rsqrt_nr(double d) {
+[[maybe_unused]] __device__ __forceinline__ double rsqrt_nr(double d) {
   double y = __builtin_amdgcn_rsq(d);
   const double hd = 0.5 * d;
   y = y * (1.5 - hd * y * y);
@@ -877,39 +877,8 @@ __device__ __forceinline__ void trsm_lower_tri(const double* As, const double* L
   if (wv & 1) trsm_tri_pair<1, 2>(As, Li, Out, r0, lane);
   else trsm_tri_pair<0, 3>(As, Li, Out, r0, lane);
 }
-// Ds(lower 16x16 blocks, diagonal blocks complete) -= Ps Ps^T: what the tile factorisation reads. The ten blocks are
-// dealt 3 / 3 / 2 / 2 to the waves (48 matrix instructions at most instead of 64); a wave reads each 16-row block of
-// Ps it needs once (NR of them), then runs its NBLK accumulators interleaved.
-template <int NR, int R0, int R1, int R2, int NBLK, int A0, int B0, int A1, int B1, int A2, int B2>
-__device__ __forceinline__ void syrk_plan(double* Ds, const double* Ps, int lane) {
-  const int li = lane & 15, lk = lane >> 4;
-  constexpr int rows[3] = {R0, R1, R2};
-  constexpr int ba[3] = {A0, A1, A2}, bb[3] = {B0, B1, B2};  // blocks as indices into rows[]: (rows[ba], rows[bb])
-  double p[NR][16];
-#pragma unroll
-  for (int r = 0; r < NR; ++r)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) p[r][s] = Ps[(16 * rows[r] + li) * GLD + 4 * s + lk];
-  d4 acc[NBLK];
-#pragma unroll
-  for (int q = 0; q < NBLK; ++q) acc[q] = load_d16(Ds + 16 * rows[ba[q]] * GLD + 16 * rows[bb[q]], GLD, lane);
-#pragma unroll
-  for (int s = 0; s < 16; ++s)
-#pragma unroll
-    for (int q = 0; q < NBLK; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-p[ba[q]][s], p[bb[q]][s], acc[q], 0, 0, 0);
-#pragma unroll
-  for (int q = 0; q < NBLK; ++q) store_d16(Ds + 16 * rows[ba[q]] * GLD + 16 * rows[bb[q]], GLD, acc[q], lane);
-}
-__device__ __forceinline__ void syrk_lower_blocks(double* Ds, const double* Ps, int wv, int lane) {
-  switch (wv) {
-    case 0: syrk_plan<2, 0, 1, 0, 3, 0, 0, 1, 0, 1, 1>(Ds, Ps, lane); break;   // (0,0) (1,0) (1,1)
-    case 1: syrk_plan<3, 0, 1, 2, 3, 2, 0, 2, 1, 2, 2>(Ds, Ps, lane); break;   // (2,0) (2,1) (2,2)
-    case 2: syrk_plan<3, 0, 1, 3, 2, 2, 0, 2, 1, 0, 0>(Ds, Ps, lane); break;   // (3,0) (3,1)
-    default: syrk_plan<2, 2, 3, 0, 2, 1, 0, 1, 1, 0, 0>(Ds, Ps, lane); break;  // (3,2) (3,3)
-  }
-}
-
-// ---- the same two products cut so that they fit AROUND the tile factorisation (persistent chain) ----
+// ---- the chain's panel solve and diagonal update (D -= P P^T on the lower 16x16 blocks), cut so that they fit AROUND the
+// tile factorisation (persistent chain) ----
 // One 16x16 block of P = As Li^T: rows [16 rb, +16), column block N (Li lower triangular: 4 (N + 1) k-steps).
 template <int N>
 __device__ __forceinline__ d4 trsm_block16(const double* As, const double* Li, int rb, int lane) {

@@ -252,7 +252,6 @@ void mavba_session::build(const mavba_problem* P, const DeviceRaw* raw) {
   lap("validate + fixed blocks");
   N = all_kept ? (int)NO_all : (int)kept.size();
   const long long* keptp = all_kept ? nullptr : kept.data();
-  auto kept_at = [keptp](long long k) { return keptp ? keptp[k] : k; };
   Nstride = std::max(32, round_up(N, 32));
   NPs = std::max(32, round_up(NP, 32));
 
