@@ -7,6 +7,8 @@
 namespace mavba {
 hipError_t device_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }  // (the product's pool lives in host_util.hip)
 void device_free(void* p) { (void)hipFree(p); }
+hipError_t copy_h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t st) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); }
+void release_staged(hipStream_t) {}
 namespace {
 // (the first blocked variant, kept here for comparison: 18 barriers, per-wave scratch)
 // Factorise the SPD tile in T (LDS, pitch GLD) and invert the factor, blocked 4 x 4 in 16x16:
