@@ -189,6 +189,7 @@ int schur_partial_stride(int kind);
 // front end + cluster kernel in one launch (problems whose every observed point is clustered; cluster shape 16 x 3):
 // a.sw.cost_partial gets one partial per cluster
 void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int num_clusters, const SchurCluster* clusters, const int* tab,
+                        const int* cl_lists,
                         const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii);
 // obs_meta / q_meta: per observation / intrinsics entry, local index << 8 | (point - cluster.p0) % kClBatch,
 // 0xFFFF for records that are not part of a cluster.

@@ -1801,10 +1801,16 @@ struct FusedShape {
 
 template <int KMAX, bool TRACE = false>
 __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
-    FrontArgs a, const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const unsigned short* __restrict__ obs_meta,
-    const unsigned short* __restrict__ q_meta, double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
+    FrontArgs a, const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ cl_lists,
+    const unsigned short* __restrict__ obs_meta, const unsigned short* __restrict__ q_meta, double* __restrict__ part_pp,
+    double* __restrict__ part_ip, double* __restrict__ part_ii) {
   using SH = ClShape<16, 3>;
   using FS = FusedShape<KMAX>;
+  // per-cluster tables (cl_lists: the cluster's 16 images, then its 3 cameras, -1 padded): camera records, intrinsics and
+  // column scales of the cluster's images are read from memory ONCE per cluster instead of once per observation - the
+  // dependent image -> camera -> intrinsics round trips sat at the head of every batch's Jacobian phase
+  __shared__ double s_rec[SH::images][9], s_kin[SH::images][9], s_sc[SH::images][6], s_ksc[SH::cams][9];
+  __shared__ int s_icam[SH::images], s_model[SH::images];
   __shared__ __attribute__((aligned(16))) double E[SH::rows * kClPitch];  // park buffer of the sums, then the entry matrix
   __shared__ double s_q[kClBatch * kClCamsMax * (FS::K3 > 0 ? FS::K3 : 1)];  // Wk sums of the batch's (point, camera) entries
   __shared__ double s_sum[kClBatch * 9];
@@ -1826,6 +1832,22 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
     s_bounds[1][i] = a.q_start[p];
   }
   for (int i = tid; i < SH::tab; i += kClThreads) s_tab[i] = tabs[(size_t)blockIdx.x * SH::tab + i];
+  {
+    const int* lists = cl_lists + (size_t)blockIdx.x * (SH::images + SH::cams);
+    if (tid < SH::images * 9) {
+      const int sl = tid / 9, e = tid - 9 * sl, img = lists[sl];
+      if (img >= 0) {
+        const int cam = a.sw.img_cam[img];
+        s_rec[sl][e] = a.sw.camrec[9 * img + e];
+        s_kin[sl][e] = a.sw.intr[9 * cam + e];
+        if (e < 6) s_sc[sl][e] = a.scale_cam[6 * img + e];
+        if (e == 0) { s_icam[sl] = cam; s_model[sl] = a.sw.cam_model[cam]; }
+      }
+    } else if (tid < SH::images * 9 + SH::cams * 9) {
+      const int t = tid - SH::images * 9, c = t / 9, k = t - 9 * c, cam = lists[SH::images + c];
+      if (cam >= 0) s_ksc[c][k] = a.scale_cam[6 * a.sw.NI + 9 * cam + k];
+    }
+  }
   cl_d4 acc[SH::acc];
 #pragma unroll
   for (int i = 0; i < SH::acc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
@@ -1878,14 +1900,23 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
     double prod[FS::NROWS];
     int cam = -1;
     if (act) {
-      cam = w.img_cam[im];
-      const int model = w.cam_model[cam];
+      int model;
       double rec[9], kin[9], X[3];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) rec[k] = w.camrec[9 * im + k];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) kin[k] = w.intr[9 * cam + k];
       X[0] = w.points[3 * (long long)pt]; X[1] = w.points[3 * (long long)pt + 1]; X[2] = w.points[3 * (long long)pt + 2];
+      if (meta != 0xFFFFu) {  // an image of the cluster's list: everything but the point comes from LDS
+        const int sl = (int)(meta >> 8);
+        cam = s_icam[sl];
+        model = s_model[sl];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { rec[k] = s_rec[sl][k]; kin[k] = s_kin[sl][k]; }
+      } else {  // (constant pose: not in the list)
+        cam = w.img_cam[im];
+        model = w.cam_model[cam];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rec[k] = w.camrec[9 * im + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) kin[k] = w.intr[9 * cam + k];
+      }
       double r[2], Jc[12], Jp[6], Jk[18];
       obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
       double wgt, half_rho;
@@ -2014,9 +2045,10 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
       for (int row = 0; row < 2; ++row)
 #pragma unroll
         for (int k = 0; k < 3; ++k) jps[row * 3 + k] = jp[row * 3 + k] * g[9 + k];
+      const double* scl = s_sc[meta >> 8];
 #pragma unroll
       for (int e = 0; e < 6; ++e) {
-        const double sc = a.scale_cam[6 * im + e];
+        const double sc = scl[e];
         const double j0 = jc[e] * sc, j1 = jc[6 + e] * sc;
         const double w0 = j0 * jps[0] + j1 * jps[3], w1 = j0 * jps[1] + j1 * jps[4], w2 = j0 * jps[2] + j1 * jps[5];
         Eo[e * kClPitch] = w0 * g[0];
@@ -2030,7 +2062,7 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
         const unsigned qm = (unsigned)s_qm[q];
         if (qm == 0xFFFFu) continue;
         const double* g = s_g + s_qpt[q] * 12;
-        const double sk = a.scale_cam[6 * w.NI + 9 * s_qcam[q] + k];
+        const double sk = s_ksc[qm >> 8][k];
         const double* W = s_q + q * FS::K3 + 3 * k;
         const double w0 = W[0] * sk * g[9], w1 = W[1] * sk * g[10], w2 = W[2] * sk * g[11];
         double* Eo = E + (SH::cam_row0 + 9 * (int)(qm >> 8) + k) * kClPitch + 3 * (int)(qm & 255u);
@@ -2088,7 +2120,7 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
   if (tid == 0) w.cost_partial[blockIdx.x] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
 }
 void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int num_clusters, const SchurCluster* clusters, const int* tab,
-                        const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii) {
+                        const int* cl_lists, const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii) {
   if (num_clusters <= 0) return;
   // MAVBA_FUSED_TRACE=<file>: the 5th launch of the process (widest model <= 8) records s_memtime stamps per wave (debugging aid)
   static const char* trace_file = std::getenv("MAVBA_FUSED_TRACE");
@@ -2100,7 +2132,7 @@ void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int n
     (void)hipMemsetAsync(tr, 0, trace_n * 8, st);
     FrontArgs b = a;
     b.trace = tr;
-    hipLaunchKernelGGL((k_schur_fused<8, true>), dim3(num_clusters), dim3(kClThreads), 0, st, b, clusters, tab, obs_meta, q_meta, part_pp, part_ip, part_ii);
+    hipLaunchKernelGGL((k_schur_fused<8, true>), dim3(num_clusters), dim3(kClThreads), 0, st, b, clusters, tab, cl_lists, obs_meta, q_meta, part_pp, part_ip, part_ii);
     std::vector<long long> hst(trace_n);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(hst.data(), tr, trace_n * 8, hipMemcpyDeviceToHost);
@@ -2118,7 +2150,7 @@ void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int n
     }
     return;
   }
-#define MAVBA_FUSED(K) hipLaunchKernelGGL((k_schur_fused<K>), dim3(num_clusters), dim3(kClThreads), 0, st, a, clusters, tab, obs_meta, q_meta, part_pp, part_ip, part_ii)
+#define MAVBA_FUSED(K) hipLaunchKernelGGL((k_schur_fused<K>), dim3(num_clusters), dim3(kClThreads), 0, st, a, clusters, tab, cl_lists, obs_meta, q_meta, part_pp, part_ip, part_ii)
   if (kmax_intr <= 0) MAVBA_FUSED(0); else if (kmax_intr <= 4) MAVBA_FUSED(4); else if (kmax_intr <= 8) MAVBA_FUSED(8); else MAVBA_FUSED(9);
 #undef MAVBA_FUSED
 }

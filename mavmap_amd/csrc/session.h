@@ -290,7 +290,7 @@ struct mavba_session {
   DevBuf<SchurCluster> d_clusters;
   DevBuf<PartialReduce> d_reduce_tasks;
   int num_reduce_tasks = 0;
-  DevBuf<int> d_cl_tab;
+  DevBuf<int> d_cl_tab, d_cl_lists;  // per cluster: slot table of its blocks; its image and camera lists (-1 padded)
   DevBuf<unsigned short> d_obs_meta, d_q_meta;
   DevBuf<unsigned char> d_pt_clustered;
   int num_clusters = 0, num_slots[3] = {0, 0, 0};

@@ -1102,11 +1102,16 @@ void mavba_session::finish_structure() {
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return clusters[a].p1 - clusters[a].p0 > clusters[b].p1 - clusters[b].p0; });
     std::vector<SchurCluster> cl_sorted(clusters.size());
     std::vector<int> tab_sorted(cl_tab.size(), -1);
+    std::vector<int> lists_sorted((size_t)std::max(num_clusters, 1) * (kClImages + kClCams), -1);  // images, then cameras of a cluster
     for (int c = 0; c < num_clusters; ++c) {
       cl_sorted[c] = clusters[order[c]];
       std::copy(cl_tab.begin() + (size_t)order[c] * kClTab, cl_tab.begin() + (size_t)(order[c] + 1) * kClTab, tab_sorted.begin() + (size_t)c * kClTab);
     }
-    d_clusters.upload(cl_sorted, st); d_cl_tab.upload(tab_sorted, st);
+    for (int c = 0; c < num_clusters; ++c) {
+      std::copy(cl_imgs.begin() + (size_t)order[c] * kClImages, cl_imgs.begin() + (size_t)(order[c] + 1) * kClImages, lists_sorted.begin() + (size_t)c * (kClImages + kClCams));
+      std::copy(cl_cams.begin() + (size_t)order[c] * kClCams, cl_cams.begin() + (size_t)(order[c] + 1) * kClCams, lists_sorted.begin() + (size_t)c * (kClImages + kClCams) + kClImages);
+    }
+    d_clusters.upload(cl_sorted, st); d_cl_tab.upload(tab_sorted, st); d_cl_lists.upload(lists_sorted, st);
     d_obs_meta.upload(obs_meta, st); d_q_meta.upload(q_meta, st); d_pt_clustered.upload(ptc, st);
   }
   // the front end can run inside the cluster kernel when every observed point is clustered (no generic term lists, no

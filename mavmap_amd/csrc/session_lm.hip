@@ -46,7 +46,7 @@ void mavba_session::launch_front(double r, bool entries) {
     // every observed point sits in a cluster: the cluster kernel evaluates the Jacobians itself and leaves the block
     // partials of S for this radius (no entry records in HBM)
     timed("schur_fused", [&] {
-      launch_schur_fused(st, f, Q > 0 ? KMAX : 0, num_clusters, d_clusters.p, d_cl_tab.p, d_obs_meta.p, d_q_meta.p, d_part[0].p, d_part[1].p,
+      launch_schur_fused(st, f, Q > 0 ? KMAX : 0, num_clusters, d_clusters.p, d_cl_tab.p, d_cl_lists.p, d_obs_meta.p, d_q_meta.p, d_part[0].p, d_part[1].p,
                          d_part[2].p);
     });
     eval_rows = num_clusters;
