@@ -612,10 +612,11 @@ __global__ void __launch_bounds__(256, 2) k_point_front(FrontArgs a) {  // two w
           double C[6];
           C[0] = sp[0] * sp[0] * C6[0]; C[1] = sp[0] * sp[1] * C6[1]; C[2] = sp[0] * sp[2] * C6[2];
           C[3] = sp[1] * sp[1] * C6[3]; C[4] = sp[1] * sp[2] * C6[4]; C[5] = sp[2] * sp[2] * C6[5];
-          C[0] += clampd(C[0], a.dmin, a.dmax) / a.radius;
-          C[3] += clampd(C[3], a.dmin, a.dmax) / a.radius;
-          C[5] += clampd(C[5], a.dmin, a.dmax) / a.radius;
-          bool fin = chol3_inv(C, G);
+          const double inv_radius = 1.0 / a.radius;
+          C[0] = __builtin_fma(clampd(C[0], a.dmin, a.dmax), inv_radius, C[0]);
+          C[3] = __builtin_fma(clampd(C[3], a.dmin, a.dmax), inv_radius, C[3]);
+          C[5] = __builtin_fma(clampd(C[5], a.dmin, a.dmax), inv_radius, C[5]);
+          bool fin = chol3_inv_fast(C, G);
           const double gs[3] = {sp[0] * g3[0], sp[1] * g3[1], sp[2] * g3[2]};
           gi_mul(G, gs, hh);
 #pragma unroll
@@ -2011,10 +2012,11 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
         double C[6];
         C[0] = sp[0] * sp[0] * C6[0]; C[1] = sp[0] * sp[1] * C6[1]; C[2] = sp[0] * sp[2] * C6[2];
         C[3] = sp[1] * sp[1] * C6[3]; C[4] = sp[1] * sp[2] * C6[4]; C[5] = sp[2] * sp[2] * C6[5];
-        C[0] += clampd(C[0], a.dmin, a.dmax) / a.radius;
-        C[3] += clampd(C[3], a.dmin, a.dmax) / a.radius;
-        C[5] += clampd(C[5], a.dmin, a.dmax) / a.radius;
-        bool fin = chol3_inv(C, G);
+        const double inv_radius = 1.0 / a.radius;
+        C[0] = __builtin_fma(clampd(C[0], a.dmin, a.dmax), inv_radius, C[0]);
+        C[3] = __builtin_fma(clampd(C[3], a.dmin, a.dmax), inv_radius, C[3]);
+        C[5] = __builtin_fma(clampd(C[5], a.dmin, a.dmax), inv_radius, C[5]);
+        bool fin = chol3_inv_fast(C, G);
         const double gs[3] = {sp[0] * g3[0], sp[1] * g3[1], sp[2] * g3[2]};
         gi_mul(G, gs, hh);
 #pragma unroll
