@@ -153,7 +153,7 @@ void launch_camera_sweep(hipStream_t st, const CamSweepArgs& a, int kmax, bool a
 void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_start,
                           const double* partial, const int* prior_start, const double* prior_res,
                           const double* prior_jac, const int* cam_img_start, const int* cam_imgs,
-                          double* img_rec, double* cam_rec, double* img_intr_tmp);
+                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams = true);
 void launch_rot_prior(hipStream_t st, int n, const int* prior_img, const double* prior_R0, double w,
                       const double* poses, double* res, double* jac, double* cost_partial);
 

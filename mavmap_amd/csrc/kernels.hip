@@ -1131,11 +1131,11 @@ __global__ void __launch_bounds__(1024) k_camera_reduce_cam(
 void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_start,
                           const double* partial, const int* prior_start, const double* prior_res,
                           const double* prior_jac, const int* cam_img_start, const int* cam_imgs,
-                          double* img_rec, double* cam_rec, double* img_intr_tmp) {
+                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams) {
   if (NI > 0)
     hipLaunchKernelGGL(k_camera_reduce_img, dim3(NI), dim3(64), 0, st, NI, img_chunk_start, partial,
                        prior_start, prior_res, prior_jac, img_rec, img_intr_tmp);
-  if (NC > 0)
+  if (NC > 0 && with_cams)  // (no free intrinsics: nobody reads the per-camera sums, they stay zero)
     hipLaunchKernelGGL(k_camera_reduce_cam, dim3(NC), dim3(1024), 0, st, cam_img_start, cam_imgs, img_intr_tmp, cam_rec);
 }
 

@@ -89,7 +89,7 @@ void mavba_session::evaluate_enqueue(double next_radius) {
   timed("camera_reduce", [&] {
     launch_camera_reduce(st, NI, NC, d_img_chunk_start.p, d_cam_partial.p, num_priors > 0 ? d_prior_start.p : nullptr,
                          d_prior_res.p, d_prior_jac.p, d_cam_img_start.p, d_cam_imgs.p, d_img_rec, d_cam_rec,
-                         d_img_intr_tmp.p);
+                         d_img_intr_tmp.p, any_intr_free);
   });
   allreduce(d_camsum.p, (long long)NI * kImgRec + (long long)NC * kCamRec, 0);
   if (!scales_ready) {
