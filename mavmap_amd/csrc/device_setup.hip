@@ -258,11 +258,15 @@ __global__ void __launch_bounds__(256) k_count_obs(int n, int NI, int NP, const 
 }
 
 // Per caller point: the 8 smallest images that see it (repeats count once), packed 16 bits each into four key words,
-// 0xFFFF padded (a point nobody sees sorts last).
+// 0xFFFF padded (a point nobody sees sorts last); and the most significant key, `tail`: 1 for a point that cannot sit in a
+// cluster whatever its neighbours are (more than kTailObs observations, or constant) - those go behind all the others, so
+// that the clustered part of the problem can take the fused kernel and only this tail the separate front end.
 __global__ void k_point_keys(int NP, const unsigned* __restrict__ cstart, const int* __restrict__ byp, const int* __restrict__ oimg,
-                             unsigned* __restrict__ w0, unsigned* __restrict__ w1, unsigned* __restrict__ w2, unsigned* __restrict__ w3) {
+                             const unsigned char* __restrict__ pconst, unsigned* __restrict__ w0, unsigned* __restrict__ w1,
+                             unsigned* __restrict__ w2, unsigned* __restrict__ w3, unsigned* __restrict__ tail) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= NP) return;
+  tail[p] = (cstart[p + 1] - cstart[p] > (unsigned)kTailObs || (pconst && pconst[p])) ? 1u : 0u;
   unsigned k[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) k[t] = 0xFFFFu;
@@ -453,12 +457,16 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   lap("sort obs by point");
   // point order: 128-bit key of the 8 smallest images, ties by the caller's index
   for (int k = 0; k < 4; ++k) w[k].alloc((size_t)std::max(NP, 1));
-  hipLaunchKernelGGL(k_point_keys, dim3((NP + 255) / 256), dim3(256), 0, st, NP, cstart.p, byp.p, r_img.p, w[0].p, w[1].p, w[2].p, w[3].p);
+  DevBuf<unsigned> wtail;
+  wtail.alloc((size_t)std::max(NP, 1));
+  hipLaunchKernelGGL(k_point_keys, dim3((NP + 255) / 256), dim3(256), 0, st, NP, cstart.p, byp.p, r_img.p,
+                     P->point_const ? r_pconst.p : (const unsigned char*)nullptr, w[0].p, w[1].p, w[2].p, w[3].p, wtail.p);
   d_pt_orig.alloc((size_t)std::max(NP, 1));
   {
     std::vector<std::pair<const unsigned*, int>> passes;
     for (int k = 3; k >= 0; --k)
       for (int b = 0; b < 4; ++b) passes.push_back({w[k].p, 8 * b});
+    passes.push_back({wtail.p, 0});  // (most significant: the tail flag)
     radix_sort_indices(st, NP, nullptr, d_pt_orig.p, S, passes);
   }
   lap("point keys + sort");

@@ -67,6 +67,7 @@ struct ClusterShape {
 };
 constexpr int kClImagesMax = 16, kClCamsMax = 3;
 constexpr int kClBatch = 32;                     // points per LDS batch -> K = 96 columns (16 -> two work-groups per CU, measured slower)
+constexpr int kTailObs = 16;                     // a point with more observations than a cluster has images sorts into the tail of the point order
 constexpr int kClMaxBatches = 64;                // a cluster spans at most kClMaxBatches * kClBatch consecutive points
 struct SchurCluster { int p0, p1; };
 

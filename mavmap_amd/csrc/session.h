@@ -274,8 +274,10 @@ struct mavba_session {
   // than a tile holds (or MAVBA_FRONT_PLANES is set): the Jacobian-plane kernels are used instead
   DevBuf<FrontTile> d_front_tiles;
   int num_front_tiles = 0;
+  DevBuf<FrontTile> d_tail_tiles;  // tiles over the points [tail_begin, NP): what the fused kernel does not cover
+  int num_tail_tiles = 0, tail_begin = 0;
   bool front_ok = false;
-  bool fused_ok = false;        // every observed point is clustered: the front end runs inside the cluster kernel (k_schur_fused)
+  bool fused_ok = false;        // every observed point before tail_begin is clustered: their front end runs inside the cluster kernel (k_schur_fused), the tail's in k_point_front
   int eval_rows = 0;            // cost partials the last evaluation pass wrote
   bool front_valid = false;     // Cu, gu, Gi, h and the entry records match the current x, scales and front_radius
   double front_radius = 0.0;
@@ -447,6 +449,7 @@ void intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::v
   void evaluate_enqueue(double next_radius = -1.0);  // the launches of evaluate() without reading the scalars back
   void launch_front(double r, bool entries);
   void build_front_tiles(const std::vector<int>& q_start);
+  void build_tiles(const std::vector<int>& q_start, int first, DevBuf<FrontTile>& out, int& count);
   void ensure_planes();
   bool fused_now() const { return fused_ok && h_pt_removed.empty(); }
   int eval_cost_rows() const { return front_ok ? eval_rows : (N > 0 ? jacobian_sweep_grid(N) : 0); }

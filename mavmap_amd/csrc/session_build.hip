@@ -67,7 +67,9 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
     // Order: the 8 smallest DISTINCT images that see the point, 16 bits each in one 128-bit key (0xFFFF padded: a point
     // nobody sees sorts last), ties by the caller's point index - a strict total order, so the result does not depend on
     // the number of threads, and the same definition as k_point_keys + the radix sort of the device path.
-    struct KeyId { unsigned long long hi, lo; int id; };
+    // ... behind the `tail` flag (most significant): points that can never be clustered - more than kTailObs observations, or
+    // constant - follow all the others (the same definition as k_point_keys)
+    struct KeyId { unsigned long long hi, lo; int id; int tail; };
     HostBuf<KeyId> keyed(NP);
     parallel_ranges(NP, [&](long long b0, long long b1) {
       for (long long p = b0; p < b1; ++p) {
@@ -83,10 +85,12 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
         kk.hi = (unsigned long long)k[0] << 48 | (unsigned long long)k[1] << 32 | (unsigned long long)k[2] << 16 | k[3];
         kk.lo = (unsigned long long)k[4] << 48 | (unsigned long long)k[5] << 32 | (unsigned long long)k[6] << 16 | k[7];
         kk.id = (int)p;
+        kk.tail = (cstart[p + 1] - cstart[p] > kTailObs || (P->point_const && P->point_const[p])) ? 1 : 0;
         keyed[p] = kk;
       }
     });
     auto before = [&](const KeyId& x, const KeyId& y) {
+      if (x.tail != y.tail) return x.tail < y.tail;
       if (x.hi != y.hi) return x.hi < y.hi;
       if (x.lo != y.lo) return x.lo < y.lo;
       return x.id < y.id;
@@ -97,10 +101,10 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
       std::vector<int> fstart;
       HostBuf<KeyId> dealt(NP);
       // (bucket NI: points without observations, whose key starts with 0xFFFF)
-      counting_sort_parallel(NP, NI + 1, [&](long long p) { return std::min((int)(keyed[p].hi >> 48), NI); }, fstart,
+      counting_sort_parallel(NP, 2 * (NI + 1), [&](long long p) { return keyed[p].tail * (NI + 1) + std::min((int)(keyed[p].hi >> 48), NI); }, fstart,
                              [&](long long p, int at) { dealt[at] = keyed[p]; });
       std::vector<int> nonempty;
-      for (int k = 0; k <= NI; ++k) if (fstart[k + 1] > fstart[k]) nonempty.push_back(k);
+      for (int k = 0; k < 2 * (NI + 1); ++k) if (fstart[k + 1] > fstart[k]) nonempty.push_back(k);
       parallel_ranges((long long)nonempty.size(), [&](long long k0, long long k1) {
         for (long long k = k0; k < k1; ++k) std::sort(dealt.data() + fstart[nonempty[k]], dealt.data() + fstart[nonempty[k] + 1], before);
       }, 2);
@@ -746,6 +750,10 @@ void mavba_session::finish_structure() {
     cl_shape = ClusterShape{16, 3};
     if (const char* e = std::getenv("MAVBA_CLUSTER_SHAPE")) cl_shape = std::atoi(e) == 12 ? ClusterShape{12, 2} : ClusterShape{16, 3};
   }
+  // The point order puts the points that can never be clustered (more than kTailObs observations, constant) behind all the
+  // others (order_on_host / k_point_keys): clusters end where that tail begins.
+  tail_begin = NP;
+  while (tail_begin > 0 && (h_pt_start[tail_begin] - h_pt_start[tail_begin - 1] > kTailObs || h_pt_const_in[tail_begin - 1])) --tail_begin;
   const ClusterShape sh = cl_shape;
   const int kClTab = sh.tab(), kClTabPP = sh.tab_pp(), kClTabIP = sh.tab_ip(), kClTabII = sh.tab_ii();
   const int kClImages = sh.images, kClCams = sh.cams;
@@ -771,7 +779,11 @@ void mavba_session::finish_structure() {
     // thread's range, reused): a point costs its observations, not a set union (2.6 -> ~1 ms at C3). Same greedy rule as
     // before - the cluster closes when the UNION of its images and the point's would not fit - so the clusters are the same.
     auto do_range = [&](int rg, std::vector<int>& in_cluster, std::vector<int>& in_point) {
-      const int r0 = rg * kRange, r1 = std::min(NP, r0 + kRange);
+      const int r0 = rg * kRange, r_end = std::min(NP, r0 + kRange);
+      // (tail points are generic by definition; no cluster's span reaches into the tail)
+      for (int p = std::max(r0, tail_begin); p < r_end; ++p)
+        if (h_pt_free[p] && (h_pt_start[p + 1] > h_pt_start[p] || q_start[p + 1] > q_start[p])) pt_mode[p] = 2;
+      const int r1 = std::min(r_end, std::max(r0, tail_begin));
       std::vector<int> cur_i, cur_c, pi;
       // (epoch tags, never reset: cluster serials are unique over all ranges - a range closes at most kRange + 1 clusters -
       // and so are point indices)
@@ -1117,11 +1129,18 @@ void mavba_session::finish_structure() {
   // the front end can run inside the cluster kernel when every observed point is clustered (no generic term lists, no
   // constant points with observations) and the clusters have the 16 x 3 shape
   {
-    long long observed = 0;
-    for (int p = 0; p < NP; ++p) observed += h_pt_start[p + 1] > h_pt_start[p];
+    // If every observed point BEFORE the tail is clustered, the clusters take the fused kernel and the tail - with the generic
+    // term lists of its free points - the separate front end, on tiles of its own.
+    long long head_observed = 0, head_clustered = 0;
+    for (int p = 0; p < tail_begin; ++p) { head_observed += h_pt_start[p + 1] > h_pt_start[p]; head_clustered += pt_mode[p] == 1; }
     const bool no_fuse = std::getenv("MAVBA_NO_FUSE") != nullptr;  // (read per session: the tests switch paths)
-    fused_ok = front_ok && !no_fuse && cl_shape.images == 16 && num_clusters > 0 && clustered_points == observed &&
-               tot[0] == 0 && tot[1] == 0 && tot[2] == 0 && num_clusters <= kFrontMaxGrid;
+    fused_ok = front_ok && !no_fuse && cl_shape.images == 16 && num_clusters > 0 && head_clustered == head_observed &&
+               clustered_points == head_clustered && num_clusters <= kFrontMaxGrid;
+    num_tail_tiles = 0;
+    if (fused_ok && h_pt_start[NP] > h_pt_start[tail_begin]) {
+      build_tiles(q_start, tail_begin, d_tail_tiles, num_tail_tiles);
+      if ((long long)num_clusters + point_front_grid(num_tail_tiles) > kFrontMaxGrid) { fused_ok = false; num_tail_tiles = 0; }
+    }
   }
   sync();
   lap("upload terms");
@@ -1130,25 +1149,31 @@ void mavba_session::finish_structure() {
 // Tiles of the J-free front end: consecutive points, at most kFrontObs observations / kFrontPts points / kFrontQ intrinsics
 // entries each; a point with more observations than that is a tile of its own (walked in windows by the kernel).
 void mavba_session::build_front_tiles(const std::vector<int>& q_start) {
-  std::vector<FrontTile> tiles;
   const bool planes_only = std::getenv("MAVBA_FRONT_PLANES") != nullptr;
   front_ok = !planes_only;
-  int p0 = 0, obs = 0, qs = 0;
-  for (int p = 0; p < NP && front_ok; ++p) {
+  for (int p = 0; p < NP && front_ok; ++p)
+    if (q_start[p + 1] - q_start[p] > kFrontQ) front_ok = false;  // a point seen by that many refined cameras: plane kernels
+  num_front_tiles = 0;
+  if (front_ok) build_tiles(q_start, 0, d_front_tiles, num_front_tiles);
+  else d_front_tiles.upload(std::vector<FrontTile>(), st);
+  front_valid = false;
+  if (!front_ok) ensure_planes();
+}
+// tiles over the points [first, NP)
+void mavba_session::build_tiles(const std::vector<int>& q_start, int first, DevBuf<FrontTile>& out, int& count) {
+  std::vector<FrontTile> tiles;
+  int p0 = first, obs = 0, qs = 0;
+  for (int p = first; p < NP; ++p) {
     const int c = h_pt_start[p + 1] - h_pt_start[p], nq = q_start[p + 1] - q_start[p];
-    if (nq > kFrontQ) { front_ok = false; break; }  // a point seen by that many refined cameras: plane kernels
     if (p > p0 && (obs + c > kFrontObs || p - p0 >= kFrontPts || qs + nq > kFrontQ)) {
       tiles.push_back(FrontTile{p0, p, h_pt_start[p0], h_pt_start[p], q_start[p0], q_start[p]});
       p0 = p; obs = 0; qs = 0;
     }
     obs += c; qs += nq;
   }
-  if (front_ok && NP > p0) tiles.push_back(FrontTile{p0, NP, h_pt_start[p0], h_pt_start[NP], q_start[p0], q_start[NP]});
-  if (!front_ok) tiles.clear();
-  num_front_tiles = (int)tiles.size();
-  d_front_tiles.upload(tiles, st);
-  front_valid = false;
-  if (!front_ok) ensure_planes();
+  if (NP > p0) tiles.push_back(FrontTile{p0, NP, h_pt_start[p0], h_pt_start[NP], q_start[p0], q_start[NP]});
+  count = (int)tiles.size();
+  out.upload(tiles, st);
 }
 
 void mavba_session::reset_state() {

@@ -50,6 +50,15 @@ void mavba_session::launch_front(double r, bool entries) {
                          d_part[2].p);
     });
     eval_rows = num_clusters;
+    if (num_tail_tiles > 0) {
+      // the points behind the clusters (long tracks with their generic term lists, constant points): sums, factors and
+      // entry records by the separate front end, its cost partials behind the clusters' ones
+      FrontArgs t = f;
+      t.tiles = d_tail_tiles.p; t.num_tiles = num_tail_tiles;
+      t.sw.cost_partial = f.sw.cost_partial + num_clusters;
+      timed("point_front", [&] { launch_point_front(st, t, Q > 0 ? KMAX : 0, true); });
+      eval_rows += point_front_grid(num_tail_tiles);
+    }
   } else {
     timed(entries ? "point_front" : "point_front_sums", [&] { launch_point_front(st, f, Q > 0 ? KMAX : 0, entries); });
     eval_rows = point_front_grid(num_front_tiles);

@@ -398,6 +398,34 @@ def test_point_seen_twice_by_one_image_and_long_tracks_mix_with_clusters(mavba, 
             assert rel_err(st[k], ref[k]) < 1e-8, (radius, k)
 
 
+def test_long_tracks_and_constant_points_behind_the_clusters(mavba, oracle, monkeypatch):
+    """The point order puts the points that can never be clustered - more than 16 observations, constant points - behind all
+    the others: the clustered part takes the fused kernel, that tail the separate front end + the generic term lists. Same
+    system as the oracle's and as the route that does not fuse; a full solve like the oracle's."""
+    p = synth.make_scene(num_images=40, num_points=1500, track_len=5, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=29,
+                         long_track_frac=0.06, long_track_len=24, spacing=5.0)
+    p.point_const[::37] = 1  # a few constant (control) points with observations
+    ref = oracle.linear_step(p, 1e3)
+    with mavba.Session(p, dict(profile_kernels=1)) as s:
+        info = s.info()
+        S, v = s.reduced_system(1e3)
+        st = s.linear_step(1e3)
+        timers = set(s.kernel_stats())
+    # both kernels ran: clusters fused, the tail through k_point_front and the term lists
+    assert "schur_fused" in timers and "point_front" in timers and "schur_clusters" not in timers
+    assert info["num_clusters"] > 0 and 0 < info["clustered_points"] < p.num_points and sum(info["schur_terms"]) > 0
+    assert rel_err(S, ref["S"]) < 1e-9 and rel_err(v, ref["v"]) < 1e-9
+    for k in ("d_poses", "d_intr", "d_points"):
+        assert rel_err(st[k], ref[k]) < 1e-8, k
+    po, ro, eo, pg, rg, eg = _solve_both(mavba, oracle, p, **global_opts())
+    assert rg["termination"] == ro["termination"] and rg["num_successful_steps"] == ro["num_successful_steps"]
+    assert_params_close(pg, po)
+    monkeypatch.setenv("MAVBA_NO_FUSE", "1")
+    with mavba.Session(p) as s:
+        S2, v2 = s.reduced_system(1e3)
+    assert rel_err(S2, S) < 1e-11 and rel_err(v2, v) < 1e-11
+
+
 def test_clusters_off_gives_the_same_system(mavba, monkeypatch):
     p = _scene("mixed")
     with mavba.Session(p) as s:
