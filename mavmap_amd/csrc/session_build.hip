@@ -947,12 +947,21 @@ void mavba_session::finish_structure() {
   int T = host_threads();
   if (N < 50000 || generic_points == 0) T = 1;
   while (T > 1 && (size_t)T * nkeys_tot > (size_t)48 << 20) T /= 2;
+  // contiguous point ranges of equal TERM work (a generic point with n observations makes ~n^2 / 2 terms; the generic points
+  // sit together at the end of the point order, so ranges of equal observation counts would leave all of it to one thread)
   std::vector<int> range(T + 1, NP);
   range[0] = 0;
-  for (int t = 1; t < T; ++t) {
-    const long long target = (long long)N * t / T;
-    range[t] = (int)(std::upper_bound(h_pt_start.begin(), h_pt_start.end(), (int)target) - h_pt_start.begin()) - 1;
-    range[t] = std::max(range[t - 1], std::min(range[t], NP));
+  if (T > 1) {
+    std::vector<double> work((size_t)NP + 1, 0.0);
+    for (int p = 0; p < NP; ++p) {
+      const double n = pt_mode[p] == 2 ? (double)(h_pt_start[p + 1] - h_pt_start[p] + q_start[p + 1] - q_start[p]) : 0.0;
+      work[p + 1] = work[p] + 0.5 * n * (n + 1.0);
+    }
+    for (int t = 1; t < T; ++t) {
+      const double target = work[NP] * t / T;
+      range[t] = (int)(std::lower_bound(work.begin(), work.end(), target) - work.begin());
+      range[t] = std::max(range[t - 1], std::min(range[t], NP));
+    }
   }
   std::vector<std::vector<int>> tcount(T * 3);
   auto run_threads = [&](const std::function<void(int)>& body) { host_run(T, body); };
