@@ -1,5 +1,6 @@
 // host_util.hip - process-wide helpers of the host side: caching device allocator, stream cache, worker threads.
 #include "session.h"
+#include <atomic>
 #include <cstring>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -301,6 +302,19 @@ void host_scratch_free(void* p, size_t bytes) {
   }
   std::free(p);
 }
+
+// The persistent factorisation needs all its work-groups resident; when a launch gives up (0.3 s), the session falls back
+// to the launch-per-panel schedule - and so do the next kPersistCooldownSessions sessions of the process, without trying.
+namespace {
+constexpr int kPersistCooldownSessions = 64;
+std::atomic<int> g_persist_cooldown{0};
+}  // namespace
+bool persistent_allowed_now() {
+  int c = g_persist_cooldown.load(std::memory_order_relaxed);
+  while (c > 0 && !g_persist_cooldown.compare_exchange_weak(c, c - 1, std::memory_order_relaxed)) {}
+  return c <= 0;
+}
+void persistent_timed_out() { g_persist_cooldown.store(kPersistCooldownSessions, std::memory_order_relaxed); }
 
 // Streams are cached too (hipStreamCreate + hipStreamDestroy cost ~2 ms per session, more than a local-BA solve).
 hipError_t stream_acquire(hipStream_t* st) {

@@ -96,6 +96,8 @@ hipError_t pinned_alloc(void** out, size_t bytes);
 void pinned_free(void* p);
 hipError_t stream_acquire(hipStream_t* st);
 void stream_release(hipStream_t st, int dev);
+bool persistent_allowed_now();   // host_util.hip: false while the process is in the cool-down after a time-out
+void persistent_timed_out();
 int host_threads();
 void host_run(int T, const std::function<void(int)>& body);
 
@@ -320,7 +322,10 @@ struct mavba_session {
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
   bool M_is_clean = false;       // d_M holds zeros outside the entries the assembly writes
-  bool allow_persistent = true;  // cleared when a persistent factorisation launch had to give up
+  // cleared when a persistent factorisation launch had to give up; a session created within the next
+  // kPersistCooldownSessions sessions of the process starts without it (a device shared with another tenant would
+  // otherwise pay the 0.3 s time-out once per bundle_adjustment() call)
+  bool allow_persistent = persistent_allowed_now();
   // The reduced camera matrix is assembled in the factorisation's elimination order: n_mat (multiple of 64)
   // columns, image i's pose block at h_off_img[i], camera c's intrinsics block at h_off_cam[c]; col_var maps a
   // matrix column back to the variable (index into the length-n_pad camera vectors), -1 for padding.

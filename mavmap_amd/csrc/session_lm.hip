@@ -212,6 +212,7 @@ void mavba_session::linear_step(double r, double* h) {
   if (h[SC_FAIL] >= 1e29 && allow_persistent) {
     std::fprintf(stderr, "mavba: persistent factorisation timed out, falling back to the launch-per-panel schedule\n");
     allow_persistent = false;
+    persistent_timed_out();
     solve_linear(r);
     candidate(r, h);
   }
