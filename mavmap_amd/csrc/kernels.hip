@@ -1892,10 +1892,8 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
     if constexpr (TRACE) tracing = bi == 1;
     mark();  // 0: top of the batch
     for (int j = tid; j <= np; j += kClThreads) s_pb[j] = a.pt_start[b0 + j];
-    for (int i = tid; i < np * 9; i += kClThreads) s_sum[i] = 0.0;
     if constexpr (KMAX > 0) {
       for (int q = tid; q < nq; q += kClThreads) { s_qcam[q] = a.q_cam[q0 + q]; s_qpt[q] = a.q_pt[q0 + q] - b0; s_qm[q] = q_meta[q0 + q]; }
-      for (int i = tid; i < nq * FS::K3; i += kClThreads) s_q[i] = 0.0;
     }
     double jc[12], jp[6];
     double prod[FS::NROWS];
@@ -1972,9 +1970,11 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
         }
         const int b = s_pb[j], e = s_pb[j + 1];
         const int* camv = s_cam - o0;
-        double acc1 = *dst;
+        // (every sum is written exactly once, in the round its row belongs to: it starts from zero. Reads past the point's last
+        // observation stay inside the park buffer / the camera list's LDS neighbourhood and are masked below.)
+        double acc1 = 0.0;
         for (int i0 = b; i0 < e; i0 += 4) {
-          const int i1 = min(i0 + 1, e - 1), i2 = min(i0 + 2, e - 1), i3 = min(i0 + 3, e - 1);
+          const int i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
           double x0 = row[i0], x1 = row[i1], x2 = row[i2], x3 = row[i3];
           if (WR > 0 && !is_pt) {
             x0 = camv[i0] == c ? x0 : 0.0; x1 = camv[i1] == c ? x1 : 0.0; x2 = camv[i2] == c ? x2 : 0.0; x3 = camv[i3] == c ? x3 : 0.0;
