@@ -198,31 +198,38 @@ int mavba_session_filter_points(mavba_session* s, double max_error, const uint8_
 static void join_ranks(mavba_session* s) {
   if (!s->sharded()) return;
   // A camera block is in the problem if ANY rank has a residual block on it; the counts
-  // reported in mavba_result become global.
-  const size_t n = (size_t)s->NI + s->NC + 4;
+  // reported in mavba_result become global. One more max-reduced flag: "this rank's process is in the cool-down after a
+  // persistent-launch time-out" - every rank then starts on the launch-per-panel schedule (the fallback inside
+  // linear_step contains a collective, so the ranks must take it together; a sharded session does not count against
+  // the cool-down).
+  const size_t nmax = (size_t)s->NI + s->NC + 1;
+  const size_t n = nmax + 4;
   std::vector<double> h(n, 0.0);
   for (int i = 0; i < s->NI; ++i) h[i] = s->h_img_used[i];
   for (int c = 0; c < s->NC; ++c) h[s->NI + c] = s->h_cam_used[c];
+  h[nmax - 1] = persistent_in_cooldown() ? 1.0 : 0.0;
   DevBuf<double> d;
   d.upload(h, s->st);
-  s->allreduce(d.p, (long long)s->NI + s->NC, 1);
+  s->allreduce(d.p, (long long)nmax, 1);
   std::vector<double> g(4, 0.0);
   long long free_pts = 0;
   for (unsigned char f : s->h_pt_free) free_pts += f;
   g[0] = s->fixed_cost; g[1] = (double)s->num_residuals; g[2] = (double)s->num_residuals_reduced; g[3] = (double)free_pts;
-  HIP_OK(hipMemcpyAsync(d.p + s->NI + s->NC, g.data(), 32, hipMemcpyHostToDevice, s->st));
-  s->allreduce(d.p + s->NI + s->NC, 4, 0);
+  HIP_OK(hipMemcpyAsync(d.p + nmax, g.data(), 32, hipMemcpyHostToDevice, s->st));
+  s->allreduce(d.p + nmax, 4, 0);
   s->download(h.data(), d.p, n * 8);
   for (int i = 0; i < s->NI; ++i) s->h_img_used[i] = h[i] != 0.0;
   for (int c = 0; c < s->NC; ++c) s->h_cam_used[c] = h[s->NI + c] != 0.0;
+  s->allow_persistent = h[nmax - 1] == 0.0;
+  s->persist_decided = true;
   s->derive_free_flags();
   long long cam_params = 0;
   for (unsigned char f : s->h_pose_free) cam_params += f;
   for (unsigned char f : s->h_intr_free) cam_params += f;
-  s->fixed_cost = h[s->NI + s->NC];
-  s->num_residuals = (long long)h[s->NI + s->NC + 1];
-  s->num_residuals_reduced = (long long)h[s->NI + s->NC + 2];
-  s->num_parameters_reduced = cam_params + 3 * (long long)h[s->NI + s->NC + 3];
+  s->fixed_cost = h[nmax];
+  s->num_residuals = (long long)h[nmax + 1];
+  s->num_residuals_reduced = (long long)h[nmax + 2];
+  s->num_parameters_reduced = cam_params + 3 * (long long)h[nmax + 3];
   s->finish_structure();
 }
 

@@ -314,6 +314,7 @@ bool persistent_allowed_now() {
   while (c > 0 && !g_persist_cooldown.compare_exchange_weak(c, c - 1, std::memory_order_relaxed)) {}
   return c <= 0;
 }
+bool persistent_in_cooldown() { return g_persist_cooldown.load(std::memory_order_relaxed) > 0; }  // (does not count a session)
 void persistent_timed_out() { g_persist_cooldown.store(kPersistCooldownSessions, std::memory_order_relaxed); }
 
 // Streams are cached too (hipStreamCreate + hipStreamDestroy cost ~2 ms per session, more than a local-BA solve).

@@ -1795,7 +1795,7 @@ struct FusedShape {
   static constexpr int ESIZE = ClShape<16, 3>::rows * kClPitch;
   static constexpr int ROUNDS = NROWS * kFuPitch <= ESIZE ? 1 : 2;
   static constexpr int NR = (NROWS + ROUNDS - 1) / ROUNDS;
-  static_assert(NR * kFuPitch <= ESIZE, "the park buffer must fit the entry matrix it aliases");
+  static_assert(NR * kFuPitch + 3 <= ESIZE, "the park buffer must fit the entry matrix it aliases (+ 3: the 4-wide summation reads run up to 3 elements past a full batch's last observation, masked)");
   static_assert(NR >= 9, "point rows must fit the first round");
 };
 }  // namespace
@@ -1820,7 +1820,7 @@ __global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
   __shared__ int s_bounds[2][kClMaxBatches + 1];
   __shared__ int s_tab[SH::tab];
   __shared__ int s_pb[kClBatch + 1];
-  __shared__ int s_cam[kClThreads];
+  __shared__ int s_cam[kClThreads + 3];  // (+ 3: the masked 4-wide reads of the summation loop past the last observation of a full batch)
   __shared__ int s_qcam[kClBatch * kClCamsMax], s_qpt[kClBatch * kClCamsMax], s_qm[kClBatch * kClCamsMax];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const SweepArgs& w = a.sw;

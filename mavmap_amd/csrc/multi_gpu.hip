@@ -121,6 +121,11 @@ int inproc_allreduce(void* vctx, void* device_ptr, int64_t count, int32_t op) {
 
 // contiguous point ranges balanced by observation count (the rule of BAProblem.shard_by_point / bench.py)
 std::vector<int> shard_bounds(const mavba_problem* P, int world) {
+  // (the same answers as the single-GPU path gives for a malformed problem - before anything is indexed)
+  if (P->num_points < 0 || P->num_obs < 0 || (P->num_obs > 0 && (!P->obs_point || !P->obs_image || !P->obs_uv)) || (P->num_points > 0 && !P->points))
+    throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null array in the problem");
+  for (long long o = 0; o < P->num_obs; ++o)
+    if (P->obs_point[o] < 0 || P->obs_point[o] >= P->num_points) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
   std::vector<long long> csum((size_t)P->num_points + 1, 0);
   for (long long o = 0; o < P->num_obs; ++o) csum[P->obs_point[o] + 1]++;
   for (int p = 0; p < P->num_points; ++p) csum[p + 1] += csum[p];
@@ -163,6 +168,21 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
   G.ptr.assign(world, nullptr); G.count.assign(world, 0); G.stream.assign(world, nullptr);
   G.stage.assign(world, nullptr); G.stage_doubles.assign(world, 0);
   G.direct = std::getenv("MAVBA_GPUS_STAGED") == nullptr;
+  const std::vector<int> bounds = shard_bounds(P, world);  // (validates the indices: nothing is created before that)
+  // the per-rank streams and staging buffers leave with this scope, whatever throws below
+  struct Cleanup {
+    InProcGroup& G; int cur;
+    ~Cleanup() {
+      for (size_t r = 0; r < G.stream.size(); ++r) {
+        if (!G.stream[r] && !G.stage[r]) continue;
+        (void)hipSetDevice(G.device[r]);
+        if (G.stream[r]) (void)hipStreamDestroy(G.stream[r]);
+        if (G.stage[r]) device_free(G.stage[r]);
+        G.stream[r] = nullptr; G.stage[r] = nullptr;
+      }
+      (void)hipSetDevice(cur);
+    }
+  } cleanup{G, cur};
   for (int a = 0; a < world && G.direct; ++a)
     for (int b = 0; b < world && G.direct; ++b) {
       if (G.device[a] == G.device[b]) continue;
@@ -182,7 +202,6 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
   }
   HIP_OK(hipSetDevice(cur));
 
-  const std::vector<int> bounds = shard_bounds(P, world);
   struct Shard {
     std::vector<double> points, uv, perr;
     std::vector<uint8_t> pconst;
@@ -236,7 +255,17 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
     // ceres leaves the user's parameter blocks untouched after NUMERICAL_FAILURE
     if (S.rc == MAVBA_OK && S.term != MAVBA_TERM_NUMERICAL_FAILURE)
       S.rc = mavba_session_get_params(s, S.poses.data(), S.intr.data(), S.points.data());
-    if (S.rc == MAVBA_OK && point_error && options->update_point_errors) S.rc = mavba_session_point_errors(s, S.perr.data());
+    if (S.rc == MAVBA_OK && point_error && options->update_point_errors) {
+      // problem.Evaluate runs on the user's blocks (bundle_adjustment.cc:583-588): after NUMERICAL_FAILURE those still hold
+      // the parameters the call started from - as mavba_solve does on one GPU
+      if (S.term == MAVBA_TERM_NUMERICAL_FAILURE) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        try { HIP_OK(hipSetDevice(s->device)); s->restore_initial_params(); } catch (const std::exception& e) { g_last_error = e.what(); S.rc = MAVBA_ERR_HIP; }
+        if (prev >= 0) (void)hipSetDevice(prev);
+      }
+      if (S.rc == MAVBA_OK) S.rc = mavba_session_point_errors(s, S.perr.data());
+    }
     if (S.rc != MAVBA_OK) { S.error = g_last_error; G.fail(); }
     if (s) mavba_session_destroy(s);
   };
@@ -244,12 +273,6 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
   for (int r = 1; r < world; ++r) threads.emplace_back(worker, r);
   worker(0);
   for (auto& t : threads) t.join();
-  for (int r = 0; r < world; ++r) {
-    (void)hipSetDevice(G.device[r]);
-    if (G.stream[r]) (void)hipStreamDestroy(G.stream[r]);
-    if (G.stage[r]) device_free(G.stage[r]);
-  }
-  (void)hipSetDevice(cur);
   for (int r = 0; r < world; ++r)
     if (sh[r].rc != MAVBA_OK && !sh[r].error.empty()) throw Failure(sh[r].rc, "rank " + std::to_string(r) + ": " + sh[r].error);
   for (int r = 0; r < world; ++r)

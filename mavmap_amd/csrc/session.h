@@ -96,7 +96,8 @@ hipError_t pinned_alloc(void** out, size_t bytes);
 void pinned_free(void* p);
 hipError_t stream_acquire(hipStream_t* st);
 void stream_release(hipStream_t st, int dev);
-bool persistent_allowed_now();   // host_util.hip: false while the process is in the cool-down after a time-out
+bool persistent_allowed_now();   // host_util.hip: false while the process is in the cool-down after a time-out (counts one session of it)
+bool persistent_in_cooldown();   // the same question without counting a session (sharded sessions: the ranks agree in join_ranks)
 void persistent_timed_out();
 int host_threads();
 void host_run(int T, const std::function<void(int)>& body);
@@ -324,8 +325,11 @@ struct mavba_session {
   bool M_is_clean = false;       // d_M holds zeros outside the entries the assembly writes
   // cleared when a persistent factorisation launch had to give up; a session created within the next
   // kPersistCooldownSessions sessions of the process starts without it (a device shared with another tenant would
-  // otherwise pay the 0.3 s time-out once per bundle_adjustment() call)
-  bool allow_persistent = persistent_allowed_now();
+  // otherwise pay the 0.3 s time-out once per bundle_adjustment() call). Decided in start(): only a single-rank session
+  // that HAS a persistent schedule consumes a session of the cool-down; the ranks of a sharded solve agree on one value
+  // in join_ranks (a rank that re-solves after a time-out issues a collective - every rank must take that branch).
+  bool allow_persistent = true;
+  bool persist_decided = false;
   // The reduced camera matrix is assembled in the factorisation's elimination order: n_mat (multiple of 64)
   // columns, image i's pose block at h_off_img[i], camera c's intrinsics block at h_off_cam[c]; col_var maps a
   // matrix column back to the variable (index into the length-n_pad camera vectors), -1 for padding.

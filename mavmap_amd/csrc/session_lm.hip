@@ -262,6 +262,10 @@ void mavba_session::candidate(double r, double* h) {
 }
 
 void mavba_session::start() {
+  if (!persist_decided) {  // (sharded sessions decided in join_ranks, for all ranks together)
+    if (chol_struct.persist_ok && !sharded()) allow_persistent = persistent_allowed_now();
+    persist_decided = true;
+  }
   evaluate();
   initial_cost = cost + fixed_cost;
   const double g0 = std::max(grad_max, std::numeric_limits<double>::epsilon());
