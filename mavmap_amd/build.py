@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libmavba.so")
 OBJDIR = os.path.join(LIBDIR, "obj")
-SOURCES = ["kernels.hip", "dense_chol.hip", "pose_refine.hip", "host_util.hip", "session_build.hip", "session_lm.hip", "scene.hip", "multi_gpu.hip", "device_setup.hip", "api.hip"]
+SOURCES = ["kernels.hip", "schur_rows.hip", "dense_chol.hip", "pose_refine.hip", "host_util.hip", "session_build.hip", "session_lm.hip", "scene.hip", "multi_gpu.hip", "device_setup.hip", "api.hip"]
 HEADERS = ["ba_math.h", "dev_reduce.h", "internal.h", "session.h", os.path.join("..", "..", "include", "mavba.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall",
          "-Wno-unused-result"]

@@ -397,6 +397,30 @@ int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   MAVBA_CATCH
 }
 
+// Probe: the front end of a linear solve (k_schur_rows / k_schur_fused, or k_point_front) for trust-region radius
+// `radius`, `reps` launches back to back at the current parameters, average milliseconds per pass (HIP events on the
+// session's stream). Leaves the session as an evaluation would.
+int mavba_session_time_front(mavba_session* s, double radius, int32_t reps, float* ms_avg) {
+  MAVBA_SESSION_TRY(s)
+  if (reps < 1) reps = 1;
+  if (!s->front_ok) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "time_front: the session runs on the plane kernels");
+  if (!s->evaluated || !s->scales_ready) s->evaluate();
+  for (int i = 0; i < 3; ++i) s->launch_front(radius, true);
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, s->st));
+  for (int i = 0; i < reps; ++i) s->launch_front(radius, true);
+  HIP_OK(hipEventRecord(e1, s->st));
+  HIP_OK(hipStreamSynchronize(s->st));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms_avg) *ms_avg = ms / reps;
+  s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
 int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
   MAVBA_SESSION_TRY(s)
   if (!out) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");

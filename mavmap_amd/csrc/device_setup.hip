@@ -263,15 +263,17 @@ __global__ void __launch_bounds__(256) k_count_obs(int n, int NI, int NP, const 
 // that the clustered part of the problem can take the fused kernel and only this tail the separate front end.
 __global__ void k_point_keys(int NP, const unsigned* __restrict__ cstart, const int* __restrict__ byp, const int* __restrict__ oimg,
                              const unsigned char* __restrict__ pconst, unsigned* __restrict__ w0, unsigned* __restrict__ w1,
-                             unsigned* __restrict__ w2, unsigned* __restrict__ w3, unsigned* __restrict__ tail) {
+                             unsigned* __restrict__ w2, unsigned* __restrict__ w3, unsigned* __restrict__ w4, unsigned* __restrict__ tail) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= NP) return;
   tail[p] = (cstart[p + 1] - cstart[p] > (unsigned)kTailObs || (pconst && pconst[p])) ? 1u : 0u;
   unsigned k[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) k[t] = 0xFFFFu;
+  unsigned hash = 0;  // of the whole image set (order_on_host: the same sum)
   for (unsigned a = cstart[p]; a < cstart[p + 1]; ++a) {
     unsigned x = (unsigned)oimg[byp[a]];
+    hash += image_set_mix(x);
     bool dup = false;
 #pragma unroll
     for (int t = 0; t < 8; ++t) dup = dup || k[t] == x;
@@ -283,6 +285,7 @@ __global__ void k_point_keys(int NP, const unsigned* __restrict__ cstart, const 
     }
   }
   w0[p] = k[0] << 16 | k[1]; w1[p] = k[2] << 16 | k[3]; w2[p] = k[4] << 16 | k[5]; w3[p] = k[6] << 16 | k[7];
+  w4[p] = hash;
 }
 
 __global__ void k_new_counts(int NP, const int* __restrict__ orig, const unsigned* __restrict__ cstart, unsigned* __restrict__ cnt_new) {
@@ -430,7 +433,7 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
   if (P->point_const) r_pconst.upload(h_pt_const_in, st);  // (still in the caller's order here)
   lap("upload");
   // counts per point / per image, index check
-  DevBuf<unsigned> cstart, pstart, istart, w[4];
+  DevBuf<unsigned> cstart, pstart, istart, w[5];
   DevBuf<int> bad;
   cstart.alloc((size_t)NP + 1); pstart.alloc((size_t)NP + 1); istart.alloc((size_t)NI + 1);
   bad.alloc(1);
@@ -455,16 +458,16 @@ void mavba_session::order_on_device(const mavba_problem* P, std::vector<int>& im
     radix_sort_indices(st, n, nullptr, byp.p, S, passes);
   }
   lap("sort obs by point");
-  // point order: 128-bit key of the 8 smallest images, ties by the caller's index
-  for (int k = 0; k < 4; ++k) w[k].alloc((size_t)std::max(NP, 1));
+  // point order: 128-bit key of the 8 smallest images, then the 32-bit hash of the whole image set, ties by the caller's index
+  for (int k = 0; k < 5; ++k) w[k].alloc((size_t)std::max(NP, 1));
   DevBuf<unsigned> wtail;
   wtail.alloc((size_t)std::max(NP, 1));
   hipLaunchKernelGGL(k_point_keys, dim3((NP + 255) / 256), dim3(256), 0, st, NP, cstart.p, byp.p, r_img.p,
-                     P->point_const ? r_pconst.p : (const unsigned char*)nullptr, w[0].p, w[1].p, w[2].p, w[3].p, wtail.p);
+                     P->point_const ? r_pconst.p : (const unsigned char*)nullptr, w[0].p, w[1].p, w[2].p, w[3].p, w[4].p, wtail.p);
   d_pt_orig.alloc((size_t)std::max(NP, 1));
   {
     std::vector<std::pair<const unsigned*, int>> passes;
-    for (int k = 3; k >= 0; --k)
+    for (int k = 4; k >= 0; --k)  // (least significant first: the image-set hash, then the eight smallest images)
       for (int b = 0; b < 4; ++b) passes.push_back({w[k].p, 8 * b});
     passes.push_back({wtail.p, 0});  // (most significant: the tail flag)
     radix_sort_indices(st, NP, nullptr, d_pt_orig.p, S, passes);

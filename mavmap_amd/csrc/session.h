@@ -293,6 +293,12 @@ struct mavba_session {
   DevBuf<SchurBlock> d_blocks;
   DevBuf<SchurChunk> d_chunks[3];
   DevBuf<SchurCluster> d_clusters;
+  // k_schur_rows (round 4): the clusters with their row counts, sorted by row class then length; rows_ok: the set-up built
+  // them and the clusters take k_schur_rows instead of k_schur_fused
+  DevBuf<SchurRowsCluster> d_rows_clusters;
+  int rows_class_first[kRowsClasses] = {0, 0}, rows_class_count[kRowsClasses] = {0, 0};
+  bool rows_ok = false;
+  bool rows_generic = false;  // some cluster has three camera slots: the general form of the intrinsics entries
   DevBuf<PartialReduce> d_reduce_tasks;
   int num_reduce_tasks = 0;
   DevBuf<int> d_cl_tab, d_cl_lists;  // per cluster: slot table of its blocks; its image and camera lists (-1 padded)
@@ -460,7 +466,8 @@ void intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::v
   void build_front_tiles(const std::vector<int>& q_start);
   void build_tiles(const std::vector<int>& q_start, int first, DevBuf<FrontTile>& out, int& count);
   void ensure_planes();
-  bool fused_now() const { return fused_ok && h_pt_removed.empty(); }
+  // (k_schur_rows masks filtered points itself; k_schur_fused has no masked instantiation)
+  bool fused_now() const { return fused_ok && (rows_ok || h_pt_removed.empty()); }
   int eval_cost_rows() const { return front_ok ? eval_rows : (N > 0 ? jacobian_sweep_grid(N) : 0); }
   void take_evaluation(const double* h) { cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]); }
   void assemble(double r);

@@ -69,13 +69,19 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
     // the number of threads, and the same definition as k_point_keys + the radix sort of the device path.
     // ... behind the `tail` flag (most significant): points that can never be clustered - more than kTailObs observations, or
     // constant - follow all the others (the same definition as k_point_keys)
-    struct KeyId { unsigned long long hi, lo; int id; int tail; };
+    // Round 4: a 32-bit hash of ALL the point's images follows the eight smallest (before the caller's index): points with
+    // the same image SET become neighbours even when their lists are longer than eight - the clusters of k_schur_rows
+    // (80 rows: 10 images + 2 cameras) are runs of such points. A sum of mixed image numbers: independent of the order
+    // of the point's observations, the same on the host and in k_point_keys.
+    struct KeyId { unsigned long long hi, lo; unsigned hash; int id; int tail; };
     HostBuf<KeyId> keyed(NP);
     parallel_ranges(NP, [&](long long b0, long long b1) {
       for (long long p = b0; p < b1; ++p) {
         unsigned k[8] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+        unsigned hash = 0;
         for (int a2 = cstart[p]; a2 < cstart[p + 1]; ++a2) {
           unsigned x = (unsigned)simg[a2];
+          hash += image_set_mix(x);
           bool dup = false;
           for (int t = 0; t < 8; ++t) dup = dup || k[t] == x;
           if (dup) continue;
@@ -84,6 +90,7 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
         KeyId kk;
         kk.hi = (unsigned long long)k[0] << 48 | (unsigned long long)k[1] << 32 | (unsigned long long)k[2] << 16 | k[3];
         kk.lo = (unsigned long long)k[4] << 48 | (unsigned long long)k[5] << 32 | (unsigned long long)k[6] << 16 | k[7];
+        kk.hash = hash;
         kk.id = (int)p;
         kk.tail = (cstart[p + 1] - cstart[p] > kTailObs || (P->point_const && P->point_const[p])) ? 1 : 0;
         keyed[p] = kk;
@@ -93,6 +100,7 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
       if (x.tail != y.tail) return x.tail < y.tail;
       if (x.hi != y.hi) return x.hi < y.hi;
       if (x.lo != y.lo) return x.lo < y.lo;
+      if (x.hash != y.hash) return x.hash < y.hash;
       return x.id < y.id;
     };
     // Points are first dealt into buckets by their FIRST image (the key's leading 16 bits; a stable counting sort),
@@ -757,7 +765,17 @@ void mavba_session::finish_structure() {
   const ClusterShape sh = cl_shape;
   const int kClTab = sh.tab(), kClTabPP = sh.tab_pp(), kClTabIP = sh.tab_ip(), kClTabII = sh.tab_ii();
   const int kClImages = sh.images, kClCams = sh.cams;
-  {
+  // Round 4: the clusters of k_schur_rows. Same greedy walk over consecutive points, but a cluster is CLOSED when its entry
+  // matrix would pass 80 rows (10 images + 2 cameras + h: 15 instead of 36 tiles of matrix instructions per batch) once it
+  // holds kRowsMinDense points; a shorter one may grow to the full 128 rows, and such a mixed cluster ends where a run of
+  // points with one image set begins that is long enough for a cluster of its own. The point order keeps equal image sets
+  // together (the hash in the key). Chosen when the front end can run inside the cluster kernel at all; otherwise - and
+  // with MAVBA_FUSED_V1 - the clusters of rounds 1-3.
+  std::vector<int> cl_ni, cl_nc;
+  const bool no_fuse_env = std::getenv("MAVBA_NO_FUSE") != nullptr;  // (read per session: the tests switch paths)
+  auto build_clusters = [&](bool rows_mode) {
+    clusters.clear(); cl_imgs.clear(); cl_cams.clear(); cl_ni.clear(); cl_nc.clear();
+    std::fill(pt_mode.begin(), pt_mode.end(), 0);
     bool use_clusters = true;
     if (const char* e = std::getenv("MAVBA_CLUSTERS")) use_clusters = std::atoi(e) != 0;
     // 128 points per cluster amortise the per-cluster costs; small problems get smaller clusters so that there
@@ -767,14 +785,19 @@ void mavba_session::finish_structure() {
     // points per cluster: small problems still give every CU ~2 clusters; large ones up to 256 (fewer partials and emits:
     // C3 0.297 -> 0.283 ms for the cluster kernel, 0.037 -> 0.031 for the finalize pass)
     int kMaxPoints = (int)std::min<long long>(256, std::max<long long>(kClBatch, round_up((int)(nfree / 512), kClBatch)));
+    if (rows_mode) kMaxPoints = (int)std::min<long long>(kRowsMaxPoints, std::max<long long>(kRowsBatch, round_up((int)(nfree / 2048), kRowsBatch)));  // (several work-groups per CU)
     if (const char* e = std::getenv("MAVBA_CLUSTER_POINTS")) kMaxPoints = std::max(1, std::atoi(e));
+    if (rows_mode) kMaxPoints = std::min(kMaxPoints, kRowsMaxPoints);
+    int kRowsMinDense = kRowsBatch;
+    if (const char* e = std::getenv("MAVBA_ROWS_MIN_DENSE")) kRowsMinDense = std::max(1, std::atoi(e));
+    const int kDenseRows = 16 * kRowsClassNT[0];
     // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
     // thread": the clusters - and with them the order in which partials are added - must not depend on the
     // machine's core count).
     const int kRange = 2048;
     const int nranges = (NP + kRange - 1) / kRange;
     std::vector<std::vector<SchurCluster>> r_clusters(nranges);
-    std::vector<std::vector<int>> r_imgs(nranges), r_cams(nranges);
+    std::vector<std::vector<int>> r_imgs(nranges), r_cams(nranges), r_ni(nranges), r_nc(nranges);
     // Membership of an image in the open cluster / in the current point is an epoch tag per image (one table per host
     // thread's range, reused): a point costs its observations, not a set union (2.6 -> ~1 ms at C3). Same greedy rule as
     // before - the cluster closes when the UNION of its images and the point's would not fit - so the clusters are the same.
@@ -784,13 +807,14 @@ void mavba_session::finish_structure() {
       for (int p = std::max(r0, tail_begin); p < r_end; ++p)
         if (h_pt_free[p] && (h_pt_start[p + 1] > h_pt_start[p] || q_start[p + 1] > q_start[p])) pt_mode[p] = 2;
       const int r1 = std::min(r_end, std::max(r0, tail_begin));
-      std::vector<int> cur_i, cur_c, pi;
+      std::vector<int> cur_i, cur_c, pi, ps, prev_ps, qs;
       // (epoch tags, never reset: cluster serials are unique over all ranges - a range closes at most kRange + 1 clusters -
       // and so are point indices)
       int cl_serial = rg * (kRange + 1);
       int cur_p0 = r0, cur_n = 0;
       auto close = [&](int p_end) {
         if (cur_n > 0) {
+          r_ni[rg].push_back((int)cur_i.size()); r_nc[rg].push_back((int)cur_c.size());
           std::sort(cur_i.begin(), cur_i.end());
           std::sort(cur_c.begin(), cur_c.end());
           r_clusters[rg].push_back(SchurCluster{cur_p0, p_end});
@@ -798,6 +822,11 @@ void mavba_session::finish_structure() {
           for (int k = 0; k < kClCams; ++k) r_cams[rg].push_back(k < (int)cur_c.size() ? cur_c[k] : -1);
         }
         cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end; ++cl_serial;
+      };
+      auto sorted_images = [&](int p, std::vector<int>& out) {
+        out.clear();
+        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) if (img_active[h_oimg[a]]) out.push_back(h_oimg[a]);
+        std::sort(out.begin(), out.end());
       };
       for (int p = r0; p < r1; ++p) {
         if (!h_pt_free[p]) continue;
@@ -820,7 +849,23 @@ void mavba_session::finish_structure() {
         };
         int ni, nc;
         grown(ni, nc);
-        if (ni > kClImages || nc > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1) {
+        bool close_now = ni > kClImages || nc > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1;
+        if (rows_mode && cur_n > 0 && !close_now) {
+          ps = pi;
+          std::sort(ps.begin(), ps.end());
+          const int rows_cur = 6 * (int)cur_i.size() + 9 * (int)cur_c.size() + 1, rows_new = 6 * ni + 9 * nc + 1;
+          if (rows_cur <= kDenseRows) {
+            close_now = rows_new > kDenseRows && cur_n >= kRowsMinDense;
+          } else if (ps != prev_ps && p + kRowsMinDense - 1 < r1) {  // a mixed cluster at the start of a run of equal image sets
+            sorted_images(p + kRowsMinDense - 1, qs);
+            close_now = qs == ps && 6 * (int)ps.size() + 9 * nq + 1 <= kDenseRows;
+          }
+          prev_ps.swap(ps);
+        } else if (rows_mode) {
+          prev_ps = pi;
+          std::sort(prev_ps.begin(), prev_ps.end());
+        }
+        if (close_now) {
           close(p);
           grown(ni, nc);
         }
@@ -840,12 +885,35 @@ void mavba_session::finish_structure() {
       clusters.insert(clusters.end(), r_clusters[rg].begin(), r_clusters[rg].end());
       cl_imgs.insert(cl_imgs.end(), r_imgs[rg].begin(), r_imgs[rg].end());
       cl_cams.insert(cl_cams.end(), r_cams[rg].begin(), r_cams[rg].end());
+      cl_ni.insert(cl_ni.end(), r_ni[rg].begin(), r_ni[rg].end());
+      cl_nc.insert(cl_nc.end(), r_nc[rg].begin(), r_nc[rg].end());
     }
+  };
+  // can the front end run inside the cluster kernel? every observed point before the tail clustered, nothing else clustered
+  auto fusable = [&]() {
+    long long head_observed = 0, head_clustered = 0, all_clustered = 0;
+    for (int p = 0; p < tail_begin; ++p) { head_observed += h_pt_start[p + 1] > h_pt_start[p]; head_clustered += pt_mode[p] == 1; }
+    for (int p = 0; p < NP; ++p) all_clustered += pt_mode[p] == 1;
+    return front_ok && !no_fuse_env && cl_shape.images == 16 && !clusters.empty() && head_clustered == head_observed &&
+           all_clustered == head_clustered && (long long)clusters.size() <= kFrontMaxGrid;
+  };
+  rows_ok = false;
+  if (front_ok && !no_fuse_env && cl_shape.images == 16 && std::getenv("MAVBA_FUSED_V1") == nullptr) {
+    build_clusters(true);
+    rows_ok = fusable();
   }
+  if (!rows_ok) build_clusters(false);
   num_clusters = (int)clusters.size();
   cluster_flops = 0.0;
-  for (const SchurCluster& c : clusters)  // batches x k-steps x 36 lower tiles x 2*16*16*4
-    cluster_flops += (double)((c.p1 - c.p0 + kClBatch - 1) / kClBatch) * (3 * kClBatch / 4) * (double)((sh.rows() / 16) * (sh.rows() / 16 + 1) / 2) * 2048.0;
+  for (size_t c = 0; c < clusters.size(); ++c) {  // batches x k-steps x lower tiles x 2*16*16*4
+    const int np = clusters[c].p1 - clusters[c].p0;
+    if (rows_ok) {
+      const int nt = kRowsClassNT[rows_class_of(cl_ni[c], cl_nc[c])];
+      cluster_flops += (double)((np + kRowsBatch - 1) / kRowsBatch) * (3 * kRowsBatch / 4) * (double)(nt * (nt + 1) / 2) * 2048.0;
+    } else {
+      cluster_flops += (double)((np + kClBatch - 1) / kClBatch) * (3 * kClBatch / 4) * (double)((sh.rows() / 16) * (sh.rows() / 16 + 1) / 2) * 2048.0;
+    }
+  }
   // local indices of every clustered observation / intrinsics entry, and which blocks a cluster touches
   std::vector<unsigned char> cl_present((size_t)std::max(num_clusters, 1) * kClTab, 0);
   parallel_ranges(num_clusters, [&](long long c0, long long c1) {
@@ -1120,7 +1188,31 @@ void mavba_session::finish_structure() {
     // the slot order and does not change
     std::vector<int> order(num_clusters);
     for (int c = 0; c < num_clusters; ++c) order[c] = c;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return clusters[a].p1 - clusters[a].p0 > clusters[b].p1 - clusters[b].p0; });
+    auto row_class = [&](int c) { return rows_ok ? rows_class_of(cl_ni[c], cl_nc[c]) : 0; };  // (k_schur_rows: one launch per row class)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      const int ca = row_class(a), cb = row_class(b);
+      if (ca != cb) return ca < cb;
+      return clusters[a].p1 - clusters[a].p0 > clusters[b].p1 - clusters[b].p0;
+    });
+    if (rows_ok) {
+      std::vector<SchurRowsCluster> rc(clusters.size());
+      for (int k = 0; k < kRowsClasses; ++k) rows_class_first[k] = rows_class_count[k] = 0;
+      rows_generic = false;
+      for (int c = 0; c < num_clusters; ++c) rows_generic = rows_generic || cl_nc[c] > 2;
+      for (int c = 0; c < num_clusters; ++c) {
+        const int o = order[c];
+        rc[c] = SchurRowsCluster{clusters[o].p0, clusters[o].p1, cl_ni[o], cl_nc[o]};
+        rows_class_count[row_class(o)]++;
+      }
+      for (int k = 1; k < kRowsClasses; ++k) rows_class_first[k] = rows_class_first[k - 1] + rows_class_count[k - 1];
+      d_rows_clusters.upload(rc, st);
+      if (std::getenv("MAVBA_CLUSTER_STATS")) {
+        long long pts[kRowsClasses] = {0, 0}, bat[kRowsClasses] = {0, 0};
+        for (int c = 0; c < num_clusters; ++c) { const int k = row_class(order[c]); pts[k] += rc[c].p1 - rc[c].p0; bat[k] += (rc[c].p1 - rc[c].p0 + kRowsBatch - 1) / kRowsBatch; }
+        for (int k = 0; k < kRowsClasses; ++k)
+          std::fprintf(stderr, "[cluster stats] k_schur_rows class %d (%d rows): %d clusters, %lld points, %lld batches\n", k, 16 * kRowsClassNT[k], rows_class_count[k], pts[k], bat[k]);
+      }
+    }
     std::vector<SchurCluster> cl_sorted(clusters.size());
     std::vector<int> tab_sorted(cl_tab.size(), -1);
     std::vector<int> lists_sorted((size_t)std::max(num_clusters, 1) * (kClImages + kClCams), -1);  // images, then cameras of a cluster
@@ -1150,6 +1242,7 @@ void mavba_session::finish_structure() {
       build_tiles(q_start, tail_begin, d_tail_tiles, num_tail_tiles);
       if ((long long)num_clusters + point_front_grid(num_tail_tiles) > kFrontMaxGrid) { fused_ok = false; num_tail_tiles = 0; }
     }
+    rows_ok = rows_ok && fused_ok;  // (if not: the clusters built for k_schur_rows are valid - only shorter - clusters of k_schur_clusters)
   }
   sync();
   lap("upload terms");
