@@ -84,15 +84,21 @@ inline unsigned image_set_mix(unsigned x) {
 // ---- k_schur_rows (schur_rows.hip): the fused front end + cluster Schur complement of round 4 ----
 // A point owns a 16-lane DPP row, a batch is 16 points (K = 48 columns of the entry matrix). The entry matrix of a cluster
 // has rows 6 * slot + e for its `ni` image slots, then 9 * slot + k for its `nc` camera slots, then the h row; clusters
-// are launched per ROW CLASS (16-row blocks NT of the matrix): 80 rows hold 10 images + 2 cameras + h (15 tiles),
-// 128 rows the general 16 x 3 list (36 tiles). Slot tables and image / camera lists keep the 16 x 3 layout of
+// are launched per ROW CLASS (16-row blocks NT of the matrix): 80 rows hold 10 images + 2 cameras + h (15 tiles), 96 rows
+// 12 + 2 (21 tiles), 128 rows the general 16 x 3 list (36 tiles). Slot tables and image / camera lists keep the 16 x 3 layout of
 // ClusterShape{16, 3}: a cluster of k_schur_rows is also a valid cluster of k_schur_clusters / k_schur_fused.
 constexpr int kRowsBatch = 16;
 constexpr int kRowsMaxPoints = 256;
-constexpr int kRowsClasses = 2;
-constexpr int kRowsClassNT[kRowsClasses] = {5, 8};
+constexpr int kRowsClasses = 3;
+constexpr int kRowsClassNT[kRowsClasses] = {5, 6, 8};
 struct SchurRowsCluster { int p0, p1, ni, nc; };
-inline int rows_class_of(int ni, int nc) { return 6 * ni + 9 * nc + 1 <= 16 * kRowsClassNT[0] ? 0 : 1; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int rows_class_of(int ni, int nc) {
+  const int rows = 6 * ni + 9 * nc + 1;
+  return rows <= 16 * kRowsClassNT[0] ? 0 : rows <= 16 * kRowsClassNT[1] ? 1 : 2;
+}
 
 // Scalars exchanged with the host every LM iteration (device array of doubles).
 // Two groups, reduced over ranks SEPARATELY (an evaluation enqueued behind an accepted step and the next candidate
@@ -215,7 +221,7 @@ int schur_partial_stride(int kind);
 void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int num_clusters, const SchurCluster* clusters, const int* tab,
                         const int* cl_lists,
                         const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii);
-void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, const int* class_first, const int* class_count,
+void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, int num_clusters,
                        const SchurRowsCluster* clusters, const int* tab, const int* cl_lists, const unsigned short* obs_meta,
                        double* part_pp, double* part_ip, double* part_ii);
 // obs_meta / q_meta: per observation / intrinsics entry, local index << 8 | (point - cluster.p0) % kClBatch,

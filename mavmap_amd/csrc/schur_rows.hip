@@ -28,6 +28,7 @@
 #include "internal.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "ba_math.h"
 #include "dev_reduce.h"
@@ -202,24 +203,26 @@ __device__ __forceinline__ void f2_emit(int lane, const f2_d4 (&acc)[F2Shape<NT>
 // GENERIC: the intrinsics entries by the general reduce-scatter (three camera slots in a cluster, or the 9-parameter model);
 // otherwise every cluster of the launch has at most two camera slots and KMAX is 4 or 8 (the in-place form: 48 registers
 // fewer - with both forms in one kernel the common one spilt ~70 registers per lane).
-template <int KMAX, int NT, bool GENERIC, bool TRACE = false>
+// One launch for all row classes: the cluster's row count selects the instantiation of the batch loop (the registers and
+// the LDS of the kernel are those of the largest class either way: two work-groups per CU).
+template <int KMAX, bool GENERIC, bool TRACE = false>
 __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     FrontArgs a, const SchurRowsCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ cl_lists,
-    const unsigned short* __restrict__ obs_meta, int first_cluster, double* __restrict__ part_pp, double* __restrict__ part_ip,
+    const unsigned short* __restrict__ obs_meta, double* __restrict__ part_pp, double* __restrict__ part_ip,
     double* __restrict__ part_ii) {
-  using SH = F2Shape<NT>;
+  using SHMAX = F2Shape<kRowsClassNT[kRowsClasses - 1]>;
   // per-cluster tables (cl_lists: the cluster's image slots, then its camera slots, -1 padded): camera records, intrinsics
   // and column scales are read from memory once per cluster
   __shared__ double s_rec[kClImagesMax][9], s_kin[kClImagesMax][9], s_sc[kClImagesMax][6], s_ksc[kClCamsMax][9];
   __shared__ int s_icam[kClImagesMax], s_model[kClImagesMax], s_lc[kClImagesMax], s_clcam[4];
-  __shared__ __attribute__((aligned(16))) double E[SH::rows * kF2Pitch];
+  __shared__ __attribute__((aligned(16))) double E[SHMAX::rows * kF2Pitch];
   __shared__ double s_red[kF2Waves];
   __shared__ int s_tab[kF2Tab];
   __shared__ int s_pstart[kRowsMaxPoints + 1];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = tid >> 4, i = tid & 15;
   const SweepArgs& w = a.sw;
   const int NPs = a.NPs;
-  const int cidx = first_cluster + blockIdx.x;
+  const int cidx = blockIdx.x;
   const SchurRowsCluster cl = clusters[cidx];
   const int npts = cl.p1 - cl.p0, nbatch = (npts + kRowsBatch - 1) / kRowsBatch;
   const int P0 = 6 * cl.ni, H = P0 + 9 * cl.nc;
@@ -245,10 +248,13 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
       if (k == 0) s_clcam[c] = cam;
     }
   }
+  double cost = 0.0;
+  auto run = [&](auto nt_const) {
+  constexpr int NT = decltype(nt_const)::value;
+  using SH = F2Shape<NT>;
   f2_d4 acc[SH::acc];
 #pragma unroll
   for (int t = 0; t < SH::acc; ++t) acc[t] = (f2_d4){0.0, 0.0, 0.0, 0.0};
-  double cost = 0.0;
   long long stamp[TRACE ? 8 : 1];
   int nstamp = 0;
   bool tracing = false;
@@ -496,6 +502,13 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     case 2: f2_emit<NT, 2>(lane, acc, P0, H, tab, part_pp, part_ip, part_ii); break;
     default: f2_emit<NT, 3>(lane, acc, P0, H, tab, part_pp, part_ip, part_ii); break;
   }
+  };  // run
+  static_assert(kRowsClasses == 3, "one instantiation of the batch loop per row class");
+  switch (rows_class_of(cl.ni, cl.nc)) {  // (uniform over the work-group)
+    case 0: run(std::integral_constant<int, kRowsClassNT[0]>{}); break;
+    case 1: run(std::integral_constant<int, kRowsClassNT[1]>{}); break;
+    default: run(std::integral_constant<int, kRowsClassNT[2]>{}); break;
+  }
   // cost partial of the cluster (fixed tree: lanes -> waves -> work-group)
   const double wsum = wave_sum(cost);
   __syncthreads();
@@ -504,32 +517,28 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   if (tid == 0) w.cost_partial[cidx] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// Clusters [first[c], first[c] + count[c]) of row class c (kRowsClassNT) take the instantiation of that class. generic: some
-// cluster has three camera slots (the 9-parameter model always takes the general form).
-void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, const int* class_first, const int* class_count,
+// generic: some cluster has three camera slots (the 9-parameter model always takes the general form of the intrinsics entries).
+void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, int num_clusters,
                        const SchurRowsCluster* clusters, const int* tab, const int* cl_lists, const unsigned short* obs_meta,
                        double* part_pp, double* part_ip, double* part_ii) {
-  // MAVBA_ROWS_TRACE=<file>: the 5th launch of the process (widest model <= 8, class 0) records s_memtime stamps per wave
+  if (num_clusters <= 0) return;
+  // MAVBA_ROWS_TRACE=<file>: the 5th launch of the process (widest model <= 8) records s_memtime stamps per wave
   static const char* trace_file = std::getenv("MAVBA_ROWS_TRACE");
   static int trace_calls = 0;
-  if (trace_file && !generic && kmax_intr > 4 && kmax_intr <= 8 && class_count[0] > 0 && ++trace_calls == 5) {
+  if (trace_file && !generic && kmax_intr > 4 && kmax_intr <= 8 && ++trace_calls == 5) {
     const size_t trace_n = (size_t)4096 * kF2Waves * 16;
     long long* tr = nullptr;
     (void)hipMalloc(reinterpret_cast<void**>(&tr), trace_n * 8);
     (void)hipMemsetAsync(tr, 0, trace_n * 8, st);
     FrontArgs b = a;
     b.trace = tr;
-    hipLaunchKernelGGL((k_schur_rows<8, kRowsClassNT[0], false, true>), dim3(class_count[0]), dim3(kF2Threads), 0, st, b, clusters, tab, cl_lists, obs_meta,
-                       class_first[0], part_pp, part_ip, part_ii);
-    if (class_count[1] > 0)
-      hipLaunchKernelGGL((k_schur_rows<8, kRowsClassNT[1], false>), dim3(class_count[1]), dim3(kF2Threads), 0, st, a, clusters, tab, cl_lists, obs_meta,
-                         class_first[1], part_pp, part_ip, part_ii);
+    hipLaunchKernelGGL((k_schur_rows<8, false, true>), dim3(num_clusters), dim3(kF2Threads), 0, st, b, clusters, tab, cl_lists, obs_meta, part_pp, part_ip, part_ii);
     std::vector<long long> hst(trace_n);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(hst.data(), tr, trace_n * 8, hipMemcpyDeviceToHost);
     (void)hipFree(tr);
     if (FILE* fp = std::fopen(trace_file, "w")) {
-      for (int g = 0; g < std::min(class_count[0], 4096); ++g)
+      for (int g = 0; g < std::min(num_clusters, 4096); ++g)
         for (int wv = 0; wv < kF2Waves; ++wv) {
           const long long* rr = hst.data() + ((size_t)g * kF2Waves + wv) * 16;
           if (rr[0] <= 0) continue;
@@ -541,17 +550,11 @@ void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool g
     }
     return;
   }
-#define MAVBA_ROWS(K, C, G)                                                                                                      \
-  if (class_count[C] > 0)                                                                                                        \
-  hipLaunchKernelGGL((k_schur_rows<K, kRowsClassNT[C], G>), dim3(class_count[C]), dim3(kF2Threads), 0, st, a, clusters, tab, cl_lists, obs_meta, \
-                     class_first[C], part_pp, part_ip, part_ii)
-#define MAVBA_ROWS_ALL(K, G) { MAVBA_ROWS(K, 0, G); MAVBA_ROWS(K, 1, G); }
-  static_assert(kRowsClasses == 2, "one launch per row class");
-  if (kmax_intr <= 0) MAVBA_ROWS_ALL(0, true)
-  else if (kmax_intr <= 4) { if (generic) MAVBA_ROWS_ALL(4, true) else MAVBA_ROWS_ALL(4, false) }
-  else if (kmax_intr <= 8) { if (generic) MAVBA_ROWS_ALL(8, true) else MAVBA_ROWS_ALL(8, false) }
-  else MAVBA_ROWS_ALL(9, true)
-#undef MAVBA_ROWS_ALL
+#define MAVBA_ROWS(K, G) hipLaunchKernelGGL((k_schur_rows<K, G>), dim3(num_clusters), dim3(kF2Threads), 0, st, a, clusters, tab, cl_lists, obs_meta, part_pp, part_ip, part_ii)
+  if (kmax_intr <= 0) MAVBA_ROWS(0, true);
+  else if (kmax_intr <= 4) { if (generic) MAVBA_ROWS(4, true); else MAVBA_ROWS(4, false); }
+  else if (kmax_intr <= 8) { if (generic) MAVBA_ROWS(8, true); else MAVBA_ROWS(8, false); }
+  else MAVBA_ROWS(9, true);
 #undef MAVBA_ROWS
 }
 

@@ -296,7 +296,7 @@ struct mavba_session {
   // k_schur_rows (round 4): the clusters with their row counts, sorted by row class then length; rows_ok: the set-up built
   // them and the clusters take k_schur_rows instead of k_schur_fused
   DevBuf<SchurRowsCluster> d_rows_clusters;
-  int rows_class_first[kRowsClasses] = {0, 0}, rows_class_count[kRowsClasses] = {0, 0};
+  int rows_class_count[kRowsClasses] = {};  // (statistics)
   bool rows_ok = false;
   bool rows_generic = false;  // some cluster has three camera slots: the general form of the intrinsics entries
   DevBuf<PartialReduce> d_reduce_tasks;

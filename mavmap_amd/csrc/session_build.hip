@@ -765,12 +765,11 @@ void mavba_session::finish_structure() {
   const ClusterShape sh = cl_shape;
   const int kClTab = sh.tab(), kClTabPP = sh.tab_pp(), kClTabIP = sh.tab_ip(), kClTabII = sh.tab_ii();
   const int kClImages = sh.images, kClCams = sh.cams;
-  // Round 4: the clusters of k_schur_rows. Same greedy walk over consecutive points, but a cluster is CLOSED when its entry
-  // matrix would pass 80 rows (10 images + 2 cameras + h: 15 instead of 36 tiles of matrix instructions per batch) once it
-  // holds kRowsMinDense points; a shorter one may grow to the full 128 rows, and such a mixed cluster ends where a run of
-  // points with one image set begins that is long enough for a cluster of its own. The point order keeps equal image sets
-  // together (the hash in the key). Chosen when the front end can run inside the cluster kernel at all; otherwise - and
-  // with MAVBA_FUSED_V1 - the clusters of rounds 1-3.
+  // Round 4: the clusters of k_schur_rows. The number of ROWS of a cluster's entry matrix decides what a batch costs (80
+  // rows = 10 images + 2 cameras + h: 15 tiles of matrix instructions; 96 rows: 21; 128 rows: 36), so clusters are formed
+  // from runs of points with one image set by estimated cost (do_range_rows) instead of "until 16 images are full". The
+  // point order keeps equal image sets together (the hash in the key). Chosen when the front end can run inside the
+  // cluster kernel at all; otherwise - and with MAVBA_FUSED_V1 - the clusters of rounds 1-3.
   std::vector<int> cl_ni, cl_nc;
   const bool no_fuse_env = std::getenv("MAVBA_NO_FUSE") != nullptr;  // (read per session: the tests switch paths)
   auto build_clusters = [&](bool rows_mode) {
@@ -785,12 +784,15 @@ void mavba_session::finish_structure() {
     // points per cluster: small problems still give every CU ~2 clusters; large ones up to 256 (fewer partials and emits:
     // C3 0.297 -> 0.283 ms for the cluster kernel, 0.037 -> 0.031 for the finalize pass)
     int kMaxPoints = (int)std::min<long long>(256, std::max<long long>(kClBatch, round_up((int)(nfree / 512), kClBatch)));
-    if (rows_mode) kMaxPoints = (int)std::min<long long>(kRowsMaxPoints, std::max<long long>(kRowsBatch, round_up((int)(nfree / 2048), kRowsBatch)));  // (several work-groups per CU)
+    // k_schur_rows: several 256-lane work-groups share a CU - about 1024 clusters fill the device; a cluster holds whole
+    // 16-point batches
+    if (rows_mode) kMaxPoints = (int)std::min<long long>(kRowsMaxPoints, std::max<long long>(2 * kRowsBatch, round_up((int)(nfree / 1024), kRowsBatch)));
     if (const char* e = std::getenv("MAVBA_CLUSTER_POINTS")) kMaxPoints = std::max(1, std::atoi(e));
     if (rows_mode) kMaxPoints = std::min(kMaxPoints, kRowsMaxPoints);
-    int kRowsMinDense = kRowsBatch;
-    if (const char* e = std::getenv("MAVBA_ROWS_MIN_DENSE")) kRowsMinDense = std::max(1, std::atoi(e));
-    const int kDenseRows = 16 * kRowsClassNT[0];
+    // cost model of the run-based greedy (cycles of one CU: per cluster, per 16-point batch of each row class; measured on
+    // C3, MAVBA_ROWS_COST="F,B0,B1,B2" overrides)
+    double kCostF = 6000.0, kCostB[kRowsClasses] = {15400.0, 17500.0, 27500.0};
+    if (const char* e = std::getenv("MAVBA_ROWS_COST")) std::sscanf(e, "%lf,%lf,%lf,%lf", &kCostF, &kCostB[0], &kCostB[1], &kCostB[2]);
     // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
     // thread": the clusters - and with them the order in which partials are added - must not depend on the
     // machine's core count).
@@ -807,7 +809,7 @@ void mavba_session::finish_structure() {
       for (int p = std::max(r0, tail_begin); p < r_end; ++p)
         if (h_pt_free[p] && (h_pt_start[p + 1] > h_pt_start[p] || q_start[p + 1] > q_start[p])) pt_mode[p] = 2;
       const int r1 = std::min(r_end, std::max(r0, tail_begin));
-      std::vector<int> cur_i, cur_c, pi, ps, prev_ps, qs;
+      std::vector<int> cur_i, cur_c, pi;
       // (epoch tags, never reset: cluster serials are unique over all ranges - a range closes at most kRange + 1 clusters -
       // and so are point indices)
       int cl_serial = rg * (kRange + 1);
@@ -822,11 +824,6 @@ void mavba_session::finish_structure() {
           for (int k = 0; k < kClCams; ++k) r_cams[rg].push_back(k < (int)cur_c.size() ? cur_c[k] : -1);
         }
         cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end; ++cl_serial;
-      };
-      auto sorted_images = [&](int p, std::vector<int>& out) {
-        out.clear();
-        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) if (img_active[h_oimg[a]]) out.push_back(h_oimg[a]);
-        std::sort(out.begin(), out.end());
       };
       for (int p = r0; p < r1; ++p) {
         if (!h_pt_free[p]) continue;
@@ -849,23 +846,7 @@ void mavba_session::finish_structure() {
         };
         int ni, nc;
         grown(ni, nc);
-        bool close_now = ni > kClImages || nc > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1;
-        if (rows_mode && cur_n > 0 && !close_now) {
-          ps = pi;
-          std::sort(ps.begin(), ps.end());
-          const int rows_cur = 6 * (int)cur_i.size() + 9 * (int)cur_c.size() + 1, rows_new = 6 * ni + 9 * nc + 1;
-          if (rows_cur <= kDenseRows) {
-            close_now = rows_new > kDenseRows && cur_n >= kRowsMinDense;
-          } else if (ps != prev_ps && p + kRowsMinDense - 1 < r1) {  // a mixed cluster at the start of a run of equal image sets
-            sorted_images(p + kRowsMinDense - 1, qs);
-            close_now = qs == ps && 6 * (int)ps.size() + 9 * nq + 1 <= kDenseRows;
-          }
-          prev_ps.swap(ps);
-        } else if (rows_mode) {
-          prev_ps = pi;
-          std::sort(prev_ps.begin(), prev_ps.end());
-        }
-        if (close_now) {
+        if (ni > kClImages || nc > kClCams || cur_n >= kMaxPoints || p - cur_p0 >= kClMaxBatches * kClBatch - 1) {
           close(p);
           grown(ni, nc);
         }
@@ -877,9 +858,94 @@ void mavba_session::finish_structure() {
       }
       close(r1);
     };
+    // k_schur_rows: the walk goes over RUNS of consecutive points with one image / camera set (the point order keeps them
+    // together). A run is appended to the open cluster when that is cheaper - in estimated cycles - than a cluster of its own:
+    // a batch costs more the more rows the cluster's entry matrix has (15 / 21 / 36 tiles), a cluster costs its tables and its
+    // emit, and a batch that is not full costs a whole one.
+    auto do_range_rows = [&](int rg, std::vector<int>& in_cluster, std::vector<int>& in_point) {
+      const int r0 = rg * kRange, r_end = std::min(NP, r0 + kRange);
+      for (int p = std::max(r0, tail_begin); p < r_end; ++p)
+        if (h_pt_free[p] && (h_pt_start[p + 1] > h_pt_start[p] || q_start[p + 1] > q_start[p])) pt_mode[p] = 2;
+      const int r1 = std::min(r_end, std::max(r0, tail_begin));
+      struct Run { int p0, p1, n; std::vector<int> imgs, cams; };
+      std::vector<Run> runs;
+      std::vector<int> pi, pc;
+      for (int p = r0; p < r1; ++p) {
+        if (!h_pt_free[p]) continue;
+        pi.clear(); pc.clear();
+        bool dup = false;
+        for (int a = h_pt_start[p]; a < h_pt_start[p + 1]; ++a) {
+          const int i = h_oimg[a];
+          if (!img_active[i]) continue;
+          if (in_point[i] == p) dup = true;
+          in_point[i] = p;
+          pi.push_back(i);
+        }
+        const int nq = q_start[p + 1] - q_start[p];
+        if (pi.empty() && nq == 0) continue;
+        if (!use_clusters || dup || (int)pi.size() > kClImages || nq > kClCams) { pt_mode[p] = 2; continue; }
+        std::sort(pi.begin(), pi.end());
+        for (int q = q_start[p]; q < q_start[p + 1]; ++q) pc.push_back(q_cam[q]);  // (ascending)
+        pt_mode[p] = 1;
+        if (!runs.empty() && runs.back().imgs == pi && runs.back().cams == pc) { runs.back().p1 = p + 1; runs.back().n++; }
+        else runs.push_back(Run{p, p + 1, 1, pi, pc});
+      }
+      auto batches = [](int n) { return (n + kRowsBatch - 1) / kRowsBatch; };
+      auto cost = [&](int n, int ni, int nc) { return kCostF + batches(n) * kCostB[rows_class_of(ni, nc)]; };
+      std::vector<int> cur_i, cur_c;
+      int cl_serial = rg * (kRange + 1), cur_p0 = r0, cur_n = 0;
+      auto close = [&](int p_end) {
+        if (cur_n > 0) {
+          r_ni[rg].push_back((int)cur_i.size()); r_nc[rg].push_back((int)cur_c.size());
+          std::sort(cur_i.begin(), cur_i.end());
+          std::sort(cur_c.begin(), cur_c.end());
+          r_clusters[rg].push_back(SchurCluster{cur_p0, p_end});
+          for (int k = 0; k < kClImages; ++k) r_imgs[rg].push_back(k < (int)cur_i.size() ? cur_i[k] : -1);
+          for (int k = 0; k < kClCams; ++k) r_cams[rg].push_back(k < (int)cur_c.size() ? cur_c[k] : -1);
+        }
+        cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end; ++cl_serial;
+      };
+      auto add = [&](const Run& R, int p_begin, int n) {
+        if (cur_n == 0) cur_p0 = p_begin;
+        for (int i : R.imgs) if (in_cluster[i] != cl_serial) { in_cluster[i] = cl_serial; cur_i.push_back(i); }
+        for (int c : R.cams) if (std::find(cur_c.begin(), cur_c.end(), c) == cur_c.end()) cur_c.push_back(c);
+        cur_n += n;
+      };
+      for (const Run& R : runs) {
+        const int rni = (int)R.imgs.size(), rnc = (int)R.cams.size();
+        bool join = false;
+        if (cur_n > 0 && cur_n + R.n <= kMaxPoints && R.p1 - cur_p0 <= kRowsMaxPoints) {
+          int ni = (int)cur_i.size(), nc = (int)cur_c.size();
+          for (int i : R.imgs) ni += in_cluster[i] != cl_serial;
+          for (int c : R.cams) nc += std::find(cur_c.begin(), cur_c.end(), c) == cur_c.end();
+          join = ni <= kClImages && nc <= kClCams &&
+                 cost(cur_n + R.n, ni, nc) <= cost(cur_n, (int)cur_i.size(), (int)cur_c.size()) + cost(R.n, rni, rnc);
+        }
+        if (join) { add(R, R.p0, R.n); continue; }
+        close(R.p0);
+        if (R.n <= kMaxPoints && R.p1 - R.p0 <= kRowsMaxPoints) { add(R, R.p0, R.n); continue; }
+        // a run longer than a cluster: equal parts of whole batches (a part's SPAN - the run may contain skipped points -
+        // must fit the kernel's table of point starts as well)
+        const int parts = (R.n + kMaxPoints - 1) / kMaxPoints;
+        const int per = std::min(kMaxPoints, round_up((R.n + parts - 1) / parts, kRowsBatch));
+        int p = R.p0, left = R.n;
+        while (left > 0) {
+          int cnt = 0, q = p;
+          while (cnt < per && q < R.p1 && q - p < kRowsMaxPoints) { cnt += pt_mode[q] == 1; ++q; }
+          add(R, p, cnt);
+          left -= cnt;
+          if (left > 0) close(q);
+          p = q;
+        }
+      }
+      close(r1);
+    };
     parallel_ranges(nranges, [&](long long g0, long long g1) {
       std::vector<int> in_cluster(NI, -1), in_point(NI, -1);
-      for (long long g = g0; g < g1; ++g) do_range((int)g, in_cluster, in_point);
+      for (long long g = g0; g < g1; ++g) {
+        if (rows_mode) do_range_rows((int)g, in_cluster, in_point);
+        else do_range((int)g, in_cluster, in_point);
+      }
     }, 2);
     for (int rg = 0; rg < nranges; ++rg) {
       clusters.insert(clusters.end(), r_clusters[rg].begin(), r_clusters[rg].end());
@@ -1188,15 +1254,18 @@ void mavba_session::finish_structure() {
     // the slot order and does not change
     std::vector<int> order(num_clusters);
     for (int c = 0; c < num_clusters; ++c) order[c] = c;
-    auto row_class = [&](int c) { return rows_ok ? rows_class_of(cl_ni[c], cl_nc[c]) : 0; };  // (k_schur_rows: one launch per row class)
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      const int ca = row_class(a), cb = row_class(b);
-      if (ca != cb) return ca < cb;
-      return clusters[a].p1 - clusters[a].p0 > clusters[b].p1 - clusters[b].p0;
-    });
+    auto row_class = [&](int c) { return rows_ok ? rows_class_of(cl_ni[c], cl_nc[c]) : 0; };
+    // (k_schur_rows: longest = most matrix instructions first - batches x tiles of the cluster's row class)
+    auto weight = [&](int c) {
+      const int np = clusters[c].p1 - clusters[c].p0;
+      if (!rows_ok) return (long long)np;
+      const int nt = kRowsClassNT[row_class(c)];
+      return (long long)((np + kRowsBatch - 1) / kRowsBatch) * (60 + nt * (nt + 1) / 2);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight(a) > weight(b); });
     if (rows_ok) {
       std::vector<SchurRowsCluster> rc(clusters.size());
-      for (int k = 0; k < kRowsClasses; ++k) rows_class_first[k] = rows_class_count[k] = 0;
+      for (int k = 0; k < kRowsClasses; ++k) rows_class_count[k] = 0;
       rows_generic = false;
       for (int c = 0; c < num_clusters; ++c) rows_generic = rows_generic || cl_nc[c] > 2;
       for (int c = 0; c < num_clusters; ++c) {
@@ -1204,10 +1273,9 @@ void mavba_session::finish_structure() {
         rc[c] = SchurRowsCluster{clusters[o].p0, clusters[o].p1, cl_ni[o], cl_nc[o]};
         rows_class_count[row_class(o)]++;
       }
-      for (int k = 1; k < kRowsClasses; ++k) rows_class_first[k] = rows_class_first[k - 1] + rows_class_count[k - 1];
       d_rows_clusters.upload(rc, st);
       if (std::getenv("MAVBA_CLUSTER_STATS")) {
-        long long pts[kRowsClasses] = {0, 0}, bat[kRowsClasses] = {0, 0};
+        long long pts[kRowsClasses] = {}, bat[kRowsClasses] = {};
         for (int c = 0; c < num_clusters; ++c) { const int k = row_class(order[c]); pts[k] += rc[c].p1 - rc[c].p0; bat[k] += (rc[c].p1 - rc[c].p0 + kRowsBatch - 1) / kRowsBatch; }
         for (int k = 0; k < kRowsClasses; ++k)
           std::fprintf(stderr, "[cluster stats] k_schur_rows class %d (%d rows): %d clusters, %lld points, %lld batches\n", k, 16 * kRowsClassNT[k], rows_class_count[k], pts[k], bat[k]);

@@ -47,7 +47,7 @@ void mavba_session::launch_front(double r, bool entries) {
     // partials of S for this radius (no entry records in HBM)
     timed("schur_fused", [&] {
       if (rows_ok)
-        launch_schur_rows(st, f, Q > 0 ? KMAX : 0, rows_generic, rows_class_first, rows_class_count, d_rows_clusters.p, d_cl_tab.p, d_cl_lists.p, d_obs_meta.p,
+        launch_schur_rows(st, f, Q > 0 ? KMAX : 0, rows_generic, num_clusters, d_rows_clusters.p, d_cl_tab.p, d_cl_lists.p, d_obs_meta.p,
                           d_part[0].p, d_part[1].p, d_part[2].p);
       else
         launch_schur_fused(st, f, Q > 0 ? KMAX : 0, num_clusters, d_clusters.p, d_cl_tab.p, d_cl_lists.p, d_obs_meta.p, d_q_meta.p, d_part[0].p, d_part[1].p,
