@@ -144,57 +144,70 @@ __device__ __forceinline__ void f2_mfma(const double* __restrict__ E, int lane, 
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-// element (R, C), R >= C, of the cluster's product -> partial slot. Rows: 6 la + r (image slot la), P0 + 9 lc + r
-// (camera slot lc), H (the h row); P0 = 6 * images of the cluster, H = P0 + 9 * cameras.
-__device__ __noinline__ void f2_store(int R, int C, double v, int P0, int H, const int* __restrict__ tab,
-                                         double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
-  if (R < P0) {                       // pose x pose
-    const int la = R / 6, r = R - 6 * la, lb = C / 6, c = C - 6 * lb;
-    if (la == lb && r < c) return;    // diagonal blocks: the finalize pass only reads r >= c
-    const int slot = tab[la * (la + 1) / 2 + lb];
-    if (slot >= 0) part_pp[(size_t)slot * 42 + r * 6 + c] = v;
-  } else if (R < H) {
-    const int lc = (R - P0) / 9, r = (R - P0) - 9 * lc;
-    if (C < P0) {                     // intrinsics x pose
-      const int la = C / 6, c = C - 6 * la;
-      const int slot = tab[kF2TabIP + lc * 16 + la];
-      if (slot >= 0) part_ip[(size_t)slot * 54 + r * 6 + c] = v;
-    } else {                          // intrinsics x intrinsics
-      const int lc2 = (C - P0) / 9, c = (C - P0) - 9 * lc2;
-      if (lc == lc2 && r < c) return;
-      const int slot = tab[kF2TabII + lc * (lc + 1) / 2 + lc2];
-      if (slot >= 0) part_ii[(size_t)slot * 90 + r * 9 + c] = v;
-    }
-  } else if (R == H) {                // h row: the right-hand-side parts of the diagonal blocks
-    if (C < P0) {
-      const int la = C / 6, r = C - 6 * la;
-      const int slot = tab[la * (la + 1) / 2 + la];
-      if (slot >= 0) part_pp[(size_t)slot * 42 + 36 + r] = v;
-    } else if (C < H) {
-      const int lc = (C - P0) / 9, r = (C - P0) - 9 * lc;
-      const int slot = tab[kF2TabII + lc * (lc + 1) / 2 + lc];
-      if (slot >= 0) part_ii[(size_t)slot * 90 + 81 + r] = v;
-    }
-  }
-}
-template <int NT, int W>
-__device__ __forceinline__ void f2_emit(int lane, const f2_d4 (&acc)[F2Shape<NT>::acc], int P0, int H, const int* __restrict__ tab,
-                                        double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
+// ---- the cluster's product leaves as block partials: staged through LDS, written block by block ----
+// The accumulators sit in the matrix instruction's D layout (a lane holds 4 elements of a 16x16 tile); a block partial is
+// 42 / 54 / 90 consecutive doubles somewhere else. Written straight from the registers every store instruction touched
+// up to 64 different cache lines (8 useful bytes in each) - 0.13 of 0.31 ms at C3, half the kernel at C2 - and the index
+// arithmetic per element was unrolled 16-36 times per lane. Now: the lower triangle goes to LDS packed by rows (the entry
+// matrix is free after the last batch), then ONE lane per output element walks the blocks in order - consecutive lanes
+// write consecutive doubles of a partial.
+__device__ __forceinline__ int f2_tri(int R) { return (R * (R + 1)) >> 1; }
+// rows [RLO, RHI) of the lower triangle, packed: element (R, C) at tri(R) - tri(RLO) + C
+template <int NT, int W, int RLO, int RHI>
+__device__ __forceinline__ void f2_stage(double* __restrict__ T, int lane, const f2_d4 (&acc)[F2Shape<NT>::acc]) {
   const int li = lane & 15, lk = lane >> 4;
   int t = 0;
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
-      if (t % kF2Waves == W) {
+      if (t % kF2Waves == W && 16 * i >= RLO && 16 * i < RHI) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int R = 16 * i + lk + 4 * r, C = 16 * j + li;  // D layout of the matrix instruction
-          if (R >= C && R <= H) f2_store(R, C, acc[t / kF2Waves][r], P0, H, tab, part_pp, part_ip, part_ii);
+          if (i > j || C <= R) T[f2_tri(R) - f2_tri(RLO) + C] = acc[t / kF2Waves][r];
         }
       }
       ++t;
     }
+}
+// One lane per output element of the blocks whose source row lies in [RLO, RHI). Rows of the product: 6 la + r (image slot
+// la), P0 + 9 lc + r (camera slot lc), H (the h row); P0 = 6 ni, H = P0 + 9 nc. tri_la / tri_lb: slot of the lower
+// triangle of image pairs -> (la, lb).
+template <int RLO, int RHI, bool ALL>
+__device__ __forceinline__ void f2_write_blocks(const double* __restrict__ T, int tid, int ni, int nc, int P0, int H,
+                                                const int* __restrict__ tab, const unsigned char* __restrict__ tri_la,
+                                                const unsigned char* __restrict__ tri_lb, double* __restrict__ part_pp,
+                                                double* __restrict__ part_ip, double* __restrict__ part_ii) {
+  auto src = [&](int R, int C) { return T[f2_tri(R) - f2_tri(RLO) + C]; };
+  auto in_pass = [&](int R) { return ALL || (R >= RLO && R < RHI); };
+  const int npp = (ni * (ni + 1)) >> 1;
+  for (int e = tid; e < npp * 42; e += kF2Threads) {  // pose x pose (+ the h row's part of the diagonal blocks)
+    const int s = e / 42, o = e - 42 * s, la = tri_la[s], lb = tri_lb[s];
+    int R, C;
+    if (o < 36) { const int r = o / 6, c = o - 6 * r; if (la == lb && r < c) continue; R = 6 * la + r; C = 6 * lb + c; }
+    else { if (la != lb) continue; R = H; C = 6 * la + (o - 36); }
+    if (!in_pass(R)) continue;
+    const int slot = tab[s];
+    if (slot >= 0) part_pp[(size_t)slot * 42 + o] = src(R, C);
+  }
+  for (int e = tid; e < nc * ni * 54; e += kF2Threads) {  // intrinsics x pose
+    const int s = e / 54, o = e - 54 * s, lc = s / ni, la = s - ni * lc, r = o / 6, c = o - 6 * r;
+    const int R = P0 + 9 * lc + r;
+    if (!in_pass(R)) continue;
+    const int slot = tab[kF2TabIP + lc * 16 + la];
+    if (slot >= 0) part_ip[(size_t)slot * 54 + o] = src(R, 6 * la + c);
+  }
+  const int nii = (nc * (nc + 1)) >> 1;
+  for (int e = tid; e < nii * 90; e += kF2Threads) {  // intrinsics x intrinsics (+ the h row's part)
+    const int s = e / 90, o = e - 90 * s, lc = tri_la[s], lc2 = tri_lb[s];
+    int R, C;
+    if (o < 81) { const int r = o / 9, c = o - 9 * r; if (lc == lc2 && r < c) continue; R = P0 + 9 * lc + r; C = P0 + 9 * lc2 + c; }
+    else { if (lc != lc2) continue; R = H; C = P0 + 9 * lc + (o - 81); }
+    if (!in_pass(R)) continue;
+    const int slot = tab[kF2TabII + s];
+    if (slot >= 0) part_ii[(size_t)slot * 90 + o] = src(R, C);
+  }
 }
 }  // namespace
 
@@ -219,6 +232,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   __shared__ double s_red[kF2Waves];
   __shared__ int s_tab[kF2Tab];
   __shared__ int s_pstart[kRowsMaxPoints + 1];
+  __shared__ unsigned char s_tri_la[kF2TabIP], s_tri_lb[kF2TabIP];  // slot la (la + 1) / 2 + lb of a lower triangle -> (la, lb)
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = tid >> 4, i = tid & 15;
   const SweepArgs& w = a.sw;
   const int NPs = a.NPs;
@@ -228,6 +242,11 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   const int P0 = 6 * cl.ni, H = P0 + 9 * cl.nc;
   for (int j = tid; j <= npts; j += kF2Threads) s_pstart[j] = a.pt_start[cl.p0 + j];
   for (int j = tid; j < kF2Tab; j += kF2Threads) s_tab[j] = tabs[(size_t)cidx * kF2Tab + j];
+  if (tid < kF2TabIP) {
+    int la = 0;
+    while (((la + 1) * (la + 2)) >> 1 <= tid) ++la;
+    s_tri_la[tid] = (unsigned char)la; s_tri_lb[tid] = (unsigned char)(tid - ((la * (la + 1)) >> 1));
+  }
   {
     const int* lists = cl_lists + (size_t)cidx * (kClImagesMax + kClCamsMax);
     if (tid < kClImagesMax * 9) {
@@ -495,12 +514,23 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
       for (int t = 0; t < nstamp; ++t) out[1 + t] = stamp[t];
     }
   }
-  const int* tab = s_tab;
-  switch (wv) {
-    case 0: f2_emit<NT, 0>(lane, acc, P0, H, tab, part_pp, part_ip, part_ii); break;
-    case 1: f2_emit<NT, 1>(lane, acc, P0, H, tab, part_pp, part_ip, part_ii); break;
-    case 2: f2_emit<NT, 2>(lane, acc, P0, H, tab, part_pp, part_ip, part_ii); break;
-    default: f2_emit<NT, 3>(lane, acc, P0, H, tab, part_pp, part_ip, part_ii); break;
+  if constexpr (!(MAVBA_ROWS_SKIP & 64)) {
+    // passes over row ranges of the packed lower triangle that fit the (free) entry matrix buffer
+    auto pass = [&](auto lo_c, auto hi_c) {
+      constexpr int RLO = decltype(lo_c)::value, RHI = decltype(hi_c)::value;
+      static_assert((RHI * (RHI + 1) - RLO * (RLO + 1)) / 2 <= SHMAX::rows * kF2Pitch, "a pass must fit the entry matrix buffer");
+      lds_barrier();  // every wave's last matrix instructions (or the previous pass's readers) are done with the buffer
+      switch (wv) {
+        case 0: f2_stage<NT, 0, RLO, RHI>(E, lane, acc); break;
+        case 1: f2_stage<NT, 1, RLO, RHI>(E, lane, acc); break;
+        case 2: f2_stage<NT, 2, RLO, RHI>(E, lane, acc); break;
+        default: f2_stage<NT, 3, RLO, RHI>(E, lane, acc); break;
+      }
+      lds_barrier();
+      f2_write_blocks<RLO, RHI, (RLO == 0 && RHI == 16 * NT)>(E, tid, cl.ni, cl.nc, P0, H, s_tab, s_tri_la, s_tri_lb, part_pp, part_ip, part_ii);
+    };
+    if constexpr (NT <= 6) pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 16 * NT>{});
+    else { pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 96>{}); pass(std::integral_constant<int, 96>{}, std::integral_constant<int, 16 * NT>{}); }
   }
   };  // run
   static_assert(kRowsClasses == 3, "one instantiation of the batch loop per row class");

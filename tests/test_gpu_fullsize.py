@@ -112,16 +112,40 @@ def test_c5_full_size_step_matches_oracle(mavba, fast_oracle, c5_full):
     generic term lists. One linear step against the oracle (block-sparse Schur complement + envelope Cholesky on all host
     cores - the same arithmetic as its dense path, tests/test_oracle.py)."""
     p = c5_full
-    radius = 1e4
-    with fast_oracle.linear_solver(fast_oracle.SPARSE):
-        ref = fast_oracle.linear_step(p, radius, jac_mode=1)
     with mavba.Session(p) as s:
         info = s.info()
         assert info["reduced_dim"] == 6 * 2000 + 18
         assert 0 < info["clustered_points"] < p.num_points and info["schur_terms"][0] > 0
-        S, v = s.reduced_system(radius)
-        st = s.linear_step(radius)
-    _check_step(st, S, v, ref, ("C5", radius))
+        for radius in (1e4, 50.0):  # the first iteration's radius and one after a few rejected steps
+            with fast_oracle.linear_solver(fast_oracle.SPARSE):
+                ref = fast_oracle.linear_step(p, radius, jac_mode=1)
+            S, v = s.reduced_system(radius)
+            st = s.linear_step(radius)
+            _check_step(st, S, v, ref, ("C5", radius))
+
+
+def test_c5_full_size_solve_matches_oracle(mavba, fast_oracle, c5_full):
+    """One COMPLETE full-size C5 solve with the reference's global-BA options (src/mapper.cc:170-174 through
+    bundle_adjustment.cc:553-612) against the oracle's sparse mode on all host cores: rotation priors, generic term lists of
+    the long tracks and the launch-per-panel factorisation of a 12 018-column system all the way to termination - same
+    iteration counts, same termination, final cost / RMSE / every kind of parameter block / point errors within 1e-6."""
+    p = c5_full
+    po, pg = p.copy(), p.copy()
+    with fast_oracle.linear_solver(fast_oracle.SPARSE):
+        ro, eo = fast_oracle.solve(po, fast_oracle.options(**global_opts()), jac_mode=1, want_point_errors=True)
+    eg = np.full(p.num_points, np.nan)
+    _, rg = mavba.bundle_adjustment(pg, global_opts(), point3D_errors=eg)
+    assert rg["termination"] == ro["termination"], (rg["termination_name"], ro["termination_name"])
+    assert rg["num_successful_steps"] == ro["num_successful_steps"]
+    assert rg["num_unsuccessful_steps"] == ro["num_unsuccessful_steps"]
+    assert rg["num_residuals"] == ro["num_residuals"]
+    assert abs(rg["initial_cost"] - ro["initial_cost"]) <= 1e-10 * ro["initial_cost"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+    rmse_g = np.sqrt(rg["final_cost"] / rg["num_residuals"])
+    rmse_o = np.sqrt(ro["final_cost"] / ro["num_residuals"])
+    assert abs(rmse_g - rmse_o) <= 1e-6 * rmse_o
+    assert_params_close(pg, po)
+    assert rel_err(eg, eo) < 1e-6
 
 
 def _solve_stepwise(s):
