@@ -89,8 +89,11 @@ PMC_KERNEL = {  # bench timer name -> rocprofv3 kernel-name prefix in profiles/*
     "backsub_points": "k_backsub_points", "schur_chunks_pp": "k_schur_chunks<6, 6", "schur_chunks_ip": "k_schur_chunks<9, 6",
     "schur_chunks_ii": "k_schur_chunks<9, 9", "schur_clusters": "k_schur_clusters", "schur_finalize": "k_schur_finalize",
     "chol_factor": "k_chol_persist", "chol_backsolve": "k_chol_backsolve_all", "point_front": "k_point_front<8, true",
-    "point_front_sums": "k_point_front<8, false", "schur_fused": "k_schur_fused",
+    "point_front_sums": "k_point_front<8, false", "schur_fused": "k_schur_rows",
 }
+# kernels every rank runs in full when the points are sharded (the reduced camera system is factorised redundantly)
+REPLICATED = {"chol_factor", "chol_backsolve", "schur_finalize", "update_cameras", "camera_reduce", "reduce", "memset_S", "scales",
+              "cam_prepare", "rot_prior"}
 
 
 PMC_ROUND = "r03"
@@ -367,9 +370,9 @@ def main():
                                 sweep_equivalent_frac=round(sweep_bytes / (dominant["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                 mfma_util=None if not mfma else (mfma.get("schur_fused") or {}).get("mfma_util"),
                                 mfma_counters=None if not mfma else mfma.get("schur_fused"))
-                roofline["note"] = ("k_schur_fused: Jacobian evaluation, per-point sums, 3x3 factors AND the Schur complement of the point "
+                roofline["note"] = ("k_schur_rows: Jacobian evaluation, per-point sums, 3x3 factors AND the Schur complement of the point "
                                     "clusters (E E^T on v_mfma_f64_16x16x4_f64) in one kernel, no Jacobian and no entry records in HBM. "
-                                    "FP64 vector and matrix instructions share the SIMD's pipe, so the kernel is bound by their SUM; "
+                                    "FP64 vector and matrix instructions share the SIMD's pipe (profiles/r04_pipe_bench_fp64.txt), so the kernel is bound by their SUM; "
                                     "achieved / frac price only SURVEY 8(d)'s Schur-formation flops sum_p (6 L_p + K_p)^2 * 6 over the "
                                     "kernel's time; executed_* = matrix-instruction flops really issued; sweep_equivalent_* = SURVEY "
                                     "8(d)'s Jacobian-sweep bytes (J counted as if written) over the same time")
@@ -450,6 +453,16 @@ def main():
                                         "reference's Ceres path; the north star's >= 10x-over-Ceres target is unmeasured")
             log("cpu_baseline:", cpu_baseline)
 
+        # Amdahl on this run's own split: what sharding the points can and cannot shorten (the exchange is left out: an upper bound)
+        rep_ms = sum(r["avg_ms"] * r["launches"] for r in table if r["kernel"] in REPLICATED) / args.steps
+        shd_ms = sum(r["avg_ms"] * r["launches"] for r in table if r["kernel"] not in REPLICATED) / args.steps
+        one_gpu_shd = shd_ms * world  # (the sharded kernels of this rank cover 1 / world of the points)
+        scaling_model = {
+            "replicated_ms_per_iteration": round(rep_ms, 4), "sharded_ms_per_iteration_this_rank": round(shd_ms, 4),
+            "expected_speedup_bound": {str(n): round((one_gpu_shd + rep_ms) / (one_gpu_shd / n + rep_ms), 3) for n in (2, 4, 8)},
+            "note": "Amdahl bound from the event timers of this run: the reduced camera system is all-reduced and then factorised "
+                    "REDUNDANTLY on every rank (chol_factor, chol_backsolve, schur_finalize, ...), only the per-point work shards. "
+                    "The all-reduce of the packed tiles and launch gaps are not in it: the measured speed-up will be lower"}
         value = args.steps / elapsed
         # HBM bytes one LM iteration moves (committed counter pass x this run's launch counts) against the algorithmic
         # bytes of ONE Jacobian sweep (48 + 16 + 2 (9 + K) 8 per observation)
@@ -472,7 +485,7 @@ def main():
             "reduced_solve": reduced_solve,
             "jacobian_sweep": jacobian_probe,
             "front_end": None if not front else {
-                "kernel": "k_point_front" if front["kernel"] == "point_front" else "k_schur_fused (front end + cluster Schur complement in one kernel: the time is the WHOLE kernel's)" + (" + k_point_front over the points behind the clusters (%.4f ms)" % front["tail_ms"] if front.get("tail_ms") else ""), "avg_ms": front["avg_ms"], "obs_per_sec": round(prob.num_obs / (front["avg_ms"] * 1e-3), 1),
+                "kernel": "k_point_front" if front["kernel"] == "point_front" else "k_schur_rows (front end + cluster Schur complement in one kernel: the time is the WHOLE kernel's)" + (" + k_point_front over the points behind the clusters (%.4f ms)" % front["tail_ms"] if front.get("tail_ms") else ""), "avg_ms": front["avg_ms"], "obs_per_sec": round(prob.num_obs / (front["avg_ms"] * 1e-3), 1),
                 "bound": "hbm", "achieved": front["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": front["frac"],
                 "front_own_bytes": front_own_bytes if front["kernel"] == "point_front" else None,
                 "own_achieved": round(front_own_bytes / (front["avg_ms"] * 1e-3) / 1e9, 1) if front["kernel"] == "point_front" else None,
@@ -489,6 +502,7 @@ def main():
                                "factor_gflop_envelope": round(info["factor_flops"] / 1e9, 3),
                                "factor_gflop_dense_equivalent": round(info["dense_factor_flops"] / 1e9, 3)},
             "cpu_baseline": cpu_baseline,
+            "scaling_model": scaling_model,
             "traffic_per_iteration": traffic_iter,
             "kernels": table,
             "solve": {"iterations": final["num_successful_steps"] + final["num_unsuccessful_steps"],

@@ -213,15 +213,20 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
     std::string error;
   };
   std::vector<Shard> sh(world);
-  // observations to their rank, input order kept
+  // observations to their rank, input order kept: count, size once, fill (no per-element growth)
   std::vector<int> rank_of_point((size_t)std::max(P->num_points, 1), 0);
   for (int r = 0; r < world; ++r) for (int p = bounds[r]; p < bounds[r + 1]; ++p) rank_of_point[p] = r;
-  for (long long o = 0; o < P->num_obs; ++o) {
-    const int p = P->obs_point[o];
-    if (p < 0 || p >= P->num_points) throw Failure(MAVBA_ERR_BAD_INDEX, "observation index out of range");
-    Shard& S = sh[rank_of_point[p]];
-    S.uv.push_back(P->obs_uv[2 * o]); S.uv.push_back(P->obs_uv[2 * o + 1]);
-    S.oimg.push_back(P->obs_image[o]); S.opt.push_back(p - bounds[rank_of_point[p]]);
+  {
+    std::vector<long long> cnt(world, 0);
+    for (long long o = 0; o < P->num_obs; ++o) cnt[rank_of_point[P->obs_point[o]]]++;  // (indices validated by shard_bounds)
+    for (int r = 0; r < world; ++r) { sh[r].uv.resize(2 * (size_t)cnt[r]); sh[r].oimg.resize((size_t)cnt[r]); sh[r].opt.resize((size_t)cnt[r]); cnt[r] = 0; }
+    for (long long o = 0; o < P->num_obs; ++o) {
+      const int p = P->obs_point[o], r = rank_of_point[p];
+      Shard& S = sh[r];
+      const size_t at = (size_t)cnt[r]++;
+      S.uv[2 * at] = P->obs_uv[2 * o]; S.uv[2 * at + 1] = P->obs_uv[2 * o + 1];
+      S.oimg[at] = P->obs_image[o]; S.opt[at] = p - bounds[r];
+    }
   }
   for (int r = 0; r < world; ++r) {
     Shard& S = sh[r];
@@ -240,6 +245,17 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
     std::memset(&S.res, 0, sizeof(S.res));
   }
 
+  // The exchange. Ranks on DISTINCT devices: one RCCL communicator per rank inside this process (ncclCommInitRank from the
+  // rank's own thread, one unique id) - the all-reduce of the reduced camera system is enqueued on the session's stream
+  // like in the process-per-GPU launch, no host barrier, no stream synchronisation per collective. Ranks that share a
+  // device (MAVBA_GPUS_SAME_DEVICE: tests on one GPU - RCCL refuses duplicates), no librccl, or MAVBA_GPUS_EXCHANGE=inproc:
+  // the peer-access kernel behind host barriers.
+  bool use_rccl = !same_device;
+  if (const char* e = std::getenv("MAVBA_GPUS_EXCHANGE")) use_rccl = use_rccl && std::string(e) != "inproc";
+  unsigned char uid[128];
+  if (use_rccl) {
+    try { rccl_unique_id(uid); } catch (const std::exception&) { use_rccl = false; }  // (librccl.so not loadable)
+  }
   std::vector<RankCtx> ctx(world);
   auto worker = [&](int r) {
     Shard& S = sh[r];
@@ -248,7 +264,12 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
     o.device = G.device[r];
     ctx[r] = RankCtx{&G, r};
     S.rc = mavba_session_create(&S.prob, &o, &s);
-    if (S.rc == MAVBA_OK) S.rc = mavba_session_set_allreduce(s, inproc_allreduce, &ctx[r], r, world);
+    if (use_rccl) {
+      // every rank must reach ncclCommInitRank or none: a rank whose set-up failed would leave the others waiting in it
+      if (S.rc != MAVBA_OK) { S.error = g_last_error; G.fail(); }
+      if (!G.barrier() && S.rc == MAVBA_OK) { S.rc = MAVBA_ERR_HIP; g_last_error = "another rank failed during set-up"; }
+    }
+    if (S.rc == MAVBA_OK) S.rc = use_rccl ? mavba_session_set_rccl(s, uid, r, world) : mavba_session_set_allreduce(s, inproc_allreduce, &ctx[r], r, world);
     int done = 0;
     if (S.rc == MAVBA_OK) S.rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &S.term);
     if (S.rc == MAVBA_OK) S.rc = mavba_session_result(s, &S.res);

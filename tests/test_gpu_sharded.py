@@ -295,6 +295,41 @@ def test_native_rccl_two_or_more_ranks(mavba, tmp_path):
     assert_params_close(dict(poses=ranks[0]["poses"], intrinsics=ranks[0]["intr"], points=pts), single, tol=1e-8)
 
 
+def test_the_drivers_multi_gpu_bench_command_with_two_ranks_on_one_gpu(mavba):
+    """Exactly the command the driver uses for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), here with the
+    two ranks SHARING this box's GPU: MAVBA_DIST_BACKEND=gloo (RCCL refuses two ranks on one device), so the exchange goes
+    through the torch.distributed hook. What it pins before an 8-GPU node exists: argument parsing and the rank / world
+    environment, the sharding of the configuration, the barrier + max-over-ranks timing, ONE JSON line from rank 0 with the
+    contract's keys, n_gpus, "scaling": "strong" and the Amdahl bound of the replicated solve."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--config", "C2", "--scale", "0.2",
+           "--no-cpu-baseline"]
+    env = dict(os.environ, MAVBA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints, nobody else
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["cpu_baseline"] is None  # (rank 0 at N = 1 only)
+    assert "sharded over 2 ranks" in d["config"]["parallelism"]
+    bound = d["scaling_model"]["expected_speedup_bound"]
+    assert 1.0 <= bound["2"] <= 2.0 and bound["2"] <= bound["4"] <= bound["8"] <= 8.0
+    assert abs(d["ms_per_step"] * d["value"] - 1e3) < 1.0  # iterations / second and milliseconds / iteration of the same clock
+
+
 @pytest.mark.parametrize("world,staged", [(2, False), (4, False), (3, True)])
 def test_one_process_several_ranks_through_mavba_solve(mavba, oracle, monkeypatch, world, staged):
     """MAVBA_GPUS=N: ONE mavba_solve call - what an unchanged mapper.cc issues through the shim - shards the points over N
