@@ -240,6 +240,8 @@ void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blo
                            const double* cam_rec, const double* scale_cam, const int* off_img, const int* off_cam,
                            double* S, double* v);
 void launch_tiles_copy(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, double* buf, bool to_buf);
+// zeroes the listed 64x64 tiles of M and the `tail_rows` rows below row ld (the right-hand-side block)
+void launch_tiles_zero(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, int tail_rows);
 // col_var[t]: variable (index into scale_cam) held by matrix column t, -1 for padding columns.
 void launch_fix_diag(hipStream_t st, int n_mat, int ld, bool add_one, const int* col_var,
                      const double* scale_cam, double* S);
@@ -351,6 +353,8 @@ struct CholStructure {
   CholFront* d_fronts = nullptr;
   CholMerge* d_merges = nullptr;
   double* d_shadow = nullptr;
+  int2* d_env_tiles = nullptr;    // (row tile, column tile) of every tile inside the envelope: what the in-place factorisation overwrites
+  int num_env_tiles = 0;
   // persistent schedule
   int active_tiles = 0;  // leading tile columns that hold a free parameter (0: all); the rest is identity with a zero right-hand side
   bool persist_ok = false;        // a schedule exists (structure consistent, fits the resident grid)

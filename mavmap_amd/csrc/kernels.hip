@@ -2340,6 +2340,25 @@ __global__ void __launch_bounds__(256) k_tiles_copy(int num_tiles, const int2* _
     if (to_buf) *b = *a; else *a = *b;
   }
 }
+__global__ void __launch_bounds__(256) k_tiles_zero(int num_tiles, const int2* __restrict__ tiles, double* __restrict__ M, int ld, int tail_rows) {
+  const int t = blockIdx.x;
+  if (t < num_tiles) {
+    const int2 rc = tiles[t];
+    double* tile = M + (size_t)rc.x * 64 * ld + (size_t)rc.y * 64;
+    for (int e = threadIdx.x; e < 2048; e += 256) {
+      const int row = e >> 5, c2 = (e & 31) * 2;
+      *reinterpret_cast<double2*>(tile + (size_t)row * ld + c2) = make_double2(0.0, 0.0);
+    }
+  } else {  // the rows below the matrix (right-hand side), spread over the remaining work-groups
+    double2* tail = reinterpret_cast<double2*>(M + (size_t)ld * ld);
+    const size_t n2 = (size_t)tail_rows * ld / 2;
+    for (size_t e = (size_t)(t - num_tiles) * 256 + threadIdx.x; e < n2; e += (size_t)(gridDim.x - num_tiles) * 256) tail[e] = make_double2(0.0, 0.0);
+  }
+}
+void launch_tiles_zero(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, int tail_rows) {
+  const int extra = std::max(1, std::min(64, (int)(((size_t)tail_rows * ld / 2 + 4095) / 4096)));
+  hipLaunchKernelGGL(k_tiles_zero, dim3(num_tiles + extra), dim3(256), 0, st, num_tiles, tiles, M, ld, tail_rows);
+}
 void launch_tiles_copy(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, double* buf, bool to_buf) {
   if (num_tiles <= 0) return;
   hipLaunchKernelGGL(k_tiles_copy, dim3(num_tiles), dim3(256), 0, st, num_tiles, tiles, M, ld, buf, to_buf ? 1 : 0);

@@ -329,6 +329,7 @@ struct mavba_session {
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
   bool M_is_clean = false;       // d_M holds zeros outside the entries the assembly writes
+  bool M_outside_clean = false;  // d_M was cleared as a whole since it was allocated: only tiles inside the envelope can be dirty
   // cleared when a persistent factorisation launch had to give up; a session created within the next
   // kPersistCooldownSessions sessions of the process starts without it (a device shared with another tenant would
   // otherwise pay the 0.3 s time-out once per bundle_adjustment() call). Decided in start(): only a single-rank session

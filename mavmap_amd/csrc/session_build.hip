@@ -680,6 +680,7 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   }
   d_M.alloc((size_t)(n_mat + 64) * n_mat); d_L.alloc((size_t)(n_mat + 64) * n_mat);
   M_is_clean = false;
+  M_outside_clean = false;  // (fresh memory: the first assembly clears all of it)
   d_ymat.alloc(n_mat); d_diag_ws.alloc((size_t)n_mat * 64);
 }
 

@@ -162,7 +162,13 @@ void mavba_session::assemble(double r) {
   // in place, makes a fresh clear necessary.
   if (!M_is_clean) {
     timed("memset_S", [&] {
-      HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st));
+      // Outside the envelope nothing ever writes: after the first full clear only the envelope's tiles (which the in-place
+      // factorisation of the launch-per-panel schedule overwrote) and the right-hand-side rows are cleared again.
+      if (M_outside_clean && chol_struct.num_env_tiles > 0 && !sharded())
+        launch_tiles_zero(st, chol_struct.num_env_tiles, chol_struct.d_env_tiles, d_M.p, n_mat, 64);
+      else
+        HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st));
+      M_outside_clean = true;
       // unit diagonal of the columns no block of S covers (padding, entirely constant blocks); the finalize pass
       // writes the diagonal of the constant parameters inside its blocks itself
       launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);

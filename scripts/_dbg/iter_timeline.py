@@ -7,7 +7,7 @@ f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mavba::", "")[:44]
-starts = [i for i, r in enumerate(rows) if name(r).startswith("k_schur_fused") or name(r).startswith("k_point_front<8, true")]
+starts = [i for i, r in enumerate(rows) if name(r).startswith("k_schur_fused") or name(r).startswith("k_schur_rows") or name(r).startswith("k_point_front<8, true")]
 iters = [rows[a:b] for a, b in zip(starts, starts[1:])]
 iters = iters[len(iters) // 3:]
 L = statistics.mode(len(it) for it in iters)
