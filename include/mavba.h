@@ -408,6 +408,8 @@ int mavba_session_linear_step(mavba_session* s, double radius, double* d_poses,
 /* Time `reps` back-to-back launches of the Jacobian-sweep kernel alone with
  * HIP events on the session's stream; *ms_avg = average per launch. */
 int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg);
+/* options.profile_kernels for the iterations that follow (the event brackets cost ~10 us per kernel: time without, profile after). */
+int mavba_session_set_profiling(mavba_session* s, int32_t on);
 /* Probe: `reps` passes of the linear solve's front end (Jacobians, point blocks, cluster Schur complements: k_schur_rows)
  * at trust-region radius `radius`; average milliseconds per pass. */
 int mavba_session_time_front(mavba_session* s, double radius, int32_t reps, float* ms_avg);

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "mavba_session_create", "mavba_session_destroy", "mavba_session_reset", "mavba_session_iterate",
     "mavba_session_result", "mavba_session_get_params", "mavba_session_point_errors",
     "mavba_session_set_allreduce", "mavba_session_eval_jacobian", "mavba_session_reduced_dim",
-    "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian", "mavba_session_time_front",
+    "mavba_session_reduced_system", "mavba_session_linear_step", "mavba_session_time_jacobian", "mavba_session_time_front", "mavba_session_set_profiling",
     "mavba_session_kernel_stats", "mavba_session_get_info", "mavba_dense_spd_solve",
     "mavba_scene_create", "mavba_scene_destroy", "mavba_scene_set_camera", "mavba_scene_set_image", "mavba_scene_add_point2d",
     "mavba_scene_add_points2d", "mavba_scene_set_point3d", "mavba_scene_link", "mavba_scene_delete_point3d", "mavba_scene_get_image", "mavba_scene_get_point3d",
@@ -84,6 +84,7 @@ def load():
     L.mavba_session_linear_step.argtypes = [sp, C.c_double, dp, dp, dp, dp]
     L.mavba_session_time_jacobian.argtypes = [sp, C.c_int32, C.POINTER(C.c_float)]
     L.mavba_session_time_front.argtypes = [sp, C.c_double, C.c_int32, C.POINTER(C.c_float)]
+    L.mavba_session_set_profiling.argtypes = [sp, C.c_int32]
     L.mavba_session_kernel_stats.argtypes = [sp, C.POINTER(A.CKernelStat), C.c_int32]
     L.mavba_session_get_info.argtypes = [sp, C.POINTER(A.CSessionInfo)]
     L.mavba_dense_spd_solve.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
@@ -509,6 +510,10 @@ class Session:
         mcc = C.c_double()
         _check(load().mavba_session_linear_step(self._h, float(radius), _d(dp), _d(di), _d(dx), C.byref(mcc)))
         return dict(d_poses=dp, d_intr=di, d_points=dx, model_cost_change=mcc.value)
+
+    def set_profiling(self, on):
+        """Event brackets around the kernels on / off for the iterations that follow."""
+        _check(load().mavba_session_set_profiling(self._h, 1 if on else 0))
 
     def time_front(self, radius=1e4, reps=20):
         """Average milliseconds of one pass of the linear solve's front end (probe)."""

@@ -397,6 +397,16 @@ int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   MAVBA_CATCH
 }
 
+// Event brackets around the kernels on / off for the iterations that follow (options.profile_kernels): a bracket costs ~10 us
+// of queue drain per kernel, so the bench times its steps without them and collects the kernel timers in a second pass.
+int mavba_session_set_profiling(mavba_session* s, int32_t on) {
+  MAVBA_SESSION_TRY(s)
+  s->sync();
+  s->opt.profile_kernels = on ? 1 : 0;
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
 // Probe: the front end of a linear solve (k_schur_rows / k_schur_fused, or k_point_front) for trust-region radius
 // `radius`, `reps` launches back to back at the current parameters, average milliseconds per pass (HIP events on the
 // session's stream). Leaves the session as an evaluation would.

@@ -188,6 +188,39 @@ void pinned_free(void* p) {
   (void)hipHostFree(p);
 }
 
+// Host-mapped, COHERENT slots (256 B) for the LM scalars a session's k_lm_snapshot publishes and its host loop polls: one
+// slab per process, slots handed out and returned (a local-BA mapper creates a session per call).
+namespace {
+struct PubPool { std::mutex m; char* slab = nullptr; std::vector<int> free_slots; bool tried = false; };
+PubPool& pub_pool() { static PubPool* p = new PubPool; return *p; }
+constexpr int kPubSlots = 256, kPubSlotBytes = 256;
+}  // namespace
+double* lm_pub_alloc() {
+  PubPool& P = pub_pool();
+  std::lock_guard<std::mutex> g(P.m);
+  if (!P.tried) {
+    P.tried = true;
+    void* q = nullptr;
+    if (hipHostMalloc(&q, (size_t)kPubSlots * kPubSlotBytes, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+      P.slab = static_cast<char*>(q);
+      std::memset(P.slab, 0, (size_t)kPubSlots * kPubSlotBytes);
+      for (int i = kPubSlots - 1; i >= 0; --i) P.free_slots.push_back(i);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  if (!P.slab || P.free_slots.empty()) return nullptr;  // (the caller falls back to the copy + synchronise read-back)
+  const int sl = P.free_slots.back();
+  P.free_slots.pop_back();
+  return reinterpret_cast<double*>(P.slab + (size_t)sl * kPubSlotBytes);
+}
+void lm_pub_free(double* p) {
+  if (!p) return;
+  PubPool& P = pub_pool();
+  std::lock_guard<std::mutex> g(P.m);
+  P.free_slots.push_back((int)((reinterpret_cast<char*>(p) - P.slab) / kPubSlotBytes));
+}
+
 // Copies between PAGEABLE host memory and the device. Handed a pageable buffer of a megabyte or more, the HIP runtime
 // page-locks it in place (a userptr registration with the kernel driver); when that memory is later freed or trimmed by
 // the allocator, the driver's MMU notifier quiesces ALL queues of the process until a worker has revalidated them -

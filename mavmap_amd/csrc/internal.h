@@ -122,6 +122,25 @@ enum {
   SC_COUNT = 16
 };
 
+// ---- the LM decision shared by the host loop and the speculative evaluation's kernels (lm_decide.h) ----
+enum { LM_REJECTED = 0, LM_ACCEPTED = 1, LM_INVALID = 2, LM_TERM_PTOL = 3, LM_TERM_FTOL = 4, LM_TERM_GTOL = 5 };
+// Loop state and options at the moment the candidate was enqueued (what k_lm_snapshot and the host loop feed lm_decide
+// with). dec: where k_lm_snapshot left {code, radius} on the device - a kernel of the speculative evaluation runs only if
+// dec[0] == LM_ACCEPTED (null: not speculative, always runs).
+struct LmSpec {
+  const double* dec;
+  const double* scal;
+  double radius, decrease_factor;                       // trust region before the decision
+  double ptol, ftol, min_rel_dec, max_radius, abs_gtol;  // options (abs_gtol = gradient_tolerance * max|g_0|)
+  int pending_eval;                                      // the scalars of the evaluation at the current point arrive with this candidate
+};
+struct LmDecision {
+  int code;
+  double radius, decrease_factor;        // trust region after the decision (unchanged by a termination)
+  double rel, step_norm, cost_change;    // for the progress line
+};
+inline LmSpec lm_spec_off() { LmSpec s{}; s.dec = nullptr; s.scal = nullptr; return s; }
+
 // ---- launch wrappers (kernels.hip) -----------------------------------------
 struct SweepArgs {
   int N, Nstride, NI, NC, KMAX;
@@ -165,6 +184,7 @@ struct FrontArgs {
   double* Epose; double* Eintr;                     // entry records (kPoseRec / kIntrRec doubles)
   double* fail;
   long long* trace;  // MAVBA_FRONT_TRACE (debugging): s_memtime stamps per work-group, else null
+  LmSpec spec;       // speculative evaluation: run only if the pending candidate is accepted, with the radius it leaves (`radius` is ignored then)
 };
 int point_front_grid(int num_tiles);
 // kmax_intr: 0 when no intrinsics block is free (no Wk products), else the widest camera model (4, 8, 9).
@@ -178,14 +198,15 @@ struct CamSweepArgs {
   const double* camrec; const double* intr; const int* img_cam; const int* cam_model;
   const double* points; const unsigned char* pt_active; double loss_b, loss_inv_b;
   double* partial;  // [num_chunks][kSweepAcc]
+  LmSpec spec;      // speculative evaluation (see FrontArgs)
 };
 void launch_camera_sweep(hipStream_t st, const CamSweepArgs& a, int kmax, bool any_intr_free);
 void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_start,
                           const double* partial, const int* prior_start, const double* prior_res,
                           const double* prior_jac, const int* cam_img_start, const int* cam_imgs,
-                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams = true);
+                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams = true, const LmSpec& spec = lm_spec_off());
 void launch_rot_prior(hipStream_t st, int n, const int* prior_img, const double* prior_R0, double w,
-                      const double* poses, double* res, double* jac, double* cost_partial);
+                      const double* poses, double* res, double* jac, double* cost_partial, const LmSpec& spec = lm_spec_off());
 
 void launch_scales(hipStream_t st, int NI, int NC, int NP, int NPs, int jacobi,
                    const unsigned char* pose_free, const unsigned char* intr_free,
@@ -197,7 +218,7 @@ void launch_state_norms(hipStream_t st, int NI, int NC, int NP, int NPs, bool ca
                         const unsigned char* pose_free, const unsigned char* intr_free,
                         const unsigned char* pt_free, const double* poses, const double* intr,
                         const double* points, const double* img_rec, const double* cam_rec,
-                        const double* gu, double* partial /*[grid][2]*/, int* grid_out);
+                        const double* gu, double* partial /*[grid][2]*/, int* grid_out, const LmSpec& spec = lm_spec_off());
 
 
 void launch_entries_pose(hipStream_t st, int N, int Nstride, int NPs, const int* obs_img,
@@ -275,7 +296,11 @@ void launch_reduce_cols(hipStream_t st, const double* partial, int rows, int col
 
 struct ReduceTask { const double* src; int rows, stride, is_max; const double* src2; int rows2; double* out; };
 struct ReduceTasks { ReduceTask t[6]; };
-void launch_reduce_tasks(hipStream_t st, const ReduceTasks& tasks, int n);
+void launch_reduce_tasks(hipStream_t st, const ReduceTasks& tasks, int n, const LmSpec& spec = lm_spec_off());
+// The decision on the candidate whose scalars sit in spec.scal: {code, radius} to dec (device) for the speculative
+// evaluation's kernels; the scalars, the decision and - last - `seq` to host_pub (host-mapped, coherent: kLmPubDoubles doubles).
+constexpr int kLmPubDoubles = SC_COUNT + 8;  // scalars | code radius decrease_factor rel step_norm cost_change - | seq
+void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq);
 
 void launch_points_to_caller(hipStream_t st, int NP, int width, const int* orig, const double* in, double* out);
 void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,

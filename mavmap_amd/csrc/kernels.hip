@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "ba_math.h"
 #include "dev_reduce.h"
+#include "lm_decide.h"
 
 namespace mavba {
 
@@ -425,6 +426,7 @@ struct FrontShape {
 template <int KMAX, bool ENTRIES, bool MASK, bool TRACE = false>
 __global__ void __launch_bounds__(256, 2) k_point_front(FrontArgs a) {  // two work-groups per CU (LDS and registers)
   using SH = FrontShape<KMAX>;
+  if (!lm_spec_go(a.spec, &a.radius)) return;  // (speculative evaluation: only behind an accepted step, with the radius it leaves)
   long long stamp[TRACE ? 12 : 1];
   int nstamp = 0;
   auto mark = [&]() { if constexpr (TRACE) { if (nstamp < 12) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
@@ -798,6 +800,7 @@ void launch_point_front(hipStream_t st, const FrontArgs& a, int kmax_intr, bool 
 // ---------------------------------------------------------------------------
 template <int K>
 __global__ void __launch_bounds__(256) k_camera_sweep(CamSweepArgs a) {
+  if (!lm_spec_go(a.spec, nullptr)) return;  // (speculative evaluation: only behind an accepted step)
   __shared__ double s_red[4 * kSweepAcc];
   const SweepChunk ch = a.chunks[blockIdx.x];
   const int cam = a.img_cam[ch.image];
@@ -997,6 +1000,7 @@ __device__ __forceinline__ void camera_gram_wave(const CamSweepArgs& a, const Sw
 }
 template <int K>
 __global__ void __launch_bounds__(256, 2) k_camera_sweep_gram(CamSweepArgs a) {
+  if (!lm_spec_go(a.spec, nullptr)) return;  // (speculative evaluation: only behind an accepted step)
   __shared__ __attribute__((aligned(16))) double s_rows[4 * 64 * kCsPitch];
   const SweepChunk ch = a.chunks[blockIdx.x];
   const int cam = a.img_cam[ch.image];
@@ -1053,7 +1057,8 @@ void launch_camera_sweep(hipStream_t st, const CamSweepArgs& a, int kmax, bool a
 // Rotation priors: one lane per prior (reference bundle_adjustment.cc:72-111, :428-444).
 __global__ void k_rot_prior(int n, const int* __restrict__ prior_img, const double* __restrict__ R0,
                             double w, const double* __restrict__ poses, double* __restrict__ res,
-                            double* __restrict__ jac, double* __restrict__ cost_partial) {
+                            double* __restrict__ jac, double* __restrict__ cost_partial, LmSpec spec) {
+  if (!lm_spec_go(spec, nullptr)) return;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   double r, j[3];
@@ -1062,9 +1067,9 @@ __global__ void k_rot_prior(int n, const int* __restrict__ prior_img, const doub
   cost_partial[q] = 0.5 * r * r;
 }
 void launch_rot_prior(hipStream_t st, int n, const int* prior_img, const double* prior_R0, double w,
-                      const double* poses, double* res, double* jac, double* cost_partial) {
+                      const double* poses, double* res, double* jac, double* cost_partial, const LmSpec& spec) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_rot_prior, dim3((n + 127) / 128), dim3(128), 0, st, n, prior_img, prior_R0, w, poses, res, jac, cost_partial);
+  hipLaunchKernelGGL(k_rot_prior, dim3((n + 127) / 128), dim3(128), 0, st, n, prior_img, prior_R0, w, poses, res, jac, cost_partial, spec);
 }
 
 // Per image: sum its chunks (fixed order) + its rotation priors -> img_rec[81] and
@@ -1072,7 +1077,8 @@ void launch_rot_prior(hipStream_t st, int n, const int* prior_img, const double*
 __global__ void __launch_bounds__(64) k_camera_reduce_img(
     int NI, const int* __restrict__ img_chunk_start, const double* __restrict__ partial,
     const int* __restrict__ prior_start, const double* __restrict__ prior_res,
-    const double* __restrict__ prior_jac, double* __restrict__ img_rec, double* __restrict__ img_intr_tmp) {
+    const double* __restrict__ prior_jac, double* __restrict__ img_rec, double* __restrict__ img_intr_tmp, LmSpec spec) {
+  if (!lm_spec_go(spec, nullptr)) return;
   const int i = blockIdx.x;
   const int c0 = img_chunk_start[i], c1 = img_chunk_start[i + 1];
   for (int e = threadIdx.x; e < kSweepAcc; e += 64) {
@@ -1100,8 +1106,9 @@ __global__ void __launch_bounds__(64) k_camera_reduce_img(
 // per element, then a fixed tree) — one 1024-thread block per camera.
 __global__ void __launch_bounds__(1024) k_camera_reduce_cam(
     const int* __restrict__ cam_img_start, const int* __restrict__ cam_imgs,
-    const double* __restrict__ img_intr_tmp, double* __restrict__ cam_rec) {
+    const double* __restrict__ img_intr_tmp, double* __restrict__ cam_rec, LmSpec spec) {
   __shared__ double s_part[16][64];
+  if (!lm_spec_go(spec, nullptr)) return;
   const int c = blockIdx.x;
   const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
   double s = 0.0;
@@ -1131,12 +1138,12 @@ __global__ void __launch_bounds__(1024) k_camera_reduce_cam(
 void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_start,
                           const double* partial, const int* prior_start, const double* prior_res,
                           const double* prior_jac, const int* cam_img_start, const int* cam_imgs,
-                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams) {
+                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams, const LmSpec& spec) {
   if (NI > 0)
     hipLaunchKernelGGL(k_camera_reduce_img, dim3(NI), dim3(64), 0, st, NI, img_chunk_start, partial,
-                       prior_start, prior_res, prior_jac, img_rec, img_intr_tmp);
+                       prior_start, prior_res, prior_jac, img_rec, img_intr_tmp, spec);
   if (NC > 0 && with_cams)  // (no free intrinsics: nobody reads the per-camera sums, they stay zero)
-    hipLaunchKernelGGL(k_camera_reduce_cam, dim3(NC), dim3(1024), 0, st, cam_img_start, cam_imgs, img_intr_tmp, cam_rec);
+    hipLaunchKernelGGL(k_camera_reduce_cam, dim3(NC), dim3(1024), 0, st, cam_img_start, cam_imgs, img_intr_tmp, cam_rec, spec);
 }
 
 // ---------------------------------------------------------------------------
@@ -1189,8 +1196,9 @@ __global__ void __launch_bounds__(256) k_state_norms(
     const unsigned char* __restrict__ intr_free, const unsigned char* __restrict__ pt_free,
     const double* __restrict__ poses, const double* __restrict__ intr, const double* __restrict__ points,
     const double* __restrict__ img_rec, const double* __restrict__ cam_rec, const double* __restrict__ gu,
-    double* __restrict__ partial) {
+    double* __restrict__ partial, LmSpec spec) {
   __shared__ double s_red[4];
+  if (!lm_spec_go(spec, nullptr)) return;
   double gmax = 0.0, x2 = 0.0;
   if ((int)blockIdx.x < gp) {
     for (int p = blockIdx.x * 256 + threadIdx.x; p < NP; p += gp * 256) {
@@ -1226,12 +1234,12 @@ void launch_state_norms(hipStream_t st, int NI, int NC, int NP, int NPs, bool ca
                         const unsigned char* pose_free, const unsigned char* intr_free,
                         const unsigned char* pt_free, const double* poses, const double* intr,
                         const double* points, const double* img_rec, const double* cam_rec,
-                        const double* gu, double* partial, int* grid_out) {
+                        const double* gu, double* partial, int* grid_out, const LmSpec& spec) {
   int gp = (NP + 255) / 256;
   if (gp > 512) gp = 512;
   const int gc = std::max(1, std::min(kStateNormsCamBlocks, (6 * NI + 9 * NC + 255) / 256));
   hipLaunchKernelGGL(k_state_norms, dim3(gp + gc), dim3(256), 0, st, NI, NC, NP, NPs, gp, cam_part ? 1 : 0,
-                     pose_free, intr_free, pt_free, poses, intr, points, img_rec, cam_rec, gu, partial);
+                     pose_free, intr_free, pt_free, poses, intr, points, img_rec, cam_rec, gu, partial, spec);
   *grid_out = gp + gc;
 }
 
@@ -2690,8 +2698,9 @@ void launch_reduce_cols(hipStream_t st, const double* partial, int rows, int col
 
 // Several independent single-block reductions in ONE launch (the scalars of an LM phase): block b handles task b,
 //   out = op(src[r * stride], r < rows)  (+ sum of src2[r], r < rows2, for the cost = observations + priors).
-__global__ void __launch_bounds__(256) k_reduce_tasks(ReduceTasks T) {
+__global__ void __launch_bounds__(256) k_reduce_tasks(ReduceTasks T, LmSpec spec) {
   __shared__ double s_red[4];
+  if (!lm_spec_go(spec, nullptr)) return;
   const ReduceTask t = T.t[blockIdx.x];
   double v = 0.0;
   for (int r = threadIdx.x; r < t.rows; r += 256) {
@@ -2707,8 +2716,23 @@ __global__ void __launch_bounds__(256) k_reduce_tasks(ReduceTasks T) {
   }
   if (threadIdx.x == 0) *t.out = total;
 }
-void launch_reduce_tasks(hipStream_t st, const ReduceTasks& T, int n) {
-  if (n > 0) hipLaunchKernelGGL(k_reduce_tasks, dim3(n), dim3(256), 0, st, T);
+// One lane: the LM decision on the device (for the speculative evaluation behind it) and the scalars to the host.
+__global__ void k_lm_snapshot(LmSpec spec, double* __restrict__ dec, double* host_pub, double seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const LmDecision d = lm_decide(spec.scal, spec);
+  dec[0] = (double)d.code; dec[1] = d.radius;
+  volatile double* out = host_pub;
+  for (int i = 0; i < SC_COUNT; ++i) out[i] = spec.scal[i];
+  out[SC_COUNT] = (double)d.code; out[SC_COUNT + 1] = d.radius; out[SC_COUNT + 2] = d.decrease_factor;
+  out[SC_COUNT + 3] = d.rel; out[SC_COUNT + 4] = d.step_norm; out[SC_COUNT + 5] = d.cost_change;
+  __threadfence_system();
+  out[SC_COUNT + 7] = seq;
+}
+void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq) {
+  hipLaunchKernelGGL(k_lm_snapshot, dim3(1), dim3(64), 0, st, spec, dec, host_pub, seq);
+}
+void launch_reduce_tasks(hipStream_t st, const ReduceTasks& T, int n, const LmSpec& spec) {
+  if (n > 0) hipLaunchKernelGGL(k_reduce_tasks, dim3(n), dim3(256), 0, st, T, spec);
 }
 
 // read-back of per-point values in the caller's order: out[orig[q]][e] = in[q][e]

@@ -32,6 +32,7 @@
 #include <vector>
 #include "ba_math.h"
 #include "dev_reduce.h"
+#include "lm_decide.h"
 
 // MAVBA_ROWS_SKIP (debug builds only, scripts/_dbg/rows_variants.sh): bit mask of parts left out to time the rest - wrong results.
 #ifndef MAVBA_ROWS_SKIP
@@ -224,6 +225,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     const unsigned short* __restrict__ obs_meta, double* __restrict__ part_pp, double* __restrict__ part_ip,
     double* __restrict__ part_ii) {
   using SHMAX = F2Shape<kRowsClassNT[kRowsClasses - 1]>;
+  if (!lm_spec_go(a.spec, &a.radius)) return;  // (speculative evaluation: only behind an accepted step, with the radius it leaves)
   // per-cluster tables (cl_lists: the cluster's image slots, then its camera slots, -1 padded): camera records, intrinsics
   // and column scales are read from memory once per cluster
   __shared__ double s_rec[kClImagesMax][9], s_kin[kClImagesMax][9], s_sc[kClImagesMax][6], s_ksc[kClCamsMax][9];

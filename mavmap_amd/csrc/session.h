@@ -96,6 +96,8 @@ hipError_t pinned_alloc(void** out, size_t bytes);
 void pinned_free(void* p);
 hipError_t stream_acquire(hipStream_t* st);
 void stream_release(hipStream_t st, int dev);
+double* lm_pub_alloc();          // host_util.hip: a 256-byte host-mapped coherent slot (null: none left / not supported)
+void lm_pub_free(double* p);
 bool persistent_allowed_now();   // host_util.hip: false while the process is in the cool-down after a time-out (counts one session of it)
 bool persistent_in_cooldown();   // the same question without counting a session (sharded sessions: the ranks agree in join_ranks)
 void persistent_timed_out();
@@ -374,6 +376,7 @@ struct mavba_session {
     // the buffers go back to the process-wide pool: nothing may still be running on them
     if (st) (void)hipStreamSynchronize(st);
     if (rccl_comm) rccl_comm_destroy(rccl_comm);
+    if (lm_pub) lm_pub_free(lm_pub);
     HostSpare<long long>::give(perm); HostSpare<int>::give(h_oimg); HostSpare<double>::give(h_points0);
     for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& e : ev_pool) (void)hipEventDestroy(e);
@@ -462,8 +465,24 @@ void intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::v
   // next_radius > 0: the trust-region radius of the linear solve that follows (the front end then writes the Schur entry
   // records in the same pass); <= 0: unknown
   void evaluate(double next_radius = -1.0);
-  void evaluate_enqueue(double next_radius = -1.0);  // the launches of evaluate() without reading the scalars back
-  void launch_front(double r, bool entries);
+  // the launches of evaluate() without reading the scalars back. spec.dec != null: the SPECULATIVE evaluation at the
+  // candidate point - every kernel returns at once unless k_lm_snapshot accepted the step, the front end takes the radius
+  // from its decision (next_radius only says "with entries")
+  void evaluate_enqueue(double next_radius = -1.0, const LmSpec& spec = lm_spec_off());
+  void launch_front(double r, bool entries, const LmSpec& spec = lm_spec_off());
+  // ---- speculative evaluation (lm_decide.h) ----
+  DevBuf<double> d_lm_dec;       // {code, radius} of k_lm_snapshot's decision
+  double* lm_pub = nullptr;      // host-mapped slot the snapshot kernel publishes to (null: the copy + synchronise read-back)
+  double lm_seq = 0.0;           // sequence number of the last publication asked for
+  LmSpec lm_spec(bool pending_eval) const {
+    LmSpec sp{};
+    sp.dec = nullptr; sp.scal = d_scal.p;
+    sp.radius = radius; sp.decrease_factor = decrease_factor;
+    sp.ptol = opt.parameter_tolerance; sp.ftol = opt.function_tolerance; sp.min_rel_dec = opt.min_relative_decrease;
+    sp.max_radius = opt.max_trust_region_radius; sp.abs_gtol = abs_gtol; sp.pending_eval = pending_eval ? 1 : 0;
+    return sp;
+  }
+  bool wait_publication(double* h);  // polls lm_pub for lm_seq; false: timed out (the caller synchronises the stream instead)
   void build_front_tiles(const std::vector<int>& q_start);
   void build_tiles(const std::vector<int>& q_start, int first, DevBuf<FrontTile>& out, int& count);
   void ensure_planes();
@@ -475,6 +494,7 @@ void intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::v
   void solve_linear(double r);
   void linear_step(double r, double* h_scal);
   void candidate(double r, double* h_scal);
+  void candidate_enqueue(double r);
   void start();
   int iterate(int max_iters, int* done);
   void point_errors(double* out);

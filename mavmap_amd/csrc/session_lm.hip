@@ -11,6 +11,8 @@
 //   src/base3d/bundle_adjustment.cc:575-598  point3D_errors
 //   src/base3d/bundle_adjustment.cc:139-225  pose_refinement
 #include "session.h"
+#include "lm_decide.h"
+#include <immintrin.h>
 
 using namespace mavba;
 
@@ -29,8 +31,9 @@ void mavba_session::ensure_planes() {
 
 // The J-free front end at the current x: cost partials, Cu, gu and - with `entries` - the points' factors and the Schur
 // entry records for trust-region radius r.
-void mavba_session::launch_front(double r, bool entries) {
+void mavba_session::launch_front(double r, bool entries, const LmSpec& spec) {
   FrontArgs f;
+  f.spec = spec;
   f.sw = sweep_args(d_camrec.p, d_intr.p, d_points.p);
   f.num_tiles = num_front_tiles; f.NPs = NPs; f.tiles = d_front_tiles.p;
   f.pt_start = d_pt_start.p; f.q_start = d_q_start.p; f.q_cam = d_q_cam.p; f.q_pt = d_q_pt.p;
@@ -71,13 +74,13 @@ void mavba_session::launch_front(double r, bool entries) {
   front_radius = r;
 }
 
-void mavba_session::evaluate_enqueue(double next_radius) {
+void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
   if (!camrec_current) timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
   camrec_current = true;
   SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
   if (front_ok) {
     // one pass: the evaluation's sums and (once the Jacobi scales exist and the next radius is known) the entries
-    launch_front(next_radius, scales_ready && next_radius > 0.0);
+    launch_front(next_radius, scales_ready && next_radius > 0.0, spec);
   } else {
     ensure_planes();
     front_valid = false;
@@ -93,16 +96,17 @@ void mavba_session::evaluate_enqueue(double next_radius) {
   c.img_cam = d_img_cam.p; c.cam_model = d_cam_model.p; c.points = d_points.p;
   c.pt_active = a.pt_active;
   c.loss_b = a.loss_b; c.loss_inv_b = a.loss_inv_b; c.partial = d_cam_partial.p;
+  c.spec = spec;
   timed("camera_sweep", [&] { launch_camera_sweep(st, c, KMAX, any_intr_free); });
   if (num_priors > 0)
     timed("rot_prior", [&] {
       launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_poses.p, d_prior_res.p,
-                       d_prior_jac.p, d_prior_cost.p);
+                       d_prior_jac.p, d_prior_cost.p, spec);
     });
   timed("camera_reduce", [&] {
     launch_camera_reduce(st, NI, NC, d_img_chunk_start.p, d_cam_partial.p, num_priors > 0 ? d_prior_start.p : nullptr,
                          d_prior_res.p, d_prior_jac.p, d_cam_img_start.p, d_cam_imgs.p, d_img_rec, d_cam_rec,
-                         d_img_intr_tmp.p, any_intr_free);
+                         d_img_intr_tmp.p, any_intr_free, spec);
   });
   allreduce(d_camsum.p, (long long)NI * kImgRec + (long long)NC * kCamRec, 0);
   if (!scales_ready) {
@@ -115,14 +119,14 @@ void mavba_session::evaluate_enqueue(double next_radius) {
   int rows = 0;
   timed("state_norms", [&] {
     launch_state_norms(st, NI, NC, NP, NPs, rank == 0, d_pose_free.p, d_intr_free.p, d_pt_free.p, d_poses.p,
-                       d_intr.p, d_points.p, d_img_rec, d_cam_rec, d_gu.p, d_norm_partial.p, &rows);
+                       d_intr.p, d_points.p, d_img_rec, d_cam_rec, d_gu.p, d_norm_partial.p, &rows, spec);
   });
   timed("reduce", [&] {
     ReduceTasks T;
     T.t[0] = ReduceTask{d_norm_partial.p, rows, 2, 1, nullptr, 0, d_scal.p + SC_GRAD_MAX};
     T.t[1] = ReduceTask{d_norm_partial.p + 1, rows, 2, 0, nullptr, 0, d_scal.p + SC_XNORM2};
     T.t[2] = ReduceTask{d_sweep_partial.p, eval_cost_rows(), 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
-    launch_reduce_tasks(st, T, 3);
+    launch_reduce_tasks(st, T, 3, spec);
   });
   if (sharded()) allreduce(d_scal.p + SC_COST, SC_EVAL_COUNT, 2);  // the evaluation's two sums, then max|g| (never the candidate's slots)
   evaluated = true; assembled = false;
@@ -230,6 +234,11 @@ void mavba_session::linear_step(double r, double* h) {
 
 // Back-substitution, candidate x + delta, and its cost. Leaves the scalars on the host.
 void mavba_session::candidate(double r, double* h) {
+  candidate_enqueue(r);
+  read_scalars(h);
+}
+// (the launches of candidate() without the read-back)
+void mavba_session::candidate_enqueue(double r) {
   const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
   // cameras first: the point back-substitution reads their step (delta_cam)
   const int rows = backsub_points_grid(NP), ugroups = update_cameras_groups(NI);
@@ -268,7 +277,6 @@ void mavba_session::candidate(double r, double* h) {
     launch_reduce_tasks(st, T, 4);
   });
   if (sharded()) allreduce(d_scal.p + SC_CAND_BEGIN, SC_CAND_COUNT, 0);  // only what the candidate wrote: an evaluation enqueued before it keeps its (already global) sums
-  read_scalars(h);
 }
 
 void mavba_session::start() {
@@ -289,6 +297,20 @@ void mavba_session::start() {
   }
 }
 
+// Polls the host-mapped slot for the publication with sequence number lm_seq (k_lm_snapshot writes it last).
+bool mavba_session::wait_publication(double* h) {
+  volatile double* pub = lm_pub;
+  const double t_end = now_s() + 2.0;
+  for (long long spin = 0;; ++spin) {
+    if (pub[SC_COUNT + 7] == lm_seq) break;
+    _mm_pause();
+    if ((spin & 0xFFFF) == 0xFFFF && now_s() > t_end) return false;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int i = 0; i < SC_COUNT; ++i) h[i] = pub[i];
+  return true;
+}
+
 // TrustRegionMinimizer::Minimize main loop (Ceres 1.8), one pass per LM iteration.
 int mavba_session::iterate(int max_iters, int* done) {
   const double t0 = now_s();
@@ -302,60 +324,112 @@ int mavba_session::iterate(int max_iters, int* done) {
   // MAVBA_DEFER_WITH_HOOK (tests): run the deferred protocol over the hook too, so that in-process ranks on ONE GPU
   // exercise the exact sequence of collectives the RCCL path issues (evaluation group, then candidate group, one read-back)
   const bool defer = (!sharded() || rccl_comm || std::getenv("MAVBA_DEFER_WITH_HOOK") != nullptr) && !opt.print_progress;
+  // Round 4: the evaluation at the candidate point is enqueued BEFORE the candidate's scalars are read (lm_decide.h): a
+  // one-lane kernel decides on the device, the evaluation's kernels return at once unless it accepted. The host reads the
+  // scalars that kernel published, runs the same decision function and either keeps the evaluation (accepted: what
+  // `defer` enqueued AFTER the read-back before - the device no longer idles through the host's turn-around) or forgets it.
+  // Not with shards (the evaluation's collective would run on a rejected step's stale sums) or the plane kernels.
+  static const bool spec_env = [] { const char* e = std::getenv("MAVBA_SPECULATE"); return !e || std::atoi(e) != 0; }();
+  const bool speculate = spec_env && defer && !sharded() && front_ok && fused_now() && rows_ok && scales_ready;
+  if (speculate && !lm_pub) { lm_pub = lm_pub_alloc(); if (lm_pub) lm_pub[SC_COUNT + 7] = -1.0; }
+  if (speculate && lm_pub && !d_lm_dec.p) d_lm_dec.alloc(2);
   bool pending_eval = false;
   while (termination == MAVBA_TERM_RUNNING && n < max_iters) {
     if (iteration >= opt.max_num_iterations) { termination = MAVBA_TERM_NO_CONVERGENCE; break; }
     ++iteration; ++n;
     double h[SC_COUNT];
-    linear_step(radius, h);
-    if (pending_eval) {
-      pending_eval = false;
-      take_evaluation(h);
-      if (grad_max <= abs_gtol) {  // the previous iteration ended the solve: this one never happened
-        termination = MAVBA_TERM_GRADIENT_TOLERANCE;
-        --iteration; --n;
-        break;
+    const LmSpec sp = lm_spec(pending_eval);
+    bool speculated = false;
+    // what the speculative evaluation changes in the session's books (restored if the step is not accepted)
+    struct Books { bool evaluated, assembled, front_valid, fail_slot_clean; double front_radius; int eval_rows; } books{};
+    if (speculate && lm_pub) {
+      solve_linear(radius);
+      candidate_enqueue(radius);
+      lm_seq += 1.0;
+      timed("lm_snapshot", [&] { launch_lm_snapshot(st, sp, d_lm_dec.p, lm_pub, lm_seq); });
+      books = Books{evaluated, assembled, front_valid, fail_slot_clean, front_radius, eval_rows};
+      std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
+      std::swap(d_camrec.p, d_ccamrec.p);
+      LmSpec ks = sp;
+      ks.dec = d_lm_dec.p;
+      evaluate_enqueue(1.0 /* "with entries": the front end takes the radius from the decision */, ks);
+      speculated = true;
+      if (!wait_publication(h)) {  // (never seen; keeps the loop alive if the mapping is not coherent on some system)
+        sync();
+        for (int i = 0; i < SC_COUNT; ++i) h[i] = lm_pub[i];
       }
+      if (opt.profile_kernels) sync();  // (flushes the event timers: a profiled pass gives up the overlap)
+      if (h[SC_FAIL] >= 1e29 && allow_persistent) {
+        // the persistent factorisation gave up: the device's decision was "invalid", the evaluation did not run; forget
+        // it and repeat the solve on the launch-per-panel schedule (linear_step does, and reads back the plain way)
+        std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
+        std::swap(d_camrec.p, d_ccamrec.p);
+        evaluated = books.evaluated; assembled = books.assembled; front_valid = books.front_valid;
+        fail_slot_clean = false; front_radius = books.front_radius; eval_rows = books.eval_rows;
+        speculated = false;
+        std::fprintf(stderr, "mavba: persistent factorisation timed out, falling back to the launch-per-panel schedule\n");
+        allow_persistent = false;
+        persistent_timed_out();
+        solve_linear(radius);
+        candidate(radius, h);
+      }
+    } else {
+      linear_step(radius, h);
     }
-    const double mcc = h[SC_MODEL_CHANGE];
-    const bool solved = h[SC_FAIL] == 0.0 && h[SC_FAIL_FRONT] == 0.0 && std::isfinite(mcc) && std::isfinite(h[SC_STEP_NORM2]);
-    const bool valid = solved && !(mcc < 0.0);
-    bool successful = false;
-    double rel = 0.0, step_norm = 0.0, cost_change = 0.0;
-    if (!valid) {
+    if (pending_eval) take_evaluation(h);  // (the evaluation at the current point, enqueued behind the previous accepted step)
+    const LmDecision dec = lm_decide(h, sp);
+    auto forget_speculation = [&] {
+      if (!speculated) return;
+      std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
+      std::swap(d_camrec.p, d_ccamrec.p);
+      evaluated = books.evaluated; assembled = books.assembled; front_valid = books.front_valid;
+      fail_slot_clean = false;  // (the speculative front end's fill did run)
+      front_radius = books.front_radius; eval_rows = books.eval_rows;
+      speculated = false;
+    };
+    if (dec.code == LM_TERM_GTOL) {  // the previous iteration ended the solve: this one never happened
+      forget_speculation();
+      pending_eval = false;
+      termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+      --iteration; --n;
+      break;
+    }
+    pending_eval = false;
+    if (dec.code == LM_INVALID) {
+      forget_speculation();
       if (++invalid_steps >= opt.max_num_consecutive_invalid_steps) { termination = MAVBA_TERM_NUMERICAL_FAILURE; ++n_fail; break; }
     } else {
       invalid_steps = 0;
-      step_norm = std::sqrt(h[SC_STEP_NORM2]);
-      const double new_cost = h[SC_NEW_COST];
-      if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { termination = MAVBA_TERM_PARAMETER_TOLERANCE; break; }
-      cost_change = cost - new_cost;
-      if (std::fabs(cost_change) < opt.function_tolerance * cost) { termination = MAVBA_TERM_FUNCTION_TOLERANCE; break; }
-      rel = cost_change / mcc;
-      successful = rel > opt.min_relative_decrease;
+      if (dec.code == LM_TERM_PTOL) { forget_speculation(); termination = MAVBA_TERM_PARAMETER_TOLERANCE; break; }
+      if (dec.code == LM_TERM_FTOL) { forget_speculation(); termination = MAVBA_TERM_FUNCTION_TOLERANCE; break; }
     }
+    const bool successful = dec.code == LM_ACCEPTED;
+    radius = dec.radius;
+    decrease_factor = dec.decrease_factor;
     if (successful) {
       ++n_success;
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
-      radius = std::min(opt.max_trust_region_radius, radius);
-      decrease_factor = 2.0;
-      std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
-      std::swap(d_camrec.p, d_ccamrec.p);  // the candidate's camera records are the new point's (camrec_current stays true)
-      if (defer) {
-        evaluate_enqueue(radius);
+      if (speculated) {
+        // the evaluation at the accepted point is already running (pointers swapped, books written by evaluate_enqueue)
+        front_radius = radius;
         pending_eval = true;
       } else {
-        evaluate(radius);
-        if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+        std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
+        std::swap(d_camrec.p, d_ccamrec.p);  // the candidate's camera records are the new point's (camrec_current stays true)
+        if (defer) {
+          evaluate_enqueue(radius);
+          pending_eval = true;
+        } else {
+          evaluate(radius);
+          if (grad_max <= abs_gtol) termination = MAVBA_TERM_GRADIENT_TOLERANCE;
+        }
       }
     } else {
+      forget_speculation();
       ++n_fail;
-      radius = radius / decrease_factor;
-      decrease_factor *= 2.0;
     }
     if (opt.print_progress)
-      std::printf("%4d %14.6e %12.2e %10.2e %10.2e %10.2e %10.2e\n", iteration, cost + fixed_cost, successful ? cost_change : 0.0,
-                  grad_max, step_norm, rel, radius);
+      std::printf("%4d %14.6e %12.2e %10.2e %10.2e %10.2e %10.2e\n", iteration, cost + fixed_cost, successful ? dec.cost_change : 0.0,
+                  grad_max, dec.step_norm, dec.rel, radius);
     if (termination == MAVBA_TERM_RUNNING && radius < opt.min_trust_region_radius) termination = MAVBA_TERM_PARAMETER_TOLERANCE;
   }
   if (pending_eval) {
