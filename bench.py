@@ -96,7 +96,7 @@ REPLICATED = {"chol_factor", "chol_backsolve", "schur_finalize", "update_cameras
               "cam_prepare", "rot_prior"}
 
 
-PMC_ROUND = "r03"
+PMC_ROUND = "r04"
 
 
 def mfma_counters(config, scale, world):

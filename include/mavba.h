@@ -388,6 +388,9 @@ int mavba_debug_elimination_tree(int32_t num_images, int32_t num_cameras, int64_
 /* Test entry of the set-up's device sort (device_setup.hip): order_out [n] = the stable ascending order of 0..n-1 by
  * keys[i] (the low `key_bytes` bytes are significant). */
 int mavba_debug_radix_sort(int32_t n, const uint32_t* keys, int32_t key_bytes, int32_t* order_out, int32_t device);
+/* Test entry: the LM accept / reject / terminate decision (csrc/lm_decide.h) by the host build and by the device build on
+ * the same n cases (16 scalars + 8 parameters each, 6 doubles out each); the speculative evaluation needs them identical. */
+int mavba_debug_lm_decide(int32_t n, const double* cases, double* out_host, double* out_device, int32_t device);
 
 /* Build the reduced camera system for the current Jacobian and trust-region
  * radius and download it: S [n][n] row-major (both triangles), v [n], with

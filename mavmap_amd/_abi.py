@@ -112,3 +112,7 @@ def as_f64(a, shape=None):
     if shape is not None:
         a = a.reshape(shape)
     return a
+
+
+# scalars of an LM iteration on the device (csrc/internal.h, SC_*): the layout mavba_debug_lm_decide takes
+SC_COST, SC_XNORM2, SC_GRAD_MAX, SC_NEW_COST, SC_STEP_NORM2, SC_MODEL_CHANGE, SC_CAND_XNORM2, SC_FAIL, SC_FAIL_FRONT = range(9)

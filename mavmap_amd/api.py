@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "mavba_scene_add_points2d", "mavba_scene_set_point3d", "mavba_scene_link", "mavba_scene_delete_point3d", "mavba_scene_get_image", "mavba_scene_get_point3d",
     "mavba_scene_get_camera", "mavba_scene_flatten", "mavba_scene_bundle_adjust",
     "mavba_rccl_unique_id", "mavba_session_set_rccl", "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
-    "mavba_debug_elimination_tree", "mavba_debug_radix_sort",
+    "mavba_debug_elimination_tree", "mavba_debug_radix_sort", "mavba_debug_lm_decide",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -115,6 +115,7 @@ def load():
     L.mavba_solve_filter_solve.argtypes = [pp, op, C.c_double, bp, rp, rp, dp, bp, C.POINTER(C.c_int64)]
     L.mavba_debug_elimination_tree.argtypes = [C.c_int32, C.c_int32, C.c_int64, ip, ip, C.c_int32, ip, ip, C.c_int32]
     L.mavba_debug_radix_sort.argtypes = [C.c_int32, C.POINTER(C.c_uint32), C.c_int32, ip, C.c_int32]
+    L.mavba_debug_lm_decide.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
     for f in EXPORTED_SYMBOLS:
         if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy", "mavba_scene_destroy"):
             getattr(L, f).restype = C.c_int
@@ -560,6 +561,16 @@ def radix_sort_order(keys, key_bytes=4, device=-1):
     out = np.zeros(len(keys), np.int32)
     _check(load().mavba_debug_radix_sort(len(keys), A.ptr(keys, C.c_uint32), int(key_bytes), A.ptr(out, C.c_int32), device))
     return out
+
+
+def debug_lm_decide(cases, device=-1):
+    """The LM decision function (csrc/lm_decide.h) on rows of 16 scalars + 8 parameters: (host results, device results), 6 columns each."""
+    cases = np.ascontiguousarray(cases, dtype=np.float64)
+    n = cases.shape[0]
+    assert cases.shape[1] == 24
+    oh, od = np.zeros((n, 6)), np.zeros((n, 6))
+    _check(load().mavba_debug_lm_decide(n, _d(cases), _d(oh), _d(od), device))
+    return oh, od
 
 
 def rccl_unique_id():

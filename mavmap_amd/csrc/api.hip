@@ -1,5 +1,6 @@
 // api.hip - the C ABI of include/mavba.h over the session object (no exception crosses it).
 #include "session.h"
+#include "lm_decide.h"
 
 namespace mavba { thread_local std::string g_last_error; }
 
@@ -393,6 +394,36 @@ int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (ms_avg) *ms_avg = ms / reps;
   s->sync();
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+// Test entry: the LM decision function (lm_decide.h) evaluated by the host build and by the device build on the same
+// `n` cases (SC_COUNT scalars + 8 parameters each); 6 doubles per case out of each. The speculative evaluation relies on
+// the two agreeing bit for bit.
+int mavba_debug_lm_decide(int32_t n, const double* cases, double* out_host, double* out_device, int32_t device) {
+  MAVBA_TRY
+  if (n < 0 || (n > 0 && (!cases || !out_host || !out_device))) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "bad argument");
+  for (int c = 0; c < n; ++c) {
+    const double* q = cases + (size_t)c * (SC_COUNT + 8);
+    LmSpec sp = lm_spec_off();
+    sp.radius = q[SC_COUNT]; sp.decrease_factor = q[SC_COUNT + 1]; sp.ptol = q[SC_COUNT + 2]; sp.ftol = q[SC_COUNT + 3];
+    sp.min_rel_dec = q[SC_COUNT + 4]; sp.max_radius = q[SC_COUNT + 5]; sp.abs_gtol = q[SC_COUNT + 6]; sp.pending_eval = q[SC_COUNT + 7] != 0.0;
+    const LmDecision d = lm_decide(q, sp);
+    double* o = out_host + (size_t)c * 6;
+    o[0] = (double)d.code; o[1] = d.radius; o[2] = d.decrease_factor; o[3] = d.rel; o[4] = d.step_norm; o[5] = d.cost_change;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); throw Failure(MAVBA_ERR_NO_DEVICE, "no HIP device: the mavba backend has no CPU path"); }
+  if (n == 0) return MAVBA_OK;
+  DeviceGuard g(device >= 0 ? device : 0);
+  double *din = nullptr, *dout = nullptr;
+  HIP_OK(hipMalloc(reinterpret_cast<void**>(&din), (size_t)n * (SC_COUNT + 8) * 8));
+  HIP_OK(hipMalloc(reinterpret_cast<void**>(&dout), (size_t)n * 6 * 8));
+  HIP_OK(hipMemcpy(din, cases, (size_t)n * (SC_COUNT + 8) * 8, hipMemcpyHostToDevice));
+  launch_lm_decide_cases(nullptr, n, din, dout);
+  HIP_OK(hipMemcpy(out_device, dout, (size_t)n * 6 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(din); (void)hipFree(dout);
   return MAVBA_OK;
   MAVBA_CATCH
 }

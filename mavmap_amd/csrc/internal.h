@@ -139,6 +139,9 @@ struct LmDecision {
   double radius, decrease_factor;        // trust region after the decision (unchanged by a termination)
   double rel, step_norm, cost_change;    // for the progress line
 };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
 inline LmSpec lm_spec_off() { LmSpec s{}; s.dec = nullptr; s.scal = nullptr; return s; }
 
 // ---- launch wrappers (kernels.hip) -----------------------------------------
@@ -301,6 +304,7 @@ void launch_reduce_tasks(hipStream_t st, const ReduceTasks& tasks, int n, const 
 // evaluation's kernels; the scalars, the decision and - last - `seq` to host_pub (host-mapped, coherent: kLmPubDoubles doubles).
 constexpr int kLmPubDoubles = SC_COUNT + 8;  // scalars | code radius decrease_factor rel step_norm cost_change - | seq
 void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq);
+void launch_lm_decide_cases(hipStream_t st, int n, const double* in, double* out);  // test entry
 
 void launch_points_to_caller(hipStream_t st, int NP, int width, const int* orig, const double* in, double* out);
 void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,

@@ -2716,17 +2716,42 @@ __global__ void __launch_bounds__(256) k_reduce_tasks(ReduceTasks T, LmSpec spec
   }
   if (threadIdx.x == 0) *t.out = total;
 }
-// One lane: the LM decision on the device (for the speculative evaluation behind it) and the scalars to the host.
-__global__ void k_lm_snapshot(LmSpec spec, double* __restrict__ dec, double* host_pub, double seq) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One wave: the LM decision on the device (for the speculative evaluation behind it) and the scalars to the host. Every lane
+// evaluates the decision (uniform) and stores ONE word of the publication - 24 stores across the host link in parallel
+// (one lane writing them in turn took 16 us) -, the sequence number follows behind a system-scope fence.
+__global__ void __launch_bounds__(64) k_lm_snapshot(LmSpec spec, double* __restrict__ dec, double* host_pub, double seq) {
+  const int lane = threadIdx.x;
   const LmDecision d = lm_decide(spec.scal, spec);
-  dec[0] = (double)d.code; dec[1] = d.radius;
+  if (lane == 0) { dec[0] = (double)d.code; dec[1] = d.radius; }
   volatile double* out = host_pub;
-  for (int i = 0; i < SC_COUNT; ++i) out[i] = spec.scal[i];
-  out[SC_COUNT] = (double)d.code; out[SC_COUNT + 1] = d.radius; out[SC_COUNT + 2] = d.decrease_factor;
-  out[SC_COUNT + 3] = d.rel; out[SC_COUNT + 4] = d.step_norm; out[SC_COUNT + 5] = d.cost_change;
+  double v = 0.0;
+  if (lane < SC_COUNT) v = spec.scal[lane];
+  else if (lane == SC_COUNT) v = (double)d.code;
+  else if (lane == SC_COUNT + 1) v = d.radius;
+  else if (lane == SC_COUNT + 2) v = d.decrease_factor;
+  else if (lane == SC_COUNT + 3) v = d.rel;
+  else if (lane == SC_COUNT + 4) v = d.step_norm;
+  else if (lane == SC_COUNT + 5) v = d.cost_change;
+  if (lane < SC_COUNT + 6) out[lane] = v;
   __threadfence_system();
-  out[SC_COUNT + 7] = seq;
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) out[SC_COUNT + 7] = seq;
+}
+// Test entry (mavba_debug_lm_decide): `n` decisions by the device build of lm_decide. in: SC_COUNT scalars + 8 parameters
+// (radius, decrease_factor, ptol, ftol, min_rel_dec, max_radius, abs_gtol, pending_eval) per case; out: 6 doubles per case.
+__global__ void k_lm_decide_cases(int n, const double* __restrict__ in, double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const double* q = in + (size_t)c * (SC_COUNT + 8);
+  LmSpec sp = lm_spec_off();
+  sp.radius = q[SC_COUNT]; sp.decrease_factor = q[SC_COUNT + 1]; sp.ptol = q[SC_COUNT + 2]; sp.ftol = q[SC_COUNT + 3];
+  sp.min_rel_dec = q[SC_COUNT + 4]; sp.max_radius = q[SC_COUNT + 5]; sp.abs_gtol = q[SC_COUNT + 6]; sp.pending_eval = q[SC_COUNT + 7] != 0.0;
+  const LmDecision d = lm_decide(q, sp);
+  double* o = out + (size_t)c * 6;
+  o[0] = (double)d.code; o[1] = d.radius; o[2] = d.decrease_factor; o[3] = d.rel; o[4] = d.step_norm; o[5] = d.cost_change;
+}
+void launch_lm_decide_cases(hipStream_t st, int n, const double* in, double* out) {
+  if (n > 0) hipLaunchKernelGGL(k_lm_decide_cases, dim3((n + 255) / 256), dim3(256), 0, st, n, in, out);
 }
 void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq) {
   hipLaunchKernelGGL(k_lm_snapshot, dim3(1), dim3(64), 0, st, spec, dec, host_pub, seq);

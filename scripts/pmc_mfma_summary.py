@@ -58,7 +58,7 @@ def group(pred):
 
 
 summary = dict(reduced_solve=group(lambda k: k.startswith("k_chol_")), schur_clusters=group(lambda k: k.startswith("k_schur_clusters")),
-               schur_fused=group(lambda k: k.startswith("k_schur_fused")))
+               schur_fused=group(lambda k: k.startswith("k_schur_fused") or k.startswith("k_schur_rows")))
 json.dump(dict(note=__doc__, summary=summary, kernels=kernels), open(out, "w"), indent=1)
 for name, g in summary.items():
     print(name, "mfma_util", g["mfma_util"], "busy", g["mfma_busy_cycles"], "gui", g["gui_active_cycles"])

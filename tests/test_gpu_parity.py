@@ -574,3 +574,37 @@ def test_pose_refinement_batch_equals_single_calls_and_the_session_path(mavba, m
     (c, r), = mavba.pose_refinement_batch([e])
     assert r["num_residuals"] == 0 and np.isnan(c)
     assert mavba.pose_refinement_batch([]) == []
+
+
+def test_the_lm_decision_is_the_same_function_on_the_host_and_on_the_device(mavba):
+    """The speculative evaluation (csrc/lm_decide.h) is enqueued before the host has read the candidate's scalars: a one-lane
+    kernel takes the accept / reject / terminate decision and the new radius on the device, the host takes them from the same
+    function on the same scalars - they must agree bit for bit (IEEE operations only, contraction off in both builds).
+    Random scalars around every threshold, failure flags, NaN / negative model changes, pending evaluations."""
+    from mavmap_amd import api
+    rng = np.random.default_rng(5)
+    n = 20000
+    c = np.zeros((n, 24))
+    cost = 10.0 ** rng.uniform(-3, 6, n)
+    c[:, A.SC_COST] = cost
+    c[:, A.SC_XNORM2] = 10.0 ** rng.uniform(-2, 8, n)
+    c[:, A.SC_GRAD_MAX] = 10.0 ** rng.uniform(-12, 3, n)
+    rel = np.where(rng.random(n) < 0.3, 10.0 ** rng.uniform(-9, -2, n), rng.uniform(-0.5, 1.5, n))   # cost decrease relative to the cost
+    c[:, A.SC_NEW_COST] = cost * (1.0 - rel * 10.0 ** rng.uniform(-6, 0, n))
+    c[:, A.SC_STEP_NORM2] = 10.0 ** rng.uniform(-20, 4, n)
+    c[:, A.SC_MODEL_CHANGE] = np.abs(cost - c[:, A.SC_NEW_COST]) * rng.uniform(0.2, 3.0, n) * np.where(rng.random(n) < 0.05, -1.0, 1.0)
+    c[:, A.SC_CAND_XNORM2] = c[:, A.SC_XNORM2]
+    bad = rng.random(n)
+    c[bad < 0.02, A.SC_FAIL] = 1.0
+    c[(bad > 0.02) & (bad < 0.04), A.SC_FAIL_FRONT] = 2.0
+    c[(bad > 0.04) & (bad < 0.05), A.SC_MODEL_CHANGE] = np.nan
+    c[(bad > 0.05) & (bad < 0.06), A.SC_STEP_NORM2] = np.inf
+    c[:, 16] = 10.0 ** rng.uniform(-3, 12, n)          # radius
+    c[:, 17] = 2.0 ** rng.integers(1, 8, n)            # decrease factor
+    c[:, 18] = 1e-8; c[:, 19] = 10.0 ** rng.uniform(-8, -3, n); c[:, 20] = 1e-3; c[:, 21] = 1e16
+    c[:, 22] = 10.0 ** rng.uniform(-12, 0, n)          # absolute gradient tolerance
+    c[:, 23] = rng.random(n) < 0.5                     # an evaluation's scalars arrive with the candidate
+    host, dev = api.debug_lm_decide(c)
+    assert np.array_equal(host, dev, equal_nan=True)
+    codes = set(host[:, 0].astype(int))
+    assert codes == {0, 1, 2, 3, 4, 5}, codes          # every outcome occurs in the sample
