@@ -1,6 +1,7 @@
 """One LM iteration's kernel timeline (start offset, duration, gap before) from a rocprofv3 kernel-trace CSV (debug harness).
 
-  python scripts/_dbg/iter_timeline.py <dir with *kernel_trace.csv>
+  python scripts/_dbg/iter_timeline.py <dir with *kernel_trace.csv> [first]
+("first": the first half of the iterations - bench.py's un-instrumented pass; its second pass carries HIP events.)
 Prints the median over the steady-state iterations, an iteration = the kernels from one k_schur_fused / k_point_front to the next."""
 import csv, sys, glob, statistics
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
@@ -9,7 +10,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mavba::", "")[:44]
 starts = [i for i, r in enumerate(rows) if name(r).startswith("k_schur_fused") or name(r).startswith("k_schur_rows") or name(r).startswith("k_point_front<8, true")]
 iters = [rows[a:b] for a, b in zip(starts, starts[1:])]
-iters = iters[len(iters) // 3:]
+iters = iters[len(iters) // 8:len(iters) // 2 - 2] if len(sys.argv) > 2 and sys.argv[2] == "first" else iters[len(iters) // 3:]
 L = statistics.mode(len(it) for it in iters)
 iters = [it for it in iters if len(it) == L]
 print("iterations used %d, kernels per iteration %d" % (len(iters), L))

@@ -16,6 +16,6 @@ MAVBA_CHOL_TRACE=$OUT/chol_trace_raw.txt timeout 300 python scripts/chol_trace.p
 rm -rf $OUT/tl; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -o w -- python $R/scripts/_dbg/window_timeline.py > /dev/null 2>&1)
 python scripts/_dbg/iter_timeline.py $OUT/tl > $OUT/window_timeline.txt 2>&1; rm -rf $OUT/tl
 rm -rf $OUT/tl3; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl3 -o b -- python $R/bench.py --steps 40 --warmup 6 --no-cpu-baseline > /dev/null 2>&1)
-python scripts/_dbg/iter_timeline.py $OUT/tl3 > $OUT/iteration_timeline_C3.txt 2>&1; rm -rf $OUT/tl3
+python scripts/_dbg/iter_timeline.py $OUT/tl3 first > $OUT/iteration_timeline_C3.txt 2>&1; rm -rf $OUT/tl3
 timeout 60 scripts/_dbg/pipe_bench > $OUT/pipe_bench_fp64.txt 2>&1
 ls -la $OUT
