@@ -792,7 +792,7 @@ void mavba_session::finish_structure() {
     if (rows_mode) kMaxPoints = std::min(kMaxPoints, kRowsMaxPoints);
     // cost model of the run-based greedy (cycles of one CU: per cluster, per 16-point batch of each row class; measured on
     // C3, MAVBA_ROWS_COST="F,B0,B1,B2" overrides)
-    double kCostF = 6000.0, kCostB[kRowsClasses] = {15400.0, 17500.0, 27500.0};
+    double kCostF = 20000.0, kCostB[kRowsClasses] = {15400.0, 17500.0, 27500.0};  // (F also stands for what a cluster costs downstream: its block partials in the finalize pass - sweep in gpurun_out/r04t_cost_sweep.txt)
     if (const char* e = std::getenv("MAVBA_ROWS_COST")) std::sscanf(e, "%lf,%lf,%lf,%lf", &kCostF, &kCostB[0], &kCostB[1], &kCostB[2]);
     // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
     // thread": the clusters - and with them the order in which partials are added - must not depend on the
