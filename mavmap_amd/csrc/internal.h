@@ -279,12 +279,14 @@ void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radiu
                            double* partial /*[grid][3]*/, int* grid_out);
 int backsub_points_grid(int NP);
 // the same from recomputed Jacobians (no entry records read); `a`: the sweep arguments of the CURRENT state,
-// delta_cam from launch_update_cameras (which runs first)
+// delta_cam from launch_update_cameras (which runs first). cost_partial != null: the candidate's cost as well (one partial per
+// work-group, backsub_points_grid of them; cand_camrec / cand_intr = the candidate cameras) - no separate k_cost_only launch
 void launch_backsub_points_jvp(hipStream_t st, int NP, int NPs, int NI, double radius, double dmin, double dmax,
                                const SweepArgs& a, const int* pt_start, const double* delta_cam,
                                const unsigned char* pt_free, const double* Gi, const double* h, const double* Cu,
                                const double* gu, const double* scale_pt, double* cand_points, double* delta_points,
-                               double* partial /*[grid][3]*/);
+                               double* partial /*[grid][3]*/, const double* cand_camrec = nullptr, const double* cand_intr = nullptr,
+                               double* cost_partial = nullptr);
 int update_cameras_groups(int NI);  // triples launch_update_cameras writes to partial3
 void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double radius, double dmin,
                            double dmax, const double* y, const double* scale_cam,
@@ -303,7 +305,7 @@ void launch_reduce_tasks(hipStream_t st, const ReduceTasks& tasks, int n, const 
 // The decision on the candidate whose scalars sit in spec.scal: {code, radius} to dec (device) for the speculative
 // evaluation's kernels; the scalars, the decision and - last - `seq` to host_pub (host-mapped, coherent: kLmPubDoubles doubles).
 constexpr int kLmPubDoubles = SC_COUNT + 8;  // scalars | code radius decrease_factor rel step_norm cost_change - | seq
-void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq);
+void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq, double* fail_slots /* SC_FAIL, SC_FAIL_FRONT: cleared behind the read */);
 void launch_lm_decide_cases(hipStream_t st, int n, const double* in, double* out);  // test entry
 
 void launch_points_to_caller(hipStream_t st, int NP, int width, const int* orig, const double* in, double* out);

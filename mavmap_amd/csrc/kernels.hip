@@ -2480,11 +2480,13 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
     const unsigned char* __restrict__ pt_free, const double* __restrict__ Gi, const double* __restrict__ h,
     const double* __restrict__ Cu, const double* __restrict__ gu, const double* __restrict__ scale_pt,
     const double* __restrict__ points, double* __restrict__ cand_points, double* __restrict__ delta_points,
-    double* __restrict__ partial) {
+    double* __restrict__ partial, const double* __restrict__ cand_camrec, const double* __restrict__ cand_intr,
+    const unsigned char* __restrict__ pt_active, double* __restrict__ cost_partial) {
   __shared__ double s_t[3][256];
+  __shared__ double s_new[3][128];  // the block's candidate points (ppb <= 128)
   __shared__ double s_red[4];
   const int tid = threadIdx.x;
-  double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
+  double a_step = 0.0, a_model = 0.0, a_x2 = 0.0, a_cost = 0.0;
   for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int p0 = blk * ppb, p1 = min(p0 + ppb, NP);
     const int o0 = pt_start[p0], o1 = pt_start[p1];
@@ -2564,13 +2566,43 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
         cand_points[3 * (size_t)p + k] = xn;
         delta_points[3 * (size_t)p + k] = d[k];
         if (fr) a_x2 += xn * xn;
+        if (cost_partial) s_new[k][tid] = xn;
       }
+    }
+    // ---- the candidate's cost over the block's observations (what k_cost_only did in a launch of its own: the pixel and
+    // the image index are re-read from the caches, the candidate point comes from LDS, the candidate cameras from memory) ----
+    if (cost_partial) {
+      __syncthreads();
+      for (int base = o0; base < o1; base += 256) {
+        const int o = base + tid;
+        if (o < o1) {
+          const int pt = obs_pt[o], im = obs_img[o];
+          const double2 m = uv[o];
+          const int cam = img_cam[im];
+          double rec[9], kin[9], r[2];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) rec[k] = cand_camrec[9 * im + k];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) kin[k] = cand_intr[9 * cam + k];
+          const double Xn[3] = {s_new[0][pt - p0], s_new[1][pt - p0], s_new[2][pt - p0]};
+          obs_residual(cam_model[cam], rec, kin, Xn, m.x, m.y, r);
+          double w, half_rho;
+          cauchy_weight(r[0] * r[0] + r[1] * r[1], loss_b, loss_inv_b, w, half_rho);
+          if (pt_active && !pt_active[pt]) half_rho = 0.0;  // filtered point: no residual block
+          a_cost += half_rho;
+        }
+      }
+      __syncthreads();  // s_new is rewritten by the next block
     }
   }
   const double s0 = block_sum_256(a_step, s_red);
   const double s1 = block_sum_256(a_model, s_red);
   const double s2 = block_sum_256(a_x2, s_red);
   if (threadIdx.x == 0) { partial[3 * blockIdx.x] = s0; partial[3 * blockIdx.x + 1] = s1; partial[3 * blockIdx.x + 2] = s2; }
+  if (cost_partial) {
+    const double s3 = block_sum_256(a_cost, s_red);
+    if (threadIdx.x == 0) cost_partial[blockIdx.x] = s3;
+  }
 }
 int backsub_points_grid(int NP) {
   int gp = (NP + 15) / 16;
@@ -2581,7 +2613,7 @@ void launch_backsub_points_jvp(hipStream_t st, int NP, int NPs, int NI, double r
                                const SweepArgs& a, const int* pt_start, const double* delta_cam,
                                const unsigned char* pt_free, const double* Gi, const double* h, const double* Cu,
                                const double* gu, const double* scale_pt, double* cand_points, double* delta_points,
-                               double* partial) {
+                               double* partial, const double* cand_camrec, const double* cand_intr, double* cost_partial) {
   const int gp = backsub_points_grid(NP);
   // points per work-group: ~224 observations at the problem's average track length (the owner lanes are the first ppb)
   const double track = NP > 0 ? (double)a.N / NP : 1.0;
@@ -2589,7 +2621,8 @@ void launch_backsub_points_jvp(hipStream_t st, int NP, int NPs, int NI, double r
   const int nblocks = (NP + ppb - 1) / ppb;
   hipLaunchKernelGGL(k_backsub_points_packed, dim3(gp), dim3(256), 0, st, NP, NPs, NI, ppb, nblocks, radius, dmin, dmax, a.loss_b,
                      a.loss_inv_b, pt_start, a.obs_img, a.obs_pt, a.uv, a.img_cam, a.cam_model, a.camrec, a.intr, delta_cam, pt_free,
-                     Gi, h, Cu, gu, scale_pt, a.points, cand_points, delta_points, partial);
+                     Gi, h, Cu, gu, scale_pt, a.points, cand_points, delta_points, partial, cand_camrec, cand_intr, a.pt_active,
+                     cost_partial);
 }
 void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radius, double dmin,
                            double dmax, const int* pt_start, const int* obs_img, const int* q_start,
@@ -2719,7 +2752,7 @@ __global__ void __launch_bounds__(256) k_reduce_tasks(ReduceTasks T, LmSpec spec
 // One wave: the LM decision on the device (for the speculative evaluation behind it) and the scalars to the host. Every lane
 // evaluates the decision (uniform) and stores ONE word of the publication - 24 stores across the host link in parallel
 // (one lane writing them in turn took 16 us) -, the sequence number follows behind a system-scope fence.
-__global__ void __launch_bounds__(64) k_lm_snapshot(LmSpec spec, double* __restrict__ dec, double* host_pub, double seq) {
+__global__ void __launch_bounds__(64) k_lm_snapshot(LmSpec spec, double* __restrict__ dec, double* host_pub, double seq, double* fail_slots) {
   const int lane = threadIdx.x;
   const LmDecision d = lm_decide(spec.scal, spec);
   if (lane == 0) { dec[0] = (double)d.code; dec[1] = d.radius; }
@@ -2736,6 +2769,9 @@ __global__ void __launch_bounds__(64) k_lm_snapshot(LmSpec spec, double* __restr
   __threadfence_system();
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) out[SC_COUNT + 7] = seq;
+  // every lane has read the scalars: the two failure slots start the next linear solve clean (the speculative front end
+  // behind this kernel and the factorisation after it add to them) - the two fill operations per iteration are gone
+  if (lane < 2 && fail_slots) fail_slots[lane] = 0.0;
 }
 // Test entry (mavba_debug_lm_decide): `n` decisions by the device build of lm_decide. in: SC_COUNT scalars + 8 parameters
 // (radius, decrease_factor, ptol, ftol, min_rel_dec, max_radius, abs_gtol, pending_eval) per case; out: 6 doubles per case.
@@ -2753,8 +2789,8 @@ __global__ void k_lm_decide_cases(int n, const double* __restrict__ in, double* 
 void launch_lm_decide_cases(hipStream_t st, int n, const double* in, double* out) {
   if (n > 0) hipLaunchKernelGGL(k_lm_decide_cases, dim3((n + 255) / 256), dim3(256), 0, st, n, in, out);
 }
-void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq) {
-  hipLaunchKernelGGL(k_lm_snapshot, dim3(1), dim3(64), 0, st, spec, dec, host_pub, seq);
+void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq, double* fail_slots) {
+  hipLaunchKernelGGL(k_lm_snapshot, dim3(1), dim3(64), 0, st, spec, dec, host_pub, seq, fail_slots);
 }
 void launch_reduce_tasks(hipStream_t st, const ReduceTasks& T, int n, const LmSpec& spec) {
   if (n > 0) hipLaunchKernelGGL(k_reduce_tasks, dim3(n), dim3(256), 0, st, T, spec);

@@ -792,7 +792,7 @@ void mavba_session::finish_structure() {
     if (rows_mode) kMaxPoints = std::min(kMaxPoints, kRowsMaxPoints);
     // cost model of the run-based greedy (cycles of one CU: per cluster, per 16-point batch of each row class; measured on
     // C3, MAVBA_ROWS_COST="F,B0,B1,B2" overrides)
-    double kCostF = 20000.0, kCostB[kRowsClasses] = {15400.0, 17500.0, 27500.0};  // (F also stands for what a cluster costs downstream: its block partials in the finalize pass - sweep in gpurun_out/r04t_cost_sweep.txt)
+    double kCostF = 20000.0, kCostB[kRowsClasses] = {15400.0, 17500.0, 27500.0};  // (F also stands for what a cluster costs downstream: its block partials in the finalize pass - sweep in profiles/r04_cluster_cost_sweep.txt)
     if (const char* e = std::getenv("MAVBA_ROWS_COST")) std::sscanf(e, "%lf,%lf,%lf,%lf", &kCostF, &kCostB[0], &kCostB[1], &kCostB[2]);
     // Greedy over consecutive points, run independently on fixed ranges of points (NOT on "one range per
     // thread": the clusters - and with them the order in which partials are added - must not depend on the
@@ -1201,11 +1201,13 @@ void mavba_session::finish_structure() {
     }
     num_slots[k] = slot;
   }
-  // long partial runs are pre-reduced in groups of 32 into extra slots; the block then points at those
+  // long partial runs are pre-reduced in groups of 32 into extra slots; the block then points at those (launch-bound
+  // problems - a local window has ~80 clusters - keep runs of up to 256 for the finalize pass itself: one launch less)
   std::vector<PartialReduce> reduce_tasks;
+  const int kPreReduceFrom = N < 200000 ? 256 : 64;
   for (SchurBlock& B : blocks) {
     const int n = B.chunk_end - B.chunk_begin;
-    if (n <= 64) continue;
+    if (n <= kPreReduceFrom) continue;
     const int first = num_slots[B.kind];
     for (int b0 = B.chunk_begin; b0 < B.chunk_end; b0 += 32)
       reduce_tasks.push_back(PartialReduce{B.kind, b0, std::min(b0 + 32, B.chunk_end), num_slots[B.kind]++});

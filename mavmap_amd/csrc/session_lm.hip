@@ -44,7 +44,8 @@ void mavba_session::launch_front(double r, bool entries, const LmSpec& spec) {
   f.trace = nullptr;
   // (one fill for the two failure slots - they are neighbours: the solve that follows this front end finds SC_FAIL clean)
   static_assert(SC_FAIL_FRONT == SC_FAIL + 1, "the two failure slots are cleared together");
-  if (entries) { HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, 2 * sizeof(double), st)); fail_slot_clean = true; }
+  // (the speculative front end runs right behind k_lm_snapshot, which has cleared both slots on the device)
+  if (entries) { if (!spec.dec) HIP_OK(hipMemsetAsync(d_scal.p + SC_FAIL, 0, 2 * sizeof(double), st)); fail_slot_clean = true; }
   if (entries && fused_now()) {
     // every observed point sits in a cluster: the cluster kernel evaluates the Jacobians itself and leaves the block
     // partials of S for this radius (no entry records in HBM)
@@ -248,6 +249,12 @@ void mavba_session::candidate_enqueue(double r) {
                           d_ccamrec.p);  // (+ the candidate's camera records: no separate cam_prepare launch)
   });
   static const bool from_entries = std::getenv("MAVBA_BACKSUB_ENTRIES") != nullptr;
+  // (round 4: for launch-bound problems the candidate's cost is summed by the back-substitution kernel itself - the observations
+  // of a block's points are in its caches, the new points in its LDS -, one launch less: a 10-image window 2.30 -> 2.19 ms. At
+  // C3 / C5 the streaming k_cost_only is the faster way to do that pass (0.091 + 0.023 against 0.123 ms), so large problems keep
+  // it. MAVBA_COST_FUSE_MAX_OBS moves the switch, 0 = never fuse)
+  static const long long fuse_max_obs = [] { const char* e = std::getenv("MAVBA_COST_FUSE_MAX_OBS"); return e ? std::atoll(e) : 200000ll; }();
+  const bool cost_separate = from_entries || (long long)N > fuse_max_obs;
   timed("backsub_points", [&] {
     if (from_entries) {
       int rows_check = 0;
@@ -257,18 +264,18 @@ void mavba_session::candidate_enqueue(double r) {
     } else {
       launch_backsub_points_jvp(st, NP, NPs, NI, r, dmin, dmax, sweep_args(d_camrec.p, d_intr.p, d_points.p), d_pt_start.p,
                                 d_delta_cam.p, d_pt_free.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p, d_cpoints.p,
-                                d_delta_pts.p, d_step_partial.p);
+                                d_delta_pts.p, d_step_partial.p, d_ccamrec.p, d_cintr.p, cost_separate ? nullptr : d_sweep_partial.p);
     }
   });
   SweepArgs a = sweep_args(d_ccamrec.p, d_cintr.p, d_cpoints.p);
-  timed("cost_only", [&] { launch_cost_only(st, a); });
+  if (cost_separate) timed("cost_only", [&] { launch_cost_only(st, a); });
   if (num_priors > 0)
     timed("rot_prior", [&] {
       launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_cposes.p, d_prior_res.p,
                        d_prior_jac.p, d_prior_cost.p);
     });
   timed("reduce", [&] {
-    const int nsweep = N > 0 ? jacobian_sweep_grid(N) : 0;
+    const int nsweep = N > 0 ? (cost_separate ? jacobian_sweep_grid(N) : rows) : 0;
     ReduceTasks T;
     T.t[0] = ReduceTask{d_step_partial.p, rows + ugroups, 3, 0, nullptr, 0, d_scal.p + SC_STEP_NORM2};
     T.t[1] = ReduceTask{d_step_partial.p + 1, rows + ugroups, 3, 0, nullptr, 0, d_scal.p + SC_MODEL_CHANGE};
@@ -346,7 +353,7 @@ int mavba_session::iterate(int max_iters, int* done) {
       solve_linear(radius);
       candidate_enqueue(radius);
       lm_seq += 1.0;
-      timed("lm_snapshot", [&] { launch_lm_snapshot(st, sp, d_lm_dec.p, lm_pub, lm_seq); });
+      timed("lm_snapshot", [&] { launch_lm_snapshot(st, sp, d_lm_dec.p, lm_pub, lm_seq, d_scal.p + SC_FAIL); });
       books = Books{evaluated, assembled, front_valid, fail_slot_clean, front_radius, eval_rows};
       std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
       std::swap(d_camrec.p, d_ccamrec.p);
