@@ -522,6 +522,7 @@ int mavba_solve(const mavba_problem* problem, const mavba_options* options, mavb
   int done = 0, term = 0;
   rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &term);
   lap("iterate");
+  if (tt) std::fprintf(stderr, "[solve]   of it waiting for the device  %8.2f ms (%d iterations)\n", 1e3 * s->pub_wait_seconds, done);
   if (rc == MAVBA_OK && result) rc = mavba_session_result(s, result);
   // ceres leaves the user's parameter blocks untouched after NUMERICAL_FAILURE
   if (rc == MAVBA_OK && term != MAVBA_TERM_NUMERICAL_FAILURE)

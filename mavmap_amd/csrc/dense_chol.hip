@@ -18,6 +18,7 @@
 //
 // At BA sizes the cost is the chain of dependent panel steps, not the flops (DESIGN.md sections 4 and 6).
 #include "internal.h"
+#include "lm_bodies.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -1650,9 +1651,12 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
 // instead of two (the persistent launch + the backward substitution cost 43 us for the 128 x 128 system of a 10-image
 // window; this is the same arithmetic: L00, L10 = A10 L00^-T, A11 - L10 L10^T, L11, then the two triangular solves with
 // the inverted diagonal tiles). M is only read.
+// UPD (round 4): the work-group goes on to the camera update of the LM step (k_update_cameras' work: it reads the solution
+// this work-group has just written) - one launch less on the 75 us iteration of a local window.
+template <bool UPD>
 __global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M, int ld, int nb_all, int nb,
                                                     double* __restrict__ fail, double* __restrict__ y,
-                                                    const int* __restrict__ scatter, double* __restrict__ y_nat) {
+                                                    const int* __restrict__ scatter, double* y_nat, CamUpdateArgs U) {
   // nb (1 or 2): the leading tile columns that hold free parameters; columns beyond them (up to nb_all tiles) are unit
   // diagonal with a zero right-hand side: their solution is 0
   __shared__ __attribute__((aligned(16))) double W[NB * GLD];
@@ -1727,22 +1731,45 @@ __global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M
     y[c] = x;
     if (scatter) { const int t = scatter[c]; if (t >= 0) y_nat[t] = x; }
   }
+  if (UPD) {
+    __shared__ double s_red[4];
+    __syncthreads();  // (the solution in the variables' order is in memory, for every lane of this work-group)
+    const int groups = (U.NI + kUpdImagesPerGroup - 1) / kUpdImagesPerGroup;
+    for (int vb = 0; vb < (groups > 0 ? groups : 1); ++vb) {
+      update_cameras_body(vb, U.NI, U.NC, U.cam_part, U.radius, U.dmin, U.dmax, y_nat, U.scale_cam, U.img_rec, U.cam_rec, U.poses, U.intr,
+                          U.cand_poses, U.cand_intr, U.delta_cam, U.partial3, U.cand_camrec, s_red);
+      __syncthreads();
+    }
+  }
 }
 
 // diag_ws: n_pad * 64 doubles (the inverses of the factor's diagonal tiles); L: second
 // (n_pad + 64) x n_pad matrix receiving the factor's off-diagonal tiles and the
 // forward-substituted right-hand side. `cs` = tile structure + launch schedule of the matrix.
-void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
+static bool chol_small_path() {
+  static const bool on = [] { const char* e = std::getenv("MAVBA_CHOL_SMALL"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+bool dense_spd_solve_is_small(int n_pad, const CholStructure& cs) {
+  const int nb = n_pad / NB;
+  const int nb_active = cs.active_tiles > 0 ? std::min(cs.active_tiles, nb) : nb;
+  return nb_active <= 2 && chol_small_path();
+}
+bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws, double* L, const CholStructure& cs,
-                            const int* y_scatter, double* y_nat, bool allow_persistent, hipEvent_t after_factor) {
+                            const int* y_scatter, double* y_nat, bool allow_persistent, hipEvent_t after_factor,
+                            const CamUpdateArgs* upd) {
   const int nb = n_pad / NB, ld = n_pad;
   double* inv = diag_ws;
-  static const bool small_path = [] { const char* e = std::getenv("MAVBA_CHOL_SMALL"); return !e || std::atoi(e) != 0; }();
   const int nb_active = cs.active_tiles > 0 ? std::min(cs.active_tiles, nb) : nb;
-  if (nb_active <= 2 && small_path) {
-    hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), 0, st, M, ld, nb, nb_active, fail, y, y_scatter, y_nat);
+  if (dense_spd_solve_is_small(n_pad, cs)) {
+    const bool with_update = upd != nullptr && y_scatter != nullptr && y_nat != nullptr;
+    if (with_update)
+      hipLaunchKernelGGL(k_chol_small<true>, dim3(1), dim3(256), 0, st, M, ld, nb, nb_active, fail, y, y_scatter, y_nat, *upd);
+    else
+      hipLaunchKernelGGL(k_chol_small<false>, dim3(1), dim3(256), 0, st, M, ld, nb, nb_active, fail, y, y_scatter, y_nat, CamUpdateArgs{});
     if (after_factor) (void)hipEventRecord(after_factor, st);  // (one launch does both halves)
-    return;
+    return with_update;
   }
   const unsigned epoch = ++cs.epoch;  // flags of this solve (forward hand-offs and backward substitution)
   if (allow_persistent && cs.persist_ok) {
@@ -1810,6 +1837,7 @@ void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
       hipLaunchKernelGGL(k_chol_backsolve, dim3(k - cs.seg_first[k] + 1), dim3(64), 0, st, L, ld, k, cs.seg_first[k], inv, z, y);
     if (y_scatter) hipLaunchKernelGGL(k_scatter_y, dim3((n_pad + 255) / 256), dim3(256), 0, st, n_pad, y_scatter, y, y_nat);
   }
+  return false;
 }
 
 }  // namespace mavba

@@ -60,6 +60,24 @@ __device__ __forceinline__ bool chol3_inv_fast(const double* C, double* Gi) {
   return (C[0] > 0.0) && (d1 > 0.0) && (d2 > 0.0);
 }
 
+// Block-wide sum for 256-thread blocks; `scratch` = 4 doubles of LDS. Result in thread 0.
+__device__ __forceinline__ double block_sum_256(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wv] = v;
+  __syncthreads();
+  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+__device__ __forceinline__ double block_max_256(double v, double* scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wv] = v;
+  __syncthreads();
+  return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 }  // namespace mavba

@@ -307,6 +307,20 @@ void launch_reduce_tasks(hipStream_t st, const ReduceTasks& tasks, int n, const 
 constexpr int kLmPubDoubles = SC_COUNT + 8;  // scalars | code radius decrease_factor rel step_norm cost_change - | seq
 void launch_lm_snapshot(hipStream_t st, const LmSpec& spec, double* dec, double* host_pub, double seq, double* fail_slots /* SC_FAIL, SC_FAIL_FRONT: cleared behind the read */);
 void launch_lm_decide_cases(hipStream_t st, int n, const double* in, double* out);  // test entry
+// k_reduce_tasks + k_lm_snapshot in one work-group (the n reductions one after the other, then the decision)
+void launch_lm_tail(hipStream_t st, const ReduceTasks& tasks, int n, const LmSpec& spec, double* dec, double* host_pub, double seq, double* fail_slots);
+// The tail of an evaluation in one work-group - k_camera_reduce_img, k_camera_reduce_cam, k_state_norms, k_reduce_tasks - for
+// problems whose images, cameras and points one work-group walks in a few microseconds (a local window). Same sums, same order.
+void state_norms_grid(int NI, int NC, int NP, int* gp, int* gc);  // point groups + camera groups of launch_state_norms
+struct EvalSmallArgs {
+  int NI, NC, NP, NPs, with_cams, cam_part, gp, gc, num_tasks;
+  const int* img_chunk_start; const double* cam_partial; const int* prior_start; const double* prior_res; const double* prior_jac;
+  const int* cam_img_start; const int* cam_imgs; double* img_rec; double* cam_rec; double* img_intr_tmp;
+  const unsigned char* pose_free; const unsigned char* intr_free; const unsigned char* pt_free;
+  const double* poses; const double* intr; const double* points; const double* gu; double* norm_partial;
+  ReduceTasks T; LmSpec spec;
+};
+void launch_eval_small(hipStream_t st, const EvalSmallArgs& a);
 
 void launch_points_to_caller(hipStream_t st, int NP, int width, const int* orig, const double* in, double* out);
 void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,
@@ -418,10 +432,20 @@ struct CholStructure {
 };
 // y_scatter (may be null): y_nat[y_scatter[t]] = y[t] for every t with y_scatter[t] >= 0 (the solution in
 // the caller's variable order when the matrix was assembled in a permuted order).
-void dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
+// upd (may be null): the camera update that follows the solve in the LM loop (launch_update_cameras' arguments; y = y_nat).
+// A system of one or two tile columns is solved by ONE work-group, which then applies the update as well: the return value
+// says whether it did (the caller skips its own launch).
+struct CamUpdateArgs {
+  int NI, NC, cam_part; double radius, dmin, dmax;
+  const double* scale_cam; const double* img_rec; const double* cam_rec; const double* poses; const double* intr;
+  double* cand_poses; double* cand_intr; double* delta_cam; double* partial3; double* cand_camrec;
+};
+bool dense_spd_solve_is_small(int n_pad, const CholStructure& cs);  // the one-work-group path will be taken
+bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws, double* L, const CholStructure& cs,
                             const int* y_scatter = nullptr, double* y_nat = nullptr, bool allow_persistent = true,
-                            hipEvent_t after_factor = nullptr /* recorded between the factorisation and the backward substitution */);
+                            hipEvent_t after_factor = nullptr /* recorded between the factorisation and the backward substitution */,
+                            const CamUpdateArgs* upd = nullptr);
 
 }  // namespace mavba
 #endif

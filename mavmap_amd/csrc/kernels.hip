@@ -16,26 +16,9 @@
 #include "ba_math.h"
 #include "dev_reduce.h"
 #include "lm_decide.h"
+#include "lm_bodies.h"
 
 namespace mavba {
-
-// Block-wide sum for 256-thread blocks; `scratch` = 4 doubles of LDS. Result in thread 0.
-__device__ __forceinline__ double block_sum_256(double v, double* scratch) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) scratch[wv] = v;
-  __syncthreads();
-  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-}
-__device__ __forceinline__ double block_max_256(double v, double* scratch) {
-  v = wave_max(v);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) scratch[wv] = v;
-  __syncthreads();
-  return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
-}
 
 // ---------------------------------------------------------------------------
 // K0: camera records (hoists sin/cos out of the per-observation work)
@@ -1073,34 +1056,13 @@ void launch_rot_prior(hipStream_t st, int n, const int* prior_img, const double*
 }
 
 // Per image: sum its chunks (fixed order) + its rotation priors -> img_rec[81] and
-// the image's intrinsics part -> img_intr_tmp[54]. One 64-lane group per image.
+// the image's intrinsics part -> img_intr_tmp[54]. One 64-lane group per image (camera_reduce_img_body, lm_bodies.h).
 __global__ void __launch_bounds__(64) k_camera_reduce_img(
     int NI, const int* __restrict__ img_chunk_start, const double* __restrict__ partial,
     const int* __restrict__ prior_start, const double* __restrict__ prior_res,
     const double* __restrict__ prior_jac, double* __restrict__ img_rec, double* __restrict__ img_intr_tmp, LmSpec spec) {
   if (!lm_spec_go(spec, nullptr)) return;
-  const int i = blockIdx.x;
-  const int c0 = img_chunk_start[i], c1 = img_chunk_start[i + 1];
-  for (int e = threadIdx.x; e < kSweepAcc; e += 64) {
-    double s = 0.0;
-    for (int c = c0; c < c1; ++c) s += partial[(size_t)c * kSweepAcc + e];
-    if (e < 27 && prior_start) {
-      for (int q = prior_start[i]; q < prior_start[i + 1]; ++q) {
-        const double* j = prior_jac + 3 * q;
-        if (e < 21) {
-          // PP upper-triangle slots touching the rvec block: (x,y) with y < 3
-          int x = 0, rem = e;
-          while (rem >= 6 - x) { rem -= 6 - x; ++x; }
-          const int y = x + rem;
-          if (y < 3) s += j[x] * j[y];
-        } else if (e - 21 < 3) {
-          s += j[e - 21] * prior_res[q];
-        }
-      }
-    }
-    if (e < kImgRec) img_rec[(size_t)i * kImgRec + e] = s;
-    else img_intr_tmp[(size_t)i * kCamRec + (e - kImgRec)] = s;
-  }
+  camera_reduce_img_body(blockIdx.x, threadIdx.x, img_chunk_start, partial, prior_start, prior_res, prior_jac, img_rec, img_intr_tmp);
 }
 // Per camera: sum the intrinsics parts of its images (fixed order: 16 interleaved partial sums
 // per element, then a fixed tree) — one 1024-thread block per camera.
@@ -1199,45 +1161,21 @@ __global__ void __launch_bounds__(256) k_state_norms(
     double* __restrict__ partial, LmSpec spec) {
   __shared__ double s_red[4];
   if (!lm_spec_go(spec, nullptr)) return;
-  double gmax = 0.0, x2 = 0.0;
-  if ((int)blockIdx.x < gp) {
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < NP; p += gp * 256) {
-      if (!pt_free[p]) continue;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        gmax = fmax(gmax, fabs(gu[k * NPs + p]));
-        const double x = points[3 * (size_t)p + k];
-        x2 += x * x;
-      }
-    }
-  } else {
-    const int ncam = 6 * NI + 9 * NC;
-    const int gc = gridDim.x - gp;  // camera blocks (one block for 3 000 columns was this kernel's long pole: 11 -> 5 us at C3)
-    for (int t = ((int)blockIdx.x - gp) * 256 + threadIdx.x; t < ncam; t += gc * 256) {
-      double g, x; bool fr;
-      if (t < 6 * NI) {
-        fr = pose_free[t] != 0; g = img_rec[(size_t)(t / 6) * kImgRec + 21 + t % 6]; x = poses[t];
-      } else {
-        const int c = (t - 6 * NI) / 9, k = (t - 6 * NI) % 9;
-        fr = intr_free[9 * c + k] != 0; g = cam_rec[(size_t)c * kCamRec + 45 + k]; x = intr[9 * c + k];
-      }
-      if (!fr) continue;
-      gmax = fmax(gmax, fabs(g));        // gradient is global after the camera-sum all-reduce
-      if (cam_part) x2 += x * x;         // counted on one rank only
-    }
-  }
-  const double m = block_max_256(gmax, s_red);
-  const double s = block_sum_256(x2, s_red);
-  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = m; partial[2 * blockIdx.x + 1] = s; }
+  // (camera blocks behind the point blocks: one block for 3 000 columns was this kernel's long pole, 11 -> 5 us at C3)
+  state_norms_body(blockIdx.x, gp, gridDim.x - gp, NI, NC, NP, NPs, cam_part, pose_free, intr_free, pt_free, poses, intr, points,
+                   img_rec, cam_rec, gu, partial, s_red);
+}
+void state_norms_grid(int NI, int NC, int NP, int* gp, int* gc) {
+  *gp = std::min(512, (NP + 255) / 256);
+  *gc = std::max(1, std::min(kStateNormsCamBlocks, (6 * NI + 9 * NC + 255) / 256));
 }
 void launch_state_norms(hipStream_t st, int NI, int NC, int NP, int NPs, bool cam_part,
                         const unsigned char* pose_free, const unsigned char* intr_free,
                         const unsigned char* pt_free, const double* poses, const double* intr,
                         const double* points, const double* img_rec, const double* cam_rec,
                         const double* gu, double* partial, int* grid_out, const LmSpec& spec) {
-  int gp = (NP + 255) / 256;
-  if (gp > 512) gp = 512;
-  const int gc = std::max(1, std::min(kStateNormsCamBlocks, (6 * NI + 9 * NC + 255) / 256));
+  int gp, gc;
+  state_norms_grid(NI, NC, NP, &gp, &gc);
   hipLaunchKernelGGL(k_state_norms, dim3(gp + gc), dim3(256), 0, st, NI, NC, NP, NPs, gp, cam_part ? 1 : 0,
                      pose_free, intr_free, pt_free, poses, intr, points, img_rec, cam_rec, gu, partial, spec);
   *grid_out = gp + gc;
@@ -2640,60 +2578,18 @@ void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radiu
   *grid_out = gp;
 }
 
-// Camera columns: step = -y, delta = s * step, candidate parameters; one block.
-constexpr int kUpdImagesPerGroup = 42;  // 252 pose parameters: one trip of a 256-thread work-group
+// Camera columns: step = -y, delta = s * step, candidate parameters (update_cameras_body, lm_bodies.h: work-group b takes
+// 42 images - one work-group looping over all 6 NI + 9 NC parameters took 22 us at C3).
 int update_cameras_groups(int NI) { return std::max(1, (NI + kUpdImagesPerGroup - 1) / kUpdImagesPerGroup); }
-// Work-group b takes the images [42 b, 42 b + 42) - whole pose blocks, so that it can write their camera records too -
-// and group 0 the intrinsics blocks as well; every group leaves one (|delta|^2, model change, |x + delta|^2) triple.
-// (One work-group looping over all 6 NI + 9 NC parameters took 22 us at C3.)
 __global__ void __launch_bounds__(256) k_update_cameras(
     int NI, int NC, int cam_part, double radius, double dmin, double dmax, const double* __restrict__ y,
     const double* __restrict__ scale_cam, const double* __restrict__ img_rec, const double* __restrict__ cam_rec,
-    const double* __restrict__ poses, const double* __restrict__ intr, double* __restrict__ cand_poses,
+    const double* __restrict__ poses, const double* __restrict__ intr, double* cand_poses,
     double* __restrict__ cand_intr, double* __restrict__ delta_cam, double* __restrict__ partial3,
     double* __restrict__ cand_camrec) {
   __shared__ double s_red[4];
-  const int i0 = blockIdx.x * kUpdImagesPerGroup, i1 = min(i0 + kUpdImagesPerGroup, NI);
-  double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
-  auto one = [&](int t) {
-    const double s = scale_cam[t];
-    double n2, g, x;
-    if (t < 6 * NI) {
-      const int i = t / 6, e = t % 6;
-      n2 = img_rec[(size_t)i * kImgRec + sym_idx(e, e, 6)]; g = img_rec[(size_t)i * kImgRec + 21 + e]; x = poses[t];
-    } else {
-      const int c = (t - 6 * NI) / 9, k = (t - 6 * NI) % 9;
-      n2 = cam_rec[(size_t)c * kCamRec + sym_idx(k, k, 9)]; g = cam_rec[(size_t)c * kCamRec + 45 + k]; x = intr[9 * c + k];
-    }
-    double d = 0.0;
-    if (s != 0.0) {
-      const double yy = y[t];
-      const double D2 = clampd(s * s * n2, dmin, dmax) / radius;
-      d = -yy * s;
-      if (cam_part) { a_model += 0.5 * yy * (s * g + D2 * yy); a_step += d * d; }
-    }
-    const double xn = x + d;
-    if (s != 0.0 && cam_part) a_x2 += xn * xn;
-    delta_cam[t] = d;
-    if (t < 6 * NI) cand_poses[t] = xn; else cand_intr[t - 6 * NI] = xn;
-  };
-  for (int t = 6 * i0 + threadIdx.x; t < 6 * i1; t += 256) one(t);
-  if (blockIdx.x == 0)
-    for (int t = 6 * NI + threadIdx.x; t < 6 * NI + 9 * NC; t += 256) one(t);
-  const double s0 = block_sum_256(a_step, s_red);
-  const double s1 = block_sum_256(a_model, s_red);
-  const double s2 = block_sum_256(a_x2, s_red);
-  if (threadIdx.x == 0) { partial3[3 * blockIdx.x] = s0; partial3[3 * blockIdx.x + 1] = s1; partial3[3 * blockIdx.x + 2] = s2; }
-  // the candidate's camera records of this group's images (k_cam_prepare's work; the stores above are the group's own)
-  if (cand_camrec) {
-    __syncthreads();
-    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-      double rec[9];
-      cam_prepare(cand_poses + 6 * i, rec);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) cand_camrec[9 * i + k] = rec[k];
-    }
-  }
+  update_cameras_body(blockIdx.x, NI, NC, cam_part, radius, dmin, dmax, y, scale_cam, img_rec, cam_rec, poses, intr, cand_poses, cand_intr,
+                      delta_cam, partial3, cand_camrec, s_red);
 }
 void launch_update_cameras(hipStream_t st, int NI, int NC, bool cam_part, double radius, double dmin,
                            double dmax, const double* y, const double* scale_cam,
@@ -2734,44 +2630,65 @@ void launch_reduce_cols(hipStream_t st, const double* partial, int rows, int col
 __global__ void __launch_bounds__(256) k_reduce_tasks(ReduceTasks T, LmSpec spec) {
   __shared__ double s_red[4];
   if (!lm_spec_go(spec, nullptr)) return;
-  const ReduceTask t = T.t[blockIdx.x];
-  double v = 0.0;
-  for (int r = threadIdx.x; r < t.rows; r += 256) {
-    const double x = t.src[(size_t)r * t.stride];
-    v = t.is_max ? fmax(v, x) : v + x;
-  }
-  double total = t.is_max ? block_max_256(v, s_red) : block_sum_256(v, s_red);
-  if (t.rows2 > 0) {
-    __syncthreads();
-    double w = 0.0;
-    for (int r = threadIdx.x; r < t.rows2; r += 256) w += t.src2[r];
-    total += block_sum_256(w, s_red);
-  }
-  if (threadIdx.x == 0) *t.out = total;
+  reduce_task_body(T.t[blockIdx.x], s_red);
 }
-// One wave: the LM decision on the device (for the speculative evaluation behind it) and the scalars to the host. Every lane
-// evaluates the decision (uniform) and stores ONE word of the publication - 24 stores across the host link in parallel
-// (one lane writing them in turn took 16 us) -, the sequence number follows behind a system-scope fence.
-__global__ void __launch_bounds__(64) k_lm_snapshot(LmSpec spec, double* __restrict__ dec, double* host_pub, double seq, double* fail_slots) {
-  const int lane = threadIdx.x;
-  const LmDecision d = lm_decide(spec.scal, spec);
-  if (lane == 0) { dec[0] = (double)d.code; dec[1] = d.radius; }
-  volatile double* out = host_pub;
-  double v = 0.0;
-  if (lane < SC_COUNT) v = spec.scal[lane];
-  else if (lane == SC_COUNT) v = (double)d.code;
-  else if (lane == SC_COUNT + 1) v = d.radius;
-  else if (lane == SC_COUNT + 2) v = d.decrease_factor;
-  else if (lane == SC_COUNT + 3) v = d.rel;
-  else if (lane == SC_COUNT + 4) v = d.step_norm;
-  else if (lane == SC_COUNT + 5) v = d.cost_change;
-  if (lane < SC_COUNT + 6) out[lane] = v;
-  __threadfence_system();
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) out[SC_COUNT + 7] = seq;
-  // every lane has read the scalars: the two failure slots start the next linear solve clean (the speculative front end
-  // behind this kernel and the factorisation after it add to them) - the two fill operations per iteration are gone
-  if (lane < 2 && fail_slots) fail_slots[lane] = 0.0;
+// One wave: the LM decision on the device and the scalars to the host (lm_snapshot_body, lm_bodies.h).
+__global__ void __launch_bounds__(64) k_lm_snapshot(LmSpec spec, double* dec, double* host_pub, double seq, double* fail_slots) {
+  lm_snapshot_body(threadIdx.x, spec, dec, host_pub, seq, fail_slots);
+}
+// The end of a candidate step in ONE work-group: its (up to four) scalar reductions side by side, then (first wave) the
+// decision and the publication - k_reduce_tasks + k_lm_snapshot without the launch in between.
+__global__ void __launch_bounds__(1024) k_lm_tail(ReduceTasks T, int n, LmSpec spec, double* dec, double* host_pub, double seq, double* fail_slots) {
+  __shared__ double s_t[4][2][4];
+  reduce_tasks_grouped(T, n, s_t);
+  if (threadIdx.x < 64) lm_snapshot_body(threadIdx.x, spec, dec, host_pub, seq, fail_slots);
+}
+// The tail of an evaluation for a small problem in ONE work-group of 1024 lanes: per-image sums (one lane per element),
+// per-camera sums, norms (four of k_state_norms' groups at a time), the three scalar reductions (side by side) -
+// k_camera_reduce_img + k_camera_reduce_cam + k_state_norms + k_reduce_tasks: 17 us of launches for ~4 us of work.
+constexpr int kEvalSmallMaxGroups = 40;  // 8192 points / 256 + camera groups
+__global__ void __launch_bounds__(1024) k_eval_small(EvalSmallArgs a) {
+  __shared__ double s_part[16][64];
+  __shared__ double s_w[kEvalSmallMaxGroups][2][4];
+  __shared__ double s_t[4][2][4];
+  if (!lm_spec_go(a.spec, nullptr)) return;
+  const int tid = threadIdx.x, g = tid >> 8, lt = tid & 255, wv = (tid >> 6) & 3, lane = tid & 63;
+  for (int q = tid; q < a.NI * kSweepAcc; q += 1024)
+    camera_reduce_img_elem(q / kSweepAcc, q % kSweepAcc, a.img_chunk_start, a.cam_partial, a.prior_start, a.prior_res, a.prior_jac, a.img_rec,
+                           a.img_intr_tmp);
+  __syncthreads();
+  if (a.with_cams) {
+    for (int c = 0; c < a.NC; ++c) {
+      if (lane < kCamRec) s_part[tid >> 6][lane] = camera_reduce_cam_part(c, tid >> 6, lane, a.cam_img_start, a.cam_imgs, a.img_intr_tmp);
+      __syncthreads();
+      if (tid < kCamRec) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += s_part[k][tid];
+        a.cam_rec[(size_t)c * kCamRec + tid] = tot;
+      }
+      __syncthreads();
+    }
+  }
+  const int nvb = a.gp + a.gc;
+  for (int vb0 = 0; vb0 < nvb; vb0 += 4) {
+    const int vb = vb0 + g;
+    if (vb < nvb) {
+      double gmax, x2;
+      state_norms_local(vb, lt, a.gp, a.gc, a.NI, a.NC, a.NP, a.NPs, a.cam_part, a.pose_free, a.intr_free, a.pt_free, a.poses, a.intr, a.points,
+                        a.img_rec, a.cam_rec, a.gu, gmax, x2);
+      const double m = wave_max(gmax), sum = wave_sum(x2);
+      if (lane == 0) { s_w[vb][0][wv] = m; s_w[vb][1][wv] = sum; }
+    }
+  }
+  __syncthreads();
+  if (tid < nvb) { a.norm_partial[2 * tid] = group4_max(s_w[tid][0]); a.norm_partial[2 * tid + 1] = group4_sum(s_w[tid][1]); }
+  __syncthreads();
+  reduce_tasks_grouped(a.T, a.num_tasks, s_t);
+}
+void launch_eval_small(hipStream_t st, const EvalSmallArgs& a) { hipLaunchKernelGGL(k_eval_small, dim3(1), dim3(1024), 0, st, a); }
+void launch_lm_tail(hipStream_t st, const ReduceTasks& T, int n, const LmSpec& spec, double* dec, double* host_pub, double seq, double* fail_slots) {
+  hipLaunchKernelGGL(k_lm_tail, dim3(1), dim3(1024), 0, st, T, n, spec, dec, host_pub, seq, fail_slots);
 }
 // Test entry (mavba_debug_lm_decide): `n` decisions by the device build of lm_decide. in: SC_COUNT scalars + 8 parameters
 // (radius, decrease_factor, ptol, ftol, min_rel_dec, max_radius, abs_gtol, pending_eval) per case; out: 6 doubles per case.

@@ -494,7 +494,16 @@ void intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::v
   void solve_linear(double r);
   void linear_step(double r, double* h_scal);
   void candidate(double r, double* h_scal);
-  void candidate_enqueue(double r);
+  // tail != null: the candidate's scalar reductions are NOT launched - the caller gets them (and their count) to run them in
+  // one work-group with the decision (launch_lm_tail)
+  void candidate_enqueue(double r, ReduceTasks* tail = nullptr, int* tail_count = nullptr);
+  // Launch merging for problems whose reduced system one work-group solves (a local window): the evaluation's reductions in
+  // one launch (k_eval_small) and the camera update inside the solve's launch (k_chol_small<true>). MAVBA_MERGE=0: off.
+  bool merge_small() const;
+  bool merge_on = true;             // MAVBA_MERGE (read in start())
+  double pub_wait_seconds = 0.0;    // host time spent polling for the device's decision (MAVBA_SETUP_TIMING prints it)
+  bool cameras_updated = false;     // the solve's launch has applied the camera update for ...
+  double cameras_updated_r = 0.0;   // ... this radius
   void start();
   int iterate(int max_iters, int* done);
   void point_errors(double* out);

@@ -104,6 +104,29 @@ void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
       launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_poses.p, d_prior_res.p,
                        d_prior_jac.p, d_prior_cost.p, spec);
     });
+  if (scales_ready && merge_small()) {
+    // a local window: per-image and per-camera sums, norms and the evaluation's three scalars by ONE work-group
+    timed("eval_small", [&] {
+      EvalSmallArgs e;
+      e.NI = NI; e.NC = NC; e.NP = NP; e.NPs = NPs; e.with_cams = any_intr_free ? 1 : 0; e.cam_part = rank == 0 ? 1 : 0;
+      state_norms_grid(NI, NC, NP, &e.gp, &e.gc);
+      e.img_chunk_start = d_img_chunk_start.p; e.cam_partial = d_cam_partial.p;
+      e.prior_start = num_priors > 0 ? d_prior_start.p : nullptr; e.prior_res = d_prior_res.p; e.prior_jac = d_prior_jac.p;
+      e.cam_img_start = d_cam_img_start.p; e.cam_imgs = d_cam_imgs.p; e.img_rec = d_img_rec; e.cam_rec = d_cam_rec;
+      e.img_intr_tmp = d_img_intr_tmp.p;
+      e.pose_free = d_pose_free.p; e.intr_free = d_intr_free.p; e.pt_free = d_pt_free.p;
+      e.poses = d_poses.p; e.intr = d_intr.p; e.points = d_points.p; e.gu = d_gu.p; e.norm_partial = d_norm_partial.p;
+      const int rows = e.gp + e.gc;
+      e.T.t[0] = ReduceTask{d_norm_partial.p, rows, 2, 1, nullptr, 0, d_scal.p + SC_GRAD_MAX};
+      e.T.t[1] = ReduceTask{d_norm_partial.p + 1, rows, 2, 0, nullptr, 0, d_scal.p + SC_XNORM2};
+      e.T.t[2] = ReduceTask{d_sweep_partial.p, eval_cost_rows(), 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
+      e.num_tasks = 3;
+      e.spec = spec;
+      launch_eval_small(st, e);
+    });
+    evaluated = true; assembled = false;
+    return;
+  }
   timed("camera_reduce", [&] {
     launch_camera_reduce(st, NI, NC, d_img_chunk_start.p, d_cam_partial.p, num_priors > 0 ? d_prior_start.p : nullptr,
                          d_prior_res.p, d_prior_jac.p, d_cam_img_start.p, d_cam_imgs.p, d_img_rec, d_cam_rec,
@@ -209,8 +232,19 @@ void mavba_session::assemble(double r) {
 void mavba_session::solve_linear(double r) {
   assemble(r);
   // (two timers: the forward factorisation - ONE kernel, k_chol_persist, on the persistent schedule - and the backward substitution)
+  CamUpdateArgs u;
+  const bool with_update = merge_small();
+  if (with_update) {
+    // (launch_update_cameras' arguments, as candidate_enqueue passes them)
+    u.NI = NI; u.NC = NC; u.cam_part = rank == 0 ? 1 : 0; u.radius = r; u.dmin = opt.min_lm_diagonal; u.dmax = opt.max_lm_diagonal;
+    u.scale_cam = d_scale_cam.p; u.img_rec = d_img_rec; u.cam_rec = d_cam_rec; u.poses = d_poses.p; u.intr = d_intr.p;
+    u.cand_poses = d_cposes.p; u.cand_intr = d_cintr.p; u.delta_cam = d_delta_cam.p;
+    u.partial3 = d_step_partial.p + 3 * (size_t)backsub_points_grid(NP); u.cand_camrec = d_ccamrec.p;
+  }
   timed_split("chol_factor", "chol_backsolve", [&](hipEvent_t mid) {
-    dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p, allow_persistent, mid);
+    cameras_updated = dense_spd_solve_device(st, d_M.p, n_mat, d_ymat.p, d_scal.p + SC_FAIL, d_diag_ws.p, d_L.p, chol_struct, d_col_var.p, d_y.p,
+                                             allow_persistent, mid, with_update ? &u : nullptr);
+    cameras_updated_r = r;
   });
   assembled = false;  // the factorisation overwrote S
   fail_slot_clean = false;
@@ -239,15 +273,17 @@ void mavba_session::candidate(double r, double* h) {
   read_scalars(h);
 }
 // (the launches of candidate() without the read-back)
-void mavba_session::candidate_enqueue(double r) {
+void mavba_session::candidate_enqueue(double r, ReduceTasks* tail, int* tail_count) {
   const double dmin = opt.min_lm_diagonal, dmax = opt.max_lm_diagonal;
   // cameras first: the point back-substitution reads their step (delta_cam)
   const int rows = backsub_points_grid(NP), ugroups = update_cameras_groups(NI);
-  timed("update_cameras", [&] {
-    launch_update_cameras(st, NI, NC, rank == 0, r, dmin, dmax, d_y.p, d_scale_cam.p, d_img_rec, d_cam_rec,
-                          d_poses.p, d_intr.p, d_cposes.p, d_cintr.p, d_delta_cam.p, d_step_partial.p + 3 * (size_t)rows,
-                          d_ccamrec.p);  // (+ the candidate's camera records: no separate cam_prepare launch)
-  });
+  if (!(cameras_updated && cameras_updated_r == r))  // (a small system: the work-group that solved it has done this already)
+    timed("update_cameras", [&] {
+      launch_update_cameras(st, NI, NC, rank == 0, r, dmin, dmax, d_y.p, d_scale_cam.p, d_img_rec, d_cam_rec,
+                            d_poses.p, d_intr.p, d_cposes.p, d_cintr.p, d_delta_cam.p, d_step_partial.p + 3 * (size_t)rows,
+                            d_ccamrec.p);  // (+ the candidate's camera records: no separate cam_prepare launch)
+    });
+  cameras_updated = false;
   static const bool from_entries = std::getenv("MAVBA_BACKSUB_ENTRIES") != nullptr;
   // (round 4: for launch-bound problems the candidate's cost is summed by the back-substitution kernel itself - the observations
   // of a block's points are in its caches, the new points in its LDS -, one launch less: a 10-image window 2.30 -> 2.19 ms. At
@@ -274,19 +310,25 @@ void mavba_session::candidate_enqueue(double r) {
       launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_cposes.p, d_prior_res.p,
                        d_prior_jac.p, d_prior_cost.p);
     });
-  timed("reduce", [&] {
+  {
     const int nsweep = N > 0 ? (cost_separate ? jacobian_sweep_grid(N) : rows) : 0;
     ReduceTasks T;
     T.t[0] = ReduceTask{d_step_partial.p, rows + ugroups, 3, 0, nullptr, 0, d_scal.p + SC_STEP_NORM2};
     T.t[1] = ReduceTask{d_step_partial.p + 1, rows + ugroups, 3, 0, nullptr, 0, d_scal.p + SC_MODEL_CHANGE};
     T.t[2] = ReduceTask{d_step_partial.p + 2, rows + ugroups, 3, 0, nullptr, 0, d_scal.p + SC_CAND_XNORM2};
     T.t[3] = ReduceTask{d_sweep_partial.p, nsweep, 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_NEW_COST};
-    launch_reduce_tasks(st, T, 4);
-  });
+    if (tail) { *tail = T; *tail_count = 4; }
+    else timed("reduce", [&] { launch_reduce_tasks(st, T, 4); });
+  }
   if (sharded()) allreduce(d_scal.p + SC_CAND_BEGIN, SC_CAND_COUNT, 0);  // only what the candidate wrote: an evaluation enqueued before it keeps its (already global) sums
 }
 
+bool mavba_session::merge_small() const {
+  return merge_on && !sharded() && NI <= 64 && NC <= 8 && NP <= 8192 && dense_spd_solve_is_small(n_mat, chol_struct);
+}
+
 void mavba_session::start() {
+  { const char* e = std::getenv("MAVBA_MERGE"); merge_on = !e || std::atoi(e) != 0; }  // (read per solve: the tests compare both ways)
   if (!persist_decided) {  // (sharded sessions decided in join_ranks, for all ranks together)
     if (chol_struct.persist_ok && !sharded()) allow_persistent = persistent_allowed_now();
     persist_decided = true;
@@ -340,6 +382,7 @@ int mavba_session::iterate(int max_iters, int* done) {
   const bool speculate = spec_env && defer && !sharded() && front_ok && fused_now() && rows_ok && scales_ready;
   if (speculate && !lm_pub) { lm_pub = lm_pub_alloc(); if (lm_pub) lm_pub[SC_COUNT + 7] = -1.0; }
   if (speculate && lm_pub && !d_lm_dec.p) d_lm_dec.alloc(2);
+  const bool merge_tail = merge_on;
   bool pending_eval = false;
   while (termination == MAVBA_TERM_RUNNING && n < max_iters) {
     if (iteration >= opt.max_num_iterations) { termination = MAVBA_TERM_NO_CONVERGENCE; break; }
@@ -351,9 +394,16 @@ int mavba_session::iterate(int max_iters, int* done) {
     struct Books { bool evaluated, assembled, front_valid, fail_slot_clean; double front_radius; int eval_rows; } books{};
     if (speculate && lm_pub) {
       solve_linear(radius);
-      candidate_enqueue(radius);
       lm_seq += 1.0;
-      timed("lm_snapshot", [&] { launch_lm_snapshot(st, sp, d_lm_dec.p, lm_pub, lm_seq, d_scal.p + SC_FAIL); });
+      if (merge_tail) {
+        // the candidate's four reductions and the decision in one work-group
+        ReduceTasks T; int nt = 0;
+        candidate_enqueue(radius, &T, &nt);
+        timed("lm_tail", [&] { launch_lm_tail(st, T, nt, sp, d_lm_dec.p, lm_pub, lm_seq, d_scal.p + SC_FAIL); });
+      } else {
+        candidate_enqueue(radius);
+        timed("lm_snapshot", [&] { launch_lm_snapshot(st, sp, d_lm_dec.p, lm_pub, lm_seq, d_scal.p + SC_FAIL); });
+      }
       books = Books{evaluated, assembled, front_valid, fail_slot_clean, front_radius, eval_rows};
       std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
       std::swap(d_camrec.p, d_ccamrec.p);
@@ -361,7 +411,10 @@ int mavba_session::iterate(int max_iters, int* done) {
       ks.dec = d_lm_dec.p;
       evaluate_enqueue(1.0 /* "with entries": the front end takes the radius from the decision */, ks);
       speculated = true;
-      if (!wait_publication(h)) {  // (never seen; keeps the loop alive if the mapping is not coherent on some system)
+      const double tw = now_s();
+      const bool published = wait_publication(h);
+      pub_wait_seconds += now_s() - tw;
+      if (!published) {  // (never seen; keeps the loop alive if the mapping is not coherent on some system)
         sync();
         for (int i = 0; i < SC_COUNT; ++i) h[i] = lm_pub[i];
       }

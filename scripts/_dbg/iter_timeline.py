@@ -11,8 +11,9 @@ name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ma
 starts = [i for i, r in enumerate(rows) if name(r).startswith("k_schur_fused") or name(r).startswith("k_schur_rows") or name(r).startswith("k_point_front<8, true")]
 iters = [rows[a:b] for a, b in zip(starts, starts[1:])]
 iters = iters[len(iters) // 8:len(iters) // 2 - 2] if len(sys.argv) > 2 and sys.argv[2] == "first" else iters[len(iters) // 3:]
-L = statistics.mode(len(it) for it in iters)
-iters = [it for it in iters if len(it) == L]
+seq = statistics.mode(tuple(name(r) for r in it) for it in iters)  # (the most frequent kernel sequence = a steady-state iteration)
+L = len(seq)
+iters = [it for it in iters if tuple(name(r) for r in it) == seq]
 print("iterations used %d, kernels per iteration %d" % (len(iters), L))
 tot_gap = 0.0
 for k in range(L):

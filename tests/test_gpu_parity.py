@@ -608,3 +608,34 @@ def test_the_lm_decision_is_the_same_function_on_the_host_and_on_the_device(mavb
     assert np.array_equal(host, dev, equal_nan=True)
     codes = set(host[:, 0].astype(int))
     assert codes == {0, 1, 2, 3, 4, 5}, codes          # every outcome occurs in the sample
+
+
+@pytest.mark.parametrize("refine_intr", [False, True])
+def test_merged_launches_of_a_local_window_equal_the_launch_per_step_loop(mavba, refine_intr, monkeypatch):
+    """Round 4: for a problem whose reduced system one work-group solves, the evaluation's reductions (k_eval_small), the
+    camera update (inside k_chol_small) and the candidate's reductions + decision (k_lm_tail) run as three launches instead
+    of nine. They walk the same device functions (lm_bodies.h) in the same order: every result is bit-identical to the
+    launch-per-step loop (MAVBA_MERGE=0)."""
+    g = synth.make_config("C1")
+    outs = []
+    for merge in ("1", "0"):
+        monkeypatch.setenv("MAVBA_MERGE", merge)
+        res = []
+        for first in (0, 2):
+            p = synth.local_ba_window(g, first)
+            p.intr_const[:] = 0 if refine_intr else 1
+            e = np.full(p.num_points, np.nan)
+            _, r = mavba.bundle_adjustment(p, {}, point3D_errors=e)
+            res.append((p.poses.copy(), p.intrinsics.copy(), p.points.copy(), e, r["final_cost"], r["num_successful_steps"],
+                        r["num_unsuccessful_steps"], r["termination"], r["final_gradient_max_norm"], r["final_trust_region_radius"]))
+        # a window with rotation priors and a constant point, 12 images (two tile columns with intrinsics)
+        q = synth.make_scene(num_images=12, num_points=1500, track_len=4, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=5, rot_priors=True)
+        q.pose_const[:2] = A.CONST_POSE
+        q.intr_const[:] = 0 if refine_intr else 1
+        _, r = mavba.bundle_adjustment(q, dict(max_num_iterations=30))
+        res.append((q.poses.copy(), q.intrinsics.copy(), q.points.copy(), r["final_cost"], r["num_successful_steps"],
+                    r["num_unsuccessful_steps"], r["termination"]))
+        outs.append(res)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
