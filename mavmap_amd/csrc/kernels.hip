@@ -2156,6 +2156,23 @@ void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurCh
 
 // Blocks that many clusters touch (every cluster touches the intrinsics blocks) would make one finalize group add
 // thousands of partials one after the other: runs of 32 are summed here first, one wave per run, same fixed order.
+// Element idx of the records [begin, end) of `part` (PS doubles each) summed in a fixed order: sixteen running sums over the
+// records begin + u, begin + 16 + u, ... and a fixed tree over them. The sixteen loads of a trip are independent and the last,
+// partial trip is predicated instead of walked one record at a time: the pass is a chain of load latencies (~0.5 us each) -
+// round 4: 8 sums + a sequential remainder took 25 such steps for the 157 partials of a local window's block, this takes 10.
+__device__ __forceinline__ double strided_sum16(const double* __restrict__ part, int PS, int idx, int begin, int end) {
+  double s[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) s[u] = 0.0;
+  for (int c = begin; c < end; c += 16) {
+    double x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x[u] = part[(size_t)min(c + u, end - 1) * PS + idx];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s[u] += (c + u < end) ? x[u] : 0.0;
+  }
+  return (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) + (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
+}
 __global__ void __launch_bounds__(256) k_partial_reduce(int num_tasks, const PartialReduce* __restrict__ tasks,
                                                         double* __restrict__ part_pp, double* __restrict__ part_ip,
                                                         double* __restrict__ part_ii) {
@@ -2164,16 +2181,7 @@ __global__ void __launch_bounds__(256) k_partial_reduce(int num_tasks, const Par
   const PartialReduce T = tasks[task];
   double* part = T.kind == BLK_PP ? part_pp : T.kind == BLK_IP ? part_ip : part_ii;
   const int PS = T.kind == BLK_PP ? 42 : T.kind == BLK_IP ? 54 : 90;
-  for (int idx = lane; idx < PS; idx += 64) {
-    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int c = T.src_begin;
-    for (; c + 8 <= T.src_end; c += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s8[u] += part[(size_t)(c + u) * PS + idx];
-    }
-    for (; c < T.src_end; ++c) s8[0] += part[(size_t)c * PS + idx];
-    part[(size_t)T.dst * PS + idx] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-  }
+  for (int idx = lane; idx < PS; idx += 64) part[(size_t)T.dst * PS + idx] = strided_sum16(part, PS, idx, T.src_begin, T.src_end);
 }
 void launch_partial_reduce(hipStream_t st, int num_tasks, const PartialReduce* tasks, double* part_pp, double* part_ip,
                            double* part_ii) {
@@ -2246,18 +2254,8 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
       v[prow0 + r] = base - s;
     }
   };
-  // one lane per element; the block's chunk partials are added in a fixed order, eight independent
-  // running sums so that the (dependent-latency) loads of a long chunk list overlap
-  for (int idx = lane; idx < PS; idx += 64) {
-    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int c = B.chunk_begin;
-    for (; c + 8 <= B.chunk_end; c += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s8[u] += part[(size_t)(c + u) * PS + idx];
-    }
-    for (; c < B.chunk_end; ++c) s8[0] += part[(size_t)c * PS + idx];
-    apply(idx, ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7])));
-  }
+  // one lane per element; the block's chunk partials are added in a fixed order (strided_sum16)
+  for (int idx = lane; idx < PS; idx += 64) apply(idx, strided_sum16(part, PS, idx, B.chunk_begin, B.chunk_end));
 }
 void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blocks,
                            const double* part_pp, const double* part_ip, const double* part_ii,

@@ -25,7 +25,13 @@ __device__ __forceinline__ void camera_reduce_img_elem(int i, int e, const int* 
                                                         double* img_rec, double* img_intr_tmp) {
   const int c0 = img_chunk_start[i], c1 = img_chunk_start[i + 1];
   double s = 0.0;
-  for (int c = c0; c < c1; ++c) s += partial[(size_t)c * kSweepAcc + e];
+  int c = c0;
+  for (; c + 4 <= c1; c += 4) {  // (four loads in flight; the additions keep their order)
+    const double x0 = partial[(size_t)c * kSweepAcc + e], x1 = partial[(size_t)(c + 1) * kSweepAcc + e];
+    const double x2 = partial[(size_t)(c + 2) * kSweepAcc + e], x3 = partial[(size_t)(c + 3) * kSweepAcc + e];
+    s += x0; s += x1; s += x2; s += x3;
+  }
+  for (; c < c1; ++c) s += partial[(size_t)c * kSweepAcc + e];
   if (e < 27 && prior_start) {
     for (int q = prior_start[i]; q < prior_start[i + 1]; ++q) {
       const double* j = prior_jac + 3 * q;

@@ -787,7 +787,9 @@ void mavba_session::finish_structure() {
     int kMaxPoints = (int)std::min<long long>(256, std::max<long long>(kClBatch, round_up((int)(nfree / 512), kClBatch)));
     // k_schur_rows: several 256-lane work-groups share a CU - about 1024 clusters fill the device; a cluster holds whole
     // 16-point batches
-    if (rows_mode) kMaxPoints = (int)std::min<long long>(kRowsMaxPoints, std::max<long long>(2 * kRowsBatch, round_up((int)(nfree / 1024), kRowsBatch)));
+    // (a local window - up to 4096 free points - gets single-batch clusters: every cluster is one work-group on a CU of its own and
+    // the kernel's time is the longest cluster's; 10-image window: 15.6 -> ~12 us, the call 2.16 -> 2.12 ms)
+    if (rows_mode) kMaxPoints = (int)std::min<long long>(kRowsMaxPoints, std::max<long long>(nfree <= 4096 ? kRowsBatch : 2 * kRowsBatch, round_up((int)(nfree / 1024), kRowsBatch)));
     if (const char* e = std::getenv("MAVBA_CLUSTER_POINTS")) kMaxPoints = std::max(1, std::atoi(e));
     if (rows_mode) kMaxPoints = std::min(kMaxPoints, kRowsMaxPoints);
     // cost model of the run-based greedy (cycles of one CU: per cluster, per 16-point batch of each row class; measured on
