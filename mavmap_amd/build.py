@@ -14,9 +14,13 @@ LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libmavba.so")
 OBJDIR = os.path.join(LIBDIR, "obj")
 SOURCES = ["kernels.hip", "schur_rows.hip", "dense_chol.hip", "pose_refine.hip", "host_util.hip", "session_build.hip", "session_lm.hip", "scene.hip", "multi_gpu.hip", "device_setup.hip", "api.hip"]
-HEADERS = ["ba_math.h", "dev_reduce.h", "internal.h", "session.h", os.path.join("..", "..", "include", "mavba.h")]
+HEADERS = ["ba_math.h", "dev_reduce.h", "internal.h", "session.h", "lm_decide.h", "lm_bodies.h", os.path.join("..", "..", "include", "mavba.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall",
          "-Wno-unused-result"]
+# Per-file additions. dense_chol.hip: matrix instructions with their accumulators in ordinary vector registers - the
+# factorisation's pivot chain reads every result back at once (v_readlane, selects), and with the accumulators in the AGPR half
+# of the file the compiler wrapped each matrix instruction in 8-16 v_accvgpr moves (3 076 of them in this file, 30 with the flag).
+FILE_FLAGS = {"dense_chol.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -38,6 +42,7 @@ def source_digest():
         with open(os.path.normpath(os.path.join(CSRC, f)), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -66,7 +71,7 @@ def build(force=False, verbose=False):
         sp = os.path.join(CSRC, src)
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(obj, [sp] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+            cmd = [hipcc] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
