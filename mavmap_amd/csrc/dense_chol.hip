@@ -118,8 +118,21 @@ __device__ __forceinline__ bool potrf_inv16(d4& acc, d4& xacc, int lane) {
 //   xacc -= U^T Xn         one instruction
 // Four dependent matrix instructions + one 4x4 scalar factorisation per FOUR pivots instead of two dependent
 // matrix instructions + rsqrt chain per pivot (measured: the 16-pivot block 4200 -> ~2000 cycles).
+// m[q] = 1 in the lane that supplies entry q of X4 (rows of the lower triangle: (0,0) (1,0) (1,1) (2,0) ... (3,3)) to the
+// matrix instruction's A operand - lane (k << 4 | i) supplies X4[i][k] -, 0 elsewhere.
+struct Pivot4Masks { double m[10]; };
+__device__ __forceinline__ Pivot4Masks pivot4_masks(int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  Pivot4Masks mk;
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k <= i; ++k) mk.m[q++] = (li == i && lk == k) ? 1.0 : 0.0;
+  return mk;
+}
 template <int B>
-__device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, int lane, bool& ok) {
+__device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, int lane, bool& ok, const Pivot4Masks& mk) {
   const int li = lane & 15, lk = lane >> 4;
   constexpr int c0 = 4 * B;
   // D4[a][b], a >= b: register B of lane (a << 4 | c0 + b)
@@ -145,7 +158,10 @@ __device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, 
   const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, d32)) * r2;
   const double t33 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, d33)));
   const double r3 = rsqrt_halley(t33);
-  ok = ok && (d00 > 0.0) && (t11 > 0.0) && (t22 > 0.0) && (t33 > 0.0);
+  // (no per-pivot test: a pivot <= 0 makes its reciprocal square root NaN - v_rsq_f64 of a negative number, 0 * inf in the
+  // correction of a zero -, the mask multiply-adds below carry it into every lane's operand and from there into every later
+  // pivot: potrf_inv16_b4 looks at the last diagonal entry of the inverse once)
+  (void)ok;
   // X4 = L4^-1 (lower)
   const double x10 = -(l10 * r0) * r1;
   const double x21 = -(l21 * r1) * r2;
@@ -153,13 +169,14 @@ __device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, 
   const double x20 = -__builtin_fma(l21, x10, l20 * r0) * r2;
   const double x31 = -__builtin_fma(l32, x21, l31 * r1) * r3;
   const double x30 = -__builtin_fma(l32, x20, __builtin_fma(l31, x10, l30 * r0)) * r3;
-  // A operand: lane (k = lk, i = li) supplies X4[i][k] for i < 4, k <= i
-  // (selects, not branches: with an if-ladder the compiler sinks the pivot chain into divergent blocks)
-  const double c0v = li == 0 ? r0 : (li == 1 ? x10 : (li == 2 ? x20 : x30));
-  const double c1v = li == 1 ? r1 : (li == 2 ? x21 : x31);
-  const double c2v = li == 2 ? r2 : x32;
-  double xa = lk == 0 ? c0v : (lk == 1 ? c1v : (lk == 2 ? c2v : r3));
-  xa = (li < 4 && lk <= li) ? xa : 0.0;
+  // A operand: lane (k = lk, i = li) supplies X4[i][k] for i < 4, k <= i. Round 4: ten multiply-adds with the lane's 0 / 1
+  // masks (at most one of them is 1) instead of a ladder of 64-bit selects - 25 v_cndmask_b32, several compares and two
+  // exec-mask regions per four pivots. Exact (x * 1 + 0); a bad pivot's NaN reaches every lane, and the solve is rejected anyway.
+  double xa = mk.m[0] * r0;
+  xa = __builtin_fma(mk.m[1], x10, xa); xa = __builtin_fma(mk.m[2], r1, xa);
+  xa = __builtin_fma(mk.m[3], x20, xa); xa = __builtin_fma(mk.m[4], x21, xa); xa = __builtin_fma(mk.m[5], r2, xa);
+  xa = __builtin_fma(mk.m[6], x30, xa); xa = __builtin_fma(mk.m[7], x31, xa); xa = __builtin_fma(mk.m[8], x32, xa);
+  xa = __builtin_fma(mk.m[9], r3, xa);
   const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
   const double ba = li >= c0 ? acc[B] : 0.0;  // columns left of the block are stale (never needed again)
   const d4 U = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, ba, zero, 0, 0, 0);
@@ -176,12 +193,14 @@ __device__ __forceinline__ bool potrf_inv16_b4(d4& acc, d4& xacc, int lane) {
   d4 xfin = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) xacc[r] = (lk + 4 * r == li) ? 1.0 : 0.0;
-  potrf_inv16_block4<0>(acc, xacc, xfin, lane, ok);
-  potrf_inv16_block4<1>(acc, xacc, xfin, lane, ok);
-  potrf_inv16_block4<2>(acc, xacc, xfin, lane, ok);
-  potrf_inv16_block4<3>(acc, xacc, xfin, lane, ok);
+  const Pivot4Masks mk = pivot4_masks(lane);
+  potrf_inv16_block4<0>(acc, xacc, xfin, lane, ok, mk);
+  potrf_inv16_block4<1>(acc, xacc, xfin, lane, ok, mk);
+  potrf_inv16_block4<2>(acc, xacc, xfin, lane, ok, mk);
+  potrf_inv16_block4<3>(acc, xacc, xfin, lane, ok, mk);
   xacc = xfin;
-  return ok;
+  const double last = readlane_d(xfin[3], 63);  // 1 / l_15,15: a number only if all sixteen pivots were positive
+  return last == last;
 }
 
 // acc += A(16x16, row-major lda) * B^T  (NT)   or   A * B (NN), K = 16, operands in LDS.

@@ -189,6 +189,13 @@ def test_dense_spd_solve(mavba, n):
     assert rel_err(x, x0) < 1e-10
     with pytest.raises(mavba.MavbaError):
         mavba.dense_spd_solve(-Amat, b)
+    # one bad pivot anywhere - first, in the middle of a 16-pivot block, the very last - must be reported (the factorisation
+    # does not test pivots one by one: the NaN of a non-positive pivot has to reach the end of its block)
+    for k in sorted({0, n // 2, n - 1}):
+        Bad = Amat.copy()
+        Bad[k, k] = -1.0
+        with pytest.raises(mavba.MavbaError):
+            mavba.dense_spd_solve(Bad, b)
 
 
 def test_edge_cases(mavba, oracle):
