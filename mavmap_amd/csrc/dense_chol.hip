@@ -1539,6 +1539,87 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   }
   for (auto& l : upd_of)
     std::sort(l.begin(), l.end(), [&](int a, int b) { return col_step[a] != col_step[b] ? col_step[a] < col_step[b] : a < b; });
+  // ---- a timing model of the launch (round 4) ----
+  // The order of a tile's updates and the place of every task in the helpers' queues used to follow the launch-per-panel
+  // step of the columns - the same number for the s-th columns of ALL nodes of a tree level. On C3's critical path that cost
+  // ~20 us: the root's first tile applied the update of one child's last column (ready last) BEFORE the other child's last
+  // two, and a tile with eight updates was queued behind another task and started 20 us late. Now the launch is simulated
+  // on the host with measured costs (MAVBA_CHOL_TRACE: ~3.5 us per tile update of a helper, 3.1 us panel solve + publish,
+  // ~12.2 us per chain column, 9.6 for a node's first): every update list is ordered by the time its inputs are ready, and
+  // the helpers' queues are filled by list scheduling (below). Only the ORDER comes from the model, never correctness.
+  constexpr double cU = 3.5, cS = 3.1, cP = 1.0, cCol = 12.2, cColFirst = 9.6, cSub = 4.0;
+  std::vector<std::pair<int, int>> id_ij((size_t)nt, {0, 0});
+  for (int k = 0; k < nb; ++k) {
+    id_ij[tile_id[(size_t)k * nb + k]] = {k, k};
+    for (int i : col_rows[k]) id_ij[tile_id[(size_t)i * nb + k]] = {i, k};
+    id_ij[tile_id[(size_t)nb * nb + k]] = {nb, k};
+  }
+  std::vector<std::vector<int>> children(nseg);
+  for (int n = 0; n < nseg; ++n) if (nodes[n].parent >= 0) children[nodes[n].parent].push_back(n);
+  struct Times { std::vector<double> L, col_begin, col_fin, pre; };  // tile published | chain column | PRE slot ready
+  // in_ready: when the two factor tiles that update k of tile (i, j) multiplies are both published
+  auto in_ready = [&](const Times& T, int i, int j, int k) {
+    double r = T.L[tile_id[(size_t)i * nb + k]];
+    if (i != j) r = std::max(r, T.L[tile_id[(size_t)j * nb + k]]);
+    return r;
+  };
+  // one task's run from `start` on: its updates in list order (each waits for its inputs); returns the end of the update phase
+  auto run_updates = [&](const Times& T, int i, int j, const std::vector<int>& list, size_t count, double start) {
+    double f = start;
+    for (size_t q = 0; q < count; ++q) f = std::max(f, in_ready(T, i, j, list[q])) + cU;
+    return f;
+  };
+  auto own_updates = [&](int j) {  // the diagonal tile's list without the chain's own (last) update
+    const int n = seg_of_tile[j];
+    const std::vector<int>& dl = upd_of[tile_id[(size_t)j * nb + j]];
+    return j == nodes[n].begin ? dl.size() : (dl.empty() ? 0 : dl.size() - 1);
+  };
+  // chain column j: begins when its predecessor (or every child node) and its PRE tiles are there
+  auto chain_column = [&](Times& T, int j) {
+    const int n = seg_of_tile[j];
+    const bool first = j == nodes[n].begin;
+    double start = 0.0;
+    if (first) { for (int c : children[n]) start = std::max(start, T.col_fin[nodes[c].end - 1]); }
+    else start = T.col_fin[j - 1];
+    start = std::max(start, std::max(T.pre[2 * j], T.pre[2 * j + 1]));
+    T.col_begin[j] = start;
+    T.col_fin[j] = start + (first ? cColFirst : cCol);
+    if (!first) T.L[tile_id[(size_t)j * nb + (j - 1)]] = start + cSub;  // (the chain solves and publishes its own panel tile)
+  };
+  auto ideal_pass = [&](Times& T) {  // every helper task on a work-group of its own, started at time 0
+    T.L.assign((size_t)nt, 0.0); T.col_begin.assign(nb, 0.0); T.col_fin.assign(nb, 0.0); T.pre.assign((size_t)2 * nb, 0.0);
+    for (int j = 0; j < nb; ++j) {
+      const int n = seg_of_tile[j];
+      const bool first = j == nodes[n].begin, last = j + 1 == nodes[n].end;
+      const size_t nd = own_updates(j);
+      if (nd) T.pre[2 * j] = run_updates(T, j, j, upd_of[tile_id[(size_t)j * nb + j]], nd, 0.0) + cP;
+      if (!first) {
+        const std::vector<int>& sl = upd_of[tile_id[(size_t)j * nb + (j - 1)]];
+        if (!sl.empty()) T.pre[2 * j + 1] = run_updates(T, j, j - 1, sl, sl.size(), 0.0) + cP;
+      }
+      chain_column(T, j);
+      auto tile_task = [&](int i) {
+        const int id = tile_id[(size_t)i * nb + j];
+        T.L[id] = std::max(run_updates(T, i, j, upd_of[id], upd_of[id].size(), 0.0), T.col_fin[j]) + cS;
+      };
+      for (int i : col_rows[j]) if (!(i == j + 1 && !last)) tile_task(i);
+      tile_task(nb);
+    }
+  };
+  Times ideal;
+  for (int round = 0; round < 2; ++round) {
+    ideal_pass(ideal);
+    for (long long id = 0; id < nt; ++id) {
+      std::vector<int>& l = upd_of[id];
+      const int i = id_ij[id].first, j = id_ij[id].second;
+      const bool own_last = i == j && j != nodes[seg_of_tile[j]].begin && !l.empty() && l.back() == j - 1;  // (checked below)
+      std::stable_sort(l.begin(), l.end() - (own_last ? 1 : 0), [&](int a, int b) {
+        const double ra = in_ready(ideal, i, j, a), rb = in_ready(ideal, i, j, b);
+        return ra != rb ? ra < rb : a < b;
+      });
+    }
+  }
+  ideal_pass(ideal);
   // ---- tasks ----
   struct Gen { CholTask t; long long key; int level; long long work; };
   std::vector<Gen> gen;
@@ -1570,7 +1651,6 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     add_task(CHOL_TASK_TILE, nb, j, upd_of[tile_id[(size_t)nb * nb + j]], sj * 8 + 6);
   }
   // ---- work-groups: one chain per concurrent node, the helpers partitioned by tree level ----
-  const int H = *std::max_element(height.begin(), height.end());
   std::vector<int> chain_wg(nseg, -1);
   int nch = 0;
   {
@@ -1579,52 +1659,74 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
       if (nodes[n].parent >= 0 && first_child[nodes[n].parent] < 0) first_child[nodes[n].parent] = n;
     for (int n = 0; n < nseg; ++n) chain_wg[n] = first_child[n] >= 0 ? chain_wg[first_child[n]] : nch++;
   }
-  std::vector<long long> work(H + 1, 0);
-  std::vector<int> ntasks(H + 1, 0), alloc(H + 1, 0);
-  long long total = 0;
-  for (const Gen& g : gen) { work[g.level] += g.work; ntasks[g.level]++; total += g.work; }
-  int levels_used = 0;
-  for (int h = 0; h <= H; ++h) levels_used += ntasks[h] > 0;
-  const int helpers = std::min<long long>(G - nch, (long long)gen.size());
-  if (helpers < levels_used || helpers < 1) return hipSuccess;
-  int given = 0;
-  for (int h = 0; h <= H; ++h)
-    if (ntasks[h] > 0) { alloc[h] = (int)std::max<long long>(1, std::min<long long>(ntasks[h], helpers * work[h] / std::max<long long>(total, 1))); given += alloc[h]; }
-  while (given > helpers) {  // (rounding up of small levels)
-    int best = -1;
-    for (int h = 0; h <= H; ++h) if (alloc[h] > 1 && (best < 0 || alloc[h] > alloc[best])) best = h;
-    if (best < 0) return hipSuccess;
-    --alloc[best]; --given;
-  }
-  while (given < helpers) {  // leftovers go where a work-group carries the most work
-    int best = -1;
-    for (int h = 0; h <= H; ++h)
-      if (alloc[h] > 0 && alloc[h] < ntasks[h] && (best < 0 || work[h] * alloc[best] > work[best] * alloc[h])) best = h;
-    if (best < 0) break;
-    ++alloc[best]; ++given;
-  }
-  const int grid = nch + given;
+  const int helpers = (int)std::min<long long>(G - nch, (long long)gen.size());
+  if (helpers < 1) return hipSuccess;
   // The persistent schedule wins where the dependent chain is the cost (C3: 4 499 tile updates, 18 per helper, solve
   // 0.71 -> 0.47 ms). A tile update costs a helper ~3.5 us (two flag polls, two write-through tile loads, one 64^3
   // product), so with hundreds of updates per helper the launch-per-panel schedule - whose trailing updates are plain
   // wide launches - is faster again (C5: 75 582 updates, 300 per helper: 3.45 ms against 4.96 ms).
-  if (mode == 1 && nupd > 100ll * given) return hipSuccess;
+  if (mode == 1 && nupd > 100ll * helpers) return hipSuccess;
+  // ---- list scheduling of the helper tasks on the simulated launch ----
+  // Tasks and chain columns are visited in the order of their finishing times on unlimited helpers (`ideal`): every input of
+  // a task finishes earlier there, so it has been placed - and given its time on the real number of helpers - before the task
+  // itself. A task goes to the work-group that is free latest among those free by the time the task has to start in order to
+  // finish on time (its updates back to back, ending with the last input's arrival; 10 us earlier for what the model does
+  // not know) - or, if none is, to the one that is free first. A work-group runs its queue in this order and every wait is
+  // for something that is earlier in it: no cycle of waits, whatever the real timing turns out to be.
+  struct Event { double t; int chain; int idx; };  // idx: column (chain) or index into gen
+  std::vector<Event> events;
+  std::vector<double> upd_end(gen.size(), 0.0);  // end of the task's update phase on unlimited helpers
+  for (size_t g = 0; g < gen.size(); ++g) {
+    const CholTask& t = gen[g].t;
+    std::vector<int> list(upd.begin() + t.ub, upd.begin() + t.ue);
+    upd_end[g] = run_updates(ideal, t.i, t.j, list, list.size(), 0.0);
+    const double fin = t.kind == CHOL_TASK_TILE ? ideal.L[tile_id[(size_t)t.i * nb + t.j]] : ideal.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1];
+    events.push_back(Event{fin, 0, (int)g});
+  }
+  for (int j = 0; j < nb; ++j) events.push_back(Event{ideal.col_fin[j], 1, j});
+  std::stable_sort(events.begin(), events.end(), [&](const Event& x, const Event& y) {
+    if (x.t != y.t) return x.t < y.t;
+    if (x.chain != y.chain) return x.chain > y.chain;
+    return x.idx < y.idx;
+  });
+  Times act;
+  act.L.assign((size_t)nt, 0.0); act.col_begin.assign(nb, 0.0); act.col_fin.assign(nb, 0.0); act.pre.assign((size_t)2 * nb, 0.0);
+  std::vector<double> free_at(helpers, 0.0);
+  std::vector<std::vector<CholTask>> helper_tasks(helpers);
+  for (const Event& ev : events) {
+    if (ev.chain) { chain_column(act, ev.idx); continue; }
+    const CholTask& t = gen[ev.idx].t;
+    const int n_upd = t.ue - t.ub;
+    const double release = std::max(0.0, upd_end[ev.idx] - cU * n_upd - 10.0);
+    int best = -1, first_free = 0;
+    for (int w = 0; w < helpers; ++w) {
+      if (free_at[w] < free_at[first_free]) first_free = w;
+      if (free_at[w] <= release && (best < 0 || free_at[w] > free_at[best])) best = w;
+    }
+    if (best < 0) best = first_free;
+    std::vector<int> list(upd.begin() + t.ub, upd.begin() + t.ue);
+    double f = run_updates(act, t.i, t.j, list, list.size(), free_at[best]);
+    if (t.kind == CHOL_TASK_TILE) {
+      f = std::max(f, act.col_fin[t.j]) + cS;
+      act.L[tile_id[(size_t)t.i * nb + t.j]] = f;
+    } else {
+      f += cP;
+      act.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1] = f;
+    }
+    free_at[best] = f;
+    helper_tasks[best].push_back(t);
+  }
+  int used = 0;
+  for (int w = 0; w < helpers; ++w) used += !helper_tasks[w].empty();
+  const int grid = nch + used;
+  predicted_forward_us = 0.0;
+  for (int j = 0; j < nb; ++j) predicted_forward_us = std::max(predicted_forward_us, act.col_fin[j]);
   std::vector<std::vector<CholTask>> wg_tasks(grid);
   for (int n = 0; n < nseg; ++n) wg_tasks[chain_wg[n]].push_back(CholTask{CHOL_TASK_CHAIN, nodes[n].begin, nodes[n].end, 0, 0});
   {
     int base = nch;
-    for (int h = 0; h <= H; ++h) {
-      if (alloc[h] == 0) continue;
-      std::vector<const Gen*> lv;
-      for (const Gen& g : gen) if (g.level == h) lv.push_back(&g);
-      std::stable_sort(lv.begin(), lv.end(), [](const Gen* a, const Gen* b) {
-        if (a->key != b->key) return a->key < b->key;
-        if (a->t.j != b->t.j) return a->t.j < b->t.j;
-        return a->t.i < b->t.i;
-      });
-      for (size_t q = 0; q < lv.size(); ++q) wg_tasks[base + (int)(q % alloc[h])].push_back(lv[q]->t);
-      base += alloc[h];
-    }
+    for (int w = 0; w < helpers; ++w)
+      if (!helper_tasks[w].empty()) wg_tasks[base++] = helper_tasks[w];
   }
   std::vector<CholTask> tasks;
   std::vector<int> wg_begin(grid + 1, 0);
@@ -1653,6 +1755,8 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   release_staged(st);
   if (e != hipSuccess) return e;
   if (std::getenv("MAVBA_CHOL_TRACE")) {
+    std::fprintf(stderr, "mavba: persistent factorisation, timing model: %.1f us forward on %d helpers (%.1f us on unlimited helpers)\n",
+                 predicted_forward_us, used, *std::max_element(ideal.col_fin.begin(), ideal.col_fin.end()));
     h_tasks = tasks; h_wg_begin = wg_begin;
     const size_t ntr = (size_t)8 * nb + (size_t)4 * tasks.size();
     if (device_alloc(reinterpret_cast<void**>(&d_trace), ntr * 8) == hipSuccess) (void)hipMemset(d_trace, 0, ntr * 8);

@@ -403,6 +403,7 @@ struct CholStructure {
   // persistent schedule
   int active_tiles = 0;  // leading tile columns that hold a free parameter (0: all); the rest is identity with a zero right-hand side
   bool persist_ok = false;        // a schedule exists (structure consistent, fits the resident grid)
+  double predicted_forward_us = 0.0;  // the timing model's forward factorisation (build_persistent)
   int persist_grid = 0;           // work-groups (<= CUs of the device, all resident)
   int persist_chain_wgs = 0;      // the first persist_chain_wgs work-groups walk the nodes' diagonals
   long long persist_tiles = 0;    // tiles with a 'published' flag
