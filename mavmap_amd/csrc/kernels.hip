@@ -2405,11 +2405,17 @@ __global__ void __launch_bounds__(256) k_backsub_points(
 // recomputed (20 bytes of input instead of a 144-byte record + the intrinsics records) and
 //   sum_a U_a^T y_a + sum_q Uk_q^T y_q = Gi ( s_p o sum_obs Jp^T (Jc (s y)_cam + Jk (s y)_intr) ),
 // with (s y) = -delta_cam from k_update_cameras (which therefore runs first).
-// ONE observation per lane: a work-group takes `ppb` consecutive points (~224 observations), every lane computes its
+// ONE observation per lane: a work-group takes `ppb` consecutive points (~224 observations) at a time, every lane computes its
 // observation's Jp^T (J_cam delta_cam), the three values go through LDS and the point's owner lane adds its observations
 // in order (a 16-lanes-per-point version kept 10 of 16 lanes busy at 10 observations per point: 0.126 vs 0.102 ms at C3).
+// Round 4: the SQ counters showed the waves parked on memory 70 % of the time (SQ_WAIT_ANY) - with two waves per SIMD a block
+// was a chain of five dependent trips to memory (block bounds -> observation -> point / image / camera index -> camera
+// tables -> the owner's point data). Now a work-group walks CONSECUTIVE blocks: the next block's bounds and its lanes'
+// observations are requested before this block's arithmetic, the owner lanes' point data before the Jacobians, and the
+// per-camera tables (intrinsics, their step, the model) sit in LDS - three trips, two of them hidden.
+constexpr int kBsCamsLds = 16;  // cameras whose intrinsics tables are staged in LDS (more: read from memory)
 __global__ void __launch_bounds__(256) k_backsub_points_packed(
-    int NP, int NPs, int NI, int ppb, int nblocks, double radius, double dmin, double dmax, double loss_b, double loss_inv_b,
+    int NP, int NPs, int NI, int NC, int N, int ppb, int nblocks, double radius, double dmin, double dmax, double loss_b, double loss_inv_b,
     const int* __restrict__ pt_start, const int* __restrict__ obs_img, const int* __restrict__ obs_pt,
     const double2* __restrict__ uv, const int* __restrict__ img_cam, const int* __restrict__ cam_model,
     const double* __restrict__ camrec, const double* __restrict__ intr, const double* __restrict__ delta_cam,
@@ -2421,50 +2427,104 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
   __shared__ double s_t[3][256];
   __shared__ double s_new[3][128];  // the block's candidate points (ppb <= 128)
   __shared__ double s_red[4];
+  __shared__ double s_kin[kBsCamsLds][9], s_dk[kBsCamsLds][9];
+  __shared__ int s_model[kBsCamsLds];
   const int tid = threadIdx.x;
+  const bool cams_lds = NC <= kBsCamsLds;
   double a_step = 0.0, a_model = 0.0, a_x2 = 0.0, a_cost = 0.0;
-  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  // blocks blockIdx.x, + gridDim.x, ... (work-groups that run side by side walk neighbouring blocks: the points are ordered by
+  // their image lists, so they share camera records in the caches - consecutive blocks per work-group lost 8 % at C5)
+  const int G = (int)gridDim.x;
+  struct Obs { int pt, im; double2 m; };
+  auto load_obs = [&](int o) {
+    Obs r{0, 0, make_double2(0.0, 0.0)};
+    if (N <= 0) return r;
+    const int oc = min(o, N - 1);  // (a lane beyond the chunk reads the last observation and drops the result)
+    r.pt = obs_pt[oc]; r.im = obs_img[oc]; r.m = uv[oc];
+    return r;
+  };
+  // one observation's three values (zero for a lane beyond the chunk or a point that is not free)
+  auto obs_term = [&](const Obs& q, bool valid, double (&t)[3]) {
+    t[0] = t[1] = t[2] = 0.0;
+    if (!valid || !pt_free[q.pt]) return;
+    const int cam = img_cam[q.im];
+    const double X[3] = {points[3 * (size_t)q.pt], points[3 * (size_t)q.pt + 1], points[3 * (size_t)q.pt + 2]};
+    double rec[9], kin[9], dc[6], dk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rec[k] = camrec[9 * q.im + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dc[k] = delta_cam[6 * q.im + k];
+    int model;
+    if (cams_lds) {
+      model = s_model[cam];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { kin[k] = s_kin[cam][k]; dk[k] = s_dk[cam][k]; }
+    } else {
+      model = cam_model[cam];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { kin[k] = intr[9 * cam + k]; dk[k] = delta_cam[6 * NI + 9 * cam + k]; }
+    }
+    double r[2], Jc[12], Jp[6], Jk[18];
+    obs_jacobian(model, rec, kin, X, q.m.x, q.m.y, r, Jc, Jp, Jk);
+    double w, half_rho;
+    cauchy_weight(r[0] * r[0] + r[1] * r[1], loss_b, loss_inv_b, w, half_rho);
+    double tau0 = 0.0, tau1 = 0.0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { tau0 += Jc[e] * dc[e]; tau1 += Jc[6 + e] * dc[e]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { tau0 += Jk[k] * dk[k]; tau1 += Jk[9 + k] * dk[k]; }
+    const double w2 = w * w;
+    tau0 *= w2; tau1 *= w2;
+    t[0] = Jp[0] * tau0 + Jp[3] * tau1; t[1] = Jp[1] * tau0 + Jp[4] * tau1; t[2] = Jp[2] * tau0 + Jp[5] * tau1;
+  };
+  // bounds of this block and of the next one, observations of this block: requested one / two blocks ahead
+  int o0 = 0, o1 = 0, o0n = 0, o1n = 0;
+  Obs cur{0, 0, make_double2(0.0, 0.0)};
+  if ((int)blockIdx.x < nblocks) {
+    const int b0 = (int)blockIdx.x;
+    o0 = pt_start[b0 * ppb]; o1 = pt_start[min(b0 * ppb + ppb, NP)];
+    if (b0 + G < nblocks) { o0n = pt_start[(b0 + G) * ppb]; o1n = pt_start[min((b0 + G) * ppb + ppb, NP)]; }
+    cur = load_obs(o0 + tid);
+  }
+  if (cams_lds) {  // (behind the first requests: they travel while the tables are staged)
+    for (int e = tid; e < 9 * NC; e += 256) { s_kin[e / 9][e % 9] = intr[e]; s_dk[e / 9][e % 9] = delta_cam[6 * NI + e]; }
+    for (int c = tid; c < NC; c += 256) s_model[c] = cam_model[c];
+    __syncthreads();
+  }
+  for (int blk = blockIdx.x; blk < nblocks; blk += G) {
     const int p0 = blk * ppb, p1 = min(p0 + ppb, NP);
-    const int o0 = pt_start[p0], o1 = pt_start[p1];
     const int p = p0 + tid;
     const bool owner = p < p1;
+    // requests that do not depend on this block's arithmetic: the next block's observations, the bounds of the one after it,
+    // the owner lanes' point data
+    int o0nn = 0, o1nn = 0;
+    Obs nxt = cur;
+    if (blk + G < nblocks) {
+      nxt = load_obs(o0n + tid);
+      if (blk + 2 * G < nblocks) { o0nn = pt_start[(blk + 2 * G) * ppb]; o1nn = pt_start[min((blk + 2 * G) * ppb + ppb, NP)]; }
+    }
     int mb = 0, me = 0;
-    if (owner) { mb = pt_start[p]; me = pt_start[p + 1]; }
+    bool fr = false;
+    double G[6] = {0, 0, 0, 0, 0, 0}, sp[3] = {0, 0, 0}, hh[3] = {0, 0, 0}, cu[3] = {0, 0, 0}, gg[3] = {0, 0, 0}, Xo[3] = {0, 0, 0};
+    if (owner) {
+      mb = pt_start[p]; me = pt_start[p + 1];
+      fr = pt_free[p] != 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Xo[k] = points[3 * (size_t)p + k];
+      if (fr) {
+        const int dg[3] = {0, 3, 5};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) G[k] = Gi[k * NPs + p];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { sp[k] = scale_pt[k * NPs + p]; hh[k] = h[k * NPs + p]; cu[k] = Cu[dg[k] * NPs + p]; gg[k] = gu[k * NPs + p]; }
+      }
+    }
     double T[3] = {0.0, 0.0, 0.0};
     for (int base = o0; base < o1; base += 256) {
       const int o = base + tid;
-      double t[3] = {0.0, 0.0, 0.0};
-      if (o < o1) {
-        const int pt = obs_pt[o];
-        if (pt_free[pt]) {
-          const int im = obs_img[o];
-          const double2 m = uv[o];
-          const int cam = img_cam[im];
-          const int model = cam_model[cam];
-          const double X[3] = {points[3 * (size_t)pt], points[3 * (size_t)pt + 1], points[3 * (size_t)pt + 2]};
-          double rec[9], kin[9], dc[6], dk[9];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) rec[k] = camrec[9 * im + k];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) kin[k] = intr[9 * cam + k];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) dc[k] = delta_cam[6 * im + k];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) dk[k] = delta_cam[6 * NI + 9 * cam + k];
-          double r[2], Jc[12], Jp[6], Jk[18];
-          obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
-          double w, half_rho;
-          cauchy_weight(r[0] * r[0] + r[1] * r[1], loss_b, loss_inv_b, w, half_rho);
-          double tau0 = 0.0, tau1 = 0.0;
-#pragma unroll
-          for (int e = 0; e < 6; ++e) { tau0 += Jc[e] * dc[e]; tau1 += Jc[6 + e] * dc[e]; }
-#pragma unroll
-          for (int k = 0; k < 9; ++k) { tau0 += Jk[k] * dk[k]; tau1 += Jk[9 + k] * dk[k]; }
-          const double w2 = w * w;
-          tau0 *= w2; tau1 *= w2;
-          t[0] = Jp[0] * tau0 + Jp[3] * tau1; t[1] = Jp[1] * tau0 + Jp[4] * tau1; t[2] = Jp[2] * tau0 + Jp[5] * tau1;
-        }
-      }
+      const Obs q = base == o0 ? cur : load_obs(o);  // (a block of more than 256 observations - long tracks - reads its further chunks here)
+      double t[3];
+      obs_term(q, o < o1, t);
       s_t[0][tid] = t[0]; s_t[1][tid] = t[1]; s_t[2][tid] = t[2];
       __syncthreads();
       if (owner) {
@@ -2474,23 +2534,18 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
       __syncthreads();
     }
     if (owner) {
-      const bool fr = pt_free[p] != 0;
-      const double X[3] = {points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2]};
       double d[3] = {0, 0, 0};
       if (fr) {
-        const double G[6] = {Gi[p], Gi[NPs + p], Gi[2 * NPs + p], Gi[3 * NPs + p], Gi[4 * NPs + p], Gi[5 * NPs + p]};
-        const double sp[3] = {scale_pt[p], scale_pt[NPs + p], scale_pt[2 * NPs + p]};
         const double q0 = -sp[0] * T[0], q1 = -sp[1] * T[1], q2 = -sp[2] * T[2];
         const double z[3] = {q0 * G[0], q0 * G[1] + q1 * G[2], q0 * G[3] + q1 * G[4] + q2 * G[5]};
-        const double tt[3] = {h[p] - z[0], h[NPs + p] - z[1], h[2 * NPs + p] - z[2]};
+        const double tt[3] = {hh[0] - z[0], hh[1] - z[1], hh[2] - z[2]};
         double yp[3];
         git_mul(G, tt, yp);
-        const int dg[3] = {0, 3, 5};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const double s = sp[k];
-          const double D2 = clampd(s * s * Cu[dg[k] * NPs + p], dmin, dmax) / radius;
-          const double gs = s * gu[k * NPs + p];
+          const double D2 = clampd(s * s * cu[k], dmin, dmax) / radius;
+          const double gs = s * gg[k];
           a_model += 0.5 * yp[k] * (gs + D2 * yp[k]);
           d[k] = -yp[k] * s;
           a_step += d[k] * d[k];
@@ -2498,7 +2553,7 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const double xn = X[k] + d[k];
+        const double xn = Xo[k] + d[k];
         cand_points[3 * (size_t)p + k] = xn;
         delta_points[3 * (size_t)p + k] = d[k];
         if (fr) a_x2 += xn * xn;
@@ -2530,6 +2585,7 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
       }
       __syncthreads();  // s_new is rewritten by the next block
     }
+    o0 = o0n; o1 = o1n; o0n = o0nn; o1n = o1nn; cur = nxt;
   }
   const double s0 = block_sum_256(a_step, s_red);
   const double s1 = block_sum_256(a_model, s_red);
@@ -2555,7 +2611,7 @@ void launch_backsub_points_jvp(hipStream_t st, int NP, int NPs, int NI, double r
   const double track = NP > 0 ? (double)a.N / NP : 1.0;
   const int ppb = std::max(1, std::min(128, (int)(224.0 / std::max(track, 1.0))));
   const int nblocks = (NP + ppb - 1) / ppb;
-  hipLaunchKernelGGL(k_backsub_points_packed, dim3(gp), dim3(256), 0, st, NP, NPs, NI, ppb, nblocks, radius, dmin, dmax, a.loss_b,
+  hipLaunchKernelGGL(k_backsub_points_packed, dim3(gp), dim3(256), 0, st, NP, NPs, NI, a.NC, a.N, ppb, nblocks, radius, dmin, dmax, a.loss_b,
                      a.loss_inv_b, pt_start, a.obs_img, a.obs_pt, a.uv, a.img_cam, a.cam_model, a.camrec, a.intr, delta_cam, pt_free,
                      Gi, h, Cu, gu, scale_pt, a.points, cand_points, delta_points, partial, cand_camrec, cand_intr, a.pt_active,
                      cost_partial);
