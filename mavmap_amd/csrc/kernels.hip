@@ -2742,6 +2742,11 @@ __global__ void __launch_bounds__(1024) k_eval_small(EvalSmallArgs a) {
 }
 void launch_eval_small(hipStream_t st, const EvalSmallArgs& a) { hipLaunchKernelGGL(k_eval_small, dim3(1), dim3(1024), 0, st, a); }
 void launch_lm_tail(hipStream_t st, const ReduceTasks& T, int n, const LmSpec& spec, double* dec, double* host_pub, double seq, double* fail_slots) {
+  if (n > 4) {  // (the merged kernel runs at most four reductions side by side)
+    launch_reduce_tasks(st, T, n);
+    launch_lm_snapshot(st, spec, dec, host_pub, seq, fail_slots);
+    return;
+  }
   hipLaunchKernelGGL(k_lm_tail, dim3(1), dim3(1024), 0, st, T, n, spec, dec, host_pub, seq, fail_slots);
 }
 // Test entry (mavba_debug_lm_decide): `n` decisions by the device build of lm_decide. in: SC_COUNT scalars + 8 parameters
