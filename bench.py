@@ -360,6 +360,10 @@ def main():
         traffic_src = f"profiles/{PMC_ROUND}_pmc_traffic_{args.config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)"
         mfma = mfma_counters(args.config, args.scale, world)
         dominant = next((r for r in table if r.get("bound")), None)
+        mdl = info.get("chol_model_forward_us", 0.0)
+        chain_note = (f" (persistent launch: the host-side timing model that fills its task queues predicts {mdl:.0f} us for the forward pass"
+                      f" - 12.2 us per dependent tile column, 9-12 us per child -> parent hand-off, profiles/r04_chol_trace_C3.txt)") if mdl > 0 else \
+                     f" (launch-per-panel schedule: {info['chain_steps']} dependent 64-column panel steps)"
         roofline = None
         if dominant:
             roofline = dict(kernel=dominant["kernel"], rocprof_kernel=PMC_KERNEL.get(dominant["kernel"]), bound=dominant["bound"],
@@ -397,8 +401,8 @@ def main():
                 roofline["note"] = (f"forward factorisation of the reduced camera system (k_chol_persist; launch-per-panel k_chol_* at C5): "
                                     f"achieved = the flops of the structured factorisation ({info['factor_flops'] / 1e9:.2f} GFLOP: "
                                     f"{info['envelope_tiles']} of {info['dense_tiles']} tiles, {info['nd_parts']} concurrent fronts) / kernel "
-                                    f"time. Bound by the dependent chain of {info['chain_steps']} 64-column panel steps, not by matrix "
-                                    f"throughput. dense_equivalent_tflops prices SURVEY 8(d)'s n^3/3 + 2 n^2 = "
+                                    f"time. Bound by the dependent chain of tile columns and child -> parent hand-offs, not by matrix "
+                                    f"throughput{chain_note}. dense_equivalent_tflops prices SURVEY 8(d)'s n^3/3 + 2 n^2 = "
                                     f"{info['dense_factor_flops'] / 1e9:.2f} GFLOP and is NOT a roofline (> peak at C5)")
         chol = next((r for r in table if r["kernel"] == "chol_factor"), None)
         back = next((r for r in table if r["kernel"] == "chol_backsolve"), None)
@@ -415,8 +419,8 @@ def main():
                                  mfma_counters=mfma,
                                  note=(f"achieved / frac = flops of the structured factorisation / time of the forward factorisation; "
                                        f"dense_equivalent_* = SURVEY 8(d)'s n^3/3 + 2n^2 over factor + backward substitution, a label "
-                                       f"for comparison with dense solvers, not a roofline. Chain of {info['chain_steps']} dependent "
-                                       f"64-column panel steps"))
+                                       f"for comparison with dense solvers, not a roofline{chain_note}"),
+                                 model_forward_us=round(info.get("chol_model_forward_us", 0.0), 1) or None)
         sweep = next((r for r in table if r["kernel"] == "jacobian_sweep"), None)
         front = next((r for r in table if r["kernel"] == "point_front"), None)
         fused = next((r for r in table if r["kernel"] == "schur_fused"), None)

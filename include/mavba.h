@@ -436,6 +436,7 @@ typedef struct mavba_session_info {
   int64_t clustered_points;    /* points whose Schur terms are formed inside a cluster          */
   int64_t cluster_partials;    /* (cluster, block) partials the clusters emit per linear solve  */
   double cluster_flops;        /* FP64 MFMA flops k_schur_clusters executes per linear solve (E E^T incl. structural zeros) */
+  double chol_model_forward_us; /* the host-side timing model's forward factorisation on the persistent schedule (0: other schedule) */
 } mavba_session_info;
 int mavba_session_get_info(mavba_session* s, mavba_session_info* out);
 

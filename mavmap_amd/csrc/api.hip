@@ -482,6 +482,7 @@ int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
   out->clustered_points = s->clustered_points;
   out->cluster_partials = s->cluster_partials;
   out->cluster_flops = s->cluster_flops;
+  out->chol_model_forward_us = cs.persist_ok ? cs.predicted_forward_us : 0.0;
   const double n = (double)s->n_full;
   out->dense_factor_flops = n * n * n / 3.0 + 2.0 * n * n;
   return MAVBA_OK;
