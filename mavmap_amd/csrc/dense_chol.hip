@@ -1661,11 +1661,6 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   }
   const int helpers = (int)std::min<long long>(G - nch, (long long)gen.size());
   if (helpers < 1) return hipSuccess;
-  // The persistent schedule wins where the dependent chain is the cost (C3: 4 499 tile updates, 18 per helper, solve
-  // 0.71 -> 0.47 ms). A tile update costs a helper ~3.5 us (two flag polls, two write-through tile loads, one 64^3
-  // product), so with hundreds of updates per helper the launch-per-panel schedule - whose trailing updates are plain
-  // wide launches - is faster again (C5: 75 582 updates, 300 per helper: 3.45 ms against 4.96 ms).
-  if (mode == 1 && nupd > 100ll * helpers) return hipSuccess;
   // ---- list scheduling of the helper tasks on the simulated launch ----
   // Tasks and chain columns are visited in the order of their finishing times on unlimited helpers (`ideal`): every input of
   // a task finishes earlier there, so it has been placed - and given its time on the real number of helpers - before the task
@@ -1721,6 +1716,14 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   const int grid = nch + used;
   predicted_forward_us = 0.0;
   for (int j = 0; j < nb; ++j) predicted_forward_us = std::max(predicted_forward_us, act.col_fin[j]);
+  for (size_t id = 0; id < act.L.size(); ++id) predicted_forward_us = std::max(predicted_forward_us, act.L[id]);  // (the last panel solves)
+  // Persistent or launch-per-panel? Rounds 2-3 drew the line at 100 tile updates per helper (C5's 75 582 updates then took
+  // 4.96 ms persistent against 3.45 ms). With the model the question is asked directly: the launch-per-panel schedule costs a
+  // step about max(18 us, 8 us + 0.026 us per 64^3 tile update) (C3: 24 steps, ~0.55 ms; C5: 69 steps, 82 k updates, 2.6 ms
+  // measured); the persistent launch what the simulation above says (C5: 1.99 ms predicted, 2.08 measured - now the faster one).
+  double lpp_us = 0.0;
+  for (const CholStep& S : steps) lpp_us += S.kind != 0 ? 12.0 : std::max(18.0, 8.0 + 0.026 * (double)S.tasks);
+  if (mode == 1 && predicted_forward_us > lpp_us) return hipSuccess;
   std::vector<std::vector<CholTask>> wg_tasks(grid);
   for (int n = 0; n < nseg; ++n) wg_tasks[chain_wg[n]].push_back(CholTask{CHOL_TASK_CHAIN, nodes[n].begin, nodes[n].end, 0, 0});
   {
