@@ -1688,8 +1688,47 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   act.L.assign((size_t)nt, 0.0); act.col_begin.assign(nb, 0.0); act.col_fin.assign(nb, 0.0); act.pre.assign((size_t)2 * nb, 0.0);
   std::vector<double> free_at(helpers, 0.0);
   std::vector<std::vector<CholTask>> helper_tasks(helpers);
+  // Self-check of the order (the property the dead-lock argument rests on, verified instead of trusted): `placed` = position in
+  // the visiting order at which a tile / a PRE slot / a column's inverse is produced; everything a task or a chain column
+  // waits for must have been placed before it. A violation (a tie, a NaN in the model after some future change) does not
+  // become a hung launch: the structure keeps the launch-per-panel schedule and says so.
+  std::vector<int> placed_tile((size_t)nt, -1), placed_pre((size_t)2 * nb, -1), placed_col(nb, -1);
+  bool order_ok = true;
+  int position = 0;
+  auto produced = [&](int where) { if (where < 0) order_ok = false; };
   for (const Event& ev : events) {
-    if (ev.chain) { chain_column(act, ev.idx); continue; }
+    ++position;
+    if (ev.chain) {
+      const int j = ev.idx, n = seg_of_tile[j];
+      const bool first = j == nodes[n].begin;
+      if (first) { for (int c : children[n]) produced(placed_col[nodes[c].end - 1]); }
+      else produced(placed_col[j - 1]);
+      if (chain_info[j] & 1) produced(placed_pre[2 * j]);
+      if (chain_info[j] & 2) produced(placed_pre[2 * j + 1]);
+      placed_col[j] = position;
+      chain_column(act, ev.idx);
+      continue;
+    }
+    {
+      // a factor tile (r, k): a helper's TILE task - or, for r = k + 1 inside one node, the chain's own panel tile, which column r
+      // publishes early in its factorisation: it needs column k and column r's PRE tiles, not the end of column r
+      auto tile_there = [&](int r, int k) {
+        if (r == k + 1 && r < nb && seg_of_tile[r] == seg_of_tile[k]) {
+          produced(placed_col[k]);
+          if (chain_info[r] & 1) produced(placed_pre[2 * r]);
+          if (chain_info[r] & 2) produced(placed_pre[2 * r + 1]);
+        } else {
+          produced(placed_tile[tile_id[(size_t)r * nb + k]]);
+        }
+      };
+      const CholTask& c = gen[ev.idx].t;
+      for (int u = c.ub; u < c.ue; ++u) {
+        tile_there(c.i, upd[u]);
+        if (c.i != c.j) tile_there(c.j, upd[u]);
+      }
+      if (c.kind == CHOL_TASK_TILE) { produced(placed_col[c.j]); placed_tile[tile_id[(size_t)c.i * nb + c.j]] = position; }
+      else placed_pre[c.kind == CHOL_TASK_PRE_DIAG ? 2 * c.j : 2 * c.i + 1] = position;
+    }
     const CholTask& t = gen[ev.idx].t;
     const int n_upd = t.ue - t.ub;
     const double release = std::max(0.0, upd_end[ev.idx] - cU * n_upd - 10.0);
@@ -1710,6 +1749,10 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     }
     free_at[best] = f;
     helper_tasks[best].push_back(t);
+  }
+  if (!order_ok) {
+    std::fprintf(stderr, "mavba: the persistent factorisation's task order failed its self-check; using the launch-per-panel schedule\n");
+    return hipSuccess;
   }
   int used = 0;
   for (int w = 0; w < helpers; ++w) used += !helper_tasks[w].empty();
