@@ -528,6 +528,7 @@ void mavba_session::point_errors(double* out) {
 void mavba_session::restart() {
   evaluated = scales_ready = started = assembled = false;
   front_valid = false;
+  cameras_updated = false;  // (a camera update done inside a solve's launch belongs to that solve's candidate only)
   // The Jacobi scales are re-estimated: which columns are constant (unit diagonal) may differ from the previous solve
   // (filter_points), so the matrix is cleared and its constant / padding diagonal rewritten once (k_fix_diag).
   M_is_clean = false;
