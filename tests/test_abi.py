@@ -96,3 +96,19 @@ def test_product_code_never_touches_the_oracle():
                     if re.search(r"oracle_lib|ba_oracle|libba_oracle|from tests|import tests", text):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_the_build_digest_covers_every_header_the_sources_include():
+    """mavmap_amd.build.is_current() decides whether the library on disk belongs to the sources: a header missing from its
+    list (round 4 found lm_decide.h and lm_bodies.h missing) would let a stale library pass for current."""
+    import re
+    from mavmap_amd import build as b
+    listed = {os.path.basename(h) for h in b.HEADERS}
+    included = set()
+    for f in os.listdir(b.CSRC):
+        if f.endswith((".hip", ".h")):
+            for m in re.finditer(r'#include\s+"([^"]+)"', open(os.path.join(b.CSRC, f)).read()):
+                included.add(os.path.basename(m.group(1)))
+    assert included <= listed, sorted(included - listed)
+    # per-file flags are part of the digest too (dense_chol.hip is built with the matrix instructions in VGPR form)
+    assert "dense_chol.hip" in b.FILE_FLAGS and set(b.FILE_FLAGS) <= set(b.SOURCES)
