@@ -391,6 +391,15 @@ int mavba_debug_radix_sort(int32_t n, const uint32_t* keys, int32_t key_bytes, i
 /* Test entry: the LM accept / reject / terminate decision (csrc/lm_decide.h) by the host build and by the device build on
  * the same n cases (16 scalars + 8 parameters each, 6 doubles out each); the speculative evaluation needs them identical. */
 int mavba_debug_lm_decide(int32_t n, const double* cases, double* out_host, double* out_device, int32_t device);
+/* Test entry (no device needed): tile structure + persistent schedule of a factorisation with `nb` tile columns, elimination
+ * tree nodes [begin, end) / parent, non-zero lower tiles (row, col), for a device of `cus` compute units.
+ * out[8] = schedule exists, modelled forward us, launch-per-panel estimate us, grid, chain work-groups, tiles, updates, nodes;
+ * tasks_out: 6 ints per task in queue order (work-group, kind, i, j, first update, end update); upd_out: the update lists;
+ * chain_info_out[nb]: bit 0 / 1 = the chain column waits for a PRE tile of its diagonal / sub-diagonal tile. */
+int mavba_debug_chol_schedule(int32_t nb, int32_t num_nodes, const int32_t* node_begin, const int32_t* node_end, const int32_t* node_parent,
+                              int64_t num_pairs, const int32_t* pair_row, const int32_t* pair_col, int32_t cus, double* out,
+                              int32_t* tasks_out, int64_t tasks_cap, int64_t* num_tasks, int32_t* upd_out, int64_t upd_cap,
+                              int64_t* num_upd, int32_t* chain_info_out);
 
 /* Build the reduced camera system for the current Jacobian and trust-region
  * radius and download it: S [n][n] row-major (both triangles), v [n], with

@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "mavba_scene_add_points2d", "mavba_scene_set_point3d", "mavba_scene_link", "mavba_scene_delete_point3d", "mavba_scene_get_image", "mavba_scene_get_point3d",
     "mavba_scene_get_camera", "mavba_scene_flatten", "mavba_scene_bundle_adjust",
     "mavba_rccl_unique_id", "mavba_session_set_rccl", "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
-    "mavba_debug_elimination_tree", "mavba_debug_radix_sort", "mavba_debug_lm_decide",
+    "mavba_debug_elimination_tree", "mavba_debug_radix_sort", "mavba_debug_lm_decide", "mavba_debug_chol_schedule",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -116,6 +116,9 @@ def load():
     L.mavba_debug_elimination_tree.argtypes = [C.c_int32, C.c_int32, C.c_int64, ip, ip, C.c_int32, ip, ip, C.c_int32]
     L.mavba_debug_radix_sort.argtypes = [C.c_int32, C.POINTER(C.c_uint32), C.c_int32, ip, C.c_int32]
     L.mavba_debug_lm_decide.argtypes = [C.c_int32, dp, dp, dp, C.c_int32]
+    i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.mavba_debug_chol_schedule.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int64, i32p, i32p, C.c_int32, dp,
+                                            i32p, C.c_int64, i64p, i32p, C.c_int64, i64p, i32p]
     for f in EXPORTED_SYMBOLS:
         if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy", "mavba_scene_destroy"):
             getattr(L, f).restype = C.c_int
@@ -571,6 +574,30 @@ def debug_lm_decide(cases, device=-1):
     oh, od = np.zeros((n, 6)), np.zeros((n, 6))
     _check(load().mavba_debug_lm_decide(n, _d(cases), _d(oh), _d(od), device))
     return oh, od
+
+
+def debug_chol_schedule(nb, nodes, pairs, cus=256):
+    """Tile structure + persistent schedule of a factorisation on the HOST (no device): `nodes` = [(begin, end, parent)] of the
+    elimination tree in tile columns, `pairs` = non-zero lower tiles (row, col). Returns a dict with the modelled times and
+    the helpers' / chains' queues: tasks = [(work-group, kind, i, j, [update columns])], kinds 0 TILE 1 PRE_DIAG 2 PRE_SUB 3 CHAIN."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.int32).reshape(-1, 3)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    nbg, ne, npar = (np.ascontiguousarray(nodes[:, k]) for k in range(3))
+    pr, pc = np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    out = np.zeros(8)
+    nt, nu = C.c_int64(), C.c_int64()
+    ci = np.zeros(nb, np.int32)
+    L = load()
+    _check(L.mavba_debug_chol_schedule(nb, len(nodes), i32(nbg), i32(ne), i32(npar), len(pairs), i32(pr), i32(pc), cus, _d(out),
+                                       None, 0, C.byref(nt), None, 0, C.byref(nu), i32(ci)))
+    tasks = np.zeros((max(nt.value, 1), 6), np.int32)
+    upd = np.zeros(max(nu.value, 1), np.int32)
+    _check(L.mavba_debug_chol_schedule(nb, len(nodes), i32(nbg), i32(ne), i32(npar), len(pairs), i32(pr), i32(pc), cus, _d(out),
+                                       i32(tasks), nt.value, C.byref(nt), i32(upd), nu.value, C.byref(nu), i32(ci)))
+    tl = [(int(t[0]), int(t[1]), int(t[2]), int(t[3]), [int(x) for x in upd[t[4]:t[5]]]) for t in tasks[:nt.value]]
+    return dict(ok=bool(out[0]), model_forward_us=float(out[1]), launch_per_panel_us=float(out[2]), grid=int(out[3]),
+                chain_wgs=int(out[4]), tiles=int(out[5]), updates=int(out[6]), nodes=int(out[7]), tasks=tl, chain_info=ci.tolist())
 
 
 def rccl_unique_id():

@@ -398,6 +398,47 @@ int mavba_session_time_jacobian(mavba_session* s, int32_t reps, float* ms_avg) {
   MAVBA_CATCH
 }
 
+// Test entry: the tile structure and the persistent schedule of a factorisation WITHOUT a device - what CholStructure::build
+// computes on the host (tree validation, envelope, update lists ordered by the timing model, the helpers' queues from list
+// scheduling). The CPU test-suite plays the queues against random task durations and checks that every launch completes.
+//   out[8]: schedule exists | modelled forward us | launch-per-panel estimate us | grid | chain work-groups | tiles | updates | nodes
+//   tasks_out: 6 ints per task in queue order (work-group, kind, i, j, first update, end update); upd_out: the update lists
+int mavba_debug_chol_schedule(int32_t nb, int32_t num_nodes, const int32_t* node_begin, const int32_t* node_end, const int32_t* node_parent,
+                              int64_t num_pairs, const int32_t* pair_row, const int32_t* pair_col, int32_t cus, double* out,
+                              int32_t* tasks_out, int64_t tasks_cap, int64_t* num_tasks, int32_t* upd_out, int64_t upd_cap,
+                              int64_t* num_upd, int32_t* chain_info_out) {
+  MAVBA_TRY
+  if (nb < 1 || num_nodes < 0 || num_pairs < 0 || !out || !num_tasks || !num_upd || cus < 2) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "bad argument");
+  std::vector<CholNode> tree;
+  for (int n = 0; n < num_nodes; ++n) tree.push_back(CholNode{node_begin[n], node_end[n], node_parent[n]});
+  std::vector<std::pair<int, int>> pairs;
+  for (int64_t q = 0; q < num_pairs; ++q) {
+    if (pair_row[q] < 0 || pair_row[q] >= nb || pair_col[q] < 0 || pair_col[q] > pair_row[q]) throw Failure(MAVBA_ERR_BAD_INDEX, "tile pair out of range");
+    pairs.emplace_back(pair_row[q], pair_col[q]);
+  }
+  CholStructure cs;
+  cs.host_only = true;
+  cs.host_only_cus = cus;
+  if (cs.build(nb, pairs, tree, nullptr) != hipSuccess) throw Failure(MAVBA_ERR_HIP, "structure build failed");
+  out[0] = cs.persist_ok ? 1.0 : 0.0; out[1] = cs.predicted_forward_us; out[2] = cs.lpp_estimate_us; out[3] = cs.persist_grid;
+  out[4] = cs.persist_chain_wgs; out[5] = (double)cs.persist_tiles; out[6] = (double)cs.persist_updates; out[7] = cs.nseg;
+  *num_tasks = (int64_t)cs.h_tasks.size();
+  *num_upd = (int64_t)cs.h_upd.size();
+  if (tasks_out && (int64_t)cs.h_tasks.size() <= tasks_cap) {
+    int wg = 0;
+    for (size_t t = 0; t < cs.h_tasks.size(); ++t) {
+      while (wg + 1 < (int)cs.h_wg_begin.size() && cs.h_wg_begin[wg + 1] <= (int)t) ++wg;
+      const CholTask& T = cs.h_tasks[t];
+      int32_t* o = tasks_out + 6 * t;
+      o[0] = wg; o[1] = T.kind; o[2] = T.i; o[3] = T.j; o[4] = T.ub; o[5] = T.ue;
+    }
+  }
+  if (upd_out && (int64_t)cs.h_upd.size() <= upd_cap) std::copy(cs.h_upd.begin(), cs.h_upd.end(), upd_out);
+  if (chain_info_out) for (int j = 0; j < nb; ++j) chain_info_out[j] = j < (int)cs.h_chain_info.size() ? cs.h_chain_info[j] : 0;
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
 // Test entry: the LM decision function (lm_decide.h) evaluated by the host build and by the device build on the same
 // `n` cases (SC_COUNT scalars + 8 parameters each); 6 doubles per case out of each. The speculative evaluation relies on
 // the two agreeing bit for bit.

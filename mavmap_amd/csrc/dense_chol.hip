@@ -1441,7 +1441,9 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   pack.insert(pack.end(), init_tiles.begin(), init_tiles.end());
   const size_t o_flags = pack.size();
   pack.resize(pack.size() + nb, 0);
-  hipError_t e = device_alloc(reinterpret_cast<void**>(&d_ints), pack.size() * sizeof(int));
+  hipError_t e = hipSuccess;
+  if (!host_only) {
+  e = device_alloc(reinterpret_cast<void**>(&d_ints), pack.size() * sizeof(int));
   if (e == hipSuccess) e = copy_h2d_staged(d_ints, pack.data(), pack.size() * sizeof(int), st);
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_fronts), std::max<size_t>(fronts.size(), 1) * sizeof(CholFront));
   if (e == hipSuccess && !fronts.empty())
@@ -1469,6 +1471,7 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   d_seg_first = d_ints + o_first;
   d_init = d_ints + o_init;
   d_flags = reinterpret_cast<unsigned*>(d_ints + o_flags);
+  }  // (!host_only)
   // persistent schedule: rows that couple to every column, schedule step of every column
   std::vector<std::vector<int>> col_rows(nb);
   std::vector<int> col_step(nb, 0);
@@ -1511,7 +1514,7 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   const bool enabled = mode != 0;
   static const int grid_cap = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST_GRID"); return e ? std::atoi(e) : 0; }();
   if (!enabled || nb < 1 || nb > 512) return hipSuccess;  // (dense tile-id table)
-  int G = device_cu_count();
+  int G = host_only ? host_only_cus : device_cu_count();
   if (grid_cap > 0) G = std::min(G, grid_cap);
   // ---- tiles with a 'published' flag: diagonal, coupled rows, right-hand-side row of every column ----
   std::vector<int> tile_id((size_t)(nb + 1) * nb, -1);
@@ -1766,7 +1769,8 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   // measured); the persistent launch what the simulation above says (C5: 1.99 ms predicted, 2.08 measured - now the faster one).
   double lpp_us = 0.0;
   for (const CholStep& S : steps) lpp_us += S.kind != 0 ? 12.0 : std::max(18.0, 8.0 + 0.026 * (double)S.tasks);
-  if (mode == 1 && predicted_forward_us > lpp_us) return hipSuccess;
+  lpp_estimate_us = lpp_us;
+  if (mode == 1 && predicted_forward_us > lpp_us && !host_only) return hipSuccess;
   std::vector<std::vector<CholTask>> wg_tasks(grid);
   for (int n = 0; n < nseg; ++n) wg_tasks[chain_wg[n]].push_back(CholTask{CHOL_TASK_CHAIN, nodes[n].begin, nodes[n].end, 0, 0});
   {
@@ -1790,6 +1794,12 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   const size_t o_ci = pack.size();
   pack.insert(pack.end(), chain_info.begin(), chain_info.end());
   const size_t nflags = (size_t)nt + 3 * (size_t)nb + 1;
+  if (host_only) {  // (the test entry reads the schedule from these)
+    h_tasks = tasks; h_wg_begin = wg_begin; h_upd = upd; h_chain_info = chain_info;
+    persist_grid = grid; persist_chain_wgs = nch; persist_tiles = nt; persist_updates = nupd;
+    persist_ok = true;
+    return hipSuccess;
+  }
   hipError_t e = device_alloc(reinterpret_cast<void**>(&d_pints), pack.size() * sizeof(int));
   if (e == hipSuccess) e = copy_h2d_staged(d_pints, pack.data(), pack.size() * sizeof(int), st);
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_tasks), tasks.size() * sizeof(CholTask));

@@ -414,8 +414,13 @@ struct CholStructure {
   unsigned* d_pflags = nullptr;   // lflag[persist_tiles] | dflag[nb] | pflag[2 nb] | abort[1]
   double* d_pre = nullptr;        // [2 nb] 64x64 tiles: the chain's tiles after the helpers' updates
   unsigned long long* d_trace = nullptr;  // MAVBA_CHOL_TRACE=<file>: stamps of the last solve, dumped on release
-  std::vector<CholTask> h_tasks;          // (kept for the trace dump only)
-  std::vector<int> h_wg_begin;
+  std::vector<CholTask> h_tasks;          // (kept for the trace dump and the host-only test entry)
+  std::vector<int> h_wg_begin, h_upd, h_chain_info;
+  // Host-only build (mavba_debug_chol_schedule, tests without a GPU): the structure and the persistent schedule are computed,
+  // nothing is allocated on or copied to a device; `host_only_cus` stands for the CU count.
+  bool host_only = false;
+  int host_only_cus = 256;
+  double lpp_estimate_us = 0.0;           // the timing model's estimate of the launch-per-panel schedule
   mutable unsigned epoch = 0;     // flags are compared with the solve's epoch: nothing is cleared between solves
   CholStructure() {}
   CholStructure(const CholStructure&) = delete;
