@@ -1305,6 +1305,16 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   nb = nb_;
   const int never = nb + 1;
   nodes = tree_in;
+  // MAVBA_CHOL_DUMP=<file>: the structure as handed over (tile columns, tree, non-zero lower tiles) - the input of
+  // mavba_debug_chol_schedule, for working on the schedule of a real problem without a device
+  if (const char* dump = host_only ? nullptr : std::getenv("MAVBA_CHOL_DUMP")) {
+    if (FILE* f = std::fopen(dump, "w")) {
+      std::fprintf(f, "%d %zu %zu\n", nb, tree_in.size(), tile_pairs.size());
+      for (const CholNode& n : tree_in) std::fprintf(f, "%d %d %d\n", n.begin, n.end, n.parent);
+      for (const auto& pr : tile_pairs) std::fprintf(f, "%d %d\n", pr.first, pr.second);
+      std::fclose(f);
+    }
+  }
   // valid tree: contiguous ascending cover of [0, nb), parents after children, exactly one root (the last node)
   auto tree_ok = [&]() {
     if (nodes.empty() || nb > kMaxBacksolveGroups) return false;  // (the per-tile backward fallback is single-segment)
@@ -1578,7 +1588,7 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     return j == nodes[n].begin ? dl.size() : (dl.empty() ? 0 : dl.size() - 1);
   };
   // chain column j: begins when its predecessor (or every child node) and its PRE tiles are there
-  auto chain_column = [&](Times& T, int j) {
+  auto chain_begin = [&](Times& T, int j) {
     const int n = seg_of_tile[j];
     const bool first = j == nodes[n].begin;
     double start = 0.0;
@@ -1586,9 +1596,10 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     else start = T.col_fin[j - 1];
     start = std::max(start, std::max(T.pre[2 * j], T.pre[2 * j + 1]));
     T.col_begin[j] = start;
-    T.col_fin[j] = start + (first ? cColFirst : cCol);
-    if (!first) T.L[tile_id[(size_t)j * nb + (j - 1)]] = start + cSub;  // (the chain solves and publishes its own panel tile)
+    if (!first) T.L[tile_id[(size_t)j * nb + (j - 1)]] = start + cSub;  // (the chain solves and publishes its own panel tile early in the column)
   };
+  auto chain_end = [&](Times& T, int j) { T.col_fin[j] = T.col_begin[j] + (j == nodes[seg_of_tile[j]].begin ? cColFirst : cCol); };
+  auto chain_column = [&](Times& T, int j) { chain_begin(T, j); chain_end(T, j); };
   auto ideal_pass = [&](Times& T) {  // every helper task on a work-group of its own, started at time 0
     T.L.assign((size_t)nt, 0.0); T.col_begin.assign(nb, 0.0); T.col_fin.assign(nb, 0.0); T.pre.assign((size_t)2 * nb, 0.0);
     for (int j = 0; j < nb; ++j) {
@@ -1672,58 +1683,68 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   // not know) - or, if none is, to the one that is free first. A work-group runs its queue in this order and every wait is
   // for something that is earlier in it: no cycle of waits, whatever the real timing turns out to be.
   struct Event { double t; int chain; int idx; };  // idx: column (chain) or index into gen
+  struct Pass { Times act; std::vector<std::vector<CholTask>> helper_tasks; double forward = 0.0; bool ok = false; };
+  auto forward_of = [&](const Times& T) {
+    double f = 0.0;
+    for (int j = 0; j < nb; ++j) f = std::max(f, T.col_fin[j]);
+    for (size_t id = 0; id < T.L.size(); ++id) f = std::max(f, T.L[id]);  // (the last panel solves)
+    return f;
+  };
+  auto run_pass = [&](const Times& est, Pass& P, int pre_pool) {
   std::vector<Event> events;
-  std::vector<double> upd_end(gen.size(), 0.0);  // end of the task's update phase on unlimited helpers
+  std::vector<double> upd_end(gen.size(), 0.0);  // end of the task's update phase in `est` when started at time 0
   for (size_t g = 0; g < gen.size(); ++g) {
     const CholTask& t = gen[g].t;
     std::vector<int> list(upd.begin() + t.ub, upd.begin() + t.ue);
-    upd_end[g] = run_updates(ideal, t.i, t.j, list, list.size(), 0.0);
-    const double fin = t.kind == CHOL_TASK_TILE ? ideal.L[tile_id[(size_t)t.i * nb + t.j]] : ideal.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1];
+    upd_end[g] = run_updates(est, t.i, t.j, list, list.size(), 0.0);
+    const double fin = t.kind == CHOL_TASK_TILE ? est.L[tile_id[(size_t)t.i * nb + t.j]] : est.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1];
     events.push_back(Event{fin, 0, (int)g});
   }
-  for (int j = 0; j < nb; ++j) events.push_back(Event{ideal.col_fin[j], 1, j});
+  // (a chain column is two events: its begin - from then on its own panel tile is on its way, tasks that multiply with it may
+  // be visited before the column ends - and its end; at equal times: ends, then helper tasks, then begins)
+  for (int j = 0; j < nb; ++j) { events.push_back(Event{est.col_fin[j], 1, j}); events.push_back(Event{est.col_begin[j], 2, j}); }
   std::stable_sort(events.begin(), events.end(), [&](const Event& x, const Event& y) {
     if (x.t != y.t) return x.t < y.t;
-    if (x.chain != y.chain) return x.chain > y.chain;
+    const int rx = x.chain == 1 ? 0 : (x.chain == 0 ? 1 : 2), ry = y.chain == 1 ? 0 : (y.chain == 0 ? 1 : 2);
+    if (rx != ry) return rx < ry;
     return x.idx < y.idx;
   });
-  Times act;
+  Times& act = P.act;
   act.L.assign((size_t)nt, 0.0); act.col_begin.assign(nb, 0.0); act.col_fin.assign(nb, 0.0); act.pre.assign((size_t)2 * nb, 0.0);
   std::vector<double> free_at(helpers, 0.0);
-  std::vector<std::vector<CholTask>> helper_tasks(helpers);
+  double work_us = 0.0, occupied_us = 0.0;
+  std::vector<std::vector<CholTask>>& helper_tasks = P.helper_tasks;
+  helper_tasks.assign(helpers, {});
   // Self-check of the order (the property the dead-lock argument rests on, verified instead of trusted): `placed` = position in
   // the visiting order at which a tile / a PRE slot / a column's inverse is produced; everything a task or a chain column
   // waits for must have been placed before it. A violation (a tie, a NaN in the model after some future change) does not
   // become a hung launch: the structure keeps the launch-per-panel schedule and says so.
-  std::vector<int> placed_tile((size_t)nt, -1), placed_pre((size_t)2 * nb, -1), placed_col(nb, -1);
+  std::vector<int> placed_tile((size_t)nt, -1), placed_pre((size_t)2 * nb, -1), placed_col(nb, -1), placed_begin(nb, -1);
   bool order_ok = true;
   int position = 0;
   auto produced = [&](int where) { if (where < 0) order_ok = false; };
   for (const Event& ev : events) {
     ++position;
-    if (ev.chain) {
+    if (ev.chain == 2) {  // column j begins: everything it waits for has been placed; its own panel tile is produced from here on
       const int j = ev.idx, n = seg_of_tile[j];
       const bool first = j == nodes[n].begin;
       if (first) { for (int c : children[n]) produced(placed_col[nodes[c].end - 1]); }
       else produced(placed_col[j - 1]);
       if (chain_info[j] & 1) produced(placed_pre[2 * j]);
       if (chain_info[j] & 2) produced(placed_pre[2 * j + 1]);
-      placed_col[j] = position;
-      chain_column(act, ev.idx);
+      placed_begin[j] = position;
+      if (!first) placed_tile[tile_id[(size_t)j * nb + (j - 1)]] = position;
+      chain_begin(act, j);
+      continue;
+    }
+    if (ev.chain == 1) {  // column j ends: its inverse is published
+      produced(placed_begin[ev.idx]);
+      placed_col[ev.idx] = position;
+      chain_end(act, ev.idx);
       continue;
     }
     {
-      // a factor tile (r, k): a helper's TILE task - or, for r = k + 1 inside one node, the chain's own panel tile, which column r
-      // publishes early in its factorisation: it needs column k and column r's PRE tiles, not the end of column r
-      auto tile_there = [&](int r, int k) {
-        if (r == k + 1 && r < nb && seg_of_tile[r] == seg_of_tile[k]) {
-          produced(placed_col[k]);
-          if (chain_info[r] & 1) produced(placed_pre[2 * r]);
-          if (chain_info[r] & 2) produced(placed_pre[2 * r + 1]);
-        } else {
-          produced(placed_tile[tile_id[(size_t)r * nb + k]]);
-        }
-      };
+      auto tile_there = [&](int r, int k) { produced(placed_tile[tile_id[(size_t)r * nb + k]]); };
       const CholTask& c = gen[ev.idx].t;
       for (int u = c.ub; u < c.ue; ++u) {
         tile_there(c.i, upd[u]);
@@ -1735,8 +1756,11 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     const CholTask& t = gen[ev.idx].t;
     const int n_upd = t.ue - t.ub;
     const double release = std::max(0.0, upd_end[ev.idx] - cU * n_upd - 10.0);
-    int best = -1, first_free = 0;
-    for (int w = 0; w < helpers; ++w) {
+    // (pre_pool > 0: the first pre_pool helpers take the PRE tasks - what the chains wait for directly - and nothing else)
+    const int w0 = pre_pool > 0 && t.kind == CHOL_TASK_TILE ? pre_pool : 0;
+    const int w1 = pre_pool > 0 && t.kind != CHOL_TASK_TILE ? pre_pool : helpers;
+    int best = -1, first_free = w0;
+    for (int w = w0; w < w1; ++w) {
       if (free_at[w] < free_at[first_free]) first_free = w;
       if (free_at[w] <= release && (best < 0 || free_at[w] > free_at[best])) best = w;
     }
@@ -1750,9 +1774,37 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
       f += cP;
       act.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1] = f;
     }
+    work_us += cU * n_upd + (t.kind == CHOL_TASK_TILE ? cS : cP);
+    occupied_us += f - free_at[best];
     free_at[best] = f;
     helper_tasks[best].push_back(t);
   }
+  if (std::getenv("MAVBA_CHOL_SCHED_DEBUG"))  // (C5: 283 ms of work, 374 ms occupied - 90 ms waiting inside tasks -, 252 helpers x 1.99 ms = 501 ms)
+    std::fprintf(stderr, "mavba:   %d helpers for the PRE tasks: work %.0f us, occupied %.0f us, helpers x forward %.0f us\n", pre_pool, work_us,
+                 occupied_us, helpers * forward_of(act));
+  P.ok = order_ok;
+  P.forward = forward_of(act);
+  };
+  // The PRE tasks are what the chains wait for directly. Besides the shared pool (0) a few sizes of a pool of helpers that take
+  // ONLY them are simulated and the shortest launch is kept (C3: no difference from 32 helpers on, shared pool kept; C5: 32 helpers
+  // for the 345 PRE tasks, 1 990 -> 1 938 us; a fixed-point iteration of the passes - start times from the previous pass's
+  // launch instead of the unlimited one - was tried on the real C5 structure and made it worse: 2 083, 2 059 us).
+  Pass best_pass;
+  {
+    int npre = 0;
+    for (const Gen& g : gen) npre += g.t.kind != CHOL_TASK_TILE;
+    for (int pool : {0, 4, 8, 16, 32, 64, 96}) {
+      if (pool > 0 && (pool >= helpers - 1 || pool > npre || npre == (int)gen.size())) continue;
+      Pass P;
+      run_pass(ideal, P, pool);
+      if (!P.ok) continue;
+      if (std::getenv("MAVBA_CHOL_SCHED_DEBUG")) std::fprintf(stderr, "mavba: schedule with %d helpers for the PRE tasks: forward %.1f us\n", pool, P.forward);
+      if (!best_pass.ok || P.forward < best_pass.forward) best_pass = std::move(P);
+    }
+  }
+  const bool order_ok = best_pass.ok;
+  std::vector<std::vector<CholTask>>& helper_tasks = best_pass.helper_tasks;
+  Times& act = best_pass.act;
   if (!order_ok) {
     std::fprintf(stderr, "mavba: the persistent factorisation's task order failed its self-check; using the launch-per-panel schedule\n");
     return hipSuccess;

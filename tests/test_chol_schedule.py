@@ -184,3 +184,27 @@ def test_the_replay_notices_a_bad_order():
     bad = dict(s, tasks=chains + [(one_wg, k, i, j, u) for _, k, i, j, u in reversed(helpers)])
     done, stuck, *_ = _replay(bad, nb)
     assert not done and stuck
+
+
+def _load_structure(name):
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"chol_structure_{name}.txt")
+    rows = [tuple(int(x) for x in line.split()) for line in open(path)]
+    nb, nn, npairs = rows[0]
+    return nb, rows[1:1 + nn], rows[1 + nn:1 + nn + npairs]
+
+
+@pytest.mark.parametrize("name,measured_us", [("C2", None), ("C3", 258.5), ("C5", 2072.8)])
+def test_the_schedules_of_the_benchmark_configurations(name, measured_us):
+    """The tile structures of C2 / C3 / C5 as the sessions hand them to CholStructure::build on the GPU box (dumped there with
+    MAVBA_CHOL_DUMP; tests/golden/chol_structure_*.txt): their queues run to the end, the persistent launch is modelled faster
+    than the launch-per-panel schedule, and the model stays near what MAVBA_CHOL_TRACE measured for the forward pass on the
+    MI355X (profiles/r04_chol_trace_C3.txt, r04_chol_trace_C5.txt) - the schedule is only as good as that agreement."""
+    nb, nodes, pairs = _load_structure(name)
+    s = api.debug_chol_schedule(nb, nodes, pairs, cus=256)
+    assert s["ok"] and s["nodes"] == len(nodes) and s["grid"] <= 256
+    assert s["model_forward_us"] < s["launch_per_panel_us"]
+    done, stuck, twice, L, dflag = _replay(s, nb)
+    assert done and not twice and dflag == set(range(nb))
+    if measured_us:
+        assert abs(s["model_forward_us"] - measured_us) < 0.08 * measured_us, s["model_forward_us"]
