@@ -194,7 +194,7 @@ def _load_structure(name):
     return nb, rows[1:1 + nn], rows[1 + nn:1 + nn + npairs]
 
 
-@pytest.mark.parametrize("name,measured_us", [("C2", None), ("C3", 258.5), ("C5", 2072.8)])
+@pytest.mark.parametrize("name,measured_us", [("C2", None), ("C3", 258.5), ("C5", 2046.4)])
 def test_the_schedules_of_the_benchmark_configurations(name, measured_us):
     """The tile structures of C2 / C3 / C5 as the sessions hand them to CholStructure::build on the GPU box (dumped there with
     MAVBA_CHOL_DUMP; tests/golden/chol_structure_*.txt): their queues run to the end, the persistent launch is modelled faster
