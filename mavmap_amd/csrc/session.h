@@ -339,6 +339,8 @@ struct mavba_session {
   // in join_ranks (a rank that re-solves after a time-out issues a collective - every rank must take that branch).
   bool allow_persistent = true;
   bool persist_decided = false;
+  bool speculate_on = true;   // MAVBA_SPECULATE, read by start() for every solve (tests compare both ways in one process)
+  void decide_persistent();
   // The reduced camera matrix is assembled in the factorisation's elimination order: n_mat (multiple of 64)
   // columns, image i's pose block at h_off_img[i], camera c's intrinsics block at h_off_cam[c]; col_var maps a
   // matrix column back to the variable (index into the length-n_pad camera vectors), -1 for padding.

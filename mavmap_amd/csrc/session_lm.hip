@@ -12,7 +12,13 @@
 //   src/base3d/bundle_adjustment.cc:139-225  pose_refinement
 #include "session.h"
 #include "lm_decide.h"
+#if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
+#define MAVBA_CPU_RELAX() _mm_pause()
+#else
+#include <thread>
+#define MAVBA_CPU_RELAX() std::this_thread::yield()
+#endif
 
 using namespace mavba;
 
@@ -229,7 +235,17 @@ void mavba_session::assemble(double r) {
   assembled = true;
 }
 
+// Persistent launch or launch-per-panel schedule for this session: decided once, at the first linear solve - whichever entry
+// point reaches it (start(), mavba_session_linear_step, the timing probes) -, so the process-wide cool-down after a
+// time-out is honoured by all of them. Sharded sessions decided in join_ranks, for all ranks together.
+void mavba_session::decide_persistent() {
+  if (persist_decided) return;
+  if (chol_struct.persist_ok && !sharded()) allow_persistent = persistent_allowed_now();
+  persist_decided = true;
+}
+
 void mavba_session::solve_linear(double r) {
+  decide_persistent();
   assemble(r);
   // (two timers: the forward factorisation - ONE kernel, k_chol_persist, on the persistent schedule - and the backward substitution)
   CamUpdateArgs u;
@@ -329,10 +345,8 @@ bool mavba_session::merge_small() const {
 
 void mavba_session::start() {
   { const char* e = std::getenv("MAVBA_MERGE"); merge_on = !e || std::atoi(e) != 0; }  // (read per solve: the tests compare both ways)
-  if (!persist_decided) {  // (sharded sessions decided in join_ranks, for all ranks together)
-    if (chol_struct.persist_ok && !sharded()) allow_persistent = persistent_allowed_now();
-    persist_decided = true;
-  }
+  { const char* e = std::getenv("MAVBA_SPECULATE"); speculate_on = !e || std::atoi(e) != 0; }  // (per solve, like MAVBA_MERGE)
+  decide_persistent();
   evaluate();
   initial_cost = cost + fixed_cost;
   const double g0 = std::max(grad_max, std::numeric_limits<double>::epsilon());
@@ -352,7 +366,7 @@ bool mavba_session::wait_publication(double* h) {
   const double t_end = now_s() + 2.0;
   for (long long spin = 0;; ++spin) {
     if (pub[SC_COUNT + 7] == lm_seq) break;
-    _mm_pause();
+    MAVBA_CPU_RELAX();
     if ((spin & 0xFFFF) == 0xFFFF && now_s() > t_end) return false;
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -378,8 +392,7 @@ int mavba_session::iterate(int max_iters, int* done) {
   // scalars that kernel published, runs the same decision function and either keeps the evaluation (accepted: what
   // `defer` enqueued AFTER the read-back before - the device no longer idles through the host's turn-around) or forgets it.
   // Not with shards (the evaluation's collective would run on a rejected step's stale sums) or the plane kernels.
-  static const bool spec_env = [] { const char* e = std::getenv("MAVBA_SPECULATE"); return !e || std::atoi(e) != 0; }();
-  const bool speculate = spec_env && defer && !sharded() && front_ok && fused_now() && rows_ok && scales_ready;
+  const bool speculate = speculate_on && defer && !sharded() && front_ok && fused_now() && rows_ok && scales_ready;
   if (speculate && !lm_pub) { lm_pub = lm_pub_alloc(); if (lm_pub) lm_pub[SC_COUNT + 7] = -1.0; }
   if (speculate && lm_pub && !d_lm_dec.p) d_lm_dec.alloc(2);
   const bool merge_tail = merge_on;
@@ -424,7 +437,8 @@ int mavba_session::iterate(int max_iters, int* done) {
         // it and repeat the solve on the launch-per-panel schedule (linear_step does, and reads back the plain way)
         std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
         std::swap(d_camrec.p, d_ccamrec.p);
-        evaluated = books.evaluated; assembled = books.assembled; front_valid = books.front_valid;
+        evaluated = books.evaluated; assembled = books.assembled;
+        front_valid = false;  // (k_lm_snapshot has cleared SC_FAIL_FRONT too: the front end runs again and rewrites it)
         fail_slot_clean = false; front_radius = books.front_radius; eval_rows = books.eval_rows;
         speculated = false;
         std::fprintf(stderr, "mavba: persistent factorisation timed out, falling back to the launch-per-panel schedule\n");

@@ -76,7 +76,37 @@ def test_c3_full_size_solve_matches_oracle(mavba, fast_oracle, c3_full):
     rmse_g = np.sqrt(rg["final_cost"] / rg["num_residuals"])
     rmse_o = np.sqrt(ro["final_cost"] / ro["num_residuals"])
     assert abs(rmse_g - rmse_o) <= 1e-6 * rmse_o
+    assert abs(rg["final_trust_region_radius"] - ro["final_trust_region_radius"]) <= 1e-7 * ro["final_trust_region_radius"]
     assert_params_close(pg, po)  # rvec, t, (fx fy cx cy), (k1 k2), (p1 p2), xi, points: each within 1e-6 of its own scale
+    assert rel_err(eg, eo) < 1e-6
+
+
+def test_c2_full_size_step_and_solve_match_oracle(mavba, fast_oracle):
+    """BASELINE config C2 at FULL size (100 images / 30 000 points / 300 000 observations, PINHOLE only) - the one
+    configuration whose dominant kernel is the factorisation, and the 4-parameter instantiation of the cluster kernel
+    at benchmark size: S, v and the LM step at two radii, then one complete solve (iterations, termination, cost,
+    every kind of parameter block, point errors) against the oracle."""
+    p = synth.make_config("C2")
+    assert (p.num_images, p.num_points, p.num_obs) == (100, 30000, 300000)
+    with mavba.Session(p) as s:
+        info = s.info()
+        assert info["reduced_dim"] == 6 * 100 + 9 and info["clustered_points"] == p.num_points
+        for radius in (1e4, 30.0):
+            ref = fast_oracle.linear_step(p, radius, jac_mode=1)
+            S, v = s.reduced_system(radius)
+            st = s.linear_step(radius)
+            _check_step(st, S, v, ref, ("C2", radius))
+    po, pg = p.copy(), p.copy()
+    ro, eo = fast_oracle.solve(po, fast_oracle.options(**global_opts()), jac_mode=1, want_point_errors=True)
+    eg = np.full(p.num_points, np.nan)
+    _, rg = mavba.bundle_adjustment(pg, global_opts(), point3D_errors=eg)
+    assert rg["termination"] == ro["termination"], (rg["termination_name"], ro["termination_name"])
+    assert rg["num_successful_steps"] == ro["num_successful_steps"]
+    assert rg["num_unsuccessful_steps"] == ro["num_unsuccessful_steps"]
+    assert abs(rg["initial_cost"] - ro["initial_cost"]) <= 1e-10 * ro["initial_cost"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * ro["final_cost"]
+    assert abs(rg["final_trust_region_radius"] - ro["final_trust_region_radius"]) <= 1e-7 * ro["final_trust_region_radius"]
+    assert_params_close(pg, po)
     assert rel_err(eg, eo) < 1e-6
 
 

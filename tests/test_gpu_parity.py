@@ -648,3 +648,41 @@ def test_merged_launches_of_a_local_window_equal_the_launch_per_step_loop(mavba,
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+
+
+def test_the_speculative_loop_equals_the_plain_loop(mavba, monkeypatch):
+    """Round 4's loop enqueues the evaluation at the candidate point BEFORE the host has read the candidate's scalars
+    (k_lm_tail decides on the device, the host repeats the decision and keeps or forgets the evaluation: books restored,
+    pointers swapped back, failure slots, the front end's radius taken from the device). MAVBA_SPECULATE=0 is the plain
+    loop. Both must walk the same path to the last bit - accepted AND rejected steps, every way a solve can end."""
+    def rough(seed, radius):
+        p = synth.make_scene(num_images=24, num_points=2500, track_len=6, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=seed, outlier_frac=0.1)
+        rng = np.random.default_rng(seed)
+        p.poses[:, :3] += rng.normal(0, 0.05, p.poses[:, :3].shape)
+        p.poses[:, 3:] += rng.normal(0, 1.5, p.poses[:, 3:].shape)
+        p.points += rng.normal(0, 1.5, p.points.shape)
+        return p, global_opts(initial_trust_region_radius=radius)
+    small = synth.make_scene(num_images=8, num_points=400, track_len=4, models=[A.MODEL_PINHOLE], seed=31, noise_px=0.05, outlier_frac=0.0)
+    cases = [rough(41, 1e14), rough(42, 1e10),                                  # 9 and 6 rejected steps (oracle run of the same scenes)
+             (_scene("mixed"), global_opts()), (_scene("priors"), global_opts()),
+             (small, global_opts(gradient_tolerance=1e-3)),                         # gradient tolerance
+             (small, global_opts(gradient_tolerance=1e-2, function_tolerance=1e-12)),
+             (small, global_opts(max_num_iterations=3)), (small, global_opts(max_num_iterations=1)),
+             (small, global_opts(parameter_tolerance=1e-3)),                        # parameter tolerance
+             (synth.local_ba_window(synth.make_config("C1"), 2), {})]              # a local window (merged launches)
+    outs = []
+    for spec in ("1", "0"):
+        monkeypatch.setenv("MAVBA_SPECULATE", spec)
+        res = []
+        for p0, kw in cases:
+            p = p0.copy()
+            e = np.full(p.num_points, np.nan)
+            _, r = mavba.bundle_adjustment(p, kw, point3D_errors=e)
+            res.append((p.poses.copy(), p.intrinsics.copy(), p.points.copy(), e, r["final_cost"], r["num_successful_steps"],
+                        r["num_unsuccessful_steps"], r["termination"], r["final_gradient_max_norm"], r["final_trust_region_radius"]))
+        outs.append(res)
+    assert sum(r[6] for r in outs[0][:2]) > 0                      # rejected steps did occur
+    assert len({r[7] for r in outs[0]}) >= 3                       # several kinds of termination
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
