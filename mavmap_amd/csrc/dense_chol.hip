@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace mavba {
 
@@ -131,9 +132,14 @@ __device__ __forceinline__ Pivot4Masks pivot4_masks(int lane) {
     for (int k = 0; k <= i; ++k) mk.m[q++] = (li == i && lk == k) ? 1.0 : 0.0;
   return mk;
 }
+// The scalar part of a 4-pivot step: the 4x4 diagonal block D4 of rows 4B..4B+3 (register B of the accumulator layout) is
+// fetched with ten v_readlane pairs, factorised and inverted redundantly by every lane, and X4 = L4^-1 is returned placed as
+// the matrix instruction's A operand (lane (k << 4 | i) holds X4[i][k], 0 elsewhere).
+// Round 5 (scripts/_dbg/pivot_bench.hip, profiles/r05_pivot_bench.txt): this part is ISSUE-bound - ~88 instructions at ~4.1
+// ticks + four v_rsq_f64 at ~17 = 428 ticks per step -, and it ADDS to the step's matrix instructions (64 ticks of the
+// shared FP64 pipe each, whether anything waits for them or not): 733 = 428 + 309 with four of them, 607 with two.
 template <int B>
-__device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, int lane, bool& ok, const Pivot4Masks& mk) {
-  const int li = lane & 15, lk = lane >> 4;
+__device__ __forceinline__ double pivot4_operand(const d4& acc, const Pivot4Masks& mk) {
   constexpr int c0 = 4 * B;
   // D4[a][b], a >= b: register B of lane (a << 4 | c0 + b)
   // The first pivot goes first and its reciprocal square root is started before the other nine values are fetched: the
@@ -160,8 +166,7 @@ __device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, 
   const double r3 = rsqrt_halley(t33);
   // (no per-pivot test: a pivot <= 0 makes its reciprocal square root NaN - v_rsq_f64 of a negative number, 0 * inf in the
   // correction of a zero -, the mask multiply-adds below carry it into every lane's operand and from there into every later
-  // pivot: potrf_inv16_b4 looks at the last diagonal entry of the inverse once)
-  (void)ok;
+  // pivot: the callers look at the LAST step's operand once)
   // X4 = L4^-1 (lower)
   const double x10 = -(l10 * r0) * r1;
   const double x21 = -(l21 * r1) * r2;
@@ -177,6 +182,14 @@ __device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, 
   xa = __builtin_fma(mk.m[3], x20, xa); xa = __builtin_fma(mk.m[4], x21, xa); xa = __builtin_fma(mk.m[5], r2, xa);
   xa = __builtin_fma(mk.m[6], x30, xa); xa = __builtin_fma(mk.m[7], x31, xa); xa = __builtin_fma(mk.m[8], x32, xa);
   xa = __builtin_fma(mk.m[9], r3, xa);
+  return xa;
+}
+template <int B>
+__device__ __forceinline__ void potrf_inv16_block4(d4& acc, d4& xacc, d4& xfin, int lane, bool& ok, const Pivot4Masks& mk) {
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int c0 = 4 * B;
+  (void)ok;
+  const double xa = pivot4_operand<B>(acc, mk);
   const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
   const double ba = li >= c0 ? acc[B] : 0.0;  // columns left of the block are stale (never needed again)
   const d4 U = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, ba, zero, 0, 0, 0);
@@ -425,6 +438,380 @@ __device__ __forceinline__ bool tile_potrf_inv_la(double* T, double* Ti, int tid
     Ti[(16 * bi + r) * GLD + 16 * bj + c] = 0.0;
   }
   __syncthreads();
+  return ok;
+}
+
+// ---- the SYSTOLIC tile factor + inverse (round 5) --------------------------------------------------------------------
+// Same contract as tile_potrf_inv_la (T: the SPD tile, lower 16x16 blocks + full diagonal blocks, destroyed; Ti <- L^-1,
+// lower, upper part zero), different organisation. scripts/_dbg/pivot_bench.hip showed why the look-ahead variant's 16-pivot
+// block costs 2 950 ticks on wave 0 and a whole tile 17 800: the wave that walks the pivots is ISSUE-bound (428 ticks of
+// scalar work per four pivots) and every matrix instruction it issues - also the two per step that only carry the running
+// inverse, and the panel / update products between the blocks - adds 64 ticks of the shared FP64 pipe on top. So here the
+// wave that holds the current diagonal block does NOTHING but the pivots (scalar part, U = X4 rows, acc -= U^T U: 607 ticks
+// per four pivots) and publishes X4 (as the matrix instruction's A operand) and the masked U rows; every other block of
+// the tile lives in the registers of ONE of the other waves for the whole factorisation and receives the same row
+// operations there, one step behind:
+//   * block (w, j), j < w, of the tile is held TRANSPOSED by wave w (its rows are then the pivot columns, i.e. the k
+//     slices of the instruction's B operand): Lt = X4 * rows  finishes four rows of L_wj^T - already in operand position -,
+//     Bt -= u^T Lt eliminates them from the rows below, and  (w, j')^T -= Lt_j'^T Lt_w,  D_w -= Lt_w^T Lt_w  are the
+//     trailing updates, rank 4 per step, straight from registers (the other row's Lt arrives through LDS);
+//   * wave c + 1 therefore holds the NEXT diagonal block complete ~300 ticks after the last pivot operand of block c is
+//     out, and walks its pivots itself: the pivot role rotates 0 -> 1 -> 2 -> 3, no block ever moves;
+//   * the inverse is the identity under the same row operations: X_cj <- X4 * rows (final), X_cj -= u^T Xn inside the
+//     pivot block row (wave 2 for row 0, wave 0 - idle after its pivots - for rows 1 and 2, wave 1 for row 3),
+//     X_ij -= Lt_i^T Xn_j below it; the below-parts are caught up from the published operands when their wave falls idle.
+// Hand-offs go through a mailbox that aliases T (dead once every wave has its blocks): 16-double X4 records, 64-double
+// records for u, Lt, Xn, one monotone progress counter per producer. A wave's LDS accesses execute in order, so a record
+// followed by its counter needs no wait in between. Every wait is bounded: a time-out marks the tile failed (never a hang).
+namespace systile {
+// offsets in doubles. The counters sit in row 0 of T's upper block (0, 1) - no wave loads the upper blocks, so they can be
+// cleared BEFORE the barrier behind the block loads -, the records fill T from double 128 to its end (4224).
+constexpr int kFlags = 16, kXA = 128, kUU = kXA + 256, kLT = kUU + 768, kXN = kLT + 1536;
+constexpr int F_XA = 0, F_U = 1, F_ROW = 1 /* + w, w = 1..3 */, F_FIN = 5, F_BAD = 6, F_DEAD = 7;
+constexpr int kSpin = 1 << 16;
+static_assert(kXN + 1536 <= NB * GLD && kFlags + 4 <= 64, "the mailbox must fit the tile it aliases");
+__host__ __device__ constexpr int pair_of(int c, int i) { return c == 0 ? i - 1 : (c == 1 ? i + 1 : 5); }
+__host__ __device__ constexpr int q_of(int c, int j) { return c * (c + 1) / 2 + j; }
+
+// (explicit LDS pointers: through generic ones every mailbox access became a system-scope FLAT access with a full drain
+// behind it - 1 050 instead of 607 ticks per pivot step. Plain ds accesses, kept in program order by compiler barriers; the
+// LDS executes one wave's accesses in order.)
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+__device__ __forceinline__ void order() { asm volatile("" ::: "memory"); }
+struct Box {
+  lds_f64* m;
+  lds_i32* f;
+  int lane, li, lk;
+  __device__ __forceinline__ void wait(int flag, int v) const {
+    int spin = 0;
+    for (;;) {
+      order();
+      if (f[flag] >= v) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spin > kSpin || ((spin & 63) == 0 && f[F_DEAD] != 0)) { f[F_DEAD] = 1; break; }
+    }
+    order();
+  }
+  // (record + counter in ONE round trip: the LDS executes this wave's reads in order, so a record read issued behind the
+  // counter read is at least as new as the counter - a dependent access costs ~130 ticks, two of them per operand were most
+  // of a follower's step)
+  __device__ __forceinline__ bool dead(int& spin) const {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spin > kSpin || ((spin & 63) == 0 && f[F_DEAD] != 0)) { f[F_DEAD] = 1; return true; }
+    return false;
+  }
+  // the pivot wave's operand of step `step` (= 4 phase + b) and, WITH_U, the masked rows u (us = 3 phase + b)
+  template <bool WITH_U>
+  __device__ __forceinline__ void fetch_pivot(int step, int us, double& xa, double& u) const {
+    int spin = 0;
+    for (;;) {
+      order();
+      const int have = WITH_U ? f[F_U] : f[F_XA];
+      const double a = m[kXA + 16 * step + 4 * lk + (li & 3)];
+      const double b = WITH_U ? m[kUU + 64 * us + lane] : 0.0;
+      order();
+      if (have >= (WITH_U ? us : step) + 1 || dead(spin)) { xa = li < 4 ? a : 0.0; u = b; return; }
+    }
+  }
+  // the same reads without waiting: issued a step ahead, under the current step's matrix instructions; take_pivot falls
+  // back to the blocking form when the counter was not there yet
+  struct Pre { int have; double a, b; };
+  template <bool WITH_U>
+  __device__ __forceinline__ Pre pre_pivot(int step, int us) const {
+    Pre p;
+    order();
+    p.have = WITH_U ? f[F_U] : f[F_XA];
+    p.a = m[kXA + 16 * step + 4 * lk + (li & 3)];
+    p.b = WITH_U ? m[kUU + 64 * us + lane] : 0.0;
+    order();
+    return p;
+  }
+  template <bool WITH_U>
+  __device__ __forceinline__ void take_pivot(const Pre& p, int step, int us, double& xa, double& u) const {
+    if (__builtin_amdgcn_readfirstlane(p.have) >= (WITH_U ? us : step) + 1) { xa = li < 4 ? p.a : 0.0; u = p.b; }
+    else fetch_pivot<WITH_U>(step, us, xa, u);
+  }
+  __device__ __forceinline__ double fetch(int flag, int need, int off) const {
+    int spin = 0;
+    for (;;) {
+      order();
+      const int have = f[flag];
+      const double v = m[off + lane];
+      order();
+      if (have >= need || dead(spin)) return v;
+    }
+  }
+  __device__ __forceinline__ void signal(int flag, int v) const { order(); if (lane == 0) f[flag] = v; order(); }
+  __device__ __forceinline__ void put(int off, double v) const { m[off + lane] = v; order(); }
+  __device__ __forceinline__ double get(int off) const { order(); return m[off + lane]; }
+  __device__ __forceinline__ void put_xa(int step, double xa) const { if (li < 4) m[kXA + 16 * step + 4 * lk + li] = xa; order(); }
+  __device__ __forceinline__ double get_xa(int step) const {
+    order();
+    const double v = m[kXA + 16 * step + 4 * lk + (li & 3)];
+    return li < 4 ? v : 0.0;
+  }
+};
+__device__ __forceinline__ d4 mm(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ d4 zero4() { return (d4){0.0, 0.0, 0.0, 0.0}; }
+__device__ __forceinline__ d4 ident4(int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (lk + 4 * r == li) ? 1.0 : 0.0;
+  return v;
+}
+// block (i, j) of the tile, transposed, in the accumulator layout: reg r of lane l = T[16 i + (l & 15)][16 j + (l >> 4) + 4 r]
+__device__ __forceinline__ d4 load_d16t(const double* Tp, int i, int j, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = Tp[(16 * i + li) * GLD + 16 * j + lk + 4 * r];
+  return v;
+}
+
+// pivot wave, block C, step B: operand out first (the next diagonal block's owner needs nothing else of the last step)
+template <int C, int B>
+__device__ __forceinline__ void pivot_step(const Box& bx, d4& acc, const Pivot4Masks& mk, bool& bad) {
+  constexpr int c0 = 4 * B;
+  const double xa = pivot4_operand<B>(acc, mk);
+#ifndef MAVBA_SYS_EXP
+#define MAVBA_SYS_EXP 0
+#endif
+  if constexpr (B < 3) {
+    // (the record stores are issued BEHIND the matrix instruction they would otherwise delay: LDS and integer work runs in
+    // its shadow, FP64 work does not. One counter for both records of a step: nobody needs the operand of steps 0..2 alone)
+    const double ba = bx.li >= c0 ? acc[B] : 0.0;
+    const d4 U = mm(xa, ba, zero4());
+    __builtin_amdgcn_sched_barrier(0);
+    if (MAVBA_SYS_EXP != 1) bx.put_xa(4 * C + B, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    const double u = bx.li >= c0 + bx.lk ? U[0] : 0.0;
+    acc = mm(-u, u, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MAVBA_SYS_EXP != 1) {
+      bx.put(kUU + 64 * (3 * C + B), u);
+      bx.signal(F_U, 3 * C + B + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    bx.put_xa(4 * C + B, xa);
+    bx.signal(F_XA, 4 * C + B + 1);
+    bad = bad || !(xa == xa);  // (a non-positive pivot anywhere in the block has turned the last operand into NaNs)
+  }
+}
+template <int C>
+__device__ __forceinline__ void pivot_block(const Box& bx, d4& acc, const Pivot4Masks& mk, bool& bad) {
+  pivot_step<C, 0>(bx, acc, mk, bad); pivot_step<C, 1>(bx, acc, mk, bad);
+  pivot_step<C, 2>(bx, acc, mk, bad); pivot_step<C, 3>(bx, acc, mk, bad);
+}
+// row owner W in phase C < W, step B: Bt[j] = block (W, j)^T for j < W, D = block (W, W)
+template <int C, int B, int W>
+__device__ __forceinline__ void row_step(const Box& bx, d4 (&Bt)[3], d4& D, Box::Pre& pre) {
+  double xa, u;
+  bx.template take_pivot<(B < 3)>(pre, 4 * C + B, 3 * C + B, xa, u);
+  const d4 ltv = mm(xa, Bt[C][B], zero4());
+  if constexpr (B < 3) pre = bx.template pre_pivot<(B + 1 < 3)>(4 * C + B + 1, 3 * C + B + 1);
+  const double lt = ltv[0];
+  bx.put(kLT + 64 * (4 * pair_of(C, W) + B), lt);
+  bx.signal(F_ROW + W, 4 * C + B + 1);
+  D = mm(-lt, lt, D);
+  if constexpr (B < 3) Bt[C] = mm(-u, lt, Bt[C]);
+#pragma unroll
+  for (int j = C + 1; j < W; ++j) {
+    const double ltj = bx.fetch(F_ROW + j, 4 * C + B + 1, kLT + 64 * (4 * pair_of(C, j) + B));
+    Bt[j] = mm(-ltj, lt, Bt[j]);
+  }
+}
+template <int C, int W>
+__device__ __forceinline__ void row_phase(const Box& bx, d4 (&Bt)[3], d4& D) {
+  Box::Pre pre = bx.template pre_pivot<true>(4 * C, 3 * C);
+  row_step<C, 0, W>(bx, Bt, D, pre); row_step<C, 1, W>(bx, Bt, D, pre); row_step<C, 2, W>(bx, Bt, D, pre); row_step<C, 3, W>(bx, Bt, D, pre);
+}
+// block row C of the inverse under the pivot block's row operations: X[j] = X_Cj, j < NJ = C + 1; xf collects the final rows
+template <int C, int B, int NJ, bool PUBLISH>
+__device__ __forceinline__ void fin_step(const Box& bx, d4 (&X)[NJ], d4 (&xf)[NJ], double (&xn)[NJ], Box::Pre& pre) {
+  double xa, u;
+  bx.template take_pivot<(B < 3)>(pre, 4 * C + B, 3 * C + B, xa, u);
+  d4 xv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) xv[j] = mm(xa, X[j][B], zero4());
+  if constexpr (B < 3) pre = bx.template pre_pivot<(B + 1 < 3)>(4 * C + B + 1, 3 * C + B + 1);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    xn[j] = xv[j][0];
+    xf[j][B] = xn[j];
+    if constexpr (PUBLISH) bx.put(kXN + 64 * (4 * q_of(C, j) + B), xn[j]);
+  }
+  if constexpr (PUBLISH) bx.signal(F_FIN, 4 * C + B + 1);
+  if constexpr (B < 3) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) X[j] = mm(-u, xn[j], X[j]);
+  }
+}
+// X -= L_ic X_cj over the four steps of phase C, from the published operands (I = the row of X, J = the column block)
+template <int C, int I, int J>
+__device__ __forceinline__ void inv_trail_phase(const Box& bx, d4& X) {
+  bx.wait(F_ROW + I, 4 * C + 4);
+  bx.wait(F_FIN, 4 * C + 4);
+  double l[4], x[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { l[b] = bx.get(kLT + 64 * (4 * pair_of(C, I) + b)); x[b] = bx.get(kXN + 64 * (4 * q_of(C, J) + b)); }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) X = mm(-l[b], x[b], X);
+}
+}  // namespace systile
+
+template <class Mark = NoMark, int DEBUG_SOLO = 0>
+__device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int tid, Mark mark = Mark()) {
+  using namespace systile;
+  const int wv = tid >> 6, lane = tid & 63;
+  // every wave takes its blocks (T is the mailbox from the barrier on); counters and the upper blocks of Ti are cleared meanwhile
+  const Pivot4Masks mk = pivot4_masks(lane);
+  Box bx{(lds_f64*)T, (lds_i32*)(T + kFlags), lane, lane & 15, lane >> 4};
+  if (tid < 8) bx.f[tid] = 0;
+  d4 Bt[3], D;
+  D = load_d16(T + 16 * wv * GLD + 16 * wv, GLD, lane);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) Bt[j] = j < wv ? load_d16t(T, wv, j, lane) : zero4();
+  {
+    double* z = Ti + (tid >> 4) * GLD + (tid & 15);  // element (r, c) of a 16x16 block
+    z[16] = 0.0; z[32] = 0.0; z[48] = 0.0; z[16 * GLD + 32] = 0.0; z[16 * GLD + 48] = 0.0; z[32 * GLD + 48] = 0.0;
+  }
+  __syncthreads();
+  bool bad = false;
+  mark(0);
+  if (DEBUG_SOLO) {  // (timing harness only: the pivot wave alone)
+    if (wv == 0) { pivot_block<0>(bx, D, mk, bad); mark(1); }
+  } else if (wv == 0) {
+    pivot_block<0>(bx, D, mk, bad);
+    mark(1);
+    // rows 1 and 2 of the inverse. What phase 0 left below its pivot row first (all of it is published by now):
+    d4 X1[2] = {zero4(), ident4(lane)}, X2[3] = {zero4(), zero4(), ident4(lane)};
+    inv_trail_phase<0, 1, 0>(bx, X1[0]);
+    inv_trail_phase<0, 2, 0>(bx, X2[0]);
+    mark(2);
+    {
+      d4 xf[2] = {zero4(), zero4()};
+      double xn[2];
+      Box::Pre pre = bx.template pre_pivot<true>(4, 3);
+      auto step = [&](auto bc) {
+        constexpr int B = decltype(bc)::value;
+        fin_step<1, B, 2, true>(bx, X1, xf, xn, pre);
+        const double lt2 = bx.fetch(F_ROW + 2, 4 + B + 1, kLT + 64 * (4 * pair_of(1, 2) + B));  // row 2 below it: X_2j -= L_21 rows * Xn_1j
+        X2[0] = mm(-lt2, xn[0], X2[0]);
+        X2[1] = mm(-lt2, xn[1], X2[1]);
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+      store_d16(Ti + 16 * GLD, GLD, xf[0], lane);
+      store_d16(Ti + 16 * GLD + 16, GLD, xf[1], lane);
+      mark(3);
+    }
+    d4 X3b[2] = {zero4(), ident4(lane)};  // X_32, X_33: the second half of the inverse's last block row (wave 1 has the first)
+    {
+      d4 xf[3] = {zero4(), zero4(), zero4()};
+      double xn[3];
+      Box::Pre pre = bx.template pre_pivot<true>(8, 6);
+      auto step = [&](auto bc) {
+        constexpr int B = decltype(bc)::value;
+        fin_step<2, B, 3, true>(bx, X2, xf, xn, pre);
+        const double lt3 = bx.fetch(F_ROW + 3, 8 + B + 1, kLT + 64 * (4 * pair_of(2, 3) + B));
+        X3b[0] = mm(-lt3, xn[2], X3b[0]);
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+#pragma unroll
+      for (int j = 0; j < 3; ++j) store_d16(Ti + 32 * GLD + 16 * j, GLD, xf[j], lane);
+      mark(4);
+    }
+    {
+      d4 xf[2] = {zero4(), zero4()};
+      double xn[2];
+      Box::Pre pre = bx.template pre_pivot<true>(12, 9);
+      fin_step<3, 0, 2, false>(bx, X3b, xf, xn, pre); fin_step<3, 1, 2, false>(bx, X3b, xf, xn, pre);
+      fin_step<3, 2, 2, false>(bx, X3b, xf, xn, pre); fin_step<3, 3, 2, false>(bx, X3b, xf, xn, pre);
+      store_d16(Ti + 48 * GLD + 32, GLD, xf[0], lane);
+      store_d16(Ti + 48 * GLD + 48, GLD, xf[1], lane);
+    }
+  } else if (wv == 1) {
+    row_phase<0, 1>(bx, Bt, D);
+    mark(1);
+    pivot_block<1>(bx, D, mk, bad);
+    mark(2);
+    // X_30, X_31 of the inverse's last block row: what phases 0 and 1 left, then phase 2 as it is published, then the row's own phase
+    d4 X3[2] = {zero4(), zero4()};
+    inv_trail_phase<0, 3, 0>(bx, X3[0]);
+    inv_trail_phase<1, 3, 0>(bx, X3[0]);
+    inv_trail_phase<1, 3, 1>(bx, X3[1]);
+    mark(3);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const double lt3 = bx.fetch(F_ROW + 3, 8 + b + 1, kLT + 64 * (4 * pair_of(2, 3) + b));
+      bx.wait(F_FIN, 8 + b + 1);
+      double xn2[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xn2[j] = bx.get(kXN + 64 * (4 * q_of(2, j) + b));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) X3[j] = mm(-lt3, xn2[j], X3[j]);
+    }
+    mark(4);
+    d4 xf[2] = {zero4(), zero4()};
+    double xn[2];
+    Box::Pre pre = bx.template pre_pivot<true>(12, 9);
+    fin_step<3, 0, 2, false>(bx, X3, xf, xn, pre); fin_step<3, 1, 2, false>(bx, X3, xf, xn, pre);
+    fin_step<3, 2, 2, false>(bx, X3, xf, xn, pre); fin_step<3, 3, 2, false>(bx, X3, xf, xn, pre);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) store_d16(Ti + 48 * GLD + 16 * j, GLD, xf[j], lane);
+    mark(5);
+  } else if (wv == 2) {
+    // row 2 of the tile and, while wave 0 walks the first block, row 0 of the inverse
+    d4 X0[1] = {ident4(lane)}, xf[1] = {zero4()};
+    double xn[1];
+    Box::Pre pre = bx.template pre_pivot<true>(0, 0);
+    auto step = [&](auto bc) {
+      constexpr int B = decltype(bc)::value;
+      double xa, u;
+      bx.template take_pivot<(B < 3)>(pre, B, B, xa, u);
+      const d4 ltv = mm(xa, Bt[0][B], zero4());
+      const d4 xnv = mm(xa, X0[0][B], zero4());
+      if constexpr (B < 3) pre = bx.template pre_pivot<(B + 1 < 3)>(B + 1, B + 1);
+      const double lt = ltv[0];
+      bx.put(kLT + 64 * (4 * pair_of(0, 2) + B), lt);
+      bx.signal(F_ROW + 2, B + 1);
+      xn[0] = xnv[0];
+      xf[0][B] = xn[0];
+      bx.put(kXN + 64 * (4 * q_of(0, 0) + B), xn[0]);
+      bx.signal(F_FIN, B + 1);
+      D = mm(-lt, lt, D);
+      if constexpr (B < 3) {
+        Bt[0] = mm(-u, lt, Bt[0]);
+        X0[0] = mm(-u, xn[0], X0[0]);
+      }
+      Bt[1] = mm(-bx.fetch(F_ROW + 1, B + 1, kLT + 64 * (4 * pair_of(0, 1) + B)), lt, Bt[1]);
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    store_d16(Ti, GLD, xf[0], lane);
+    mark(1);
+    row_phase<1, 2>(bx, Bt, D);
+    mark(2);
+    pivot_block<2>(bx, D, mk, bad);
+    mark(3);
+  } else {
+    row_phase<0, 3>(bx, Bt, D);
+    mark(1);
+    row_phase<1, 3>(bx, Bt, D);
+    mark(2);
+    row_phase<2, 3>(bx, Bt, D);
+    mark(3);
+    pivot_block<3>(bx, D, mk, bad);
+    mark(4);
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) bx.f[F_BAD] = 1;
+  __syncthreads();
+  const bool ok = bx.f[F_BAD] == 0 && bx.f[F_DEAD] == 0;
+  __syncthreads();  // (T - the mailbox - may be refilled by the caller from here on)
   return ok;
 }
 

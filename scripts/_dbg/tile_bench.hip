@@ -84,6 +84,8 @@ __global__ void __launch_bounds__(256) k_bench(const double* A, double* Xout, lo
   const int tid = threadIdx.x;
   long long total = 0;
   long long marks[20];
+  __shared__ long long wmarks[32];
+  if (tid < 32) wmarks[tid] = 0;
   for (int i = 0; i < 20; ++i) marks[i] = 0;
   for (int rep = 0; rep < reps; ++rep) {
     load_tile(A, NB, T, tid);
@@ -102,6 +104,7 @@ __global__ void __launch_bounds__(256) k_bench(const double* A, double* Xout, lo
       auto mark = [&](int id) { if (tid == 0) marks[id] += clock64() - t0; };
       tile_potrf_inv_la(T, Ti, tid, NoPhaseHook(), mark);
     }
+
     else if (variant == 2) {  // 4 x potrf_inv16 alone (timing only)
       if (tid < 64) for (int cb = 0; cb < 4; ++cb) {
         d4 a = load_d16(T + 16 * cb * GLD + 16 * cb, GLD, tid), x;
@@ -112,7 +115,33 @@ __global__ void __launch_bounds__(256) k_bench(const double* A, double* Xout, lo
     __syncthreads();
     total += clock64() - t0;
   }
-  if (tid == 0) { cyc[0] = total / reps; for (int i = 0; i < 20; ++i) cyc[1 + i] = marks[i] / reps; }
+  __syncthreads();
+  if (tid == 0) { cyc[0] = total / reps; for (int i = 0; i < 20; ++i) cyc[1 + i] = marks[i] / reps; if (variant == 8 || variant == 9) for (int i = 0; i < 32; ++i) cyc[1 + i] = wmarks[i] / reps; }
+  store_tile(Xout, NB, Ti, tid);
+}
+// the systolic variants in a kernel of their own (register allocation as in the product's callers)
+template <int VAR>
+__global__ void __launch_bounds__(256) k_bench_sys(const double* A, double* Xout, long long* cyc, int reps) {
+  __shared__ __attribute__((aligned(16))) double T[NB * GLD];
+  __shared__ __attribute__((aligned(16))) double Ti[NB * GLD];
+  __shared__ long long wmarks[32];
+  const int tid = threadIdx.x;
+  if (tid < 32) wmarks[tid] = 0;
+  long long total = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    load_tile(A, NB, T, tid);
+    for (int i = tid; i < NB * GLD; i += 256) Ti[i] = 0.0;
+    __syncthreads();
+    const long long t0 = clock64();
+    auto mark = [&](int id) { if ((tid & 63) == 0) wmarks[(tid >> 6) * 8 + id] += clock64() - t0; };
+    if (VAR == 6) tile_potrf_inv_sys(T, Ti, tid);
+    else if (VAR == 8) tile_potrf_inv_sys(T, Ti, tid, mark);
+    else tile_potrf_inv_sys<decltype(mark), 1>(T, Ti, tid, mark);
+    __syncthreads();
+    total += clock64() - t0;
+  }
+  __syncthreads();
+  if (tid == 0) { cyc[0] = total / reps; for (int i = 0; i < 32; ++i) cyc[1 + i] = wmarks[i] / reps; }
   store_tile(Xout, NB, Ti, tid);
 }
 __global__ void k_rsq(const double* d, double* out_nr, double* out_h, double* out_seed, int n) {
@@ -134,9 +163,11 @@ int main() {
   for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) L[i * n + j] = 0.0;
   for (int c = 0; c < n; ++c) for (int i = c; i < n; ++i) { double v = (i == c) ? 1.0 : 0.0; for (int k = c; k < i; ++k) v -= L[i * n + k] * X[k * n + c]; X[i * n + c] = v / L[i * n + i]; }
   double *dA, *dX; long long* dc;
-  hipMalloc(&dA, n * n * 8); hipMalloc(&dX, n * n * 8); hipMalloc(&dc, 8 * 32);
+  hipMalloc(&dA, n * n * 8); hipMalloc(&dX, n * n * 8); hipMalloc(&dc, 8 * 40);
   hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
-  for (int v = 0; v < 6; ++v) {
+  const int order[10] = {0, 1, 2, 3, 4, 6, 8, 9, 5, 7};  // (5 and 7: variants 1 and 6 on a tile whose last 32 columns are padding)
+  for (int oi = 0; oi < 10; ++oi) {
+    const int v = order[oi];
     if (v == 5) {  // the last 32 columns are padding (identity): the look-ahead variant skips their pivots
       for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (i >= 32 || j >= 32) A[i * n + j] = i == j ? 1.0 : 0.0;
       hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
@@ -146,13 +177,18 @@ int main() {
       for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) L[i * n + j] = 0.0;
       for (int c = 0; c < n; ++c) for (int i = c; i < n; ++i) { double vv = (i == c) ? 1.0 : 0.0; for (int k = c; k < i; ++k) vv -= L[i * n + k] * X[k * n + c]; X[i * n + c] = vv / L[i * n + i]; }
     }
-    hipLaunchKernelGGL(k_bench, dim3(1), dim3(256), 0, 0, dA, dX, dc, v == 5 ? 1 : v, 20);
+    const int kv = v == 5 ? 1 : (v == 7 ? 6 : v);
+    if (kv == 6) hipLaunchKernelGGL(k_bench_sys<6>, dim3(1), dim3(256), 0, 0, dA, dX, dc, 20);
+    else if (kv == 8) hipLaunchKernelGGL(k_bench_sys<8>, dim3(1), dim3(256), 0, 0, dA, dX, dc, 20);
+    else if (kv == 9) hipLaunchKernelGGL(k_bench_sys<9>, dim3(1), dim3(256), 0, 0, dA, dX, dc, 20);
+    else hipLaunchKernelGGL(k_bench, dim3(1), dim3(256), 0, 0, dA, dX, dc, kv, 20);
     hipDeviceSynchronize();
     std::vector<double> Xd(n * n); long long c;
     hipMemcpy(Xd.data(), dX, n * n * 8, hipMemcpyDeviceToHost); hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
     double err = 0, mx = 0, up = 0;
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { if ((v == 2 || v == 3) && (i / 16 != j / 16)) continue; mx = std::fmax(mx, std::fabs(X[i * n + j])); if (j <= i) err = std::fmax(err, std::fabs(Xd[i * n + j] - X[i * n + j])); else up = std::fmax(up, std::fabs(Xd[i * n + j])); }
     printf("variant %d: %lld cycles/tile, inverse max err %.2e (scale %.2e), upper max %.2e\n", v, c, err, mx, up);
+    if (v == 8 || v == 9) { long long m[33]; hipMemcpy(m, dc, 8 * 33, hipMemcpyDeviceToHost); for (int w = 0; w < 4; ++w) { printf("  wave %d way points:", w); for (int i = 0; i < 6; ++i) printf(" %d:%lld", i, m[1 + 8 * w + i]); printf("\n"); } }
     if (v == 4) { long long m[21]; hipMemcpy(m, dc, 8 * 21, hipMemcpyDeviceToHost); printf("  way points of wave 0 (cycles from start):"); for (int i = 1; i <= 16; ++i) printf(" %d:%lld", i, m[1 + i]); printf("\n"); }
   }
   {
