@@ -468,8 +468,10 @@ namespace systile {
 // cleared BEFORE the barrier behind the block loads -, the records fill T from double 128 to its end (4224).
 constexpr int kFlags = 16, kXA = 128, kUU = kXA + 256, kLT = kUU + 768, kXN = kLT + 1536;
 constexpr int F_XA = 0, F_U = 1, F_ROW = 1 /* + w, w = 1..3 */, F_FIN = 5, F_BAD = 6, F_DEAD = 7;
+constexpr int F_PROW = 8 /* + w: row block w of the chain's panel tile is in LDS */, F_PST = 12 /* + w: ... and drained to memory */;
+constexpr int kNumFlags = 16;
 constexpr int kSpin = 1 << 16;
-static_assert(kXN + 1536 <= NB * GLD && kFlags + 4 <= 64, "the mailbox must fit the tile it aliases");
+static_assert(kXN + 1536 <= NB * GLD && kFlags + kNumFlags / 2 <= 64, "the mailbox must fit the tile it aliases");
 __host__ __device__ constexpr int pair_of(int c, int i) { return c == 0 ? i - 1 : (c == 1 ? i + 1 : 5); }
 __host__ __device__ constexpr int q_of(int c, int j) { return c * (c + 1) / 2 + j; }
 
@@ -662,14 +664,23 @@ __device__ __forceinline__ void inv_trail_phase(const Box& bx, d4& X) {
 }
 }  // namespace systile
 
-template <class Mark = NoMark, int DEBUG_SOLO = 0>
-__device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int tid, Mark mark = Mark()) {
+// `Panel`: the persistent chain's column prologue, fused in (round 5). With a sub-diagonal tile As (LDS) and the PREVIOUS
+// column's inverse still in Ti, wave w first solves ITS 16 rows of the panel tile P = As Li^T - transposed, Pt = Li As_w^T, so
+// that the result's registers are the k slices of a matrix instruction's operands -, leaves them in Cs (row-major, for the
+// other waves and for the store to memory), downdates its own diagonal block from registers (D_w -= P_w P_w^T) and then its
+// off-diagonal blocks as the rows above arrive in Cs. Wave 0 therefore starts on the pivots after 56 matrix instructions
+// and no barrier; the waves with more blocks catch up under its scalar work.
+// Wave 2 has nothing to do once it has walked its pivots (a quarter of the tile's time): `panel.prefetch_poll()` before them
+// and `panel.prefetch()` behind them let the chain bring the NEXT column's tiles into LDS meanwhile.
+struct NoPanel { static constexpr bool enabled = false; };
+template <class Mark = NoMark, int DEBUG_SOLO = 0, class Panel = NoPanel>
+__device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int tid, Mark mark = Mark(), Panel panel = Panel()) {
   using namespace systile;
   const int wv = tid >> 6, lane = tid & 63;
   // every wave takes its blocks (T is the mailbox from the barrier on); counters and the upper blocks of Ti are cleared meanwhile
   const Pivot4Masks mk = pivot4_masks(lane);
   Box bx{(lds_f64*)T, (lds_i32*)(T + kFlags), lane, lane & 15, lane >> 4};
-  if (tid < 8) bx.f[tid] = 0;
+  if (tid < kNumFlags) bx.f[tid] = 0;
   d4 Bt[3], D;
   D = load_d16(T + 16 * wv * GLD + 16 * wv, GLD, lane);
 #pragma unroll
@@ -679,12 +690,74 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
     z[16] = 0.0; z[32] = 0.0; z[48] = 0.0; z[16 * GLD + 32] = 0.0; z[16 * GLD + 48] = 0.0; z[32 * GLD + 48] = 0.0;
   }
   __syncthreads();
+  bool with_panel = false;
+  if constexpr (Panel::enabled) with_panel = panel.sub;
+  if constexpr (Panel::enabled) if (with_panel) {
+    // (measured and dropped: row block 0 of P - what the first pivots wait for - solved by the four waves side by side, one
+    // column block each. Wave 0 then starts 1 700 ticks earlier, but the 8-16 extra matrix instructions come on top of the
+    // followers' 72-104: wave 1 is late for ITS pivots and the column takes 11.1 instead of 10.2 us)
+    const int li = lane & 15, lk = lane >> 4;
+    d4 Pt[4];
+    {
+      const double* pa = panel.As + (16 * wv + li) * GLD + lk;
+      double a[16], b0[4], b1[8], b2[12], b3[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { a[q] = pa[4 * q]; b3[q] = Ti[(48 + li) * GLD + lk + 4 * q]; }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) b2[q] = Ti[(32 + li) * GLD + lk + 4 * q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b1[q] = Ti[(16 + li) * GLD + lk + 4 * q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b0[q] = Ti[li * GLD + lk + 4 * q];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) Pt[n] = zero4();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (q < 4) Pt[0] = mm(b0[q], a[q], Pt[0]);
+        if (q < 8) Pt[1] = mm(b1[q], a[q], Pt[1]);
+        if (q < 12) Pt[2] = mm(b2[q], a[q], Pt[2]);
+        Pt[3] = mm(b3[q], a[q], Pt[3]);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) panel.Cs[(16 * wv + li) * GLD + 16 * n + lk + 4 * r] = Pt[n][r];
+    order();
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D = mm(-Pt[n][r], Pt[n][r], D);
+    bx.signal(F_PROW + wv, 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (j < wv) {
+        bx.wait(F_PROW + j, 1);
+        double pj[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pj[q] = panel.Cs[(16 * j + li) * GLD + 4 * q + lk];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Bt[j] = mm(-pj[q], Pt[q >> 2][q & 3], Bt[j]);
+      }
+    if (wv != 0) panel.store_rows(wv, lane);  // (wave 0: behind its pivots)
+  }
+  // first store into Ti: every wave must be done with the previous column's inverse it still held (the panel solve above)
+  auto ti_free = [&]() {
+    if constexpr (Panel::enabled) if (with_panel) {
+      bx.wait(F_PROW + 0, 1); bx.wait(F_PROW + 1, 1); bx.wait(F_PROW + 2, 1); bx.wait(F_PROW + 3, 1);
+    }
+  };
+  // this wave's rows of the panel tile have reached memory
+  auto panel_drained = [&]() {
+    if constexpr (Panel::enabled) if (with_panel) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bx.signal(F_PST + wv, 1); }
+  };
   bool bad = false;
   mark(0);
   if (DEBUG_SOLO) {  // (timing harness only: the pivot wave alone)
     if (wv == 0) { pivot_block<0>(bx, D, mk, bad); mark(1); }
   } else if (wv == 0) {
     pivot_block<0>(bx, D, mk, bad);
+    if constexpr (Panel::enabled) if (with_panel) panel.store_rows(0, lane);
     mark(1);
     // rows 1 and 2 of the inverse. What phase 0 left below its pivot row first (all of it is published by now):
     d4 X1[2] = {zero4(), ident4(lane)}, X2[3] = {zero4(), zero4(), ident4(lane)};
@@ -704,9 +777,11 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
       step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+      ti_free();
       store_d16(Ti + 16 * GLD, GLD, xf[0], lane);
       store_d16(Ti + 16 * GLD + 16, GLD, xf[1], lane);
-      mark(3);
+      panel_drained();
+        mark(3);
     }
     d4 X3b[2] = {zero4(), ident4(lane)};  // X_32, X_33: the second half of the inverse's last block row (wave 1 has the first)
     {
@@ -723,7 +798,7 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
       step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
 #pragma unroll
       for (int j = 0; j < 3; ++j) store_d16(Ti + 32 * GLD + 16 * j, GLD, xf[j], lane);
-      mark(4);
+        mark(4);
     }
     {
       d4 xf[2] = {zero4(), zero4()};
@@ -739,6 +814,11 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
     mark(1);
     pivot_block<1>(bx, D, mk, bad);
     mark(2);
+    if constexpr (Panel::enabled) if (with_panel) {  // the panel tile goes public once all four row blocks are in memory
+      panel_drained();
+      bx.wait(F_PST + 0, 1); bx.wait(F_PST + 2, 1); bx.wait(F_PST + 3, 1);
+      panel.publish(lane);
+    }
     // X_30, X_31 of the inverse's last block row: what phases 0 and 1 left, then phase 2 as it is published, then the row's own phase
     d4 X3[2] = {zero4(), zero4()};
     inv_trail_phase<0, 3, 0>(bx, X3[0]);
@@ -761,6 +841,7 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
     Box::Pre pre = bx.template pre_pivot<true>(12, 9);
     fin_step<3, 0, 2, false>(bx, X3, xf, xn, pre); fin_step<3, 1, 2, false>(bx, X3, xf, xn, pre);
     fin_step<3, 2, 2, false>(bx, X3, xf, xn, pre); fin_step<3, 3, 2, false>(bx, X3, xf, xn, pre);
+    ti_free();
 #pragma unroll
     for (int j = 0; j < 2; ++j) store_d16(Ti + 48 * GLD + 16 * j, GLD, xf[j], lane);
     mark(5);
@@ -792,16 +873,26 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
     };
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
     step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    ti_free();
     store_d16(Ti, GLD, xf[0], lane);
     mark(1);
     row_phase<1, 2>(bx, Bt, D);
+    panel_drained();
     mark(2);
+    int next_state = 0;
+    if constexpr (Panel::enabled) next_state = panel.prefetch_poll();  // (the flag loads travel under the pivots)
     pivot_block<2>(bx, D, mk, bad);
+    if constexpr (Panel::enabled) {
+      // As and Cs are read by the panel prologue and by the row stores only: every wave is past them (a formality by now)
+      if (with_panel) { bx.wait(F_PST + 0, 1); bx.wait(F_PST + 1, 1); bx.wait(F_PST + 3, 1); }  // (drained = stored = read out of Cs; As was read before that)
+      panel.prefetch(next_state, lane);
+    }
     mark(3);
   } else {
     row_phase<0, 3>(bx, Bt, D);
     mark(1);
     row_phase<1, 3>(bx, Bt, D);
+    panel_drained();
     mark(2);
     row_phase<2, 3>(bx, Bt, D);
     mark(3);
@@ -813,6 +904,16 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
   const bool ok = bx.f[F_BAD] == 0 && bx.f[F_DEAD] == 0;
   __syncthreads();  // (T - the mailbox - may be refilled by the caller from here on)
   return ok;
+}
+
+// The tile factorisation the kernels call (no hooks): the systolic one; -DMAVBA_TILE_LA=1 builds the round-2..4 look-ahead
+// variant instead (A/B timing, scripts/_dbg).
+#ifndef MAVBA_TILE_LA
+#define MAVBA_TILE_LA 0
+#endif
+__device__ __forceinline__ bool tile_factor_inverse(double* T, double* Ti, int tid) {
+  if constexpr (MAVBA_TILE_LA != 0) return tile_potrf_inv_la(T, Ti, tid);
+  else return tile_potrf_inv_sys(T, Ti, tid);
 }
 
 // acc (2x2 MFMA tiles of the wave's 32x32 quadrant) = As(rows wr..) * Bs(rows wc..)^T, K = 64.
@@ -869,7 +970,7 @@ __global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M
     for (int f = tid; f < nflags; f += 256) flags[f] = 0u;
   load_tile(M + (size_t)t * NB * ld + (size_t)t * NB, ld, T, tid);
   __syncthreads();
-  const bool ok = tile_potrf_inv_la(T, Ti, tid);
+  const bool ok = tile_factor_inverse(T, Ti, tid);
   if (tid == 0 && !ok) atomicAdd(fail, 1.0);
   store_tile(inv + (size_t)t * NB * NB, NB, Ti, tid);
 }
@@ -1005,7 +1106,7 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
       for (int r = 0; r < 4; ++r)
         Cs[(wr + 16 * m + lk + 4 * r) * GLD + wc + 16 * n + li] = cin[m][n][r] - acc[m][n][r];
   __syncthreads();
-  const bool ok = tile_potrf_inv_la(Cs, As, tid);
+  const bool ok = tile_factor_inverse(Cs, As, tid);
   if (tid == 0 && !ok) atomicAdd(fail, 1.0);
   store_tile(inv + (size_t)(k + 1) * NB * NB, NB, As, tid);
 }
@@ -1404,6 +1505,76 @@ __device__ __forceinline__ void quadrant_sub(d4 acc[2][2], const d4 p[2][2]) {
 }
 }  // namespace
 
+// The persistent chain's panel tile inside the systolic tile factorisation (tile_potrf_inv_sys, `Panel`): where the solved
+// rows go - system-scope 16-byte stores like store_tile_coh, 16 rows per wave - and how the tile is published.
+struct ChainPanel {
+  static constexpr bool enabled = true;
+  const double* As;  // the sub-diagonal tile A_{j, j-1} with every earlier update (LDS)
+  double* Cs;        // receives P = A L^-T (LDS, row-major)
+  double* Pg;        // P's place in the factor (memory)
+  size_t ld;
+  unsigned* lflag;   // P's flag
+  unsigned ep;
+  bool sub;          // false: a node's first column - no panel tile
+  __device__ __forceinline__ void store_rows(int wv, int lane) const {
+    const __amdgpu_buffer_rsrc_t r = tile_rsrc(Pg);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = lane + 64 * q;
+      const int row = 16 * wv + (idx >> 5), c2 = (idx & 31) * 2;
+      const i4v v = *reinterpret_cast<const i4v*>(Cs + row * GLD + c2);
+      __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(((size_t)row * ld + c2) * 8), 0, kCoherent);
+    }
+  }
+  __device__ __forceinline__ void publish(int lane) const { if (lane == 0) mavba::publish(lflag, ep); }
+  // the next column's tiles: sub-diagonal -> As, diagonal -> Cs (which is the NEXT column's T: the chain swaps the two)
+  const double* next_sub; size_t next_sub_ld; bool next_sub_coh;
+  const double* next_diag; size_t next_diag_ld; bool next_diag_coh;
+  const unsigned* next_f0; const unsigned* next_f1;  // the helpers' flags of the two tiles (null: nothing to wait for)
+  int* loaded;  // (LDS) set to 1 when both tiles are in place
+  bool more;
+  __device__ __forceinline__ int prefetch_poll() const {
+    if (!more) return 0;
+    int r = 1;
+    if (next_f0 && __hip_atomic_load(next_f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) r = 0;
+    if (next_f1 && __hip_atomic_load(next_f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) r = 0;
+    return r;
+  }
+  // one wave moves a 64x64 tile: 32 x (64 lanes x 16 B), eight requests in flight
+  __device__ __forceinline__ void wave_load_tile(const double* G, size_t gld, bool coherent, double* S, int lane) const {
+    const __amdgpu_buffer_rsrc_t r = tile_rsrc(G);
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+      i4v v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int idx = lane + 64 * (8 * g + q);
+        const int row = idx >> 5, c2 = (idx & 31) * 2;
+        const int off = (int)(((size_t)row * gld + c2) * 8);
+        v[q] = coherent ? __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kCoherent) : __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int idx = lane + 64 * (8 * g + q);
+        const int row = idx >> 5, c2 = (idx & 31) * 2;
+        *reinterpret_cast<i4v*>(S + row * GLD + c2) = v[q];
+      }
+    }
+  }
+  __device__ __forceinline__ void prefetch(int state, int lane) const {
+    if (!more) return;
+    state = __builtin_amdgcn_readfirstlane(state);
+    if (!state) state = __builtin_amdgcn_readfirstlane(prefetch_poll());  // (one more look: this wave has nothing else to do)
+    if (!state) return;
+    if (next_sub) wave_load_tile(next_sub, next_sub_ld, next_sub_coh, const_cast<double*>(As), lane);
+    wave_load_tile(next_diag, next_diag_ld, next_diag_coh, Cs, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *reinterpret_cast<volatile int*>(loaded) = 1;
+  }
+};
+
+constexpr bool kSysPrefetch = false;
+
 struct CholPersistArgs {
   const double* M; double* L; double* inv; double* pre;
   int ld, nb;
@@ -1422,6 +1593,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
   __shared__ __attribute__((aligned(16))) double Ds[NB * GLD];  // the chain's diagonal tile (As still holds the sub-diagonal one)
   __shared__ int s_ok, s_ok2;
   __shared__ int s_rows[4];  // per wave: the chain column (+ 1) whose row block of the panel tile is complete in Cs
+  __shared__ int s_next;  // (systolic chain) the next column's tiles are in LDS
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
   const int nb = A.nb;
@@ -1510,11 +1682,13 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
     // travel while the matrix cores factorise; otherwise the chain waits for them afterwards.
     TileRegs Rsub, Rdiag;
     bool have_next = false;  // Rsub / Rdiag hold column j's tiles
+    bool next_in_lds = false;  // (systolic chain) wave 2 of the previous column has put them into As / the spare tile buffer
+    int sys_flip = 0;
     for (int j = T.i; j < T.j; ++j) {
       const int info = A.chain_info[j];
       const bool sub = j > T.i;
       stamp((size_t)8 * j);
-      if (!have_next) {
+      if (!have_next && !next_in_lds) {
         const unsigned* f0 = (sub && (info & 2)) ? A.pflag + 2 * j + 1 : nullptr;
         const unsigned* f1 = (info & 1) ? A.pflag + 2 * j : nullptr;
         if ((f0 || f1) && !wait2(f0, f1)) { alive = false; break; }
@@ -1535,6 +1709,59 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       // accumulators; it is drained after phase 0 and published after phase 1.
       const bool more = j + 1 < T.j;
       const int seq = j + 1;
+      // Round 5. A node's FIRST column has no panel tile: it is the plain systolic tile factorisation (7.4 us against the
+      // look-ahead variant's 10.3 at the persistent launch's clock). For the columns WITH a panel tile the fused form below
+      // (tile_potrf_inv_sys + ChainPanel: panel solve and diagonal update in the prologue, every wave on its own program)
+      // was built, tested and measured - 10.3 us per column against 9.2 + 1.5 for the round-3 arrangement that hides the
+      // panel work inside the look-ahead variant's longer phases: wave 0 cannot start on the pivots before it has solved
+      // its 16 rows of P and downdated block (0, 0) (56 matrix instructions, 4 100 ticks), and spreading that over the
+      // waves makes wave 1 late for ITS pivots (11.1 us). No gain: those columns keep the round-3 code;
+      // -DMAVBA_CHAIN_FUSED_PANEL=1 builds the fused form (scripts/_dbg A/B).
+#ifndef MAVBA_CHAIN_FUSED_PANEL
+#define MAVBA_CHAIN_FUSED_PANEL 0
+#endif
+      if (MAVBA_TILE_LA == 0 && (MAVBA_CHAIN_FUSED_PANEL != 0 || !sub)) {
+        (void)seq;
+        // (the diagonal tile is factorised in Tcur, the panel tile lands in Pcur; the two buffers swap roles every column
+        // because wave 2 prefetches the NEXT diagonal tile into Pcur while Tcur is still the factorisation's mailbox)
+        double* const Tcur = Ds;  // (with kSysPrefetch the two would swap roles every column: sys_flip; fixed pointers keep
+        double* const Pcur = Cs;  // every access a plain LDS access - through a runtime choice they became FLAT ones)
+        if (!next_in_lds) {
+          if (sub) tile_regs_to_lds(Rsub, As, tid);
+          tile_regs_to_lds(Rdiag, Tcur, tid);
+        }
+        if (tid == 0) s_next = 0;
+        __syncthreads();
+        stamp((size_t)8 * j + 2);
+        stamp((size_t)8 * j + 3); stamp((size_t)8 * j + 4); stamp((size_t)8 * j + 5);
+        ChainPanel cp;
+        cp.As = As; cp.Cs = Pcur; cp.Pg = sub ? A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB : nullptr; cp.ld = ld;
+        cp.lflag = sub ? A.lflag + A.tile_id[(size_t)j * nb + (j - 1)] : nullptr; cp.ep = ep; cp.sub = sub;
+        // (the prefetch by wave 2 is built but switched off: the helpers deliver a column's tiles just in time - their queues
+        // are list-scheduled against the chain -, so the flags are almost never up a third of a column ahead, and when they
+        // were, 64 system-scope loads by one wave took longer than the wave's idle time: 13.4 instead of 10.2 us per column)
+        cp.more = more && kSysPrefetch; cp.loaded = &s_next;
+        cp.next_sub = nullptr; cp.next_diag = nullptr; cp.next_f0 = cp.next_f1 = nullptr;
+        cp.next_sub_ld = cp.next_diag_ld = 0; cp.next_sub_coh = cp.next_diag_coh = false;
+        if (more) {
+          const int ni = A.chain_info[j + 1];
+          if (ni & 2) { cp.next_sub = A.pre + (size_t)(2 * (j + 1) + 1) * NB * NB; cp.next_sub_ld = NB; cp.next_sub_coh = true; cp.next_f0 = A.pflag + 2 * (j + 1) + 1; }
+          else { cp.next_sub = A.M + (size_t)(j + 1) * NB * ld + (size_t)j * NB; cp.next_sub_ld = ld; }
+          if (ni & 1) { cp.next_diag = A.pre + (size_t)(2 * (j + 1)) * NB * NB; cp.next_diag_ld = NB; cp.next_diag_coh = true; cp.next_f1 = A.pflag + 2 * (j + 1); }
+          else { cp.next_diag = A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB; cp.next_diag_ld = ld; }
+        }
+        const bool ok = tile_potrf_inv_sys<NoMark, 0, ChainPanel>(Tcur, Bs, tid, NoMark(), cp);
+        if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
+        stamp((size_t)8 * j + 6);
+        store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
+        drain_stores();
+        __syncthreads();
+        next_in_lds = *reinterpret_cast<volatile int*>(&s_next) != 0;
+        ++sys_flip;
+        if (tid == 0) publish(A.dflag + j, ep);
+        stamp((size_t)8 * j + 7);
+        continue;
+      }
       if (sub) {
         tile_regs_to_lds(Rsub, As, tid);
         tile_regs_to_lds(Rdiag, Ds, tid);
@@ -1947,7 +2174,8 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   // on the host with measured costs (MAVBA_CHOL_TRACE: ~3.5 us per tile update of a helper, 3.1 us panel solve + publish,
   // ~12.2 us per chain column, 9.6 for a node's first): every update list is ordered by the time its inputs are ready, and
   // the helpers' queues are filled by list scheduling (below). Only the ORDER comes from the model, never correctness.
-  constexpr double cU = 3.5, cS = 3.1, cP = 1.0, cCol = 12.2, cColFirst = 9.6, cSub = 4.0;
+  // (round 5: a node's first column is the systolic tile factorisation - 7.4 us of factor + load and publish)
+  constexpr double cU = 3.5, cS = 3.1, cP = 1.0, cCol = 12.2, cColFirst = MAVBA_TILE_LA != 0 ? 9.6 : 7.4, cSub = 4.0;
   std::vector<std::pair<int, int>> id_ij((size_t)nt, {0, 0});
   for (int k = 0; k < nb; ++k) {
     id_ij[tile_id[(size_t)k * nb + k]] = {k, k};
@@ -2356,7 +2584,7 @@ __global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M
   if (nb > 1) load_tile(M + (size_t)NB * ld, ld, P, tid);
   if (tid < nb * NB) vv[tid] = M[(size_t)nb_all * NB * ld + tid];
   __syncthreads();
-  bool ok = tile_potrf_inv_la(W, I0, tid);
+  bool ok = tile_factor_inverse(W, I0, tid);
   __syncthreads();
   auto lower_mv = [&](const double* Li, const double* in, double* out) {  // out = Li in   (Li lower, upper part zero)
     if (wv == 0) {
@@ -2395,7 +2623,7 @@ __global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M
     __syncthreads();
     quadrant_to_lds(W, wr, wc, lane, cur);
     __syncthreads();
-    ok = tile_potrf_inv_la(W, I1, tid) && ok;
+    ok = tile_factor_inverse(W, I1, tid) && ok;
     __syncthreads();
     lower_mv(I1, xx + NB, zz + NB);   // z1
     __syncthreads();
