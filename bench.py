@@ -474,12 +474,25 @@ def main():
         rep_ms = sum(r["avg_ms"] * r["launches"] for r in table if r["kernel"] in REPLICATED) / args.steps
         shd_ms = sum(r["avg_ms"] * r["launches"] for r in table if r["kernel"] not in REPLICATED) / args.steps
         one_gpu_shd = shd_ms * world  # (the sharded kernels of this rank cover 1 / world of the points)
+        packed_bytes = (info["envelope_tiles"] * 4096 + info["matrix_dim"]) * 8.0
+
+        def exchange_ms(n):
+            bw = min(50.0 * (n - 1), 300.0) * 1e9
+            return 1e3 * (20e-6 + 2.0 * (n - 1) / n * packed_bytes / bw) + 2 * 0.02
+
         scaling_model = {
             "replicated_ms_per_iteration": round(rep_ms, 4), "sharded_ms_per_iteration_this_rank": round(shd_ms, 4),
             "expected_speedup_bound": {str(n): round((one_gpu_shd + rep_ms) / (one_gpu_shd / n + rep_ms), 3) for n in (2, 4, 8)},
+            "expected_speedup_with_exchange": {str(n): round((one_gpu_shd + rep_ms) / (one_gpu_shd / n + rep_ms + exchange_ms(n)), 3)
+                                               for n in (2, 4, 8)},
+            "exchange_ms": {str(n): round(exchange_ms(n), 4) for n in (2, 4, 8)},
+            "packed_tiles_mb": round(packed_bytes / 1e6, 1),
             "note": "Amdahl bound from the event timers of this run: the reduced camera system is all-reduced and then factorised "
                     "REDUNDANTLY on every rank (chol_factor, chol_backsolve, schur_finalize, ...), only the per-point work shards. "
-                    "The all-reduce of the packed tiles and launch gaps are not in it: the measured speed-up will be lower"}
+                    "expected_speedup_with_exchange adds the all-reduce of the packed tiles + right-hand side and two small "
+                    "collectives per iteration, priced as 20 us + 2 (R-1)/R bytes / min(50 (R-1), 300) GB/s (one xGMI link per "
+                    "peer): the honest expectation for this design. profiles/r05_multi_gpu_pricing.txt prices the alternatives "
+                    "(subtree-aligned shards, subtree-to-rank factorisation: 1.36x at C3, 2.35x at C5 on 8 ranks) on the real structures"}
         value = args.steps / elapsed
         # HBM bytes one LM iteration moves (committed counter pass x this run's launch counts) against the algorithmic
         # bytes of ONE Jacobian sweep (48 + 16 + 2 (9 + K) 8 per observation)

@@ -4,7 +4,7 @@ schedule ideas without a device: earliest- vs latest-finish visiting order, pool
 import sys, collections, time
 sys.path.insert(0, "/root/repo")
 from mavmap_amd import api
-cU, cS, cP, cCol, cColFirst, cSub = 3.5, 3.1, 1.0, 12.2, 9.6, 4.0
+cU, cS, cP, cCol, cColFirst, cSub = 3.5, 3.1, 1.0, 12.2, 7.4, 4.0  # (round 5: a node's first column is the systolic tile factorisation)
 def load(path):
     rows = [tuple(int(x) for x in l.split()) for l in open(path)]
     nb, nn, npairs = rows[0]
