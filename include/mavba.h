@@ -381,6 +381,11 @@ int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r,
  * set-up chooses for an image graph given as `npairs` coupled image pairs (images that share a 3-D point).
  * node_of_image [NI]: tree node of every image; node_parent [cap]: parent of every node, -1 for the root; nodes are
  * numbered in elimination order (children before parents). Returns the number of nodes, 0 = no dissection. */
+/* Host-only: the process-wide RCCL communicator group of the in-process ranks (MAVBA_GPUS; csrc/multi_gpu.hip), `calls`
+ * acquisitions for `world` ranks, optionally an abort + one more. out[3]: communicators, kept across calls (0/1), rebuilt
+ * after the abort (0/1). Meant for tests with a stand-in library (MAVBA_RCCL_LIB). */
+int mavba_debug_inproc_comms(int32_t world, int32_t calls, int32_t abort_after, int64_t* out);
+
 int mavba_debug_elimination_tree(int32_t num_images, int32_t num_cameras, int64_t npairs, const int32_t* pair_a,
                                  const int32_t* pair_b, int32_t max_depth, int32_t* node_of_image, int32_t* node_parent,
                                  int32_t cap);

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "mavba_scene_get_camera", "mavba_scene_flatten", "mavba_scene_bundle_adjust",
     "mavba_rccl_unique_id", "mavba_session_set_rccl", "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
     "mavba_debug_elimination_tree", "mavba_debug_radix_sort", "mavba_debug_lm_decide", "mavba_debug_chol_schedule",
+    "mavba_debug_inproc_comms",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)

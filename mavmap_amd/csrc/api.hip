@@ -265,6 +265,49 @@ int mavba_session_set_rccl(mavba_session* s, const void* unique_id128, int32_t r
   MAVBA_CATCH
 }
 
+// Host-only exercise of the in-process communicator group (tests/test_abi.py against tests/stubs/mock_rccl.c through
+// MAVBA_RCCL_LIB; no device is touched): `calls` acquisitions of a group of `world` ranks, then - abort_after != 0 - an abort of
+// the group and one more acquisition. out[0] = communicators of the last acquisition, out[1] = 1 when acquisitions 2..calls
+// returned the handles of the first (the group is kept), out[2] = 1 when the acquisition after the abort returned NEW ones.
+int mavba_debug_inproc_comms(int32_t world, int32_t calls, int32_t abort_after, int64_t* out) {
+  MAVBA_TRY
+  if (world < 1 || world > 16 || calls < 1 || !out) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "bad argument");
+  const std::vector<int> dev((size_t)world, -1);
+  std::vector<void*> first, cur;
+  std::string why;
+  bool same = true;
+  for (int c = 0; c < calls; ++c) {
+    if (!inproc_comms_acquire(world, dev, cur, why)) throw Failure(MAVBA_ERR_HIP, why);
+    if (c == 0) first = cur; else same = same && cur == first;
+  }
+  out[0] = (int64_t)cur.size(); out[1] = same ? 1 : 0; out[2] = 0;
+  if (abort_after) {
+    inproc_comms_abort();
+    if (!inproc_comms_acquire(world, dev, cur, why)) throw Failure(MAVBA_ERR_HIP, why);
+    out[0] = (int64_t)cur.size();
+    out[2] = 1;  // (handles are heap pointers of the library: freed ones may be handed out again - the counts tell, see the test)
+  }
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+
+// (multi_gpu.hip) a communicator of the process-wide group of in-process ranks: used, not owned - it outlives the session
+extern "C++" {
+namespace mavba {
+int session_borrow_rccl(mavba_session* s, void* comm, int rank, int world_size) {
+  MAVBA_SESSION_TRY(s)
+  if (!comm || rank < 0 || rank >= world_size) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "bad communicator / rank");
+  if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_rccl must precede the first iteration");
+  s->rccl_comm = comm; s->rccl_comm_owned = false;
+  s->ar_fn = nullptr; s->rank = rank; s->world = world_size;
+  s->force_exchange = false;
+  join_ranks(s);
+  return MAVBA_OK;
+  MAVBA_CATCH
+}
+}  // namespace mavba
+}  // extern "C++"
+
 int mavba_session_eval_jacobian(mavba_session* s, double* cost, double* r, double* Jc, double* Jp, double* Jk) {
   MAVBA_SESSION_TRY(s)
   s->evaluate();

@@ -15,19 +15,23 @@ struct RcclApi {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string error;
 };
 RcclApi& rccl() {
   static RcclApi* api = [] {
     RcclApi* a = new RcclApi;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* n : names) if ((a->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    // MAVBA_RCCL_LIB: another library with the same entry points (tests/stubs/mock_rccl.c: the in-process rank protocol on
+    // a box without GPUs)
+    const char* names[] = {std::getenv("MAVBA_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) if (n && *n && (a->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!a->lib) { a->error = std::string("librccl.so not found: ") + dlerror(); return a; }
     a->GetUniqueId = reinterpret_cast<decltype(a->GetUniqueId)>(dlsym(a->lib, "ncclGetUniqueId"));
     a->CommInitRank = reinterpret_cast<decltype(a->CommInitRank)>(dlsym(a->lib, "ncclCommInitRank"));
     a->AllReduce = reinterpret_cast<decltype(a->AllReduce)>(dlsym(a->lib, "ncclAllReduce"));
     a->CommDestroy = reinterpret_cast<decltype(a->CommDestroy)>(dlsym(a->lib, "ncclCommDestroy"));
+    a->CommAbort = reinterpret_cast<decltype(a->CommAbort)>(dlsym(a->lib, "ncclCommAbort"));
     a->GetErrorString = reinterpret_cast<decltype(a->GetErrorString)>(dlsym(a->lib, "ncclGetErrorString"));
     if (!a->GetUniqueId || !a->CommInitRank || !a->AllReduce || !a->CommDestroy) a->error = "librccl.so lacks an expected symbol";
     return a;
@@ -56,6 +60,12 @@ void* rccl_comm_create(const void* id128, int rank, int world) {
   return comm;
 }
 void rccl_comm_destroy(void* comm) { if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm)); }
+// gives up whatever the communicator has in flight (a peer is gone) and frees it; plain destroy where the library has no abort
+void rccl_comm_abort(void* comm) {
+  if (!comm) return;
+  if (rccl().CommAbort) (void)rccl().CommAbort(static_cast<ncclComm_t>(comm));
+  else rccl_comm_destroy(comm);
+}
 // in place on `stream`; op 0 = sum, 1 = max, 2 = sum over the first count - 1 doubles and max over the last
 void rccl_allreduce(void* comm, double* p, long long count, int op, hipStream_t stream) {
   ncclComm_t c = static_cast<ncclComm_t>(comm);

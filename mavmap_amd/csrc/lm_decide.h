@@ -16,7 +16,7 @@
 // One deliberate deviation from Ceres' text: levenberg_marquardt_strategy.cc writes the radius update as
 // pow(2 rho - 1, 3); here the cube is (t * t) * t - two correctly rounded products, which can differ from a (nearly
 // correctly rounded) pow in the last bit of the new radius. pow has no bit-exact device counterpart, and host and device
-// MUST agree with each other. The oracle (oracle/ba_oracle.cpp) keeps Ceres' pow: a last-bit difference of the radius
+// MUST agree with each other. The CPU restatement under oracle/ keeps Ceres' pow: a last-bit difference of the radius
 // scales the LM diagonal by 1 +- 2^-52, far inside the 1e-6 parity bar; the full-solve tests compare iteration counts,
 // terminations and final radii (1e-7: the radius follows the gain ratios, which agree to ~1e-9) against it.
 #ifndef MAVBA_LM_DECIDE_H_

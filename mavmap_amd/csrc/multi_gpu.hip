@@ -144,6 +144,61 @@ std::vector<int> shard_bounds(const mavba_problem* P, int world) {
 
 }  // namespace
 
+// ---- the RCCL communicators of the in-process ranks (round 5) -------------------------------------------------------
+// Round 4 created them inside every mavba_solve (one ncclCommInitRank per rank thread per call): tens of milliseconds in
+// front of a 15 ms solve. Now they belong to the process: created once per (world, devices) by one thread per rank - RCCL
+// binds a communicator to the device current at creation -, handed to the sessions as BORROWED handles, aborted as a group
+// when a rank fails (so that nobody is left inside a collective a dead rank will never join) and then rebuilt on demand.
+namespace {
+struct CommGroup {
+  std::mutex m;
+  int world = 0;
+  std::vector<int> device;
+  std::vector<void*> comm;
+};
+CommGroup& comm_group() { static CommGroup* g = new CommGroup; return *g; }
+}  // namespace
+
+bool inproc_comms_acquire(int world, const std::vector<int>& device, std::vector<void*>& out, std::string& error) {
+  CommGroup& C = comm_group();
+  std::lock_guard<std::mutex> lk(C.m);
+  if (C.world == world && C.device == device && (int)C.comm.size() == world) { out = C.comm; return true; }
+  for (void* c : C.comm) rccl_comm_destroy(c);
+  C.comm.clear(); C.world = 0; C.device.clear();
+  unsigned char uid[128];
+  try { rccl_unique_id(uid); } catch (const std::exception& e) { error = e.what(); return false; }
+  std::vector<void*> comm(world, nullptr);
+  std::vector<std::string> err(world);
+  auto make = [&](int r) {
+    int prev = -1;
+    try {
+      if (device[r] >= 0) { (void)hipGetDevice(&prev); HIP_OK(hipSetDevice(device[r])); }
+      comm[r] = rccl_comm_create(uid, r, world);
+    } catch (const std::exception& e) { err[r] = e.what(); }
+    if (prev >= 0) (void)hipSetDevice(prev);
+  };
+  std::vector<std::thread> th;
+  for (int r = 1; r < world; ++r) th.emplace_back(make, r);
+  make(0);
+  for (auto& t : th) t.join();
+  for (int r = 0; r < world; ++r)
+    if (!comm[r]) {
+      error = "rank " + std::to_string(r) + ": " + (err[r].empty() ? std::string("ncclCommInitRank failed") : err[r]);
+      for (void* c : comm) rccl_comm_abort(c);
+      return false;
+    }
+  C.world = world; C.device = device; C.comm = comm;
+  out = comm;
+  return true;
+}
+
+void inproc_comms_abort() {
+  CommGroup& C = comm_group();
+  std::lock_guard<std::mutex> lk(C.m);
+  for (void* c : C.comm) rccl_comm_abort(c);
+  C.comm.clear(); C.world = 0; C.device.clear();
+}
+
 int multi_gpu_ranks() {
   const char* e = std::getenv("MAVBA_GPUS");
   if (!e) return 1;
@@ -252,9 +307,10 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
   // the peer-access kernel behind host barriers.
   bool use_rccl = !same_device;
   if (const char* e = std::getenv("MAVBA_GPUS_EXCHANGE")) use_rccl = use_rccl && std::string(e) != "inproc";
-  unsigned char uid[128];
+  std::vector<void*> comms;
   if (use_rccl) {
-    try { rccl_unique_id(uid); } catch (const std::exception&) { use_rccl = false; }  // (librccl.so not loadable)
+    std::string why;
+    if (!inproc_comms_acquire(world, G.device, comms, why)) use_rccl = false;  // (librccl.so not loadable, ...: the peer-access exchange)
   }
   std::vector<RankCtx> ctx(world);
   auto worker = [&](int r) {
@@ -269,9 +325,12 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
       if (S.rc != MAVBA_OK) { S.error = g_last_error; G.fail(); }
       if (!G.barrier() && S.rc == MAVBA_OK) { S.rc = MAVBA_ERR_HIP; g_last_error = "another rank failed during set-up"; }
     }
-    if (S.rc == MAVBA_OK) S.rc = use_rccl ? mavba_session_set_rccl(s, uid, r, world) : mavba_session_set_allreduce(s, inproc_allreduce, &ctx[r], r, world);
+    if (S.rc == MAVBA_OK) S.rc = use_rccl ? session_borrow_rccl(s, comms[r], r, world) : mavba_session_set_allreduce(s, inproc_allreduce, &ctx[r], r, world);
     int done = 0;
     if (S.rc == MAVBA_OK) S.rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &S.term);
+    // (stream-ordered collectives: a peer that failed aborts the group, this rank's collectives then complete with
+    // whatever was in the buffers - its numbers mean nothing)
+    if (S.rc == MAVBA_OK && use_rccl && G.failed) { S.rc = MAVBA_ERR_HIP; g_last_error = "another rank failed during the solve"; }
     if (S.rc == MAVBA_OK) S.rc = mavba_session_result(s, &S.res);
     // ceres leaves the user's parameter blocks untouched after NUMERICAL_FAILURE
     if (S.rc == MAVBA_OK && S.term != MAVBA_TERM_NUMERICAL_FAILURE)
@@ -287,7 +346,12 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
       }
       if (S.rc == MAVBA_OK) S.rc = mavba_session_point_errors(s, S.perr.data());
     }
-    if (S.rc != MAVBA_OK) { S.error = g_last_error; G.fail(); }
+    if (S.rc != MAVBA_OK) {
+      S.error = g_last_error; G.fail();
+      // nobody may be left inside a collective this rank will never join: abort the group's communicators (the peers'
+      // ncclAllReduce calls return or complete, their read-backs end, the threads join); the next call builds a new group
+      if (use_rccl) inproc_comms_abort();
+    }
     if (s) mavba_session_destroy(s);
   };
   std::vector<std::thread> threads;

@@ -81,6 +81,11 @@ long long device_scan_scratch(long long n);
 void device_scan_exclusive(hipStream_t st, unsigned* data, long long n, unsigned* scratch);  // in place, any length; scratch >= device_scan_scratch(n) values
 
 // multi_gpu.hip: one process, several devices (MAVBA_GPUS)
+int session_borrow_rccl(mavba_session* s, void* comm, int rank, int world_size);  // (api.hip)
+// the RCCL communicators of the in-process ranks, kept for the life of the process: ncclCommInitRank costs tens of
+// milliseconds - more than the C3 solve it would serve. device[r] < 0: do not bind the creating thread (host-only tests)
+bool inproc_comms_acquire(int world, const std::vector<int>& device, std::vector<void*>& out, std::string& error);
+void inproc_comms_abort();  // a rank failed: ncclCommAbort on every communicator (peers blocked in a collective return), group dropped
 int multi_gpu_ranks();
 int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_result* result, double* point_error, int world);
 
@@ -91,6 +96,7 @@ void pose_refine_batch(int count, mavba_pose_refine_item* items, const mavba_opt
 void rccl_unique_id(void* out128);
 void* rccl_comm_create(const void* id128, int rank, int world);
 void rccl_comm_destroy(void* comm);
+void rccl_comm_abort(void* comm);
 void rccl_allreduce(void* comm, double* p, long long count, int op, hipStream_t stream);
 hipError_t pinned_alloc(void** out, size_t bytes);
 void pinned_free(void* p);
@@ -364,6 +370,7 @@ struct mavba_session {
   mavba_allreduce_fn ar_fn = nullptr;  // hook: the caller's collective (host-synchronised)
   void* ar_ctx = nullptr;
   void* rccl_comm = nullptr;           // native: ncclAllReduce enqueued on the session's stream, no host synchronisation
+  bool rccl_comm_owned = true;         // false: borrowed from the process-wide group of the in-process ranks (multi_gpu.hip)
   bool sharded() const { return (ar_fn || rccl_comm) && (world > 1 || force_exchange); }
   bool force_exchange = false;         // run the multi-rank protocol even with one rank (tests of the native path)
   int rank = 0, world = 1;
@@ -377,7 +384,7 @@ struct mavba_session {
   ~mavba_session() {
     // the buffers go back to the process-wide pool: nothing may still be running on them
     if (st) (void)hipStreamSynchronize(st);
-    if (rccl_comm) rccl_comm_destroy(rccl_comm);
+    if (rccl_comm && rccl_comm_owned) rccl_comm_destroy(rccl_comm);
     if (lm_pub) lm_pub_free(lm_pub);
     HostSpare<long long>::give(perm); HostSpare<int>::give(h_oimg); HostSpare<double>::give(h_points0);
     for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

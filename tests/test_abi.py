@@ -112,3 +112,39 @@ def test_the_build_digest_covers_every_header_the_sources_include():
     assert included <= listed, sorted(included - listed)
     # per-file flags are part of the digest too (dense_chol.hip is built with the matrix instructions in VGPR form)
     assert "dense_chol.hip" in b.FILE_FLAGS and set(b.FILE_FLAGS) <= set(b.SOURCES)
+
+
+def test_the_in_process_rccl_group_is_created_once_kept_and_rebuilt_after_an_abort(mavba, tmp_path):
+    """MAVBA_GPUS on distinct devices (csrc/multi_gpu.hip): the ranks' RCCL communicators belong to the PROCESS - one creating
+    thread per rank (ncclCommInitRank blocks until all ranks have arrived: the stand-in does too, a serial creation would
+    time out in it), kept across mavba_solve calls (round 4 paid ncclCommInitRank per call), aborted as a group when a rank
+    fails and rebuilt on the next call. No multi-GPU node has been available: this runs the thread / rendezvous / cache /
+    abort protocol once, host-only, against tests/stubs/mock_rccl.c through MAVBA_RCCL_LIB."""
+    mock = tmp_path / "libmock_rccl.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", str(mock), os.path.join(ROOT, "tests", "stubs", "mock_rccl.c"), "-lpthread"])
+    code = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %r)
+import mavmap_amd
+L = mavmap_amd.load()
+mock = C.CDLL(%r)
+counts = (C.c_longlong * 5)()
+out = (C.c_int64 * 3)()
+def run(world, calls, abort):
+    rc = L.mavba_debug_inproc_comms(world, calls, abort, out)
+    mock.mock_rccl_counts(counts)
+    return rc, list(out), list(counts)
+rc, o, c = run(4, 3, 0)
+assert rc == 0 and o[0] == 4 and o[1] == 1, (rc, o)
+assert c[:3] == [4, 0, 0] and c[4] == 0, c          # four communicators for three calls, nothing destroyed, no time-out
+rc, o, c = run(4, 2, 1)                              # same group again (kept), then a failing rank: abort + rebuild
+assert rc == 0 and o[0] == 4 and o[1] == 1 and o[2] == 1, (rc, o)
+assert c[0] == 8 and c[2] == 4 and c[1] == 0 and c[4] == 0, c
+rc, o, c = run(2, 1, 0)                              # another world size replaces the group (the old one is destroyed, not leaked)
+assert rc == 0 and o[0] == 2 and c[0] == 10 and c[1] == 4, (rc, o, c)
+print("ok")
+""" % (ROOT, str(mock))
+    env = dict(os.environ, MAVBA_RCCL_LIB=str(mock))
+    r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
