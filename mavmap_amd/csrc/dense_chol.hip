@@ -1616,6 +1616,9 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
   if ((int)blockIdx.x == A.drop_wg) return;
   bool alive = true;
   auto stamp = [&](size_t slot) { if (A.trace && tid == 0) A.trace[slot] = wall_clock64(); };
+  // (slots 3 / 4 of a chain column: the SHADER clock before and after the tile factorisation - against the 100 MHz stamps 2 / 6
+  // they give the clock the launch really runs at)
+  auto stamp_clk = [&](size_t slot) { if (A.trace && tid == 0) A.trace[slot] = (unsigned long long)clock64(); };
   for (int ti = A.wg_begin[blockIdx.x]; alive && ti < A.wg_begin[blockIdx.x + 1]; ++ti) {
     const CholTask T = A.tasks[ti];
     const size_t tslot = (size_t)8 * nb + (size_t)4 * ti;
@@ -1733,7 +1736,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         if (tid == 0) s_next = 0;
         __syncthreads();
         stamp((size_t)8 * j + 2);
-        stamp((size_t)8 * j + 3); stamp((size_t)8 * j + 4); stamp((size_t)8 * j + 5);
+        stamp_clk((size_t)8 * j + 3); stamp((size_t)8 * j + 5);
         ChainPanel cp;
         cp.As = As; cp.Cs = Pcur; cp.Pg = sub ? A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB : nullptr; cp.ld = ld;
         cp.lflag = sub ? A.lflag + A.tile_id[(size_t)j * nb + (j - 1)] : nullptr; cp.ep = ep; cp.sub = sub;
@@ -1752,6 +1755,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         }
         const bool ok = tile_potrf_inv_sys<NoMark, 0, ChainPanel>(Tcur, Bs, tid, NoMark(), cp);
         if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
+        stamp_clk((size_t)8 * j + 4);
         stamp((size_t)8 * j + 6);
         store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
         drain_stores();
@@ -1785,8 +1789,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         __syncthreads();
       }
       stamp((size_t)8 * j + 2);
-      stamp((size_t)8 * j + 3);
-      stamp((size_t)8 * j + 4);
+      stamp_clk((size_t)8 * j + 3);
       stamp((size_t)8 * j + 5);
       auto next_ready = [&]() {
         const int ni = A.chain_info[j + 1];
@@ -1855,6 +1858,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       };
       const bool ok = tile_potrf_inv_la(Ds, Bs, tid, in_factor, NoMark(), phase0);
       if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
+      stamp_clk((size_t)8 * j + 4);
       stamp((size_t)8 * j + 6);
       store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
       drain_stores();

@@ -43,6 +43,13 @@ for r in C:
     seq = [t[0], t[1], t[2], t[6], t[7]]
     d = np.diff(seq) / 100.0
     print(f"{j:3d} {n:3d} | {us(t[0]):7.1f} " + " ".join(f"{x:7.1f}" for x in d) + f" | {us(t[7]):7.1f}")
+ok = C[:, 2] > 0
+ticks = (C[ok, 2 + 4] - C[ok, 2 + 3]).astype(float)
+wall = (C[ok, 2 + 6] - C[ok, 2 + 2]).astype(float) / 100.0
+good = (ticks > 0) & (wall > 0)
+if good.any():
+    print("shader clock over the tile factorisations (s_memtime ticks per us of the 100 MHz clock): median %.0f, min %.0f, max %.0f"
+          % (np.median(ticks[good] / wall[good]), (ticks[good] / wall[good]).min(), (ticks[good] / wall[good]).max()))
 print("total forward us:", us(max(C[:, 9].max(), T[:, 8].max())))
 # helpers: lateness of PRE tasks relative to when the chain started waiting for them
 kinds = {0: "TILE", 1: "PRE_DIAG", 2: "PRE_SUB"}

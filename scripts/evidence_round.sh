@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit for a round's committed evidence beyond scripts/measure_all.sh: latencies, set-up phases, phase traces.
-#   bash scripts/evidence_round.sh r04      (results under gpurun_out/<tag>/, copied to profiles/<tag>_* by the caller)
+#   bash scripts/evidence_round.sh r05      (results under gpurun_out/<tag>/, copied to profiles/<tag>_* by the caller)
 set -u
 export TMPDIR=/tmp
 TAG=${1:-r04}
@@ -18,4 +18,6 @@ python scripts/_dbg/iter_timeline.py $OUT/tl > $OUT/window_timeline.txt 2>&1; rm
 rm -rf $OUT/tl3; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl3 -o b -- python $R/bench.py --steps 40 --warmup 6 --no-cpu-baseline > /dev/null 2>&1)
 python scripts/_dbg/iter_timeline.py $OUT/tl3 first > $OUT/iteration_timeline_C3.txt 2>&1; rm -rf $OUT/tl3
 timeout 60 scripts/_dbg/pipe_bench > $OUT/pipe_bench_fp64.txt 2>&1
+{ timeout 60 scripts/_dbg/pivot_bench; timeout 60 scripts/_dbg/tile_bench; } > $OUT/tile_bench.txt 2>&1
+MAVBA_CHOL_TRACE=$OUT/chol_trace_raw.txt timeout 300 python scripts/chol_trace.py C2 > $OUT/chol_trace_C2.txt 2>&1; rm -f $OUT/chol_trace_raw.txt
 ls -la $OUT
