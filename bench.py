@@ -92,7 +92,7 @@ PMC_KERNEL = {  # bench timer name -> rocprofv3 kernel-name prefix in profiles/*
     "point_front_sums": "k_point_front<8, false", "schur_fused": "k_schur_rows",
 }
 # kernels every rank runs in full when the points are sharded (the reduced camera system is factorised redundantly)
-REPLICATED = {"chol_factor", "chol_backsolve", "schur_finalize", "update_cameras", "camera_reduce", "reduce", "memset_S", "scales",
+REPLICATED = {"chol_factor", "chol_backsolve", "schur_finalize", "update_cameras", "camera_reduce", "eval_tail", "reduce", "memset_S", "scales",
               "cam_prepare", "rot_prior"}
 
 

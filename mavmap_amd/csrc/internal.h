@@ -314,6 +314,7 @@ void launch_lm_tail(hipStream_t st, const ReduceTasks& tasks, int n, const LmSpe
 void state_norms_grid(int NI, int NC, int NP, int* gp, int* gc);  // point groups + camera groups of launch_state_norms
 struct EvalSmallArgs {
   int NI, NC, NP, NPs, with_cams, cam_part, gp, gc, num_tasks;
+  int first_group = 0;  // k_eval_tail: the norm groups below this one (the points') were done by k_eval_head
   const int* img_chunk_start; const double* cam_partial; const int* prior_start; const double* prior_res; const double* prior_jac;
   const int* cam_img_start; const int* cam_imgs; double* img_rec; double* cam_rec; double* img_intr_tmp;
   const unsigned char* pose_free; const unsigned char* intr_free; const unsigned char* pt_free;
@@ -321,6 +322,10 @@ struct EvalSmallArgs {
   ReduceTasks T; LmSpec spec;
 };
 void launch_eval_small(hipStream_t st, const EvalSmallArgs& a);
+// the same for problems of any size, as TWO launches (round 5): per-image sums and the points' norm groups side by side
+// in one grid, then one work-group for the per-camera sums, the cameras' norm groups and the three reductions
+void launch_eval_head_tail(hipStream_t st, const EvalSmallArgs& a);
+bool eval_head_tail_fits(int gc);
 
 void launch_points_to_caller(hipStream_t st, int NP, int width, const int* orig, const double* in, double* out);
 void launch_point_errors(hipStream_t st, int NP, const int* pt_start, const double* rnorm,

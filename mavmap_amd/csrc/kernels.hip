@@ -2741,6 +2741,69 @@ __global__ void __launch_bounds__(1024) k_eval_small(EvalSmallArgs a) {
   reduce_tasks_grouped(a.T, a.num_tasks, s_t);
 }
 void launch_eval_small(hipStream_t st, const EvalSmallArgs& a) { hipLaunchKernelGGL(k_eval_small, dim3(1), dim3(1024), 0, st, a); }
+// Round 5: the tail of an evaluation of a LARGE problem was four dependent launches of 5-7 us each (k_camera_reduce_img,
+// k_camera_reduce_cam, k_state_norms, k_reduce_tasks) for a few microseconds of work. Two launches: k_eval_head - the
+// per-image sums (four images per 256-lane work-group) and the POINTS' norm groups, independent of each other, in one
+// grid -, k_eval_tail - one 1024-lane work-group: per-camera sums, the CAMERAS' norm groups (they need those sums),
+// the three reductions over the partials of both kernels. The same device functions in the same order as the launches they
+// replace (lm_bodies.h): bit-identical results. Not with shards (the camera sums are all-reduced between the two halves).
+__global__ void __launch_bounds__(256) k_eval_head(EvalSmallArgs a, int img_blocks) {
+  __shared__ double s_red[4];
+  if (!lm_spec_go(a.spec, nullptr)) return;
+  if ((int)blockIdx.x < img_blocks) {
+    const int i = 4 * blockIdx.x + (threadIdx.x >> 6);
+    if (i < a.NI) camera_reduce_img_body(i, threadIdx.x & 63, a.img_chunk_start, a.cam_partial, a.prior_start, a.prior_res, a.prior_jac, a.img_rec, a.img_intr_tmp);
+    return;
+  }
+  state_norms_body(blockIdx.x - img_blocks, a.gp, a.gc, a.NI, a.NC, a.NP, a.NPs, a.cam_part, a.pose_free, a.intr_free, a.pt_free, a.poses, a.intr,
+                   a.points, a.img_rec, a.cam_rec, a.gu, a.norm_partial, s_red);
+}
+__global__ void __launch_bounds__(1024) k_eval_tail(EvalSmallArgs a) {
+  __shared__ double s_part[16][64];
+  __shared__ double s_w[kStateNormsCamBlocks][2][4];
+  __shared__ double s_t[4][2][4];
+  if (!lm_spec_go(a.spec, nullptr)) return;
+  const int tid = threadIdx.x, g = tid >> 8, lt = tid & 255, wv = (tid >> 6) & 3, lane = tid & 63;
+  if (a.with_cams) {
+    for (int c = 0; c < a.NC; ++c) {
+      if (lane < kCamRec) s_part[tid >> 6][lane] = camera_reduce_cam_part(c, tid >> 6, lane, a.cam_img_start, a.cam_imgs, a.img_intr_tmp);
+      __syncthreads();
+      if (tid < kCamRec) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += s_part[k][tid];
+        a.cam_rec[(size_t)c * kCamRec + tid] = tot;
+      }
+      __syncthreads();
+    }
+  }
+  const int nvb = a.gp + a.gc;
+  for (int vb0 = a.first_group; vb0 < nvb; vb0 += 4) {
+    const int vb = vb0 + g;
+    if (vb < nvb) {
+      double gmax, x2;
+      state_norms_local(vb, lt, a.gp, a.gc, a.NI, a.NC, a.NP, a.NPs, a.cam_part, a.pose_free, a.intr_free, a.pt_free, a.poses, a.intr, a.points,
+                        a.img_rec, a.cam_rec, a.gu, gmax, x2);
+      const double m = wave_max(gmax), sum = wave_sum(x2);
+      if (lane == 0) { s_w[vb - a.first_group][0][wv] = m; s_w[vb - a.first_group][1][wv] = sum; }
+    }
+  }
+  __syncthreads();
+  if (tid < nvb - a.first_group) {
+    a.norm_partial[2 * (a.first_group + tid)] = group4_max(s_w[tid][0]);
+    a.norm_partial[2 * (a.first_group + tid) + 1] = group4_sum(s_w[tid][1]);
+  }
+  __syncthreads();
+  reduce_tasks_grouped(a.T, a.num_tasks, s_t);
+}
+void launch_eval_head_tail(hipStream_t st, const EvalSmallArgs& a) {
+  const int img_blocks = (a.NI + 3) / 4;
+  hipLaunchKernelGGL(k_eval_head, dim3(img_blocks + a.gp), dim3(256), 0, st, a, img_blocks);
+  EvalSmallArgs b = a;
+  b.first_group = a.gp;
+  hipLaunchKernelGGL(k_eval_tail, dim3(1), dim3(1024), 0, st, b);
+}
+bool eval_head_tail_fits(int gc) { return gc <= kStateNormsCamBlocks; }
 void launch_lm_tail(hipStream_t st, const ReduceTasks& T, int n, const LmSpec& spec, double* dec, double* host_pub, double seq, double* fail_slots) {
   if (n > 4) {  // (the merged kernel runs at most four reductions side by side)
     launch_reduce_tasks(st, T, n);

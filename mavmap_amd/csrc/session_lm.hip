@@ -133,6 +133,33 @@ void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
     evaluated = true; assembled = false;
     return;
   }
+  if (scales_ready && merge_on && !sharded() && NI <= 160) {
+    // a medium problem on one rank: the evaluation's tail as two launches instead of four (k_eval_head / k_eval_tail, kernels.hip).
+    // Measured: C2 (100 images) 24.0 -> 16.1 us; at C3 (500 images, two cameras of 250) the ONE work-group of the second launch
+    // takes 34.5 us against 28.8 for the four launches - large problems keep those.
+    EvalSmallArgs e;
+    e.NI = NI; e.NC = NC; e.NP = NP; e.NPs = NPs; e.with_cams = any_intr_free ? 1 : 0; e.cam_part = rank == 0 ? 1 : 0;
+    state_norms_grid(NI, NC, NP, &e.gp, &e.gc);
+    if (eval_head_tail_fits(e.gc)) {
+      timed("eval_tail", [&] {
+        e.img_chunk_start = d_img_chunk_start.p; e.cam_partial = d_cam_partial.p;
+        e.prior_start = num_priors > 0 ? d_prior_start.p : nullptr; e.prior_res = d_prior_res.p; e.prior_jac = d_prior_jac.p;
+        e.cam_img_start = d_cam_img_start.p; e.cam_imgs = d_cam_imgs.p; e.img_rec = d_img_rec; e.cam_rec = d_cam_rec;
+        e.img_intr_tmp = d_img_intr_tmp.p;
+        e.pose_free = d_pose_free.p; e.intr_free = d_intr_free.p; e.pt_free = d_pt_free.p;
+        e.poses = d_poses.p; e.intr = d_intr.p; e.points = d_points.p; e.gu = d_gu.p; e.norm_partial = d_norm_partial.p;
+        const int rows = e.gp + e.gc;
+        e.T.t[0] = ReduceTask{d_norm_partial.p, rows, 2, 1, nullptr, 0, d_scal.p + SC_GRAD_MAX};
+        e.T.t[1] = ReduceTask{d_norm_partial.p + 1, rows, 2, 0, nullptr, 0, d_scal.p + SC_XNORM2};
+        e.T.t[2] = ReduceTask{d_sweep_partial.p, eval_cost_rows(), 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
+        e.num_tasks = 3;
+        e.spec = spec;
+        launch_eval_head_tail(st, e);
+      });
+      evaluated = true; assembled = false;
+      return;
+    }
+  }
   timed("camera_reduce", [&] {
     launch_camera_reduce(st, NI, NC, d_img_chunk_start.p, d_cam_partial.p, num_priors > 0 ? d_prior_start.p : nullptr,
                          d_prior_res.p, d_prior_jac.p, d_cam_img_start.p, d_cam_imgs.p, d_img_rec, d_cam_rec,

@@ -686,3 +686,33 @@ def test_the_speculative_loop_equals_the_plain_loop(mavba, monkeypatch):
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+
+
+def test_merged_evaluation_tail_of_a_large_problem_equals_the_four_launches(mavba, monkeypatch):
+    """Round 5: for problems of up to 160 images on one rank the tail of an evaluation - per-image sums, per-camera sums, norms, the
+    three scalar reductions - is two launches (k_eval_head / k_eval_tail) instead of four. They run the device functions of the
+    four kernels in the same order: bit-identical to the launch-per-step loop (MAVBA_MERGE=0) - with free intrinsics,
+    rotation priors, constant points and more camera columns than one norm group."""
+    p1 = synth.make_config("C3", scale=0.12, seed=21)                       # 60 images: 378 camera columns, two cameras
+    p2 = synth.make_scene(num_images=90, num_points=6000, track_len=6, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=22, rot_priors=True)
+    p2.point_const[::11] = 1
+    p3 = synth.make_scene(num_images=70, num_points=5000, track_len=5, models=[A.MODEL_CATA], seed=23, refine_camera_params=False)
+    assert all(6 * q.num_images > 128 and q.num_images <= 160 for q in (p1, p2, p3))   # (beyond the one-work-group path of local windows)
+    outs = []
+    for merge in ("1", "0"):
+        monkeypatch.setenv("MAVBA_MERGE", merge)
+        res = []
+        for p0 in (p1, p2, p3):
+            p = p0.copy()
+            e = np.full(p.num_points, np.nan)
+            with mavba.Session(p, dict(global_opts(), profile_kernels=1)) as s:
+                r = s.solve()
+                x = s.get_params()
+                timers = set(s.kernel_stats())
+            res.append((x[0], x[1], x[2], r["final_cost"], r["num_successful_steps"], r["num_unsuccessful_steps"], r["termination"],
+                        r["final_gradient_max_norm"], r["final_trust_region_radius"]))
+            assert ("eval_tail" in timers) == (merge == "1"), timers
+        outs.append(res)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
