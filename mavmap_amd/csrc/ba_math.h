@@ -145,6 +145,56 @@ MAVBA_HD void project(int model, const double* cam, const double* Xc, double& u,
   }
 }
 
+// project<true> with the intrinsics Jacobian already contracted with a step dk: tk = Jk dk (2-vector) instead of Jk[18]
+// (the same expressions as above, the zero entries never formed).
+MAVBA_HD void project_dk(int model, const double* cam, const double* Xc, const double* dk, double& u, double& v, double* A,
+                         double& tk0, double& tk1) {
+  const double fx = cam[0], fy = cam[1];
+  double zz = Xc[2], nrm = 0.0;
+  if (model == MAVBA_M_CATA) {
+    nrm = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
+    zz = Xc[2] + cam[8] * nrm;
+  }
+  const double iz = 1.0 / zz;
+  const double un = Xc[0] * iz, vn = Xc[1] * iz;
+  double ud = un, vd = vn;
+  double D0 = 1.0, D1 = 0.0, D2 = 0.0, D3 = 1.0;
+  double su = 0.0, sv = 0.0;  // the distortion parameters' part of d(ud, vd)
+  if (model != MAVBA_M_PINHOLE) {
+    const double k1 = cam[4], k2 = cam[5], p1 = cam[6], p2 = cam[7];
+    const double u2 = un * un, v2 = vn * vn, uvn = un * vn, r2 = u2 + v2;
+    const double radial = k1 * r2 + k2 * r2 * r2;
+    ud = un + (un * radial + 2.0 * p1 * uvn + p2 * (r2 + 2.0 * u2));
+    vd = vn + (vn * radial + 2.0 * p2 * uvn + p1 * (r2 + 2.0 * v2));
+    const double drad2 = 2.0 * (k1 + 2.0 * k2 * r2);
+    D0 = 1.0 + radial + u2 * drad2 + 2.0 * p1 * vn + 6.0 * p2 * un;
+    D1 = uvn * drad2 + 2.0 * p1 * un + 2.0 * p2 * vn;
+    D2 = D1;
+    D3 = 1.0 + radial + v2 * drad2 + 2.0 * p2 * un + 6.0 * p1 * vn;
+    const double dr = r2 * (dk[4] + r2 * dk[5]);  // d radial
+    su = un * dr + 2.0 * uvn * dk[6] + (r2 + 2.0 * u2) * dk[7];
+    sv = vn * dr + (r2 + 2.0 * v2) * dk[6] + 2.0 * uvn * dk[7];
+  }
+  u = fx * ud + cam[2];
+  v = fy * vd + cam[3];
+  double dz0 = 0.0, dz1 = 0.0, dz2 = 1.0;
+  if (model == MAVBA_M_CATA) {
+    if (nrm > 0.0) {
+      const double s = cam[8] / nrm;
+      dz0 = s * Xc[0]; dz1 = s * Xc[1]; dz2 = 1.0 + s * Xc[2];
+    }
+    const double dun = -un * nrm * iz, dvn = -vn * nrm * iz;  // d(un, vn)/d xi
+    su += (D0 * dun + D1 * dvn) * dk[8];
+    sv += (D2 * dun + D3 * dvn) * dk[8];
+  }
+  const double n0 = iz - un * iz * dz0, n1 = -un * iz * dz1, n2 = -un * iz * dz2;
+  const double n3 = -vn * iz * dz0, n4 = iz - vn * iz * dz1, n5 = -vn * iz * dz2;
+  A[0] = fx * (D0 * n0 + D1 * n3); A[1] = fx * (D0 * n1 + D1 * n4); A[2] = fx * (D0 * n2 + D1 * n5);
+  A[3] = fy * (D2 * n0 + D3 * n3); A[4] = fy * (D2 * n1 + D3 * n4); A[5] = fy * (D2 * n2 + D3 * n5);
+  tk0 = ud * dk[0] + dk[2] + fx * su;
+  tk1 = vd * dk[1] + dk[3] + fy * sv;
+}
+
 // Raw residual only.
 MAVBA_HD void obs_residual(int model, const double* rec, const double* cam, const double* X,
                            double uo, double vo, double* r) {
@@ -182,6 +232,37 @@ MAVBA_HD void obs_jacobian(int model, const double* rec, const double* cam, cons
     Jc[6 * i + 2] = -(n[2] + b * m1[2] + c * m2[2]);
     Jc[6 * i + 3] = Ai[0]; Jc[6 * i + 4] = Ai[1]; Jc[6 * i + 5] = Ai[2];
   }
+}
+
+// The point back-substitution's term of one observation WITHOUT the Jacobian (round 5): it needs
+//   t = Jp^T tau,  tau = J_cam delta_cam = Jc (dw, dt) + Jk dk     (2-vector, later scaled by the loss weight squared)
+// and with Jc = [ -(A_i x Xr) Jl | A_i ],  Jp = A R  (obs_jacobian above) both collapse to directional derivatives:
+//   Jc (dw, dt) = A (dt + (Jl dw) x Xr)         the first-order motion of the camera-frame point, one cross product
+//   Jp^T tau    = R^T (A^T tau)                 two cross products
+// instead of the six + four cross products and the 12 + 6 Jacobian entries per observation that were built only to be
+// contracted again (k_backsub_points_packed spent two thirds of its FP64 instructions there).
+// Returns the raw residual in r (for the loss weight) and tau, t UNWEIGHTED: t = Jp^T (Jc dc + Jk dk).
+MAVBA_HD void obs_backsub_term(int model, const double* rec, const double* cam, const double* X, double uo, double vo,
+                               const double* dc, const double* dk, double* r, double* t) {
+  double Xr[3], Xc[3], u, v, A[6], tk0, tk1;
+  transform_point(rec, X, Xr, Xc);
+  project_dk(model, cam, Xc, dk, u, v, A, tk0, tk1);
+  r[0] = u - uo; r[1] = v - vo;
+  const double a = rec[6], b = rec[7], c = rec[8];
+  // om = Jl dw = dw + b (w x dw) + c (w x (w x dw))
+  double m1[3], m2[3], om[3], dX[3];
+  cross3(rec, dc, m1);
+  cross3(rec, m1, m2);
+  om[0] = dc[0] + b * m1[0] + c * m2[0]; om[1] = dc[1] + b * m1[1] + c * m2[1]; om[2] = dc[2] + b * m1[2] + c * m2[2];
+  cross3(om, Xr, dX);
+  dX[0] += dc[3]; dX[1] += dc[4]; dX[2] += dc[5];
+  const double tau0 = A[0] * dX[0] + A[1] * dX[1] + A[2] * dX[2] + tk0;
+  const double tau1 = A[3] * dX[0] + A[4] * dX[1] + A[5] * dX[2] + tk1;
+  // q = A^T tau, t = R^T q = q - a (w x q) + b (w x (w x q))
+  const double q[3] = {A[0] * tau0 + A[3] * tau1, A[1] * tau0 + A[4] * tau1, A[2] * tau0 + A[5] * tau1};
+  cross3(rec, q, m1);
+  cross3(rec, m1, m2);
+  t[0] = q[0] - a * m1[0] + b * m2[0]; t[1] = q[1] - a * m1[1] + b * m2[1]; t[2] = q[2] - a * m1[2] + b * m2[2];
 }
 
 // Cauchy robustifier on s = |r|^2: returns the row weight sqrt(rho') and the

@@ -2464,18 +2464,13 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
 #pragma unroll
       for (int k = 0; k < 9; ++k) { kin[k] = intr[9 * cam + k]; dk[k] = delta_cam[6 * NI + 9 * cam + k]; }
     }
-    double r[2], Jc[12], Jp[6], Jk[18];
-    obs_jacobian(model, rec, kin, X, q.m.x, q.m.y, r, Jc, Jp, Jk);
+    // (round 5: directional derivatives instead of the full Jacobian - obs_backsub_term, ba_math.h)
+    double r[2], tt[3];
+    obs_backsub_term(model, rec, kin, X, q.m.x, q.m.y, dc, dk, r, tt);
     double w, half_rho;
     cauchy_weight(r[0] * r[0] + r[1] * r[1], loss_b, loss_inv_b, w, half_rho);
-    double tau0 = 0.0, tau1 = 0.0;
-#pragma unroll
-    for (int e = 0; e < 6; ++e) { tau0 += Jc[e] * dc[e]; tau1 += Jc[6 + e] * dc[e]; }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { tau0 += Jk[k] * dk[k]; tau1 += Jk[9 + k] * dk[k]; }
     const double w2 = w * w;
-    tau0 *= w2; tau1 *= w2;
-    t[0] = Jp[0] * tau0 + Jp[3] * tau1; t[1] = Jp[1] * tau0 + Jp[4] * tau1; t[2] = Jp[2] * tau0 + Jp[5] * tau1;
+    t[0] = w2 * tt[0]; t[1] = w2 * tt[1]; t[2] = w2 * tt[2];
   };
   // bounds of this block and of the next one, observations of this block: requested one / two blocks ahead
   int o0 = 0, o1 = 0, o0n = 0, o1n = 0;

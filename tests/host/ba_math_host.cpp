@@ -14,6 +14,12 @@ void hm_obs_residual(int model, const double* pose, const double* cam, const dou
   mavba::cam_prepare(pose, rec);
   mavba::obs_residual(model, rec, cam, X, uv[0], uv[1], r);
 }
+void hm_obs_backsub_term(int model, const double* pose, const double* cam, const double* X, const double* uv,
+                         const double* dc, const double* dk, double* r, double* t) {
+  double rec[9];
+  mavba::cam_prepare(pose, rec);
+  mavba::obs_backsub_term(model, rec, cam, X, uv[0], uv[1], dc, dk, r, t);
+}
 void hm_rot_prior(const double* w, const double* w0, double weight, double* res, double* jac) {
   double R0[9];
   mavba::rot_matrix_colmajor(w0, R0);

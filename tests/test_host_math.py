@@ -79,6 +79,28 @@ def test_obs_jacobian_matches_oracle_jets(host, oracle, model):
         assert np.abs(r2 - r0).max() <= 1e-11 * max(1.0, np.abs(r0).max())
 
 
+@pytest.mark.parametrize("model", [1, 2, 3])
+def test_backsub_term_by_directional_derivatives_equals_the_contracted_jacobian(host, oracle, model):
+    """k_backsub_points_packed needs t = Jp^T (Jc dc + Jk dk) per observation; round 5 evaluates it as directional derivatives
+    (obs_backsub_term: A (dt + (Jl dw) x Xr), R^T A^T tau) instead of building the Jacobian and contracting it. Against the
+    oracle's Jets, for every model, over small and large rotations."""
+    rng = np.random.default_rng(100 + model)
+    for it in range(600):
+        scale = [1e-3, 0.3, 1.5, 3.1][it % 4]
+        pose, X, cam, uv = _case(rng, model, scale)
+        if it % 37 == 0:
+            pose[:3] = 0.0
+        dc = rng.normal(0, 1, 6) * np.array([1e-2, 1e-2, 1e-2, 0.1, 0.1, 0.1])
+        dk = np.zeros(9)
+        dk[:A.MODEL_NUM_PARAMS[model]] = rng.normal(0, 1, A.MODEL_NUM_PARAMS[model]) * 1e-2
+        r0, Jc0, Jp0, Jk0 = oracle.obs_jacobian(0, model, pose, X, cam, uv)
+        t0 = Jp0.T @ (Jc0 @ dc + Jk0 @ dk)
+        r, t = np.zeros(2), np.zeros(3)
+        host.hm_obs_backsub_term(model, d(pose), d(cam), d(X), d(uv), d(dc), d(dk), d(r), d(t))
+        assert np.abs(r - r0).max() <= 1e-11 * max(1.0, np.abs(r0).max())
+        assert np.abs(t - t0).max() <= 1e-10 * max(1.0, np.abs(t0).max()), (model, it, t, t0)
+
+
 def test_tiny_rotation_is_more_accurate_than_ceres_formula(host, oracle):
     """For 0 < |rvec| ~ 1e-9 the Rodrigues form the reference differentiates through (ceres <= 1.8)
     loses ~7 digits in d/d rvec; the series used on the device does not. Both must agree with the
