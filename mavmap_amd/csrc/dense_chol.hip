@@ -740,6 +740,7 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
         for (int q = 0; q < 16; ++q) Bt[j] = mm(-pj[q], Pt[q >> 2][q & 3], Bt[j]);
       }
     if (wv != 0) panel.store_rows(wv, lane);  // (wave 0: behind its pivots)
+    mark(6);
   }
   // first store into Ti: every wave must be done with the previous column's inverse it still held (the panel solve above)
   auto ti_free = [&]() {
