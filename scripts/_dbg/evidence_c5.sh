@@ -2,7 +2,7 @@
 # C5 evidence: chain trace of the persistent launch, HBM traffic and matrix-pipe counters of the C5 bench
 set -u
 export TMPDIR=/tmp
-R=$PWD; OUT=$R/gpurun_out/r04c5; mkdir -p $OUT
+R=$PWD; OUT=$R/gpurun_out/${1:-r05}c5; mkdir -p $OUT
 MAVBA_CHOL_TRACE=$OUT/raw.txt timeout 200 python scripts/chol_trace.py C5 > $OUT/chol_trace_C5.txt 2>&1; rm -f $OUT/raw.txt
 grep -E "timing model|total forward|PRE_|TILE" $OUT/chol_trace_C5.txt
 rm -rf $R/gpurun_out/pmc
