@@ -1574,7 +1574,7 @@ struct ChainPanel {
   }
 };
 
-constexpr bool kSysPrefetch = false;
+[[maybe_unused]] constexpr bool kSysPrefetch = false;
 
 struct CholPersistArgs {
   const double* M; double* L; double* inv; double* pre;
@@ -1583,6 +1583,8 @@ struct CholPersistArgs {
   unsigned* lflag; unsigned* dflag; unsigned* pflag; unsigned* abort_flag;
   unsigned epoch;
   double* fail;
+  // the backward substitution as the launch's tail (round 5; bs_y == null: separate launch)
+  double* bs_y; unsigned* bs_flags; const int* bs_seg_of_tile; const int* bs_seg_first; int bs_nseg; const int* bs_scatter; double* bs_y_nat;
   int drop_wg;                // test hook (MAVBA_CHOL_TEST_DROP_WG): this work-group does nothing, as if it were never resident
   unsigned long long* trace;  // MAVBA_CHOL_TRACE: 100 MHz wall-clock stamps, [8 per chain column | 4 per task], else null
 };
@@ -1687,7 +1689,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
     TileRegs Rsub, Rdiag;
     bool have_next = false;  // Rsub / Rdiag hold column j's tiles
     bool next_in_lds = false;  // (systolic chain) wave 2 of the previous column has put them into As / the spare tile buffer
-    int sys_flip = 0;
+    [[maybe_unused]] int sys_flip = 0;
     for (int j = T.i; j < T.j; ++j) {
       const int info = A.chain_info[j];
       const bool sub = j > T.i;
@@ -1738,6 +1740,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         __syncthreads();
         stamp((size_t)8 * j + 2);
         stamp_clk((size_t)8 * j + 3); stamp((size_t)8 * j + 5);
+#if MAVBA_CHAIN_FUSED_PANEL
         ChainPanel cp;
         cp.As = As; cp.Cs = Pcur; cp.Pg = sub ? A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB : nullptr; cp.ld = ld;
         cp.lflag = sub ? A.lflag + A.tile_id[(size_t)j * nb + (j - 1)] : nullptr; cp.ep = ep; cp.sub = sub;
@@ -1755,6 +1758,11 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
           else { cp.next_diag = A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB; cp.next_diag_ld = ld; }
         }
         const bool ok = tile_potrf_inv_sys<NoMark, 0, ChainPanel>(Tcur, Bs, tid, NoMark(), cp);
+#else
+        // (the product build: only a node's FIRST column comes here - the plain tile factorisation, no panel code in the kernel)
+        (void)Pcur;
+        const bool ok = tile_potrf_inv_sys(Tcur, Bs, tid);
+#endif
         if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
         stamp_clk((size_t)8 * j + 4);
         stamp((size_t)8 * j + 6);
@@ -1869,6 +1877,100 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
     }
   }
   if (!alive && tid == 0) atomicAdd(A.fail, 1e30);
+  // ---- the backward substitution, same launch (round 5) ----
+  // k_chol_backsolve_all's rows, owned the same way (work-group b: rows nb-1-b, nb-1-b-G, ...), entered when this work-group's
+  // forward tasks are done. No cycle of waits: forward tasks never wait for a backward row, and a backward row waits for
+  // forward outputs and for rows ABOVE it only. What a separate launch got from the kernel boundary is explicit here: a row
+  // starts when its column's inverse and its right-hand-side tile are published (their flags), everything another CU wrote in
+  // THIS launch is read with system-scope loads, and the factor tiles of a row are complete once ANY x_i it needs is (x_i's
+  // owner waited for column i's inverse, and column i's diagonal tile needed every tile (i, k) before that).
+#ifdef MAVBA_BS_IN_LAUNCH  // (not in the product build: its mere presence costs the forward pass 1-2 us - scripts/_dbg/ab_bs_tail.sh)
+  if (A.bs_y != nullptr && alive) {
+    double (*part)[NB] = reinterpret_cast<double (*)[NB]>(As);   // 4 x NB
+    double (*xs)[16] = reinterpret_cast<double (*)[16]>(As + 4 * NB);
+    const double* z = A.L + (size_t)nb * NB * ld;
+    auto cload = [&](const double* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    for (int k = nb - 1 - (int)blockIdx.x; k >= 0 && alive; k -= (int)gridDim.x) {
+      if (!wait2(A.dflag + k, A.lflag + A.tile_id[(size_t)nb * nb + k])) { alive = false; break; }
+      const int sk = A.bs_seg_of_tile[k];
+      double acc = (wv == 0) ? cload(z + (size_t)k * NB + lane) : 0.0;
+      double li[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) li[q] = cload(A.inv + (size_t)k * NB * NB + (size_t)(16 * wv + q) * NB + lane);
+      int i = nb - 1;
+      while (i > k && A.bs_seg_first[i * A.bs_nseg + sk] > k) --i;
+      bool ok = true;
+      // (every wave polls for itself, as in the separate kernel; lane 0 decides, the wave follows)
+      auto wave_wait = [&](int row) {
+        int good = 1;
+        if (lane == 0) good = wait_flag(A.bs_flags + row, ep, A.abort_flag) ? 1 : 0;
+        return __builtin_amdgcn_readfirstlane(good) != 0;
+      };
+      double l[16];
+      if (i > k) {
+        ok = wave_wait(i);
+        const double* Lt = A.L + (size_t)i * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) l[q] = cload(Lt + (size_t)q * ld);
+      }
+      while (i > k && ok) {
+        int nx = i - 1;
+        while (nx > k && A.bs_seg_first[nx * A.bs_nseg + sk] > k) --nx;
+        double ln[16];
+        if (nx > k) {
+          const double* Lt = A.L + (size_t)nx * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) ln[q] = cload(Lt + (size_t)q * ld);
+        }
+        ok = wave_wait(i);
+        if (lane < 16) xs[wv][lane] = cload(A.bs_y + (size_t)i * NB + 16 * wv + lane);
+        wave_lds_sync();
+        const double* xi = xs[wv];
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          a0 = __builtin_fma(l[q], xi[q], a0);
+          a1 = __builtin_fma(l[q + 1], xi[q + 1], a1);
+        }
+        acc -= a0 + a1;
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) l[q] = ln[q];
+        i = nx;
+      }
+      part[wv][lane] = acc;
+      if (lane == 0 && !ok) s_ok = 0;  // (wait2 left 1 there; a wave whose wait was abandoned takes the whole work-group out)
+      __syncthreads();
+      if (s_ok == 0) { alive = false; break; }
+      const double r = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+      __syncthreads();
+      if (wv == 0) part[0][lane] = r;
+      __syncthreads();
+      double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        b0 = __builtin_fma(li[q], part[0][16 * wv + q], b0);
+        b1 = __builtin_fma(li[q + 1], part[0][16 * wv + q + 1], b1);
+      }
+      __syncthreads();
+      part[wv][lane] = b0 + b1;
+      __syncthreads();
+      if (wv == 0) {
+        const double x = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        __hip_atomic_store(A.bs_y + (size_t)k * NB + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(&A.bs_flags[k], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (A.bs_scatter) {
+          const int t = A.bs_scatter[k * NB + lane];
+          if (t >= 0) A.bs_y_nat[t] = x;
+        }
+      }
+      __syncthreads();
+    }
+    if (!alive && tid == 0) atomicAdd(A.fail, 1e30);
+  }
+#endif
 }
 
 void CholStructure::release() {
@@ -2691,12 +2793,27 @@ bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
     return with_update;
   }
   const unsigned epoch = ++cs.epoch;  // flags of this solve (forward hand-offs and backward substitution)
+  bool merged_backsolve = false;
   if (allow_persistent && cs.persist_ok) {
     CholPersistArgs A;
     A.M = M; A.L = L; A.inv = inv; A.pre = cs.d_pre; A.ld = ld; A.nb = nb;
     A.tasks = cs.d_tasks; A.wg_begin = cs.d_wg_begin; A.upd = cs.d_upd; A.tile_id = cs.d_tile_id; A.chain_info = cs.d_chain_info;
     A.lflag = cs.d_pflags; A.dflag = cs.d_pflags + cs.persist_tiles; A.pflag = A.dflag + nb; A.abort_flag = A.pflag + 2 * nb;
     A.epoch = epoch; A.fail = fail; A.trace = cs.d_trace;
+    // -DMAVBA_BS_IN_LAUNCH + MAVBA_CHOL_BACKSOLVE_IN_LAUNCH=1: the backward substitution as the tail of this launch (no second
+    // launch, no gap). Built in round 5 for the ~10 us of launch + gap, verified bit-identical to the separate launch, measured
+    // SLOWER and compiled out: inside the launch every factor tile has to be read with system-scope loads (another CU wrote it
+    // in the same launch; the separate kernel reads through the caches behind the kernel boundary) - C3 0.265 + 0.036 ->
+    // 0.310 + 0.005 ms, C2 0.105 + 0.015 -> 0.120 + 0.005 ms -, and the tail's mere presence in the kernel cost the forward
+    // pass 1-2 us (A/B in one visit, scripts/_dbg/ab_bs_tail.sh).
+#ifdef MAVBA_BS_IN_LAUNCH
+    const bool bs_in = [] { const char* e = std::getenv("MAVBA_CHOL_BACKSOLVE_IN_LAUNCH"); return e && std::atoi(e) != 0; }();
+#else
+    const bool bs_in = false;
+#endif
+    merged_backsolve = bs_in && nb <= kMaxBacksolveGroups && cs.persist_grid >= 1;
+    A.bs_y = merged_backsolve ? y : nullptr; A.bs_flags = cs.d_flags; A.bs_seg_of_tile = cs.d_seg_of_tile; A.bs_seg_first = cs.d_seg_first;
+    A.bs_nseg = cs.nseg; A.bs_scatter = y_scatter; A.bs_y_nat = y_nat;
     static const int drop = [] { const char* e = std::getenv("MAVBA_CHOL_TEST_DROP_WG"); return e ? std::atoi(e) : -1; }();
     A.drop_wg = drop;
     // Two persistent launches must never share the device (each needs every CU for its resident grid): launches of
@@ -2746,7 +2863,9 @@ bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
   }
   if (after_factor) (void)hipEventRecord(after_factor, st);
   double* z = L + (size_t)n_pad * ld;
-  if (nb <= kMaxBacksolveGroups) {
+  if (merged_backsolve) {
+    // (done inside k_chol_persist)
+  } else if (nb <= kMaxBacksolveGroups) {
     const int cus = device_cu_count();
     hipLaunchKernelGGL(k_chol_backsolve_all, dim3(std::min(nb, cus > 0 ? 2 * cus : 64)), dim3(256), 0, st, L, ld, nb, cs.nseg, cs.d_seg_of_tile, cs.d_seg_first,
                        inv, z, y, cs.d_flags, epoch, y_scatter, y_nat);

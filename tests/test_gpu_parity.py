@@ -716,3 +716,4 @@ def test_merged_evaluation_tail_of_a_large_problem_equals_the_four_launches(mavb
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+
