@@ -2466,6 +2466,11 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
     }
     // (round 5: directional derivatives instead of the full Jacobian - obs_backsub_term, ba_math.h)
     double r[2], tt[3];
+#ifndef MAVBA_BS_SKIP  // (timing-only builds, scripts/_dbg/backsub_variants.sh: 1 = no arithmetic, 2 = no owner summation)
+#define MAVBA_BS_SKIP 0
+#endif
+    if (MAVBA_BS_SKIP & 1) { r[0] = rec[0] + kin[0] + dc[0] + dk[0]; r[1] = X[0] + q.m.x; tt[0] = rec[3]; tt[1] = X[1]; tt[2] = q.m.y; }
+    else
     obs_backsub_term(model, rec, kin, X, q.m.x, q.m.y, dc, dk, r, tt);
     double w, half_rho;
     cauchy_weight(r[0] * r[0] + r[1] * r[1], loss_b, loss_inv_b, w, half_rho);
@@ -2523,7 +2528,7 @@ __global__ void __launch_bounds__(256) k_backsub_points_packed(
       s_t[0][tid] = t[0]; s_t[1][tid] = t[1]; s_t[2][tid] = t[2];
       __syncthreads();
       if (owner) {
-        const int b = max(mb, base), e = min(me, base + 256);
+        const int b = max(mb, base), e = (MAVBA_BS_SKIP & 2) ? min(me, max(mb, base) + 1) : min(me, base + 256);
         for (int i = b; i < e; ++i) { T[0] += s_t[0][i - base]; T[1] += s_t[1][i - base]; T[2] += s_t[2][i - base]; }
       }
       __syncthreads();
