@@ -65,6 +65,32 @@ MAVBA_HD void cam_prepare(const double* pose, double* rec) {
   rec[6] = a; rec[7] = b; rec[8] = c;
 }
 
+// 1 / x and 1 / sqrt(x) per observation (round 5). The IEEE division and sqrt + division of the device build are 20-35
+// FP64 instructions each on a pipe that every per-observation kernel is bound by; the hardware seeds (v_rcp_f64 / v_rsq_f64,
+// ~2^-24 relative) with two Newton steps / one third-order step are 5-6 and end within 1-2 ulp (measured for the rsqrt:
+// 1.4e-16 against 1.1e-16 correctly rounded, scripts/_dbg/tile_bench.hip). Host builds (tests, the fixed-cost blocks) keep
+// the IEEE forms: the two agree to ~2e-16, far inside every tolerance of the parity tests.
+MAVBA_HD double rcp_obs(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+#else
+  return 1.0 / x;
+#endif
+}
+MAVBA_HD double rsqrt_obs(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  const double h = __builtin_fma(-(x * y), y, 1.0);
+  return __builtin_fma(y * h, __builtin_fma(0.375, h, 0.5), y);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 // out = m x w
 MAVBA_HD void cross3(const double* m, const double* w, double* out) {
   out[0] = m[1] * w[2] - m[2] * w[1];
@@ -96,7 +122,7 @@ MAVBA_HD void project(int model, const double* cam, const double* Xc, double& u,
     nrm = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
     zz = Xc[2] + cam[8] * nrm;
   }
-  const double iz = 1.0 / zz;
+  const double iz = rcp_obs(zz);
   const double un = Xc[0] * iz, vn = Xc[1] * iz;
   double ud = un, vd = vn;
   double D0 = 1.0, D1 = 0.0, D2 = 0.0, D3 = 1.0;  // d(ud,vd)/d(un,vn)
@@ -155,7 +181,7 @@ MAVBA_HD void project_dk(int model, const double* cam, const double* Xc, const d
     nrm = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
     zz = Xc[2] + cam[8] * nrm;
   }
-  const double iz = 1.0 / zz;
+  const double iz = rcp_obs(zz);
   const double un = Xc[0] * iz, vn = Xc[1] * iz;
   double ud = un, vd = vn;
   double D0 = 1.0, D1 = 0.0, D2 = 0.0, D3 = 1.0;
@@ -270,7 +296,7 @@ MAVBA_HD void obs_backsub_term(int model, const double* rec, const double* cam, 
 MAVBA_HD void cauchy_weight(double s, double b, double inv_b, double& w, double& half_rho) {
   const double sum = 1.0 + s * inv_b;
   half_rho = 0.5 * b * log(sum);
-  w = 1.0 / sqrt(sum);
+  w = rsqrt_obs(sum);
 }
 
 // ---------------------------------------------------------------------------
