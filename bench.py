@@ -369,7 +369,7 @@ def main():
         dominant = next((r for r in table if r.get("bound")), None)
         mdl = info.get("chol_model_forward_us", 0.0)
         chain_note = (f" (persistent launch: the host-side timing model that fills its task queues predicts {mdl:.0f} us for the forward pass"
-                      f" - 12.2 us per dependent tile column, 9-12 us per child -> parent hand-off, profiles/r04_chol_trace_C3.txt)") if mdl > 0 else \
+                      f" - 12.2 us per dependent tile column, 9-12 us per child -> parent hand-off, profiles/r05_chol_trace_C3.txt)") if mdl > 0 else \
                      f" (launch-per-panel schedule: {info['chain_steps']} dependent 64-column panel steps)"
         roofline = None
         if dominant:
