@@ -765,7 +765,10 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
   MAVBA_TRY
   if (device >= 0) HIP_OK(hipSetDevice(device));
   hipStream_t st;
-  HIP_OK(hipStreamCreate(&st));
+  HIP_OK(stream_acquire(&st));  // (the cached stream the sessions use: a process that solves one thing at a time stays on one stream)
+  int st_dev = 0;
+  (void)hipGetDevice(&st_dev);
+  struct Release { hipStream_t st; int dev; ~Release() { (void)hipStreamSynchronize(st); release_staged(st); stream_release(st, dev); } } rel{st, st_dev};
   const int n_pad = std::max(64, round_up(n, 64));
   std::vector<double> M((size_t)(n_pad + 64) * n_pad, 0.0);
   for (int i = 0; i < n_pad; ++i) M[(size_t)i * n_pad + i] = 1.0;
@@ -791,7 +794,6 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
     std::memcpy(x, y.data(), (size_t)n * 8);
     if (fail != 0.0) { g_last_error = "matrix is not positive definite"; rc = MAVBA_ERR_INVALID_ARGUMENT; }
   }
-  (void)hipStreamDestroy(st);
   return rc;
   MAVBA_CATCH
 }

@@ -2816,17 +2816,29 @@ bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
     A.bs_nseg = cs.nseg; A.bs_scatter = y_scatter; A.bs_y_nat = y_nat;
     static const int drop = [] { const char* e = std::getenv("MAVBA_CHOL_TEST_DROP_WG"); return e ? std::atoi(e) : -1; }();
     A.drop_wg = drop;
-    // Two persistent launches must never share the device (each needs every CU for its resident grid): launches of
-    // this process - sessions on other streams / threads - are chained through an event.
+    // Two persistent launches must never share the device (each needs every CU for its resident grid). Launches on ONE stream
+    // are ordered by the stream; as soon as a second stream of this process launches one (sessions on other threads), the
+    // device is drained once and from then on every launch waits for the previous one's event and records its own. A process
+    // that only ever uses one stream per device - MAVMAP's serial calls: the stream cache hands the same one to every session -
+    // never pays for the event: recorded between this launch and the back-substitution it cost 4-5 us per solve (round 5,
+    // A/B in one visit: C2 3 891 -> 3 954 iter/s). The remembered stream is only compared, never used.
     {
       static std::mutex chain_m;
       static hipEvent_t last[64] = {};
+      static hipStream_t only_stream[64] = {};
+      static bool chained[64] = {};
       int dev = 0;
       (void)hipGetDevice(&dev);
+      const bool tracked = dev >= 0 && dev < 64;
       std::lock_guard<std::mutex> g(chain_m);
-      if (dev >= 0 && dev < 64 && last[dev]) (void)hipStreamWaitEvent(st, last[dev], 0);
+      if (tracked && !chained[dev]) {
+        if (!only_stream[dev]) only_stream[dev] = st;
+        else if (only_stream[dev] != st) { chained[dev] = true; (void)hipDeviceSynchronize(); }
+      }
+      const bool chain = tracked && chained[dev];
+      if (chain && last[dev]) (void)hipStreamWaitEvent(st, last[dev], 0);
       hipLaunchKernelGGL(k_chol_persist, dim3(cs.persist_grid), dim3(256), 0, st, A);
-      if (dev >= 0 && dev < 64) {
+      if (chain) {
         if (!last[dev]) (void)hipEventCreateWithFlags(&last[dev], hipEventDisableTiming);
         if (last[dev]) (void)hipEventRecord(last[dev], st);
       }
