@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <iterator>
 #include <mutex>
 #include <type_traits>
 
@@ -2240,6 +2241,14 @@ int device_cu_count() {
 hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& col_rows, const std::vector<int>& col_step,
                                            const std::vector<int>& height, hipStream_t st) {
   persist_ok = false;
+  const bool sched_debug = std::getenv("MAVBA_CHOL_SCHED_DEBUG") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!sched_debug) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "mavba:   schedule builder: %-28s %8.3f ms\n", what, 1e3 * std::chrono::duration<double>(t - t_last).count());
+    t_last = t;
+  };
   // MAVBA_CHOL_PERSIST: 0 = never, 1 (default) = when it pays, 2 = whenever a schedule exists
   static const int mode = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST"); return e ? std::atoi(e) : 1; }();
   const bool enabled = mode != 0;
@@ -2273,6 +2282,7 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   }
   for (auto& l : upd_of)
     std::sort(l.begin(), l.end(), [&](int a, int b) { return col_step[a] != col_step[b] ? col_step[a] < col_step[b] : a < b; });
+  lap("update lists");
   // ---- a timing model of the launch (round 4) ----
   // The order of a tile's updates and the place of every task in the helpers' queues used to follow the launch-per-panel
   // step of the columns - the same number for the s-th columns of ALL nodes of a tree level. On C3's critical path that cost
@@ -2299,10 +2309,13 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     return r;
   };
   // one task's run from `start` on: its updates in list order (each waits for its inputs); returns the end of the update phase
-  auto run_updates = [&](const Times& T, int i, int j, const std::vector<int>& list, size_t count, double start) {
+  auto run_updates_at = [&](const Times& T, int i, int j, const int* list, size_t count, double start) {
     double f = start;
     for (size_t q = 0; q < count; ++q) f = std::max(f, in_ready(T, i, j, list[q])) + cU;
     return f;
+  };
+  auto run_updates = [&](const Times& T, int i, int j, const std::vector<int>& list, size_t count, double start) {
+    return run_updates_at(T, i, j, list.data(), count, start);
   };
   auto own_updates = [&](int j) {  // the diagonal tile's list without the chain's own (last) update
     const int n = seg_of_tile[j];
@@ -2356,6 +2369,7 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     }
   }
   ideal_pass(ideal);
+  lap("ideal passes + list order");
   // ---- tasks ----
   struct Gen { CholTask t; long long key; int level; long long work; };
   std::vector<Gen> gen;
@@ -2397,6 +2411,7 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   }
   const int helpers = (int)std::min<long long>(G - nch, (long long)gen.size());
   if (helpers < 1) return hipSuccess;
+  lap("tasks");
   // ---- list scheduling of the helper tasks on the simulated launch ----
   // Tasks and chain columns are visited in the order of their finishing times on unlimited helpers (`ideal`): every input of
   // a task finishes earlier there, so it has been placed - and given its time on the real number of helpers - before the task
@@ -2405,7 +2420,7 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   // not know) - or, if none is, to the one that is free first. A work-group runs its queue in this order and every wait is
   // for something that is earlier in it: no cycle of waits, whatever the real timing turns out to be.
   struct Event { double t; int chain; int idx; };  // idx: column (chain) or index into gen
-  struct Pass { Times act; std::vector<std::vector<CholTask>> helper_tasks; double forward = 0.0; bool ok = false; };
+  struct Pass { Times act; std::vector<std::pair<int, int>> placed; double forward = 0.0; bool ok = false; };  // placed: (helper, task) in visiting order
   auto forward_of = [&](const Times& T) {
     double f = 0.0;
     for (int j = 0; j < nb; ++j) f = std::max(f, T.col_fin[j]);
@@ -2413,63 +2428,59 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
     return f;
   };
   struct OrderKeys { std::vector<double> task, begin, fin; };  // visiting times other than the estimate's own (null: those)
-  auto run_pass = [&](const Times& est, Pass& P, int pre_pool, const OrderKeys* keys) {
-  std::vector<Event> events;
-  std::vector<double> upd_end(gen.size(), 0.0);  // end of the task's update phase in `est` when started at time 0
-  for (size_t g = 0; g < gen.size(); ++g) {
-    const CholTask& t = gen[g].t;
-    std::vector<int> list(upd.begin() + t.ub, upd.begin() + t.ue);
-    upd_end[g] = run_updates(est, t.i, t.j, list, list.size(), 0.0);
-    const double fin = t.kind == CHOL_TASK_TILE ? est.L[tile_id[(size_t)t.i * nb + t.j]] : est.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1];
-    events.push_back(Event{keys ? keys->task[g] : fin, 0, (int)g});
-  }
-  // (a chain column is two events: its begin - from then on its own panel tile is on its way, tasks that multiply with it may
-  // be visited before the column ends - and its end; at equal times: ends, then helper tasks, then begins)
-  for (int j = 0; j < nb; ++j) {
-    events.push_back(Event{keys ? keys->fin[j] : est.col_fin[j], 1, j});
-    events.push_back(Event{keys ? keys->begin[j] : est.col_begin[j], 2, j});
-  }
-  std::stable_sort(events.begin(), events.end(), [&](const Event& x, const Event& y) {
-    if (x.t != y.t) return x.t < y.t;
-    const int rx = x.chain == 1 ? 0 : (x.chain == 0 ? 1 : 2), ry = y.chain == 1 ? 0 : (y.chain == 0 ? 1 : 2);
-    if (rx != ry) return rx < ry;
-    return x.idx < y.idx;
-  });
-  Times& act = P.act;
-  act.L.assign((size_t)nt, 0.0); act.col_begin.assign(nb, 0.0); act.col_fin.assign(nb, 0.0); act.pre.assign((size_t)2 * nb, 0.0);
-  std::vector<double> free_at(helpers, 0.0);
-  double work_us = 0.0, occupied_us = 0.0;
-  std::vector<std::vector<CholTask>>& helper_tasks = P.helper_tasks;
-  helper_tasks.assign(helpers, {});
-  // Self-check of the order (the property the dead-lock argument rests on, verified instead of trusted): `placed` = position in
-  // the visiting order at which a tile / a PRE slot / a column's inverse is produced; everything a task or a chain column
-  // waits for must have been placed before it. A violation (a tie, a NaN in the model after some future change) does not
-  // become a hung launch: the structure keeps the launch-per-panel schedule and says so.
-  std::vector<int> placed_tile((size_t)nt, -1), placed_pre((size_t)2 * nb, -1), placed_col(nb, -1), placed_begin(nb, -1);
-  bool order_ok = true;
-  int position = 0;
-  auto produced = [&](int where) { if (where < 0) order_ok = false; };
-  for (const Event& ev : events) {
-    ++position;
-    if (ev.chain == 2) {  // column j begins: everything it waits for has been placed; its own panel tile is produced from here on
-      const int j = ev.idx, n = seg_of_tile[j];
-      const bool first = j == nodes[n].begin;
-      if (first) { for (int c : children[n]) produced(placed_col[nodes[c].end - 1]); }
-      else produced(placed_col[j - 1]);
-      if (chain_info[j] & 1) produced(placed_pre[2 * j]);
-      if (chain_info[j] & 2) produced(placed_pre[2 * j + 1]);
-      placed_begin[j] = position;
-      if (!first) placed_tile[tile_id[(size_t)j * nb + (j - 1)]] = position;
-      chain_begin(act, j);
-      continue;
+  // A visiting order = the events sorted by their times (the estimate's own, or `keys`), the end of every task's update phase in
+  // the estimate when started at time 0, and the self-check of the order - all of it the same for every pool size that is
+  // simulated on this order, so it is made once (it was two thirds of a pass).
+  struct Order { std::vector<Event> events; std::vector<double> upd_end; bool ok = false; };
+  auto make_order = [&](const Times& est, const OrderKeys* keys, Order& O) {
+    std::vector<Event>& events = O.events;
+    events.clear();
+    events.reserve(gen.size() + 2 * (size_t)nb);
+    O.upd_end.assign(gen.size(), 0.0);
+    for (size_t g = 0; g < gen.size(); ++g) {
+      const CholTask& t = gen[g].t;
+      O.upd_end[g] = run_updates_at(est, t.i, t.j, upd.data() + t.ub, (size_t)(t.ue - t.ub), 0.0);
+      const double fin = t.kind == CHOL_TASK_TILE ? est.L[tile_id[(size_t)t.i * nb + t.j]] : est.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1];
+      events.push_back(Event{keys ? keys->task[g] : fin, 0, (int)g});
     }
-    if (ev.chain == 1) {  // column j ends: its inverse is published
-      produced(placed_begin[ev.idx]);
-      placed_col[ev.idx] = position;
-      chain_end(act, ev.idx);
-      continue;
+    // (a chain column is two events: its begin - from then on its own panel tile is on its way, tasks that multiply with it may
+    // be visited before the column ends - and its end; at equal times: ends, then helper tasks, then begins)
+    for (int j = 0; j < nb; ++j) {
+      events.push_back(Event{keys ? keys->fin[j] : est.col_fin[j], 1, j});
+      events.push_back(Event{keys ? keys->begin[j] : est.col_begin[j], 2, j});
     }
-    {
+    std::stable_sort(events.begin(), events.end(), [&](const Event& x, const Event& y) {
+      if (x.t != y.t) return x.t < y.t;
+      const int rx = x.chain == 1 ? 0 : (x.chain == 0 ? 1 : 2), ry = y.chain == 1 ? 0 : (y.chain == 0 ? 1 : 2);
+      if (rx != ry) return rx < ry;
+      return x.idx < y.idx;
+    });
+    // Self-check of the order (the property the dead-lock argument rests on, verified instead of trusted): `placed` = position in
+    // the visiting order at which a tile / a PRE slot / a column's inverse is produced; everything a task or a chain column
+    // waits for must have been placed before it. A violation (a tie, a NaN in the model after some future change) does not
+    // become a hung launch: the structure keeps the launch-per-panel schedule and says so.
+    std::vector<int> placed_tile((size_t)nt, -1), placed_pre((size_t)2 * nb, -1), placed_col(nb, -1), placed_begin(nb, -1);
+    bool order_ok = true;
+    int position = 0;
+    auto produced = [&](int where) { if (where < 0) order_ok = false; };
+    for (const Event& ev : events) {
+      ++position;
+      if (ev.chain == 2) {  // column j begins: everything it waits for has been placed; its own panel tile is produced from here on
+        const int j = ev.idx, n = seg_of_tile[j];
+        const bool first = j == nodes[n].begin;
+        if (first) { for (int c : children[n]) produced(placed_col[nodes[c].end - 1]); }
+        else produced(placed_col[j - 1]);
+        if (chain_info[j] & 1) produced(placed_pre[2 * j]);
+        if (chain_info[j] & 2) produced(placed_pre[2 * j + 1]);
+        placed_begin[j] = position;
+        if (!first) placed_tile[tile_id[(size_t)j * nb + (j - 1)]] = position;
+        continue;
+      }
+      if (ev.chain == 1) {  // column j ends: its inverse is published
+        produced(placed_begin[ev.idx]);
+        placed_col[ev.idx] = position;
+        continue;
+      }
       auto tile_there = [&](int r, int k) { produced(placed_tile[tile_id[(size_t)r * nb + k]]); };
       const CholTask& c = gen[ev.idx].t;
       for (int u = c.ub; u < c.ue; ++u) {
@@ -2479,37 +2490,62 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
       if (c.kind == CHOL_TASK_TILE) { produced(placed_col[c.j]); placed_tile[tile_id[(size_t)c.i * nb + c.j]] = position; }
       else placed_pre[c.kind == CHOL_TASK_PRE_DIAG ? 2 * c.j : 2 * c.i + 1] = position;
     }
-    const CholTask& t = gen[ev.idx].t;
-    const int n_upd = t.ue - t.ub;
-    const double release = std::max(0.0, upd_end[ev.idx] - cU * n_upd - 10.0);
-    // (pre_pool > 0: the first pre_pool helpers take the PRE tasks - what the chains wait for directly - and nothing else)
-    const int w0 = pre_pool > 0 && t.kind == CHOL_TASK_TILE ? pre_pool : 0;
-    const int w1 = pre_pool > 0 && t.kind != CHOL_TASK_TILE ? pre_pool : helpers;
-    int best = -1, first_free = w0;
-    for (int w = w0; w < w1; ++w) {
-      if (free_at[w] < free_at[first_free]) first_free = w;
-      if (free_at[w] <= release && (best < 0 || free_at[w] > free_at[best])) best = w;
+    O.ok = order_ok;
+  };
+  // The launch on `helpers` work-groups, the tasks visited in the order O (pre_pool > 0: the first pre_pool helpers take the
+  // PRE tasks - what the chains wait for directly - and nothing else).
+  auto run_pass = [&](const Order& O, Pass& P, int pre_pool) {
+    Times& act = P.act;
+    act.L.assign((size_t)nt, 0.0); act.col_begin.assign(nb, 0.0); act.col_fin.assign(nb, 0.0); act.pre.assign((size_t)2 * nb, 0.0);
+    std::vector<double> free_at(helpers, 0.0);
+    // The helpers of a pool kept sorted by (free time ascending, index DESCENDING) in one small array: the two choices below -
+    // the helper that is free latest among those free by `release`, else the one that is free first, the lowest index among
+    // equals both times - are the last element of a prefix and the last element of the first group of equals; the chosen
+    // helper's new time moves it up by one rotation (instead of a scan of all helpers per task).
+    struct FreeKey { double t; int w; };
+    auto free_less = [](const FreeKey& a, const FreeKey& b) { return a.t != b.t ? a.t < b.t : a.w > b.w; };
+    std::vector<FreeKey> pool_free[2];  // [0]: the PRE pool (helpers [0, pre_pool)), [1]: the others
+    for (int w = helpers - 1; w >= 0; --w) pool_free[w < pre_pool ? 0 : 1].push_back(FreeKey{0.0, w});
+    double work_us = 0.0, occupied_us = 0.0;
+    P.placed.clear();
+    P.placed.reserve(gen.size());
+    for (const Event& ev : O.events) {
+      if (ev.chain == 2) { chain_begin(act, ev.idx); continue; }
+      if (ev.chain == 1) { chain_end(act, ev.idx); continue; }
+      const CholTask& t = gen[ev.idx].t;
+      const int n_upd = t.ue - t.ub;
+      const double release = std::max(0.0, O.upd_end[ev.idx] - cU * n_upd - 10.0);
+      std::vector<FreeKey>& pool = pool_free[pre_pool > 0 && t.kind != CHOL_TASK_TILE ? 0 : 1];
+      // latest free time <= release, lowest index among equals: the element before the first one that is free later
+      auto it = std::upper_bound(pool.begin(), pool.end(), FreeKey{release, -1}, free_less);
+      // (none is free by then: the earliest, lowest index among equals)
+      if (it == pool.begin()) it = std::upper_bound(pool.begin(), pool.end(), FreeKey{pool.front().t, -1}, free_less);
+      --it;
+      const int best = it->w;
+      double f = run_updates_at(act, t.i, t.j, upd.data() + t.ub, (size_t)n_upd, free_at[best]);
+      if (t.kind == CHOL_TASK_TILE) {
+        f = std::max(f, act.col_fin[t.j]) + cS;
+        act.L[tile_id[(size_t)t.i * nb + t.j]] = f;
+      } else {
+        f += cP;
+        act.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1] = f;
+      }
+      work_us += cU * n_upd + (t.kind == CHOL_TASK_TILE ? cS : cP);
+      occupied_us += f - free_at[best];
+      free_at[best] = f;
+      {  // its new place: times only grow, so it moves towards the end
+        const FreeKey moved{f, best};
+        auto to = std::upper_bound(it + 1, pool.end(), moved, free_less);
+        std::move(it + 1, to, it);
+        *(to - 1) = moved;
+      }
+      P.placed.push_back({best, ev.idx});
     }
-    if (best < 0) best = first_free;
-    std::vector<int> list(upd.begin() + t.ub, upd.begin() + t.ue);
-    double f = run_updates(act, t.i, t.j, list, list.size(), free_at[best]);
-    if (t.kind == CHOL_TASK_TILE) {
-      f = std::max(f, act.col_fin[t.j]) + cS;
-      act.L[tile_id[(size_t)t.i * nb + t.j]] = f;
-    } else {
-      f += cP;
-      act.pre[t.kind == CHOL_TASK_PRE_DIAG ? 2 * t.j : 2 * t.i + 1] = f;
-    }
-    work_us += cU * n_upd + (t.kind == CHOL_TASK_TILE ? cS : cP);
-    occupied_us += f - free_at[best];
-    free_at[best] = f;
-    helper_tasks[best].push_back(t);
-  }
-  if (std::getenv("MAVBA_CHOL_SCHED_DEBUG"))  // (C5: 283 ms of work, 374 ms occupied - 90 ms waiting inside tasks -, 252 helpers x 1.99 ms = 501 ms)
-    std::fprintf(stderr, "mavba:   %d helpers for the PRE tasks: work %.0f us, occupied %.0f us, helpers x forward %.0f us\n", pre_pool, work_us,
-                 occupied_us, helpers * forward_of(act));
-  P.ok = order_ok;
-  P.forward = forward_of(act);
+    if (sched_debug)  // (C5: 283 ms of work, 374 ms occupied - 90 ms waiting inside tasks -, 252 helpers x 1.99 ms = 501 ms)
+      std::fprintf(stderr, "mavba:   %d helpers for the PRE tasks: work %.0f us, occupied %.0f us, helpers x forward %.0f us\n", pre_pool, work_us,
+                   occupied_us, helpers * forward_of(act));
+    P.ok = O.ok;
+    P.forward = forward_of(act);
   };
   // The PRE tasks are what the chains wait for directly. Besides the shared pool (0) a few sizes of a pool of helpers that take
   // ONLY them are simulated and the shortest launch is kept (C3: no difference from 32 helpers on, shared pool kept; C5: 32 helpers
@@ -2519,12 +2555,28 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   {
     int npre = 0;
     for (const Gen& g : gen) npre += g.t.kind != CHOL_TASK_TILE;
-    for (int pool : {0, 4, 8, 16, 32, 64, 96}) {
-      if (pool > 0 && (pool >= helpers - 1 || pool > npre || npre == (int)gen.size())) continue;
-      Pass P;
-      run_pass(ideal, P, pool, nullptr);
+    // (the candidates are independent simulations: one host thread each where a pass is long enough to pay for waking the
+    // workers - C5: ~1 ms per pass, C3: 0.07 ms -; the choice among them goes in the fixed order)
+    Order order;
+    auto run_candidates = [&](const std::vector<int>& pools, const OrderKeys* keys, std::vector<Pass>& cand) {
+      cand.assign(pools.size(), Pass{});
+      make_order(ideal, keys, order);
+      const int T = gen.size() >= 2000 ? std::max(1, std::min(host_threads(), (int)pools.size())) : 1;
+      host_run(T, [&](int t) {
+        for (size_t q = (size_t)t; q < pools.size(); q += (size_t)T) {
+          const int pool = pools[q];
+          if (pool > 0 && (pool >= helpers - 1 || pool > npre || npre == (int)gen.size())) continue;
+          run_pass(order, cand[q], pool);
+        }
+      });
+    };
+    const std::vector<int> pools = {0, 4, 8, 16, 32, 64, 96};
+    std::vector<Pass> cand;
+    run_candidates(pools, nullptr, cand);
+    for (size_t q = 0; q < pools.size(); ++q) {
+      Pass& P = cand[q];
       if (!P.ok) continue;
-      if (std::getenv("MAVBA_CHOL_SCHED_DEBUG")) std::fprintf(stderr, "mavba: schedule with %d helpers for the PRE tasks: forward %.1f us\n", pool, P.forward);
+      if (sched_debug) std::fprintf(stderr, "mavba: schedule with %d helpers for the PRE tasks: forward %.1f us\n", pools[q], P.forward);
       if (!best_pass.ok || P.forward < best_pass.forward) best_pass = std::move(P);
     }
     // Where the helpers are the bottleneck (the launch takes much longer than on unlimited helpers) the ORDER of the visit matters:
@@ -2582,18 +2634,20 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
           need_pre[2 * j + 1] = std::min(need_pre[2 * j + 1], lb);
         }
       }
-      for (int pool : {0, 32}) {
-        if (pool > 0 && (pool >= helpers - 1 || pool > npre || npre == (int)gen.size())) continue;
-        Pass P;
-        run_pass(ideal, P, pool, &K);
+      const std::vector<int> pools2 = {0, 32};
+      run_candidates(pools2, &K, cand);
+      for (size_t q = 0; q < pools2.size(); ++q) {
+        Pass& P = cand[q];
         if (!P.ok) continue;
-        if (std::getenv("MAVBA_CHOL_SCHED_DEBUG")) std::fprintf(stderr, "mavba: latest-finish order, %d helpers for the PRE tasks: forward %.1f us\n", pool, P.forward);
+        if (sched_debug) std::fprintf(stderr, "mavba: latest-finish order, %d helpers for the PRE tasks: forward %.1f us\n", pools2[q], P.forward);
         if (P.forward < 0.98 * best_pass.forward) best_pass = std::move(P);
       }
     }
   }
+  lap("list scheduling passes");
   const bool order_ok = best_pass.ok;
-  std::vector<std::vector<CholTask>>& helper_tasks = best_pass.helper_tasks;
+  std::vector<std::vector<CholTask>> helper_tasks(helpers);  // the helpers' queues of the pass that is kept, in visiting order
+  for (const auto& hp : best_pass.placed) helper_tasks[hp.first].push_back(gen[hp.second].t);
   Times& act = best_pass.act;
   if (!order_ok) {
     std::fprintf(stderr, "mavba: the persistent factorisation's task order failed its self-check; using the launch-per-panel schedule\n");
@@ -2636,6 +2690,7 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   const size_t o_ci = pack.size();
   pack.insert(pack.end(), chain_info.begin(), chain_info.end());
   const size_t nflags = (size_t)nt + 3 * (size_t)nb + 1;
+  lap("queues");
   if (host_only) {  // (the test entry reads the schedule from these)
     h_tasks = tasks; h_wg_begin = wg_begin; h_upd = upd; h_chain_info = chain_info;
     persist_grid = grid; persist_chain_wgs = nch; persist_tiles = nt; persist_updates = nupd;

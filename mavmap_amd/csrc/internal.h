@@ -7,6 +7,7 @@
 
 #include <utility>
 #include <vector>
+#include <functional>
 
 namespace mavba {
 
@@ -341,6 +342,9 @@ void device_free(void* p);
 hipError_t copy_h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t st);       // asynchronous; staging released by release_staged
 hipError_t copy_d2h_staged_sync(void* dst, const void* src, size_t bytes, hipStream_t st);  // returns with the data in dst
 void release_staged(hipStream_t st);  // call behind a synchronisation of st
+// host worker threads of the set-up passes (host_util.hip): body(0 .. T-1), T <= host_threads(); calls are serialised, never nest them
+int host_threads();
+void host_run(int T, const std::function<void(int)>& body);
 
 // ---- dense SPD solve (dense_chol.hip) --------------------------------------
 // M: (n_pad + 64) x n_pad row-major, n_pad % 64 == 0. Rows [0, n_pad) hold the
