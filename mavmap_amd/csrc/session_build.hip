@@ -1114,9 +1114,19 @@ void mavba_session::finish_structure() {
     count[k].assign(nkeys[k], 0);
     mandatory[k].assign(nkeys[k], 0);
     if (generic_points > 0) {
-      for (int t = 0; t < T; ++t)
-        for (size_t key = 0; key < nkeys[k]; ++key) count[k][key] += tcount[t * 3 + k][key];
-      for (size_t key = 0; key < nkeys[k]; ++key) tot[k] += count[k][key];
+      // (dense tables of NI x NI keys per thread: at C5 - 4 M keys, 8 threads - summing them on one thread was ~15 ms of the set-up)
+      std::mutex tot_m;
+      parallel_ranges((long long)nkeys[k], [&](long long b0, long long b1) {
+        long long sum = 0;
+        for (long long key = b0; key < b1; ++key) {
+          int c = 0;
+          for (int t = 0; t < T; ++t) c += tcount[t * 3 + k][(size_t)key];
+          count[k][(size_t)key] = c;
+          sum += c;
+        }
+        std::lock_guard<std::mutex> g(tot_m);
+        tot[k] += sum;
+      }, 1 << 18);
     }
   }
   for (int i = 0; i < NI; ++i) {
@@ -1167,8 +1177,23 @@ void mavba_session::finish_structure() {
   for (int k = 0; k < 3; ++k) {
     cursor[k].assign(count[k].size(), 0);
     std::vector<size_t> keys;
-    for (size_t key = 0; key < count[k].size(); ++key)
-      if (count[k][key] != 0 || mandatory[k][key] || cref[k][key] != 0) keys.push_back(key);
+    {
+      // (ascending keys; fixed slices gathered by the host threads and joined in order)
+      const long long nk = (long long)count[k].size();
+      const int slices = nk >= (1 << 18) ? 64 : 1;
+      std::vector<std::vector<size_t>> part(slices);
+      parallel_ranges(slices, [&](long long s0, long long s1) {
+        for (long long sl = s0; sl < s1; ++sl) {
+          const long long b0 = nk * sl / slices, b1 = nk * (sl + 1) / slices;
+          for (long long key = b0; key < b1; ++key)
+            if (count[k][(size_t)key] != 0 || mandatory[k][(size_t)key] || cref[k][(size_t)key] != 0) part[sl].push_back((size_t)key);
+        }
+      }, 2);
+      size_t total = 0;
+      for (const auto& v : part) total += v.size();
+      keys.reserve(total);
+      for (const auto& v : part) keys.insert(keys.end(), v.begin(), v.end());
+    }
     if (k == BLK_PP || k == BLK_IP) {
       // (the order as one precomputed integer per block: the comparator with its divisions was 1 ms of the C3 set-up)
       const unsigned long long nc = (unsigned long long)ncols[k];
@@ -1228,10 +1253,12 @@ void mavba_session::finish_structure() {
   // per-thread cursors: block offset + what the threads owning earlier points put into the block
   if (generic_points > 0) {
     for (int k = 0; k < 3; ++k)
-      for (size_t key = 0; key < nkeys[k]; ++key) {
-        int run = cursor[k][key];
-        for (int t = 0; t < T; ++t) { const int c = tcount[t * 3 + k][key]; tcount[t * 3 + k][key] = run; run += c; }
-      }
+      parallel_ranges((long long)nkeys[k], [&](long long b0, long long b1) {
+        for (long long key = b0; key < b1; ++key) {
+          int run = cursor[k][(size_t)key];
+          for (int t = 0; t < T; ++t) { const int c = tcount[t * 3 + k][(size_t)key]; tcount[t * 3 + k][(size_t)key] = run; run += c; }
+        }
+      }, 1 << 18);
     run_threads([&](int t) {
       enumerate(range[t], range[t + 1], [&](int kind, int r, int c, int x, int y) {
         terms[kind][(size_t)tcount[t * 3 + kind][(size_t)r * ncols[kind] + c]++] = make_int2(x, y);
