@@ -18,11 +18,14 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -39,18 +42,63 @@ int host_threads() {
   }();
   return n;
 }
+// The threads are started once and kept (a bundle_adjustment() call has six parallel passes; starting and joining 31 threads
+// for each of them was milliseconds of a 40 ms call). job(t) runs on worker t = 1 .. T-1 while the caller does t = 0; calls
+// are serialised. The pool is never destroyed: its threads may outlive static destruction.
+class Workers {
+  std::mutex m, run_m;
+  std::condition_variable cv_start, cv_done;
+  const std::function<void(int)>* job = nullptr;
+  int job_T = 0, remaining = 0;
+  unsigned long long generation = 0;
+  int n = 0;
+  void loop(int id) {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_start.wait(lk, [&] { return generation != seen; });
+      seen = generation;
+      if (id < job_T) {
+        const std::function<void(int)>* j = job;
+        lk.unlock();
+        (*j)(id);
+        lk.lock();
+        if (--remaining == 0) cv_done.notify_one();
+      }
+    }
+  }
+
+ public:
+  explicit Workers(int count) : n(count) {
+    for (int i = 1; i < count; ++i) { std::thread t([this, i] { loop(i); }); t.detach(); }
+  }
+  int size() const { return n; }
+  void run(int T, const std::function<void(int)>& body) {  // body(0 .. T-1), T <= size()
+    std::lock_guard<std::mutex> one(run_m);
+    {
+      std::unique_lock<std::mutex> lk(m);
+      job = &body; job_T = T; remaining = T - 1; ++generation;
+    }
+    cv_start.notify_all();
+    body(0);
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return remaining == 0; });
+    job = nullptr; job_T = 0;
+  }
+};
+Workers& workers() {
+  static Workers* W = new Workers(host_threads());
+  return *W;
+}
 // body(begin, end, thread) over [0, n) in contiguous ranges; small jobs stay on the calling thread
 template <class F>
 void parallel_for(size_t n, F body) {
   const int T = n < 64 ? 1 : host_threads();
   if (T == 1) { body((size_t)0, n, 0); return; }
-  std::vector<std::thread> th;
   // ranges of 1/(4T) of the work, dealt round-robin: images differ a lot in their number of 2-D points
   const size_t chunks = (size_t)4 * T;
-  for (int t = 1; t < T; ++t)
-    th.emplace_back([&, t] { for (size_t c = t; c < chunks; c += T) body(n * c / chunks, n * (c + 1) / chunks, t); });
-  for (size_t c = 0; c < chunks; c += T) body(n * c / chunks, n * (c + 1) / chunks, 0);
-  for (auto& x : th) x.join();
+  const std::function<void(int)> job = [&](int t) { for (size_t c = (size_t)t; c < chunks; c += (size_t)T) body(n * c / chunks, n * (c + 1) / chunks, t); };
+  workers().run(T, job);
 }
 
 const double kEps = std::numeric_limits<double>::epsilon();
