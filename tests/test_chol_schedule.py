@@ -211,3 +211,30 @@ def test_the_schedules_of_the_benchmark_configurations(name, measured_us):
         # (within 2 % where the chains are the critical path - C3 -, 10 % optimistic where the helpers are - C5: the model does not
         # know about the memory traffic of 252 helpers re-reading tiles at once)
         assert abs(s["model_forward_us"] - measured_us) < 0.12 * measured_us, s["model_forward_us"]
+
+
+def _schedule_digest_in_a_fresh_process(name, threads):
+    """The queues of a benchmark structure built by a process with `threads` host workers (the count is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, json, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.test_chol_schedule import _load_structure\n"
+        "from mavmap_amd import api\n"
+        "nb, nodes, pairs = _load_structure(%r)\n"
+        "s = api.debug_chol_schedule(nb, nodes, pairs, cus=256)\n"
+        "print(hashlib.sha256(json.dumps([s['ok'], s['model_forward_us'], s['grid'], s['tasks'], s['chain_info']]).encode()).hexdigest())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), name)
+    env = dict(os.environ, MAVBA_HOST_THREADS=str(threads))
+    return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True, timeout=300).stdout.strip()
+
+
+def test_the_schedule_does_not_depend_on_the_number_of_host_threads():
+    """C5's structure is large enough for the candidate launches to be simulated on the host workers (one pool size per
+    thread); the kept schedule - queues, update orders, modelled time - must be the one a single thread finds."""
+    one = _schedule_digest_in_a_fresh_process("C5", 1)
+    assert len(one) == 64
+    assert _schedule_digest_in_a_fresh_process("C5", 4) == one
+    assert _schedule_digest_in_a_fresh_process("C5", 16) == one
