@@ -238,3 +238,30 @@ def test_the_schedule_does_not_depend_on_the_number_of_host_threads():
     assert len(one) == 64
     assert _schedule_digest_in_a_fresh_process("C5", 4) == one
     assert _schedule_digest_in_a_fresh_process("C5", 16) == one
+
+
+def _digest(s):
+    import hashlib
+    import json
+    return hashlib.sha256(json.dumps([s["ok"], s["model_forward_us"], s["launch_per_panel_us"], s["grid"], s["chain_wgs"], s["tiles"],
+                                      s["updates"], s["nodes"], s["tasks"], s["chain_info"]]).encode()).hexdigest()[:16]
+
+
+def test_the_schedules_are_the_ones_of_the_scan_based_builder():
+    """Round 5 rebuilt the builder for speed (one visiting order per estimate, helpers in a sorted array, candidate launches on
+    host threads). tests/golden/chol_schedule_digests.json holds the digests of the schedules the previous builder - a scan over
+    all helpers per task, everything redone per simulated pool size - produced for C2 / C3 / C5 on 256 / 64 / 32 work-groups and
+    for 40 random structures on 8 / 16 / 64 / 256: the queues, the update orders and the modelled times must be those."""
+    import json
+    import os
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chol_schedule_digests.json")))
+    for name in ("C2", "C3", "C5"):
+        nb, nodes, pairs = _load_structure(name)
+        for cus in (256, 64, 32):
+            assert _digest(api.debug_chol_schedule(nb, nodes, pairs, cus=cus)) == golden[f"{name}/{cus}"], (name, cus)
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        nodes, nb = _random_tree(rng, depth=int(rng.integers(1, 6)))
+        pairs = _random_pairs(rng, nodes, nb)
+        for cus in (8, 16, 64, 256):
+            assert _digest(api.debug_chol_schedule(nb, nodes, pairs, cus=cus)) == golden[f"r{seed}/{cus}"], (seed, cus)
