@@ -91,6 +91,39 @@ MAVBA_HD double rsqrt_obs(double x) {
 #endif
 }
 
+// log(x) per observation, x >= 1 and finite (the Cauchy loss: x = 1 + s / b), round 6. The library's log is ~90 vector
+// instructions per observation in every kernel that needs the cost (it carries a double-double tail for < 1 ulp); this one
+// is 35: x = 2^e m with m in [sqrt(1/2), sqrt(2)), t = (m - 1) / (m + 1) <= 0.1716, log m = 2 t (1 + t^2/3 + ... + t^20/21)
+// (the tail is below 7e-19 of the leading term), e ln 2 in two parts. Error <= 2 ulp (tests/test_host_math.py compares
+// the same arithmetic on the host with log over 1 <= x < 1e12); host builds keep the library's.
+// (the series, given x = 2^e m with m in [0.5, 1): host-callable for the test)
+MAVBA_HD double log_from_parts(double m, int e) {
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m;
+  e = low ? e - 1 : e;
+  const double f = m - 1.0, d = m + 1.0;
+  const double r = rcp_obs(d);
+  double t = f * r;
+  t = __builtin_fma(r, __builtin_fma(-t, d, f), t);
+  const double t2 = t * t;
+  double p = 1.0 / 21.0;
+  p = __builtin_fma(p, t2, 1.0 / 19.0); p = __builtin_fma(p, t2, 1.0 / 17.0); p = __builtin_fma(p, t2, 1.0 / 15.0);
+  p = __builtin_fma(p, t2, 1.0 / 13.0); p = __builtin_fma(p, t2, 1.0 / 11.0); p = __builtin_fma(p, t2, 1.0 / 9.0);
+  p = __builtin_fma(p, t2, 1.0 / 7.0); p = __builtin_fma(p, t2, 1.0 / 5.0); p = __builtin_fma(p, t2, 1.0 / 3.0);
+  const double t3 = t * t2;
+  const double ed = (double)e;
+  // log m = 2 t + 2 t^3 p; e ln 2 = e hi + e lo with hi = the leading 32 bits of ln 2 (e hi is exact)
+  const double lm = __builtin_fma(t3 + t3, p, t + t);
+  return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
+}
+MAVBA_HD double log_obs(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return log_from_parts(__builtin_amdgcn_frexp_mant(x), __builtin_amdgcn_frexp_exp(x));
+#else
+  return log(x);
+#endif
+}
+
 // out = m x w
 MAVBA_HD void cross3(const double* m, const double* w, double* out) {
   out[0] = m[1] * w[2] - m[2] * w[1];
@@ -295,7 +328,7 @@ MAVBA_HD void obs_backsub_term(int model, const double* rec, const double* cam, 
 // block cost rho/2. inv_b = 1/a^2, b = a^2.
 MAVBA_HD void cauchy_weight(double s, double b, double inv_b, double& w, double& half_rho) {
   const double sum = 1.0 + s * inv_b;
-  half_rho = 0.5 * b * log(sum);
+  half_rho = 0.5 * b * log_obs(sum);
   w = rsqrt_obs(sum);
 }
 

@@ -92,7 +92,16 @@ constexpr int kRowsBatch = 16;
 constexpr int kRowsMaxPoints = 256;
 constexpr int kRowsClasses = 3;
 constexpr int kRowsClassNT[kRowsClasses] = {5, 6, 8};
-struct SchurRowsCluster { int p0, p1, ni, nc; };
+// emit_off / emit_n: the cluster's emit map (rows_emit_map below) - where every element of its block partials comes from in the
+// packed lower triangle of its product; one map per (ni, nc), passes as in the kernel (a 128-row triangle leaves in two).
+struct SchurRowsCluster { int p0, p1, ni, nc, emit_off, emit_n[2], flags; };
+// the lists of a k_schur_rows cluster: 16 image slots, the camera of each, 3 camera slots, 1 pad
+constexpr int kRowsListsCam = kClImagesMax, kRowsListsCams = 2 * kClImagesMax, kRowsLists = 2 * kClImagesMax + kClCamsMax + 1;
+constexpr int kRowsUnplaced = 1;  // flags: two camera slots, but some point has more than 8 observations of one of them (see lanemap)
+// One entry of an emit map: source index in the pass's packed triangle (13 bits), offset inside the destination partial
+// (7 bits), index of the partial's slot in the cluster's slot table (8 bits).
+constexpr unsigned rows_emit_entry(int src, int o, int tab_index) { return (unsigned)src | (unsigned)o << 13 | (unsigned)tab_index << 20; }
+constexpr int kRowsPassSplit = 96;  // rows [0, 96) and [96, 128) of a 128-row product are staged one after the other
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -248,7 +257,14 @@ void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int n
                         const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii);
 void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, int num_clusters,
                        const SchurRowsCluster* clusters, const int* tab, const int* cl_lists, const unsigned short* obs_meta,
-                       double* part_pp, double* part_ip, double* part_ii);
+                       const unsigned long long* lanemap, const unsigned* emit_map, double* part_pp, double* part_ip, double* part_ii);
+// The emit map of a cluster shape (host): for pass 0 and pass 1, in the order the lanes walk them, one rows_emit_entry per
+// element of the block partials the shape can touch - pose x pose (42 per image pair: the 6 x 6 block, lower triangle only on
+// the diagonal, + the h row's 6 on the diagonal), intrinsics x pose (54), intrinsics x intrinsics (90: 9 x 9 + the h row's 9).
+void rows_emit_map(int ni, int nc, std::vector<unsigned>& pass0, std::vector<unsigned>& pass1);
+// lanemap: per point, nibble i = which of the point's observations lane i of its 16-lane row takes (kRowsLanesIdentity: lane i takes
+// observation i). In a cluster with two camera slots the observations of slot 0 sit in lanes 0-7, those of slot 1 in lanes 8-15.
+constexpr unsigned long long kRowsLanesIdentity = 0xFEDCBA9876543210ull;
 // obs_meta / q_meta: per observation / intrinsics entry, local index << 8 | (point - cluster.p0) % kClBatch,
 // 0xFFFF for records that are not part of a cluster.
 void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters, const SchurCluster* clusters, const int* tab,

@@ -50,23 +50,37 @@ static_assert((2 * kF2Pitch) % 8 == 4, "pitch must spread the 16 operand rows ov
 constexpr int kF2TabIP = 136, kF2TabII = 184, kF2Tab = 190;
 
 // ---- DPP within a 16-lane row ----
+// (bound_ctrl: every control used here reads a lane of the row, so the "old" value is never kept - with bound_ctrl = 0 the
+// compiler materialised it all the same: one v_mov_b32 0 in front of every DPP move, 162 of the 1 400 vector instructions
+// of a batch, profiles/r06_isa_by_line_k_schur_rows.txt)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 constexpr int kDppMirror = 0x140;      // lane i <-> 15 - i
 constexpr int kDppHalfMirror = 0x141;  // i <-> 7 - i inside each half row
 constexpr int kDppQuadRev = 0x1B;      // quad_perm [3,2,1,0]: i <-> 3 - i inside each quad
 constexpr int kDppQuadSwap = 0xB1;     // quad_perm [1,0,3,2]: i <-> i ^ 1
+// (Round 6, measured and dropped - scripts/_dbg/issue_bench.hip, profiles/r06_issue_bench.txt, profiles/r06_ab_swizzle.txt: the
+// same exchanges as ds_swizzle_b32 are LDS-pipe instructions that issue next to the other wave's vector or matrix
+// instructions, and with both halves fetched the reduce-scatter's selects become adds under the execution mask - 17 % fewer
+// vector instructions per batch, and the kernel was 4 % SLOWER (C3 0.2731 against 0.2625 ms, A/B/A/B in one visit): seven
+// dependent LDS round trips per batch that the second wave of the SIMD does not cover.)
+template <int CTRL>
+__device__ __forceinline__ double xlane_f64(double v) { return dpp_f64<CTRL>(v); }
 // Sum over the row, the same bits in all 16 lanes: at every step both partners add the same two numbers.
-__device__ __forceinline__ double row16_allsum(double v) {
-  v += dpp_f64<kDppMirror>(v);
-  v += dpp_f64<kDppHalfMirror>(v);
-  v += dpp_f64<kDppQuadRev>(v);
-  v += dpp_f64<kDppQuadSwap>(v);
-  return v;
+template <int NV>
+__device__ __forceinline__ void row16_allsum(double (&v)[NV]) {
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] += dpp_f64<kDppMirror>(v[e]);
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] += dpp_f64<kDppHalfMirror>(v[e]);
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] += dpp_f64<kDppQuadRev>(v[e]);
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] += dpp_f64<kDppQuadSwap>(v[e]);
 }
 // One halving step of the reduce-scatter: NU values in v[0, NU) -> the pair's sums of the half this lane keeps in v[0, NU/2).
 template <int CTRL, int NU, int N>
@@ -152,11 +166,15 @@ __device__ __forceinline__ void f2_mfma(const double* __restrict__ E, int lane, 
 // arithmetic per element was unrolled 16-36 times per lane. Now: the lower triangle goes to LDS packed by rows (the entry
 // matrix is free after the last batch), then ONE lane per output element walks the blocks in order - consecutive lanes
 // write consecutive doubles of a partial.
-__device__ __forceinline__ int f2_tri(int R) { return (R * (R + 1)) >> 1; }
-// rows [RLO, RHI) of the lower triangle, packed: element (R, C) at tri(R) - tri(RLO) + C
+__host__ __device__ constexpr int f2_tri(int R) { return (R * (R + 1)) >> 1; }
+// rows [RLO, RHI) of the lower triangle, packed: element (R, C) at tri(R) - tri(RLO) + C.
+// Round 6: R = 16 i + 4 r + lk, so tri(R) = tri(16 i + 4 r) + (16 i + 4 r) lk + tri(lk): per lane ONE base (tri(lk) + li) and
+// ONE multiple of lk per accumulator row; everything else is an immediate offset of the store. (Round 5 evaluated
+// tri(R) - tri(RLO) + C per element: 1 400 integer instructions in the three instantiations.)
 template <int NT, int W, int RLO, int RHI>
 __device__ __forceinline__ void f2_stage(double* __restrict__ T, int lane, const f2_d4 (&acc)[F2Shape<NT>::acc]) {
   const int li = lane & 15, lk = lane >> 4;
+  const double* Tl = T + (f2_tri(lk) + li);
   int t = 0;
 #pragma unroll
   for (int i = 0; i < NT; ++i)
@@ -165,49 +183,34 @@ __device__ __forceinline__ void f2_stage(double* __restrict__ T, int lane, const
       if (t % kF2Waves == W && 16 * i >= RLO && 16 * i < RHI) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int R = 16 * i + lk + 4 * r, C = 16 * j + li;  // D layout of the matrix instruction
-          if (i > j || C <= R) T[f2_tri(R) - f2_tri(RLO) + C] = acc[t / kF2Waves][r];
+          const int R0 = 16 * i + 4 * r;  // the row without the lane's part: R = R0 + lk, C = 16 j + li (D layout of the matrix instruction)
+          double* dst = const_cast<double*>(Tl) + R0 * lk + (f2_tri(R0) - f2_tri(RLO) + 16 * j);
+          if (i > j || li <= lk + 4 * r) *dst = acc[t / kF2Waves][r];
         }
       }
       ++t;
     }
 }
-// One lane per output element of the blocks whose source row lies in [RLO, RHI). Rows of the product: 6 la + r (image slot
-// la), P0 + 9 lc + r (camera slot lc), H (the h row); P0 = 6 ni, H = P0 + 9 nc. tri_la / tri_lb: slot of the lower
-// triangle of image pairs -> (la, lb).
-template <int RLO, int RHI, bool ALL>
-__device__ __forceinline__ void f2_write_blocks(const double* __restrict__ T, int tid, int ni, int nc, int P0, int H,
-                                                const int* __restrict__ tab, const unsigned char* __restrict__ tri_la,
-                                                const unsigned char* __restrict__ tri_lb, double* __restrict__ part_pp,
-                                                double* __restrict__ part_ip, double* __restrict__ part_ii) {
-  auto src = [&](int R, int C) { return T[f2_tri(R) - f2_tri(RLO) + C]; };
-  auto in_pass = [&](int R) { return ALL || (R >= RLO && R < RHI); };
-  const int npp = (ni * (ni + 1)) >> 1;
-  for (int e = tid; e < npp * 42; e += kF2Threads) {  // pose x pose (+ the h row's part of the diagonal blocks)
-    const int s = e / 42, o = e - 42 * s, la = tri_la[s], lb = tri_lb[s];
-    int R, C;
-    if (o < 36) { const int r = o / 6, c = o - 6 * r; if (la == lb && r < c) continue; R = 6 * la + r; C = 6 * lb + c; }
-    else { if (la != lb) continue; R = H; C = 6 * la + (o - 36); }
-    if (!in_pass(R)) continue;
-    const int slot = tab[s];
-    if (slot >= 0) part_pp[(size_t)slot * 42 + o] = src(R, C);
-  }
-  for (int e = tid; e < nc * ni * 54; e += kF2Threads) {  // intrinsics x pose
-    const int s = e / 54, o = e - 54 * s, lc = s / ni, la = s - ni * lc, r = o / 6, c = o - 6 * r;
-    const int R = P0 + 9 * lc + r;
-    if (!in_pass(R)) continue;
-    const int slot = tab[kF2TabIP + lc * 16 + la];
-    if (slot >= 0) part_ip[(size_t)slot * 54 + o] = src(R, 6 * la + c);
-  }
-  const int nii = (nc * (nc + 1)) >> 1;
-  for (int e = tid; e < nii * 90; e += kF2Threads) {  // intrinsics x intrinsics (+ the h row's part)
-    const int s = e / 90, o = e - 90 * s, lc = tri_la[s], lc2 = tri_lb[s];
-    int R, C;
-    if (o < 81) { const int r = o / 9, c = o - 9 * r; if (lc == lc2 && r < c) continue; R = P0 + 9 * lc + r; C = P0 + 9 * lc2 + c; }
-    else { if (lc != lc2) continue; R = H; C = P0 + 9 * lc + (o - 81); }
-    if (!in_pass(R)) continue;
-    const int slot = tab[kF2TabII + s];
-    if (slot >= 0) part_ii[(size_t)slot * 90 + o] = src(R, C);
+// One lane per output element: the cluster's emit map (built per (ni, nc) at set-up, rows_emit_map) says where the element
+// sits in the staged triangle and where it goes - slot-table index and offset inside the partial; s_dst holds the partials'
+// addresses (null: the cluster does not touch that block). Consecutive lanes write consecutive doubles of a partial.
+// (Round 5 derived all of that per element: two divisions, two table look-ups and the triangle index in a dependent chain,
+// 600 ticks per trip of the loop.)
+__device__ __forceinline__ void f2_write_blocks(const double* __restrict__ T, int tid, const unsigned* __restrict__ map, int n,
+                                                double* const* __restrict__ s_dst) {
+  // eight elements per lane and trip: the map entries are requested together, then the table / triangle reads, then the stores
+  // (one element per trip was a chain of a global load, two LDS reads and a store - ~800 ticks each, 19 trips per cluster)
+  constexpr int U = 8;
+  for (int e0 = tid; e0 < n; e0 += U * kF2Threads) {
+    unsigned m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) m[u] = e0 + u * kF2Threads < n ? map[e0 + u * kF2Threads] : 0u;
+    double* d[U];
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { d[u] = e0 + u * kF2Threads < n ? s_dst[m[u] >> 20] : nullptr; v[u] = T[m[u] & 8191u]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (d[u]) d[u][(m[u] >> 13) & 127u] = v[u];
   }
 }
 }  // namespace
@@ -222,19 +225,21 @@ __device__ __forceinline__ void f2_write_blocks(const double* __restrict__ T, in
 template <int KMAX, bool GENERIC, bool TRACE = false>
 __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     FrontArgs a, const SchurRowsCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ cl_lists,
-    const unsigned short* __restrict__ obs_meta, double* __restrict__ part_pp, double* __restrict__ part_ip,
-    double* __restrict__ part_ii) {
+    const unsigned short* __restrict__ obs_meta, const unsigned long long* __restrict__ lanemap,
+    const unsigned* __restrict__ emit_map, double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
   using SHMAX = F2Shape<kRowsClassNT[kRowsClasses - 1]>;
   if (!lm_spec_go(a.spec, &a.radius)) return;  // (speculative evaluation: only behind an accepted step, with the radius it leaves)
-  // per-cluster tables (cl_lists: the cluster's image slots, then its camera slots, -1 padded): camera records, intrinsics
-  // and column scales are read from memory once per cluster
+  long long t_entry = 0, t_loop0 = 0, t_loop1 = 0;  // (TRACE: the cluster's time line - entry, tables ready, batches done, end)
+  if constexpr (TRACE) t_entry = (long long)__builtin_amdgcn_s_memtime();
+  // per-cluster tables (cl_lists, kRowsLists ints per cluster: its image slots, the camera of every image slot, its camera
+  // slots; -1 padded): camera records, intrinsics and column scales are read from memory once per cluster
   __shared__ double s_rec[kClImagesMax][9], s_kin[kClImagesMax][9], s_sc[kClImagesMax][6], s_ksc[kClCamsMax][9];
   __shared__ int s_icam[kClImagesMax], s_model[kClImagesMax], s_lc[kClImagesMax], s_clcam[4];
   __shared__ __attribute__((aligned(16))) double E[SHMAX::rows * kF2Pitch];
   __shared__ double s_red[kF2Waves];
-  __shared__ int s_tab[kF2Tab];
+  __shared__ double* s_dst[kF2Tab];  // the cluster's block partials by slot-table index (null: block not touched)
   __shared__ int s_pstart[kRowsMaxPoints + 1];
-  __shared__ unsigned char s_tri_la[kF2TabIP], s_tri_lb[kF2TabIP];  // slot la (la + 1) / 2 + lb of a lower triangle -> (la, lb)
+  __shared__ unsigned long long s_lanes[kRowsMaxPoints];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = tid >> 4, i = tid & 15;
   const SweepArgs& w = a.sw;
   const int NPs = a.NPs;
@@ -243,32 +248,58 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   const int npts = cl.p1 - cl.p0, nbatch = (npts + kRowsBatch - 1) / kRowsBatch;
   const int P0 = 6 * cl.ni, H = P0 + 9 * cl.nc;
   for (int j = tid; j <= npts; j += kF2Threads) s_pstart[j] = a.pt_start[cl.p0 + j];
-  for (int j = tid; j < kF2Tab; j += kF2Threads) s_tab[j] = tabs[(size_t)cidx * kF2Tab + j];
-  if (tid < kF2TabIP) {
-    int la = 0;
-    while (((la + 1) * (la + 2)) >> 1 <= tid) ++la;
-    s_tri_la[tid] = (unsigned char)la; s_tri_lb[tid] = (unsigned char)(tid - ((la * (la + 1)) >> 1));
+  for (int j = tid; j < npts; j += kF2Threads) s_lanes[j] = lanemap[cl.p0 + j];
+  if (tid < kF2Tab) {
+    const int slot = tabs[(size_t)cidx * kF2Tab + tid];
+    s_dst[tid] = slot < 0 ? nullptr : tid < kF2TabIP ? part_pp + (size_t)slot * 42 : tid < kF2TabII ? part_ip + (size_t)slot * 54 : part_ii + (size_t)slot * 90;
   }
   {
-    const int* lists = cl_lists + (size_t)cidx * (kClImagesMax + kClCamsMax);
+    const int* lists = cl_lists + (size_t)cidx * kRowsLists;
     if (tid < kClImagesMax * 9) {
       const int sl = tid / 9, e = tid - 9 * sl, img = lists[sl];
       if (img >= 0) {
-        const int cam = w.img_cam[img];
+        const int cam = lists[kRowsListsCam + sl];  // (= img_cam[img], noted at set-up: one dependent load less per cluster)
         s_rec[sl][e] = w.camrec[9 * img + e];
         s_kin[sl][e] = w.intr[9 * cam + e];
         if (e < 6) s_sc[sl][e] = a.scale_cam[6 * img + e];
         if (e == 0) {
           s_icam[sl] = cam; s_model[sl] = w.cam_model[cam];
-          s_lc[sl] = cam == lists[kClImagesMax] ? 0 : cam == lists[kClImagesMax + 1] ? 1 : cam == lists[kClImagesMax + 2] ? 2 : -1;  // the camera's slot (-1: constant intrinsics)
+          s_lc[sl] = cam == lists[kRowsListsCams] ? 0 : cam == lists[kRowsListsCams + 1] ? 1 : cam == lists[kRowsListsCams + 2] ? 2 : -1;  // the camera's slot (-1: constant intrinsics)
         }
       }
     } else if (tid < kClImagesMax * 9 + kClCamsMax * 9) {
-      const int t = tid - kClImagesMax * 9, c = t / 9, k = t - 9 * c, cam = lists[kClImagesMax + c];
+      const int t = tid - kClImagesMax * 9, c = t / 9, k = t - 9 * c, cam = lists[kRowsListsCams + c];
       if (cam >= 0) s_ksc[c][k] = a.scale_cam[6 * w.NI + 9 * cam + k];
       if (k == 0) s_clcam[c] = cam;
     }
   }
+  // A batch's loads - every lane's observation, the row's point - are requested before the PREVIOUS batch's matrix
+  // instructions start and travel under them; the first batch's are requested HERE, next to the tables' (its point starts and
+  // lane maps straight from memory: behind the tables' barrier they were one more exposed round trip per cluster).
+  bool act_n = false, free_n = false, seen_n = false;
+  int im_n = 0;
+  double2 m_n = make_double2(0.0, 0.0);
+  unsigned meta_n = 0xFFFFu;
+  double X_n[3] = {0.0, 0.0, 0.0}, sp_n[3] = {0.0, 0.0, 0.0};
+  auto request_point = [&](int pj, int ob, int cnt, unsigned long long lm) {
+    const int p = cl.p0 + pj;
+    const bool on = w.pt_active == nullptr || w.pt_active[p] != 0;  // (a point filtered out of the resident problem has no residual blocks)
+    // the observation this lane takes: nibble i of the point's lane map (15 in an empty lane of a point with fewer than 16)
+    const int oi = (int)(((i & 8) ? (unsigned)(lm >> 32) : (unsigned)lm) >> (4 * (i & 7))) & 15;
+    seen_n = cnt > 0;
+    act_n = on && oi < cnt;
+    if (act_n) { im_n = w.obs_img[ob + oi]; m_n = w.uv[ob + oi]; meta_n = obs_meta[ob + oi]; }
+    X_n[0] = w.points[3 * (size_t)p]; X_n[1] = w.points[3 * (size_t)p + 1]; X_n[2] = w.points[3 * (size_t)p + 2];
+    free_n = a.pt_free[p] != 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sp_n[k] = a.scale_pt[(size_t)k * NPs + p];
+  };
+  auto request_batch = [&](int bj) {
+    const int pj = bj * kRowsBatch + r;
+    act_n = free_n = seen_n = false;
+    if (pj < npts) { const int ob = s_pstart[pj]; request_point(pj, ob, s_pstart[pj + 1] - ob, s_lanes[pj]); }
+  };
+  if (r < npts) { const int ob = a.pt_start[cl.p0 + r]; request_point(r, ob, a.pt_start[cl.p0 + r + 1] - ob, lanemap[cl.p0 + r]); }
   double cost = 0.0;
   auto run = [&](auto nt_const) {
   constexpr int NT = decltype(nt_const)::value;
@@ -281,29 +312,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   bool tracing = false;
   auto mark = [&]() { if constexpr (TRACE) { if (tracing && nstamp < 8) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
   __syncthreads();
-  // A batch's loads - every lane's observation, the row's point - are requested before the PREVIOUS batch's matrix
-  // instructions start and travel under them.
-  bool act_n = false, free_n = false, seen_n = false;
-  int im_n = 0;
-  double2 m_n = make_double2(0.0, 0.0);
-  unsigned meta_n = 0xFFFFu;
-  double X_n[3] = {0.0, 0.0, 0.0}, sp_n[3] = {0.0, 0.0, 0.0};
-  auto request_batch = [&](int bj) {
-    const int pj = bj * kRowsBatch + r;
-    act_n = free_n = seen_n = false;
-    if (pj < npts) {
-      const int p = cl.p0 + pj, ob = s_pstart[pj], cnt = s_pstart[pj + 1] - ob;
-      const bool on = w.pt_active == nullptr || w.pt_active[p] != 0;  // (a point filtered out of the resident problem has no residual blocks)
-      seen_n = cnt > 0;
-      act_n = on && i < cnt;
-      if (act_n) { im_n = w.obs_img[ob + i]; m_n = w.uv[ob + i]; meta_n = obs_meta[ob + i]; }
-      X_n[0] = w.points[3 * (size_t)p]; X_n[1] = w.points[3 * (size_t)p + 1]; X_n[2] = w.points[3 * (size_t)p + 2];
-      free_n = a.pt_free[p] != 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) sp_n[k] = a.scale_pt[(size_t)k * NPs + p];
-    }
-  };
-  if (nbatch > 0) request_batch(0);
+  if constexpr (TRACE) t_loop0 = (long long)__builtin_amdgcn_s_memtime();
   for (int bi = 0; bi < nbatch; ++bi) {
     const int pj = bi * kRowsBatch + r;
     const bool valid = pj < npts, act = act_n, own_free = free_n, seen = seen_n;
@@ -319,11 +328,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     // observation's contribution to the intrinsics entries of ITS camera
     constexpr int K3 = KMAX > 0 ? 3 * KMAX : 1;
     const double sp[3] = {own_free ? own_sp[0] : 0.0, own_free ? own_sp[1] : 0.0, own_free ? own_sp[2] : 0.0};
-    double jc[12], jps[6], s9[9], P[K3];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) jc[e] = 0.0;
-#pragma unroll
-    for (int e = 0; e < 6; ++e) jps[e] = 0.0;
+    double jc[12], jps[6], s9[9], P[K3];  // (jc, jps: written and read by the lanes with an observation only - no zeros for the others)
 #pragma unroll
     for (int e = 0; e < 9; ++e) s9[e] = 0.0;
 #pragma unroll
@@ -372,9 +377,12 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
       s9[6] = jp[0] * rr0 + jp[3] * rr1; s9[7] = jp[1] * rr0 + jp[4] * rr1; s9[8] = jp[2] * rr0 + jp[5] * rr1;
 #pragma unroll
       for (int e = 0; e < 6; ++e) jps[e] = jp[e] * sp[e % 3];
+      // (an observation whose camera's intrinsics are constant contributes nothing to the intrinsics rows: its weight there is 0 -
+      // the reduce-scatter below then needs no masks. GENERIC keeps the plain weight: it selects by camera slot.)
+      const double wgt_k = (GENERIC || mylc >= 0) ? wgt : 0.0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
-        const double k0 = wgt * Jk[k], k1 = wgt * Jk[9 + k];
+        const double k0 = wgt_k * Jk[k], k1 = wgt_k * Jk[9 + k];
 #pragma unroll
         for (int t = 0; t < 3; ++t) P[3 * k + t] = k0 * jps[t] + k1 * jps[3 + t];
       }
@@ -382,8 +390,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     mark();  // 1: Jacobian + products
     // ---- the point block's sums: all-reduce over the row, bit-identical in its 16 lanes ----
 #if !(MAVBA_ROWS_SKIP & 16)
-#pragma unroll
-    for (int e = 0; e < 9; ++e) s9[e] = row16_allsum(s9[e]);
+    row16_allsum(s9);
 #endif
     // ---- every lane factorises its point's damped 3x3 block (the same arithmetic on the same bits in the 16 lanes) ----
     double G[6] = {0, 0, 0, 0, 0, 0}, hh[3] = {0, 0, 0};
@@ -434,14 +441,17 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     if (act && meta != 0xFFFFu && !(MAVBA_ROWS_SKIP & 8)) {  // (0xFFFF: the image's pose is constant - it has no rows; the sums above included it)
       double* Eo = col + 6 * (int)(meta >> 8) * kF2Pitch;
       const double* scl = s_sc[meta >> 8];
+      // U = (Jc'^T Jp') Gi^T = Jc'^T (Jp' Gi^T): the 2 x 3 factor once (12 multiply-adds), then two per element - 60 FP64
+      // instructions per observation instead of 84 for the 6 x 3 product followed by Gi^T
+      const double m00 = jps[0] * G[0], m01 = jps[0] * G[1] + jps[1] * G[2], m02 = jps[0] * G[3] + jps[1] * G[4] + jps[2] * G[5];
+      const double m10 = jps[3] * G[0], m11 = jps[3] * G[1] + jps[4] * G[2], m12 = jps[3] * G[3] + jps[4] * G[4] + jps[5] * G[5];
 #pragma unroll
       for (int e = 0; e < 6; ++e) {
         const double sc = scl[e];
         const double j0 = jc[e] * sc, j1 = jc[6 + e] * sc;
-        const double w0 = j0 * jps[0] + j1 * jps[3], w1 = j0 * jps[1] + j1 * jps[4], w2 = j0 * jps[2] + j1 * jps[5];
-        Eo[e * kF2Pitch] = w0 * G[0];
-        Eo[e * kF2Pitch + 1] = w0 * G[1] + w1 * G[2];
-        Eo[e * kF2Pitch + 2] = w0 * G[3] + w1 * G[4] + w2 * G[5];
+        Eo[e * kF2Pitch] = j0 * m00 + j1 * m10;
+        Eo[e * kF2Pitch + 1] = j0 * m01 + j1 * m11;
+        Eo[e * kF2Pitch + 2] = j0 * m02 + j1 * m12;
       }
     }
     if (i < 3 && own_free && seen) col[H * kF2Pitch + i] = hh[i];
@@ -458,14 +468,22 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
       };
       if constexpr (!GENERIC) {
         static_assert(KMAX == 8 || KMAX == 4, "the in-place form is written for 4 and 8 parameters");
-        // IN PLACE: lanes 0-7 of the row collect camera slot 0, lanes 8-15 slot 1 (first halving: i <-> 15 - i; an observation
-        // contributes to one of them), then the 3 K values halve inside the 8 lanes
-        const bool up1 = i >= 8;
-        const bool keepm = mylc == (up1 ? 1 : 0), sendm = mylc == (up1 ? 0 : 1);
+        // IN PLACE: lanes 0-7 of the row end with camera slot 0's sums, lanes 8-15 with slot 1's, then the 3 K values halve
+        // inside the 8 lanes. Round 6: with two camera slots the SET-UP has put every observation into a lane of its
+        // camera's half (the point's lane map; a cluster where that is impossible - more than 8 observations of one camera
+        // in a point - is flagged and keeps the selects), so the first halving - i <-> 15 - i with a keep and a send
+        // select per value, 24 x 7 instructions - is gone; with one slot it is a plain sum of the mirrored lanes.
+        if (cl.nc < 2) {
 #pragma unroll
-        for (int u = 0; u < K3; ++u) {
-          const double keep = keepm ? P[u] : 0.0, send = sendm ? P[u] : 0.0;
-          P[u] = keep + dpp_f64<kDppMirror>(send);
+          for (int u = 0; u < K3; ++u) P[u] += xlane_f64<kDppMirror>(P[u]);
+        } else if (cl.flags & kRowsUnplaced) {  // (a point of the cluster has more than 8 observations of one slot: keep / send by camera, as in round 4)
+          const bool up1 = i >= 8;
+          const bool keepm = mylc == (up1 ? 1 : 0), sendm = mylc == (up1 ? 0 : 1);
+#pragma unroll
+          for (int u = 0; u < K3; ++u) {
+            const double keep = keepm ? P[u] : 0.0, send = sendm ? P[u] : 0.0;
+            P[u] = keep + xlane_f64<kDppMirror>(send);
+          }
         }
         rs_step<kDppHalfMirror, K3>(P, (i & 7) >= 4);
         rs_step<kDppQuadRev, K3 / 2>(P, (i & 3) >= 2);
@@ -474,7 +492,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
           if ((i >> 3) < cl.nc) write_row(i >> 3, i & 7, P);
         } else {
 #pragma unroll
-          for (int t = 0; t < 3; ++t) P[t] += dpp_f64<kDppQuadSwap>(P[t]);  // 3 values left for 2 lanes: both add, the even one writes
+          for (int t = 0; t < 3; ++t) P[t] += xlane_f64<kDppQuadSwap>(P[t]);  // 3 values left for 2 lanes: both add, the even one writes
           if ((i >> 3) < cl.nc && (i & 1) == 0) write_row(i >> 3, (i & 7) >> 1, P);
         }
       } else {
@@ -510,6 +528,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     mark();  // 4: matrix instructions issued
   }
   if constexpr (TRACE) {
+    t_loop1 = (long long)__builtin_amdgcn_s_memtime();
     if (a.trace && lane == 0 && blockIdx.x < 4096) {
       long long* out = a.trace + ((size_t)blockIdx.x * kF2Waves + wv) * 16;
       out[0] = nstamp;
@@ -529,10 +548,11 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
         default: f2_stage<NT, 3, RLO, RHI>(E, lane, acc); break;
       }
       lds_barrier();
-      f2_write_blocks<RLO, RHI, (RLO == 0 && RHI == 16 * NT)>(E, tid, cl.ni, cl.nc, P0, H, s_tab, s_tri_la, s_tri_lb, part_pp, part_ip, part_ii);
+      constexpr int PASS = RLO == 0 ? 0 : 1;
+      f2_write_blocks(E, tid, emit_map + cl.emit_off + (PASS ? cl.emit_n[0] : 0), cl.emit_n[PASS], s_dst);
     };
     if constexpr (NT <= 6) pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 16 * NT>{});
-    else { pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 96>{}); pass(std::integral_constant<int, 96>{}, std::integral_constant<int, 16 * NT>{}); }
+    else { pass(std::integral_constant<int, 0>{}, std::integral_constant<int, kRowsPassSplit>{}); pass(std::integral_constant<int, kRowsPassSplit>{}, std::integral_constant<int, 16 * NT>{}); }
   }
   };  // run
   static_assert(kRowsClasses == 3, "one instantiation of the batch loop per row class");
@@ -547,12 +567,45 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   if (lane == 0) s_red[wv] = wsum;
   __syncthreads();
   if (tid == 0) w.cost_partial[cidx] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  if constexpr (TRACE) {
+    if (a.trace && lane == 0 && blockIdx.x < 4096) {
+      long long* out = a.trace + ((size_t)blockIdx.x * kF2Waves + wv) * 16;
+      out[9] = t_entry; out[10] = t_loop0; out[11] = t_loop1; out[12] = (long long)__builtin_amdgcn_s_memtime();
+      out[13] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID | XCC_ID << 32: where the wave ran
+      out[14] = ((long long)nbatch << 8) | rows_class_of(cl.ni, cl.nc);
+    }
+  }
+}
+
+void rows_emit_map(int ni, int nc, std::vector<unsigned>& pass0, std::vector<unsigned>& pass1) {
+  pass0.clear(); pass1.clear();
+  const bool two = kRowsClassNT[rows_class_of(ni, nc)] > 6;  // (the kernel stages a product of more than 96 rows in two passes)
+  const int P0 = 6 * ni, H = P0 + 9 * nc;
+  auto put = [&](int R, int C, int o, int tab_index) {
+    const int pass = two && R >= kRowsPassSplit ? 1 : 0;
+    (pass ? pass1 : pass0).push_back(rows_emit_entry(f2_tri(R) - (pass ? f2_tri(kRowsPassSplit) : 0) + C, o, tab_index));
+  };
+  for (int la = 0; la < ni; ++la)  // pose x pose (+ the h row's part of the diagonal blocks)
+    for (int lb = 0; lb <= la; ++lb)
+      for (int o = 0; o < 42; ++o) {
+        if (o < 36) { const int r = o / 6, c = o % 6; if (la == lb && r < c) continue; put(6 * la + r, 6 * lb + c, o, f2_tri(la) + lb); }
+        else if (la == lb) put(H, 6 * la + (o - 36), o, f2_tri(la) + lb);
+      }
+  for (int lc = 0; lc < nc; ++lc)  // intrinsics x pose
+    for (int la = 0; la < ni; ++la)
+      for (int o = 0; o < 54; ++o) put(P0 + 9 * lc + o / 6, 6 * la + o % 6, o, kF2TabIP + lc * 16 + la);
+  for (int lc = 0; lc < nc; ++lc)  // intrinsics x intrinsics (+ the h row's part)
+    for (int lc2 = 0; lc2 <= lc; ++lc2)
+      for (int o = 0; o < 90; ++o) {
+        if (o < 81) { const int r = o / 9, c = o % 9; if (lc == lc2 && r < c) continue; put(P0 + 9 * lc + r, P0 + 9 * lc2 + c, o, kF2TabII + f2_tri(lc) + lc2); }
+        else if (lc == lc2) put(H, P0 + 9 * lc + (o - 81), o, kF2TabII + f2_tri(lc) + lc2);
+      }
 }
 
 // generic: some cluster has three camera slots (the 9-parameter model always takes the general form of the intrinsics entries).
 void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, int num_clusters,
                        const SchurRowsCluster* clusters, const int* tab, const int* cl_lists, const unsigned short* obs_meta,
-                       double* part_pp, double* part_ip, double* part_ii) {
+                       const unsigned long long* lanemap, const unsigned* emit_map, double* part_pp, double* part_ip, double* part_ii) {
   if (num_clusters <= 0) return;
   // MAVBA_ROWS_TRACE=<file>: the 5th launch of the process (widest model <= 8) records s_memtime stamps per wave
   static const char* trace_file = std::getenv("MAVBA_ROWS_TRACE");
@@ -564,7 +617,7 @@ void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool g
     (void)hipMemsetAsync(tr, 0, trace_n * 8, st);
     FrontArgs b = a;
     b.trace = tr;
-    hipLaunchKernelGGL((k_schur_rows<8, false, true>), dim3(num_clusters), dim3(kF2Threads), 0, st, b, clusters, tab, cl_lists, obs_meta, part_pp, part_ip, part_ii);
+    hipLaunchKernelGGL((k_schur_rows<8, false, true>), dim3(num_clusters), dim3(kF2Threads), 0, st, b, clusters, tab, cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii);
     std::vector<long long> hst(trace_n);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(hst.data(), tr, trace_n * 8, hipMemcpyDeviceToHost);
@@ -573,16 +626,18 @@ void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool g
       for (int g = 0; g < std::min(num_clusters, 4096); ++g)
         for (int wv = 0; wv < kF2Waves; ++wv) {
           const long long* rr = hst.data() + ((size_t)g * kF2Waves + wv) * 16;
-          if (rr[0] <= 0) continue;
+          if (rr[12] <= 0) continue;
+          // cluster, wave, number of phase stamps (second batch; 0 for a one-batch cluster), 8 phase stamps, then the cluster's
+          // time line: entry, tables ready, batches done, end, HW_ID, batches << 8 | row class
           std::fprintf(fp, "%d %d", g, wv);
-          for (int t = 0; t < (int)rr[0]; ++t) std::fprintf(fp, " %lld", rr[1 + t]);
+          for (int t = 0; t < 15; ++t) std::fprintf(fp, " %lld", rr[t]);
           std::fprintf(fp, "\n");
         }
       std::fclose(fp);
     }
     return;
   }
-#define MAVBA_ROWS(K, G) hipLaunchKernelGGL((k_schur_rows<K, G>), dim3(num_clusters), dim3(kF2Threads), 0, st, a, clusters, tab, cl_lists, obs_meta, part_pp, part_ip, part_ii)
+#define MAVBA_ROWS(K, G) hipLaunchKernelGGL((k_schur_rows<K, G>), dim3(num_clusters), dim3(kF2Threads), 0, st, a, clusters, tab, cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii)
   if (kmax_intr <= 0) MAVBA_ROWS(0, true);
   else if (kmax_intr <= 4) { if (generic) MAVBA_ROWS(4, true); else MAVBA_ROWS(4, false); }
   else if (kmax_intr <= 8) { if (generic) MAVBA_ROWS(8, true); else MAVBA_ROWS(8, false); }

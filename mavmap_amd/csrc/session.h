@@ -304,6 +304,9 @@ struct mavba_session {
   // k_schur_rows (round 4): the clusters with their row counts, sorted by row class then length; rows_ok: the set-up built
   // them and the clusters take k_schur_rows instead of k_schur_fused
   DevBuf<SchurRowsCluster> d_rows_clusters;
+  DevBuf<int> d_rows_lists;                 // k_schur_rows: kRowsLists ints per cluster (internal.h)
+  DevBuf<unsigned> d_rows_emit;             // k_schur_rows: the emit maps of the cluster shapes present (rows_emit_map)
+  DevBuf<unsigned long long> d_rows_lanes;  // k_schur_rows: per point, which observation each lane of its row takes (internal.h)
   int rows_class_count[kRowsClasses] = {};  // (statistics)
   bool rows_ok = false;
   bool rows_generic = false;  // some cluster has three camera slots: the general form of the intrinsics entries

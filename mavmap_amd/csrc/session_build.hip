@@ -985,6 +985,13 @@ void mavba_session::finish_structure() {
   }
   // local indices of every clustered observation / intrinsics entry, and which blocks a cluster touches
   std::vector<unsigned char> cl_present((size_t)std::max(num_clusters, 1) * kClTab, 0);
+  // k_schur_rows, round 6: the lane every observation of a point takes in the point's 16-lane row. In a cluster with two camera
+  // slots the observations of slot 0 go to lanes 0-7 and those of slot 1 to lanes 8-15 (observations of cameras with constant
+  // intrinsics fill what is left), so that the kernel's reduce-scatter of the intrinsics rows starts inside the halves. A point
+  // with more than 8 observations of one slot cannot be placed: its cluster is flagged (kRowsUnplaced) and keeps the selects.
+  std::vector<unsigned long long> rows_lanes;
+  std::vector<unsigned char> cl_unplaced((size_t)std::max(num_clusters, 1), 0);
+  if (rows_ok) rows_lanes.assign((size_t)std::max(NP, 1), kRowsLanesIdentity);
   parallel_ranges(num_clusters, [&](long long c0, long long c1) {
     int loc[kClImagesMax], prev_loc[kClImagesMax];
     std::vector<int> slot_of(NI, 0);  // image -> its place in the cluster's list (only read for the cluster's own images)
@@ -996,6 +1003,33 @@ void mavba_session::finish_structure() {
       while (nc < kClCams && cams[nc] >= 0) ++nc;
       unsigned char* pres = &cl_present[(size_t)cl * kClTab];
       int prev_n = -1;
+      if (rows_ok && nc == 2) {
+        for (int p = clusters[cl].p0; p < clusters[cl].p1; ++p) {
+          const int ob = h_pt_start[p], cnt = h_pt_start[p + 1] - ob;
+          if (cnt > kRowsBatch) { cl_unplaced[cl] = 1; continue; }
+          int half_n[2] = {0, 0}, lane_of[kRowsBatch];
+          bool fits = true;
+          for (int a = 0; a < cnt; ++a) {  // observations of the two slots first, in their order
+            const int c = h_img_cam[h_oimg[ob + a]];
+            const int lc = c == cams[0] ? 0 : c == cams[1] ? 1 : -1;
+            lane_of[a] = -1;
+            if (lc < 0) continue;
+            if (half_n[lc] == 8) { fits = false; break; }
+            lane_of[a] = 8 * lc + half_n[lc]++;
+          }
+          if (!fits) { cl_unplaced[cl] = 1; continue; }
+          unsigned used = 0;
+          for (int a = 0; a < cnt; ++a) if (lane_of[a] >= 0) used |= 1u << lane_of[a];
+          for (int a = 0, l = 0; a < cnt; ++a) {  // the others: the free lanes, ascending
+            if (lane_of[a] >= 0) continue;
+            while (used & (1u << l)) ++l;
+            lane_of[a] = l; used |= 1u << l;
+          }
+          unsigned long long lm = cnt < kRowsBatch ? ~0ull : 0ull;  // (nibble 15 = no observation; a point with 16 has none empty)
+          for (int a = 0; a < cnt; ++a) lm = (lm & ~(15ull << (4 * lane_of[a]))) | ((unsigned long long)a << (4 * lane_of[a]));
+          rows_lanes[p] = lm;
+        }
+      }
       for (int p = clusters[cl].p0; p < clusters[cl].p1; ++p) {
         if (pt_mode[p] != 1) continue;
         int n = 0;
@@ -1300,17 +1334,43 @@ void mavba_session::finish_structure() {
       for (int k = 0; k < kRowsClasses; ++k) rows_class_count[k] = 0;
       rows_generic = false;
       for (int c = 0; c < num_clusters; ++c) rows_generic = rows_generic || cl_nc[c] > 2;
+      d_rows_lanes.upload(rows_lanes, st);
+      // the emit maps of the shapes present: one per (ni, nc), concatenated
+      std::vector<unsigned> emit_all, e0, e1;
+      int emit_of[kClImagesMax + 1][kClCamsMax + 1][3];
+      for (auto& x : emit_of) for (auto& y : x) y[0] = -1;
       for (int c = 0; c < num_clusters; ++c) {
         const int o = order[c];
-        rc[c] = SchurRowsCluster{clusters[o].p0, clusters[o].p1, cl_ni[o], cl_nc[o]};
+        int* eo = emit_of[cl_ni[o]][cl_nc[o]];
+        if (eo[0] < 0) {
+          rows_emit_map(cl_ni[o], cl_nc[o], e0, e1);
+          eo[0] = (int)emit_all.size(); eo[1] = (int)e0.size(); eo[2] = (int)e1.size();
+          emit_all.insert(emit_all.end(), e0.begin(), e0.end());
+          emit_all.insert(emit_all.end(), e1.begin(), e1.end());
+        }
+        rc[c] = SchurRowsCluster{clusters[o].p0, clusters[o].p1, cl_ni[o], cl_nc[o], eo[0], {eo[1], eo[2]}, cl_unplaced[o] ? kRowsUnplaced : 0};
         rows_class_count[row_class(o)]++;
       }
       d_rows_clusters.upload(rc, st);
+      d_rows_emit.upload(emit_all, st);
+      std::vector<int> rl((size_t)std::max(num_clusters, 1) * kRowsLists, -1);
+      for (int c = 0; c < num_clusters; ++c) {
+        const int o = order[c];
+        int* L = &rl[(size_t)c * kRowsLists];
+        for (int k = 0; k < kClImages; ++k) { const int img = cl_imgs[(size_t)o * kClImages + k]; L[k] = img; L[kRowsListsCam + k] = img >= 0 ? h_img_cam[img] : -1; }
+        for (int k = 0; k < kClCams; ++k) L[kRowsListsCams + k] = cl_cams[(size_t)o * kClCams + k];
+      }
+      d_rows_lists.upload(rl, st);
       if (std::getenv("MAVBA_CLUSTER_STATS")) {
         long long pts[kRowsClasses] = {}, bat[kRowsClasses] = {};
         for (int c = 0; c < num_clusters; ++c) { const int k = row_class(order[c]); pts[k] += rc[c].p1 - rc[c].p0; bat[k] += (rc[c].p1 - rc[c].p0 + kRowsBatch - 1) / kRowsBatch; }
         for (int k = 0; k < kRowsClasses; ++k)
           std::fprintf(stderr, "[cluster stats] k_schur_rows class %d (%d rows): %d clusters, %lld points, %lld batches\n", k, 16 * kRowsClassNT[k], rows_class_count[k], pts[k], bat[k]);
+        long long hist[kClImagesMax + 1][kClCamsMax + 1][2] = {}, unplaced = 0;
+        for (int c = 0; c < num_clusters; ++c) { hist[rc[c].ni][rc[c].nc][0]++; hist[rc[c].ni][rc[c].nc][1] += (rc[c].p1 - rc[c].p0 + kRowsBatch - 1) / kRowsBatch; unplaced += (rc[c].flags & kRowsUnplaced) != 0; }
+        std::fprintf(stderr, "[cluster stats] k_schur_rows clusters / batches by (images, cameras):");
+        for (int i = 0; i <= kClImagesMax; ++i) for (int k = 0; k <= kClCamsMax; ++k) if (hist[i][k][0]) std::fprintf(stderr, " (%d,%d) %lld/%lld", i, k, hist[i][k][0], hist[i][k][1]);
+        std::fprintf(stderr, "; clusters that keep the selects: %lld\n", unplaced);
       }
     }
     std::vector<SchurCluster> cl_sorted(clusters.size());

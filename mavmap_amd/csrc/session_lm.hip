@@ -57,8 +57,8 @@ void mavba_session::launch_front(double r, bool entries, const LmSpec& spec) {
     // partials of S for this radius (no entry records in HBM)
     timed("schur_fused", [&] {
       if (rows_ok)
-        launch_schur_rows(st, f, Q > 0 ? KMAX : 0, rows_generic, num_clusters, d_rows_clusters.p, d_cl_tab.p, d_cl_lists.p, d_obs_meta.p,
-                          d_part[0].p, d_part[1].p, d_part[2].p);
+        launch_schur_rows(st, f, Q > 0 ? KMAX : 0, rows_generic, num_clusters, d_rows_clusters.p, d_cl_tab.p, d_rows_lists.p, d_obs_meta.p,
+                          d_rows_lanes.p, d_rows_emit.p, d_part[0].p, d_part[1].p, d_part[2].p);
       else
         launch_schur_fused(st, f, Q > 0 ? KMAX : 0, num_clusters, d_clusters.p, d_cl_tab.p, d_cl_lists.p, d_obs_meta.p, d_q_meta.p, d_part[0].p, d_part[1].p,
                            d_part[2].p);

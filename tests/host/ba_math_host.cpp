@@ -30,4 +30,6 @@ int hm_chol3_inv(const double* C, double* Gi) { return mavba::chol3_inv(C, Gi) ?
 void hm_cauchy(double s, double a, double* w, double* half_rho) {
   mavba::cauchy_weight(s, a * a, 1.0 / (a * a), *w, *half_rho);
 }
+// the device build's log series (log_obs) on the host: frexp supplies the parts the hardware instructions give the kernel
+double hm_log_series(double x) { int e; const double m = std::frexp(x, &e); return mavba::log_from_parts(m, e); }
 }

@@ -171,3 +171,17 @@ def test_problem_replay_file_round_trip(tmp_path):
         f.write(b"XX")
     with pytest.raises(ValueError):
         BAProblem.load(path)
+
+
+def test_log_series_of_the_device_build(host):
+    """log_obs (ba_math.h, round 6): the kernels' short log for the Cauchy cost - the same series evaluated on the host -
+    against the library's over the range the loss feeds it (1 + s / b, s >= 0)."""
+    host.hm_log_series.restype = C.c_double
+    host.hm_log_series.argtypes = [C.c_double]
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([1.0 + 10.0 ** rng.uniform(-16, 0, 4000), 10.0 ** rng.uniform(0, 12, 4000), [1.0, 2.0, 0.5 ** 0.5 * 2, 2.0 ** 0.5, 4.0]])
+    got = np.array([host.hm_log_series(float(x)) for x in xs])
+    ref = np.log(xs)
+    assert got[-5] == 0.0
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+    assert err[ref > 0].max() <= 4.5e-16, err.max()
