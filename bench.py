@@ -170,6 +170,71 @@ def count_pp_terms(prob):
     return int(np.sum(cnt * (cnt + 1) // 2))
 
 
+def measure_other_config(name, steps, warmup, device):
+    """A short pass over another BASELINE config on this GPU (single rank): LM iterations/s without instrumentation, then the
+    same steps with HIP events for the dominant kernel and its roofline fraction. No CPU baseline, no counters."""
+    import mavmap_amd
+    from mavmap_amd import synth, _abi as A
+    t0 = time.time()
+    prob = synth.make_config(name)
+    opts = dict(max_num_iterations=200, function_tolerance=1e-6, gradient_tolerance=1e-10, device=device, profile_kernels=0)
+    with mavmap_amd.Session(prob, opts) as sess:
+        import torch
+
+        def run_steps(k):
+            remaining, idle = k, 0
+            while remaining > 0:
+                done, term = sess.iterate(remaining)
+                remaining -= done
+                idle = idle + 1 if done == 0 else 0
+                if idle > 2:
+                    raise RuntimeError("bench: solver makes no progress")
+                if term != A.TERM_RUNNING and remaining > 0:
+                    sess.reset()
+        run_steps(warmup)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        run_steps(steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t
+        sess.reset()
+        sess.set_profiling(True)
+        run_steps(warmup)
+        s0 = sess.kernel_stats()
+        run_steps(steps)
+        torch.cuda.synchronize()
+        s1 = sess.kernel_stats()
+        sess.set_profiling(False)
+        info = sess.info()
+        per = {}
+        for k, v in s1.items():
+            b = s0.get(k, dict(launches=0, total_ms=0.0))
+            n, ms = v["launches"] - b["launches"], v["total_ms"] - b["total_ms"]
+            if n > 0:
+                per[k] = dict(launches=n, total_ms=ms, avg_ms=ms / n)
+        tot = sum(v["total_ms"] for v in per.values()) or 1.0
+        rows = []
+        for k, v in sorted(per.items(), key=lambda kv: -kv[1]["total_ms"]):
+            bound, amount, unit = algorithmic_work(k, prob, info)
+            row = dict(kernel=k, avg_ms=round(v["avg_ms"], 5), share=round(v["total_ms"] / tot, 4))
+            if bound:
+                peak = HBM_PEAK_GBS if bound == "hbm" else FP64_MFMA_PEAK_TFLOPS
+                ach = amount / (v["avg_ms"] * 1e-3) / (1e9 if bound == "hbm" else 1e12)
+                row.update(bound=bound, achieved=round(ach, 3), peak=peak, unit="GB/s" if bound == "hbm" else "TFLOP/s", frac=round(ach / peak, 4))
+            rows.append(row)
+        dom = next((r for r in rows if r.get("bound")), None)
+        sess.reset()
+        final = sess.solve()
+    out = {"workload": WORKLOADS[name], "value": round(steps / elapsed, 3), "unit": "iter/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * elapsed / steps, 4), "dominant_kernel": dom, "kernels": rows[:6],
+           "solve": {"iterations": final["num_successful_steps"] + final["num_unsuccessful_steps"], "termination": final["termination_name"],
+                     "rmse_px": round(float(np.sqrt(final["final_cost"] / max(final["num_residuals"], 1))), 6),
+                     "setup_seconds": round(final["setup_seconds"], 4)},
+           "wall_seconds": round(time.time() - t0, 1)}
+    log(f"other config {name}: {out['value']} iter/s, {out['ms_per_step']} ms per iteration, dominant {dom['kernel'] if dom else None}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +245,7 @@ def main():
     ap.add_argument("--problem", default=None, help="replay file (BAProblem.save / the shim's MAVBA_DUMP_DIR) instead of a synthetic config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short C2 / C5 passes of the default single-GPU run (--no-cpu-baseline skips them too: the tuning scripts' form)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -262,6 +328,19 @@ def main():
             from mavmap_amd.dist import make_allreduce
             sess.set_allreduce(make_allreduce(torch.device(f"cuda:{local_rank}")), rank, world)
             exchange = "torch.distributed all-reduce hook (host-synchronised)"
+
+    # who takes part (N > 1): every rank's device and shard, and a count of the ranks through the SAME exchange the solve uses
+    # (the session's collective sums a one per rank) - the first run on a multi-GPU node should be readable from the line alone
+    rank_info = dict(rank=rank, local_rank=local_rank, device=torch.cuda.get_device_name(local_rank), pid=os.getpid(),
+                     points=int(prob.num_points), observations=int(prob.num_obs))
+    ranks = [rank_info]
+    ranks_confirmed = 1
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_info)
+        one = torch.ones(1, dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(one)
+        ranks_confirmed = int(round(float(one.item())))
 
     def run_steps(k):
         remaining, solves, idle = k, 0, 0
@@ -500,6 +579,17 @@ def main():
                     "collectives per iteration, priced as 20 us + 2 (R-1)/R bytes / min(50 (R-1), 300) GB/s (one xGMI link per "
                     "peer): the honest expectation for this design. profiles/r05_multi_gpu_pricing.txt prices the alternatives "
                     "(subtree-aligned shards, subtree-to-rank factorisation: 1.36x at C3, 2.35x at C5 on 8 ranks) on the real structures"}
+        # the other single-GPU configurations of BASELINE.json, short passes (the driver times only this command: C2 and C5,
+        # whose dominant kernel is the factorisation, would otherwise be builder-only numbers)
+        other_configs = None
+        if world == 1 and args.config == "C3" and args.scale == 1.0 and not args.problem and not args.no_other_configs and not args.no_cpu_baseline:
+            sess.close()
+            other_configs = {}
+            for name, k in (("C2", 60), ("C5", 30)):
+                try:
+                    other_configs[name] = measure_other_config(name, k, 6, local_rank)
+                except Exception as e:  # noqa: BLE001
+                    other_configs[name] = {"error": str(e)}
         value = args.steps / elapsed
         # HBM bytes one LM iteration moves (committed counter pass x this run's launch counts) against the algorithmic
         # bytes of ONE Jacobian sweep (48 + 16 + 2 (9 + K) 8 per observation)
@@ -544,6 +634,13 @@ def main():
                                "factor_gflop_dense_equivalent": round(info["dense_factor_flops"] / 1e9, 3)},
             "cpu_baseline": cpu_baseline,
             "scaling_model": scaling_model,
+            "ranks": {"world": world, "confirmed_by_all_reduce": ranks_confirmed, "exchange": exchange, "per_rank": ranks,
+                      "observations_max_over_mean": round(max(r["observations"] for r in ranks) / max(1.0, float(np.mean([r["observations"] for r in ranks]))), 4),
+                      "exchanged_bytes_per_linear_solve": 0 if world == 1 else int(packed_bytes + 8 * (81 * full.num_images + 54 * full.num_cameras) + 8 * 16),
+                      "note": "per linear solve every rank all-reduces the packed non-zero tiles of the reduced camera system + its right-hand side, "
+                              "the camera-side sums (81 doubles per image, 54 per camera) and two groups of scalars; the speculative evaluation "
+                              "of the single-GPU loop is off when sharded (its collective would re-sum a rejected step's sums): ~40 us per iteration"},
+            "other_configs": other_configs,
             "traffic_per_iteration": traffic_iter,
             "kernels": table,
             "solve": {"iterations": final["num_successful_steps"] + final["num_unsuccessful_steps"],

@@ -274,18 +274,22 @@ int mavba_debug_inproc_comms(int32_t world, int32_t calls, int32_t abort_after, 
   if (world < 1 || world > 16 || calls < 1 || !out) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "bad argument");
   const std::vector<int> dev((size_t)world, -1);
   std::vector<void*> first, cur;
+  std::shared_ptr<RcclGuard> guard, guard0;
   std::string why;
   bool same = true;
   for (int c = 0; c < calls; ++c) {
-    if (!inproc_comms_acquire(world, dev, cur, why)) throw Failure(MAVBA_ERR_HIP, why);
+    if (!inproc_comms_acquire(world, dev, cur, guard, why)) throw Failure(MAVBA_ERR_HIP, why);
+    if (c == 0) guard0 = guard;
     if (c == 0) first = cur; else same = same && cur == first;
   }
   out[0] = (int64_t)cur.size(); out[1] = same ? 1 : 0; out[2] = 0;
   if (abort_after) {
     inproc_comms_abort();
-    if (!inproc_comms_acquire(world, dev, cur, why)) throw Failure(MAVBA_ERR_HIP, why);
+    if (!inproc_comms_acquire(world, dev, cur, guard, why)) throw Failure(MAVBA_ERR_HIP, why);
     out[0] = (int64_t)cur.size();
-    out[2] = 1;  // (handles are heap pointers of the library: freed ones may be handed out again - the counts tell, see the test)
+    // (handles are heap pointers of the library: freed ones may be handed out again - the counts tell, see the test.) The old
+    // group's guard says "aborted" to whoever still holds it, the new group has a guard of its own:
+    out[2] = (guard0 && guard0->aborted && guard && guard != guard0 && !guard->aborted) ? 1 : 0;
   }
   return MAVBA_OK;
   MAVBA_CATCH
@@ -294,11 +298,11 @@ int mavba_debug_inproc_comms(int32_t world, int32_t calls, int32_t abort_after, 
 // (multi_gpu.hip) a communicator of the process-wide group of in-process ranks: used, not owned - it outlives the session
 extern "C++" {
 namespace mavba {
-int session_borrow_rccl(mavba_session* s, void* comm, int rank, int world_size) {
+int session_borrow_rccl(mavba_session* s, void* comm, const std::shared_ptr<RcclGuard>& guard, int rank, int world_size) {
   MAVBA_SESSION_TRY(s)
   if (!comm || rank < 0 || rank >= world_size) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "bad communicator / rank");
   if (s->started) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "set_rccl must precede the first iteration");
-  s->rccl_comm = comm; s->rccl_comm_owned = false;
+  s->rccl_comm = comm; s->rccl_comm_owned = false; s->rccl_guard = guard;
   s->ar_fn = nullptr; s->rank = rank; s->world = world_size;
   s->force_exchange = false;
   join_ranks(s);

@@ -675,7 +675,7 @@ __device__ __forceinline__ void inv_trail_phase(const Box& bx, d4& X) {
 // and `panel.prefetch()` behind them let the chain bring the NEXT column's tiles into LDS meanwhile.
 struct NoPanel { static constexpr bool enabled = false; };
 template <class Mark = NoMark, int DEBUG_SOLO = 0, class Panel = NoPanel>
-__device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int tid, Mark mark = Mark(), Panel panel = Panel()) {
+__device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int tid, Mark mark = Mark(), Panel panel = Panel(), bool* stalled = nullptr) {
   using namespace systile;
   const int wv = tid >> 6, lane = tid & 63;
   // every wave takes its blocks (T is the mailbox from the barrier on); counters and the upper blocks of Ti are cleared meanwhile
@@ -904,6 +904,7 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
   if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) bx.f[F_BAD] = 1;
   __syncthreads();
   const bool ok = bx.f[F_BAD] == 0 && bx.f[F_DEAD] == 0;
+  if (stalled) *stalled = bx.f[F_DEAD] != 0;  // (a mailbox wait ran out: NOT "the matrix is not positive definite" - the caller decides)
   __syncthreads();  // (T - the mailbox - may be refilled by the caller from here on)
   return ok;
 }
@@ -1758,13 +1759,18 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
           if (ni & 1) { cp.next_diag = A.pre + (size_t)(2 * (j + 1)) * NB * NB; cp.next_diag_ld = NB; cp.next_diag_coh = true; cp.next_f1 = A.pflag + 2 * (j + 1); }
           else { cp.next_diag = A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB; cp.next_diag_ld = ld; }
         }
-        const bool ok = tile_potrf_inv_sys<NoMark, 0, ChainPanel>(Tcur, Bs, tid, NoMark(), cp);
+        bool stalled = false;
+        const bool ok = tile_potrf_inv_sys<NoMark, 0, ChainPanel>(Tcur, Bs, tid, NoMark(), cp, &stalled);
 #else
         // (the product build: only a node's FIRST column comes here - the plain tile factorisation, no panel code in the kernel)
         (void)Pcur;
-        const bool ok = tile_potrf_inv_sys(Tcur, Bs, tid);
+        bool stalled = false;
+        const bool ok = tile_potrf_inv_sys(Tcur, Bs, tid, NoMark(), NoPanel(), &stalled);
 #endif
-        if (tid == 0 && !ok) atomicAdd(A.fail, 1.0);
+        // (a wave of the tile that never got its record - ~64 k spins - is a stall of this launch, not a bad pivot: reported like
+        // the launch's own time-outs, so the solve is repeated on the launch-per-panel schedule instead of being taken for "not
+        // positive definite" - ADVICE r5)
+        if (tid == 0 && !ok) atomicAdd(A.fail, stalled ? 1e30 : 1.0);
         stamp_clk((size_t)8 * j + 4);
         stamp((size_t)8 * j + 6);
         store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);

@@ -17,6 +17,7 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
   std::string error;
 };
 RcclApi& rccl() {
@@ -33,6 +34,7 @@ RcclApi& rccl() {
     a->CommDestroy = reinterpret_cast<decltype(a->CommDestroy)>(dlsym(a->lib, "ncclCommDestroy"));
     a->CommAbort = reinterpret_cast<decltype(a->CommAbort)>(dlsym(a->lib, "ncclCommAbort"));
     a->GetErrorString = reinterpret_cast<decltype(a->GetErrorString)>(dlsym(a->lib, "ncclGetErrorString"));
+    a->CommGetAsyncError = reinterpret_cast<decltype(a->CommGetAsyncError)>(dlsym(a->lib, "ncclCommGetAsyncError"));
     if (!a->GetUniqueId || !a->CommInitRank || !a->AllReduce || !a->CommDestroy) a->error = "librccl.so lacks an expected symbol";
     return a;
   }();
@@ -65,6 +67,12 @@ void rccl_comm_abort(void* comm) {
   if (!comm) return;
   if (rccl().CommAbort) (void)rccl().CommAbort(static_cast<ncclComm_t>(comm));
   else rccl_comm_destroy(comm);
+}
+int rccl_comm_async_error(void* comm) {
+  if (!comm || !rccl().CommGetAsyncError) return 0;
+  ncclResult_t e = ncclSuccess;
+  if (rccl().CommGetAsyncError(static_cast<ncclComm_t>(comm), &e) != ncclSuccess) return 1;
+  return e == ncclSuccess ? 0 : (int)e;
 }
 // in place on `stream`; op 0 = sum, 1 = max, 2 = sum over the first count - 1 doubles and max over the last
 void rccl_allreduce(void* comm, double* p, long long count, int op, hipStream_t stream) {
@@ -391,6 +399,7 @@ class HostWorkers {
   const std::function<void(int)>* job = nullptr;
   int job_T = 0, remaining = 0;
   unsigned long long generation = 0;
+  std::exception_ptr error;  // the first exception a body threw in the current run()
 
   void loop(int id) {
     unsigned long long seen = 0;
@@ -401,8 +410,10 @@ class HostWorkers {
       if (id < job_T) {
         const std::function<void(int)>* j = job;
         lk.unlock();
-        (*j)(id);
+        std::exception_ptr e;
+        try { (*j)(id); } catch (...) { e = std::current_exception(); }  // (rethrown by run() on the calling thread)
         lk.lock();
+        if (e && !error) error = e;
         if (--remaining == 0) cv_done.notify_one();
       }
     }
@@ -420,6 +431,10 @@ class HostWorkers {
     cv_start.notify_all();
     cv_done.wait(lk, [&] { return remaining == 0; });
     job = nullptr;
+    std::exception_ptr e = error;
+    error = nullptr;
+    lk.unlock();
+    if (e) std::rethrow_exception(e);  // (a Failure thrown inside a parallel pass reaches the C ABI's catch like any other)
   }
 };
 int host_threads() {

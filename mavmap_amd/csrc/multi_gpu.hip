@@ -155,18 +155,46 @@ struct CommGroup {
   int world = 0;
   std::vector<int> device;
   std::vector<void*> comm;
+  std::shared_ptr<RcclGuard> guard;  // of the CURRENT communicators; a session keeps its group's guard alive
 };
 CommGroup& comm_group() { static CommGroup* g = new CommGroup; return *g; }
+// One multi-GPU solve of the process at a time on the RCCL path: the group is a process-wide singleton - two
+// concurrent solves would interleave their collectives on the same communicators in rank-inconsistent order, a solve with
+// other devices would destroy the group under a running one, one solve's abort would free the other's handles.
+std::mutex& rccl_solve_mutex() { static std::mutex* m = new std::mutex; return *m; }
 }  // namespace
 
-bool inproc_comms_acquire(int world, const std::vector<int>& device, std::vector<void*>& out, std::string& error) {
+bool inproc_comms_acquire(int world, const std::vector<int>& device, std::vector<void*>& out, std::shared_ptr<RcclGuard>& guard,
+                          std::string& error) {
   CommGroup& C = comm_group();
   std::lock_guard<std::mutex> lk(C.m);
-  if (C.world == world && C.device == device && (int)C.comm.size() == world) { out = C.comm; return true; }
+  if (C.world == world && C.device == device && (int)C.comm.size() == world) {
+    // a cached group is reused only while every communicator is healthy (one in an asynchronous error state would fail or hang
+    // every later collective)
+    bool healthy = true;
+    for (void* c : C.comm) healthy = healthy && rccl_comm_async_error(c) == 0;
+    if (healthy) { out = C.comm; guard = C.guard; return true; }
+    for (void* c : C.comm) rccl_comm_abort(c);
+    C.comm.clear(); C.world = 0; C.device.clear(); C.guard.reset();
+  }
   for (void* c : C.comm) rccl_comm_destroy(c);
-  C.comm.clear(); C.world = 0; C.device.clear();
+  C.comm.clear(); C.world = 0; C.device.clear(); C.guard.reset();
   unsigned char uid[128];
   try { rccl_unique_id(uid); } catch (const std::exception& e) { error = e.what(); return false; }
+  // everything that can fail without the peers goes first: a creator that threw before ncclCommInitRank would leave the other
+  // ranks waiting in the rendezvous for good (and this thread in join() with the group's mutex held)
+  {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (int r = 0; r < world; ++r)
+      if (device[r] >= 0 && hipSetDevice(device[r]) != hipSuccess) {
+        (void)hipGetLastError();
+        if (prev >= 0) (void)hipSetDevice(prev);
+        error = "rank " + std::to_string(r) + ": device " + std::to_string(device[r]) + " cannot be selected";
+        return false;
+      }
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
   std::vector<void*> comm(world, nullptr);
   std::vector<std::string> err(world);
   auto make = [&](int r) {
@@ -187,16 +215,25 @@ bool inproc_comms_acquire(int world, const std::vector<int>& device, std::vector
       for (void* c : comm) rccl_comm_abort(c);
       return false;
     }
-  C.world = world; C.device = device; C.comm = comm;
-  out = comm;
+  C.world = world; C.device = device; C.comm = comm; C.guard = std::make_shared<RcclGuard>();
+  out = comm; guard = C.guard;
   return true;
 }
 
+// Called by a rank that failed: first nobody may START another collective on the handles (the guard, exclusively - waits
+// for the peers that are inside an enqueue call), then the communicators are aborted (what is in flight on the devices is
+// given up, the peers' read-backs end) and freed. Peers find `aborted` set before they touch a handle again.
 void inproc_comms_abort() {
   CommGroup& C = comm_group();
   std::lock_guard<std::mutex> lk(C.m);
-  for (void* c : C.comm) rccl_comm_abort(c);
-  C.comm.clear(); C.world = 0; C.device.clear();
+  if (C.guard) {
+    std::unique_lock<std::shared_mutex> g(C.guard->m);
+    C.guard->aborted = true;
+    for (void* c : C.comm) rccl_comm_abort(c);
+  } else {
+    for (void* c : C.comm) rccl_comm_abort(c);
+  }
+  C.comm.clear(); C.world = 0; C.device.clear(); C.guard.reset();
 }
 
 int multi_gpu_ranks() {
@@ -231,7 +268,7 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
       for (size_t r = 0; r < G.stream.size(); ++r) {
         if (!G.stream[r] && !G.stage[r]) continue;
         (void)hipSetDevice(G.device[r]);
-        if (G.stream[r]) (void)hipStreamDestroy(G.stream[r]);
+        if (G.stream[r]) { (void)hipStreamSynchronize(G.stream[r]); stream_release(G.stream[r], G.device[r]); }  // (back to the process's stream cache)
         if (G.stage[r]) device_free(G.stage[r]);
         G.stream[r] = nullptr; G.stage[r] = nullptr;
       }
@@ -246,7 +283,7 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
     }
   for (int a = 0; a < world; ++a) {
     HIP_OK(hipSetDevice(G.device[a]));
-    HIP_OK(hipStreamCreate(&G.stream[a]));
+    HIP_OK(stream_acquire(&G.stream[a]));  // (the exchange kernel's stream, from the cache the sessions use: created once per device and process)
     if (G.direct)
       for (int b = 0; b < world; ++b)
         if (G.device[a] != G.device[b]) {
@@ -308,9 +345,12 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
   bool use_rccl = !same_device;
   if (const char* e = std::getenv("MAVBA_GPUS_EXCHANGE")) use_rccl = use_rccl && std::string(e) != "inproc";
   std::vector<void*> comms;
+  std::shared_ptr<RcclGuard> guard;
+  std::unique_lock<std::mutex> one_rccl_solve;  // held from here to the end of the call on the RCCL path
   if (use_rccl) {
+    one_rccl_solve = std::unique_lock<std::mutex>(rccl_solve_mutex());
     std::string why;
-    if (!inproc_comms_acquire(world, G.device, comms, why)) use_rccl = false;  // (librccl.so not loadable, ...: the peer-access exchange)
+    if (!inproc_comms_acquire(world, G.device, comms, guard, why)) { use_rccl = false; one_rccl_solve.unlock(); }  // (librccl.so not loadable, ...: the peer-access exchange)
   }
   std::vector<RankCtx> ctx(world);
   auto worker = [&](int r) {
@@ -325,7 +365,7 @@ int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_
       if (S.rc != MAVBA_OK) { S.error = g_last_error; G.fail(); }
       if (!G.barrier() && S.rc == MAVBA_OK) { S.rc = MAVBA_ERR_HIP; g_last_error = "another rank failed during set-up"; }
     }
-    if (S.rc == MAVBA_OK) S.rc = use_rccl ? session_borrow_rccl(s, comms[r], r, world) : mavba_session_set_allreduce(s, inproc_allreduce, &ctx[r], r, world);
+    if (S.rc == MAVBA_OK) S.rc = use_rccl ? session_borrow_rccl(s, comms[r], guard, r, world) : mavba_session_set_allreduce(s, inproc_allreduce, &ctx[r], r, world);
     int done = 0;
     if (S.rc == MAVBA_OK) S.rc = mavba_session_iterate(s, options->max_num_iterations + 1, &done, &S.term);
     // (stream-ordered collectives: a peer that failed aborts the group, this rank's collectives then complete with

@@ -273,6 +273,17 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
       if (k == 0) s_clcam[c] = cam;
     }
   }
+  double cost = 0.0;
+  auto run = [&](auto nt_const) {
+  constexpr int NT = decltype(nt_const)::value;
+  using SH = F2Shape<NT>;
+  f2_d4 acc[SH::acc];
+#pragma unroll
+  for (int t = 0; t < SH::acc; ++t) acc[t] = (f2_d4){0.0, 0.0, 0.0, 0.0};
+  long long stamp[TRACE ? 8 : 1];
+  int nstamp = 0;
+  bool tracing = false;
+  auto mark = [&]() { if constexpr (TRACE) { if (tracing && nstamp < 8) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
   // A batch's loads - every lane's observation, the row's point - are requested before the PREVIOUS batch's matrix
   // instructions start and travel under them; the first batch's are requested HERE, next to the tables' (its point starts and
   // lane maps straight from memory: behind the tables' barrier they were one more exposed round trip per cluster).
@@ -300,17 +311,6 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     if (pj < npts) { const int ob = s_pstart[pj]; request_point(pj, ob, s_pstart[pj + 1] - ob, s_lanes[pj]); }
   };
   if (r < npts) { const int ob = a.pt_start[cl.p0 + r]; request_point(r, ob, a.pt_start[cl.p0 + r + 1] - ob, lanemap[cl.p0 + r]); }
-  double cost = 0.0;
-  auto run = [&](auto nt_const) {
-  constexpr int NT = decltype(nt_const)::value;
-  using SH = F2Shape<NT>;
-  f2_d4 acc[SH::acc];
-#pragma unroll
-  for (int t = 0; t < SH::acc; ++t) acc[t] = (f2_d4){0.0, 0.0, 0.0, 0.0};
-  long long stamp[TRACE ? 8 : 1];
-  int nstamp = 0;
-  bool tracing = false;
-  auto mark = [&]() { if constexpr (TRACE) { if (tracing && nstamp < 8) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
   __syncthreads();
   if constexpr (TRACE) t_loop0 = (long long)__builtin_amdgcn_s_memtime();
   for (int bi = 0; bi < nbatch; ++bi) {

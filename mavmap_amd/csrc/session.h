@@ -15,6 +15,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -81,10 +82,12 @@ long long device_scan_scratch(long long n);
 void device_scan_exclusive(hipStream_t st, unsigned* data, long long n, unsigned* scratch);  // in place, any length; scratch >= device_scan_scratch(n) values
 
 // multi_gpu.hip: one process, several devices (MAVBA_GPUS)
-int session_borrow_rccl(mavba_session* s, void* comm, int rank, int world_size);  // (api.hip)
+struct RcclGuard;
+int session_borrow_rccl(mavba_session* s, void* comm, const std::shared_ptr<RcclGuard>& guard, int rank, int world_size);  // (api.hip)
 // the RCCL communicators of the in-process ranks, kept for the life of the process: ncclCommInitRank costs tens of
 // milliseconds - more than the C3 solve it would serve. device[r] < 0: do not bind the creating thread (host-only tests)
-bool inproc_comms_acquire(int world, const std::vector<int>& device, std::vector<void*>& out, std::string& error);
+bool inproc_comms_acquire(int world, const std::vector<int>& device, std::vector<void*>& out, std::shared_ptr<RcclGuard>& guard,
+                          std::string& error);
 void inproc_comms_abort();  // a rank failed: ncclCommAbort on every communicator (peers blocked in a collective return), group dropped
 int multi_gpu_ranks();
 int solve_multi_gpu(const mavba_problem* P, const mavba_options* options, mavba_result* result, double* point_error, int world);
@@ -98,6 +101,14 @@ void* rccl_comm_create(const void* id128, int rank, int world);
 void rccl_comm_destroy(void* comm);
 void rccl_comm_abort(void* comm);
 void rccl_allreduce(void* comm, double* p, long long count, int op, hipStream_t stream);
+int rccl_comm_async_error(void* comm);  // 0: healthy (or the library has no ncclCommGetAsyncError)
+// The communicators of the in-process ranks are BORROWED by their sessions (multi_gpu.hip). A rank that fails aborts the whole
+// group - ncclCommAbort frees the handles - while its peers may still be enqueueing collectives on them: every use of a
+// borrowed handle holds this guard shared and looks at `aborted` first; the abort takes it exclusively.
+struct RcclGuard {
+  std::shared_mutex m;
+  bool aborted = false;  // (written under the exclusive lock, read under the shared one)
+};
 hipError_t pinned_alloc(void** out, size_t bytes);
 void pinned_free(void* p);
 hipError_t stream_acquire(hipStream_t* st);
@@ -374,6 +385,7 @@ struct mavba_session {
   void* ar_ctx = nullptr;
   void* rccl_comm = nullptr;           // native: ncclAllReduce enqueued on the session's stream, no host synchronisation
   bool rccl_comm_owned = true;         // false: borrowed from the process-wide group of the in-process ranks (multi_gpu.hip)
+  std::shared_ptr<RcclGuard> rccl_guard;  // borrowed handles only: the group's abort guard
   bool sharded() const { return (ar_fn || rccl_comm) && (world > 1 || force_exchange); }
   bool force_exchange = false;         // run the multi-rank protocol even with one rank (tests of the native path)
   int rank = 0, world = 1;
@@ -440,7 +452,16 @@ struct mavba_session {
 
   void allreduce(double* dptr, long long count, int op) {
     if (!sharded()) return;
-    if (rccl_comm) { rccl_allreduce(rccl_comm, dptr, count, op, st); return; }
+    if (rccl_comm) {
+      if (rccl_guard) {
+        std::shared_lock<std::shared_mutex> lk(rccl_guard->m);
+        if (rccl_guard->aborted) throw Failure(MAVBA_ERR_HIP, "the communicator group was aborted (another rank failed)");
+        rccl_allreduce(rccl_comm, dptr, count, op, st);
+      } else {
+        rccl_allreduce(rccl_comm, dptr, count, op, st);
+      }
+      return;
+    }
     sync();
     if (ar_fn(ar_ctx, dptr, count, op) != 0) throw Failure(MAVBA_ERR_HIP, "all-reduce hook failed");
   }

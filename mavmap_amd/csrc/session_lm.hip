@@ -225,7 +225,10 @@ void mavba_session::assemble(double r) {
     timed("memset_S", [&] {
       // Outside the envelope nothing ever writes: after the first full clear only the envelope's tiles (which the in-place
       // factorisation of the launch-per-panel schedule overwrote) and the right-hand-side rows are cleared again.
-      if (M_outside_clean && chol_struct.num_env_tiles > 0 && !sharded())
+      // (Sharded sessions too, round 6: what the exchange leaves behind - the SUM over ranks in tiles this rank's assembly does not
+      // rewrite - lies in the tiles that travel, all inside the envelope every rank agreed on; rounds 3-5 cleared the whole
+      // dense array before every solve of a sharded session: 90 MB at C3, 1.2 GB at C5 per LM iteration.)
+      if (M_outside_clean && chol_struct.num_env_tiles > 0)
         launch_tiles_zero(st, chol_struct.num_env_tiles, chol_struct.d_env_tiles, d_M.p, n_mat, 64);
       else
         HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st));

@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <iomanip>
 #include <iostream>
@@ -52,6 +53,7 @@ class Workers {
   int job_T = 0, remaining = 0;
   unsigned long long generation = 0;
   int n = 0;
+  std::exception_ptr error;  // the first exception a worker's job threw in the current run()
   void loop(int id) {
     unsigned long long seen = 0;
     std::unique_lock<std::mutex> lk(m);
@@ -61,8 +63,10 @@ class Workers {
       if (id < job_T) {
         const std::function<void(int)>* j = job;
         lk.unlock();
-        (*j)(id);
+        std::exception_ptr e;
+        try { (*j)(id); } catch (...) { e = std::current_exception(); }  // (handed to the caller of run(); the thread lives on)
         lk.lock();
+        if (e && !error) error = e;
         if (--remaining == 0) cv_done.notify_one();
       }
     }
@@ -80,10 +84,17 @@ class Workers {
       job = &body; job_T = T; remaining = T - 1; ++generation;
     }
     cv_start.notify_all();
-    body(0);
+    // Exception safe: whatever body(0) throws, the workers are waited for before `body` - which they run through
+    // a pointer - and the caller's captures leave scope; the first exception of any thread is rethrown here.
+    std::exception_ptr mine;
+    try { body(0); } catch (...) { mine = std::current_exception(); }
     std::unique_lock<std::mutex> lk(m);
     cv_done.wait(lk, [&] { return remaining == 0; });
     job = nullptr; job_T = 0;
+    std::exception_ptr e = mine ? mine : error;
+    error = nullptr;
+    lk.unlock();
+    if (e) std::rethrow_exception(e);
   }
 };
 Workers& workers() {
