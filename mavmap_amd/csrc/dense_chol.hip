@@ -1642,6 +1642,11 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[m][n][r] = C[(size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li];
       }
+      // (Round 6, measured and dropped - profiles/r06_ab_update_prefetch.txt: requesting update u + 1's two tiles into registers
+      // before update u's product - a look at their flags without waiting, loads in flight under the 64 matrix instructions -
+      // took C5's launch from 1.97 to 1.87 ms and made C3's and C2's 2 % SLOWER (0.264 -> 0.270, 0.101 -> 0.103 ms: one more
+      // round trip before a barrier on lists whose inputs are rarely there early); with the look issued an iteration ahead
+      // it lost at C5 too. C5's helpers are bound by the 4.7 GB of system-scope tile reads, not by their latency.)
       for (int u = T.ub; u < T.ue; ++u) {
         const int k = A.upd[u];
         const unsigned* f0 = A.lflag + A.tile_id[(size_t)i * nb + k];
