@@ -68,10 +68,7 @@ def algorithmic_work(stats_name, prob, sess_info):
         return "hbm", (96 + 48 + 8 + 192.0) * n_obs, "B"
     if stats_name == "backsub_points":
         # k_backsub_points_packed recomputes the Jacobians: pixel + image index per observation (20 B), per point its
-        # coordinates, factor, h, diagonal, gradient, scales in and candidate + step out (216 B). (The entry-record
-        # kernel behind MAVBA_BACKSUB_ENTRIES reads 192 B / observation + 288 B / (point, camera) instead.)
-        if os.environ.get("MAVBA_BACKSUB_ENTRIES"):
-            return "hbm", 192.0 * n_obs + 288.0 * sess_info["intr_entries"] + 48.0 * n_pts, "B"
+        # coordinates, factor, h, diagonal, gradient, scales in and candidate + step out (216 B).
         return "hbm", 20.0 * n_obs + 216.0 * n_pts, "B"
     if stats_name == "schur_chunks_pp":
         return "hbm", 296.0 * sess_info["schur_terms"][0], "B"

@@ -673,6 +673,8 @@ __device__ __forceinline__ void inv_trail_phase(const Box& bx, d4& X) {
 // and no barrier; the waves with more blocks catch up under its scalar work.
 // Wave 2 has nothing to do once it has walked its pivots (a quarter of the tile's time): `panel.prefetch_poll()` before them
 // and `panel.prefetch()` behind them let the chain bring the NEXT column's tiles into LDS meanwhile.
+// (`Panel`: hooks of the fused chain column of round 5 - ChainPanel, scripts/_dbg/pruned_r06.patch; with NoPanel every one of them
+// is compiled out)
 struct NoPanel { static constexpr bool enabled = false; };
 template <class Mark = NoMark, int DEBUG_SOLO = 0, class Panel = NoPanel>
 __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int tid, Mark mark = Mark(), Panel panel = Panel(), bool* stalled = nullptr) {
@@ -909,15 +911,9 @@ __device__ __forceinline__ bool tile_potrf_inv_sys(double* T, double* Ti, int ti
   return ok;
 }
 
-// The tile factorisation the kernels call (no hooks): the systolic one; -DMAVBA_TILE_LA=1 builds the round-2..4 look-ahead
-// variant instead (A/B timing, scripts/_dbg).
-#ifndef MAVBA_TILE_LA
-#define MAVBA_TILE_LA 0
-#endif
-__device__ __forceinline__ bool tile_factor_inverse(double* T, double* Ti, int tid) {
-  if constexpr (MAVBA_TILE_LA != 0) return tile_potrf_inv_la(T, Ti, tid);
-  else return tile_potrf_inv_sys(T, Ti, tid);
-}
+// The tile factorisation the kernels call (no hooks): the systolic one. (The look-ahead variant of rounds 2-4,
+// tile_potrf_inv_la, stays as the persistent chain's tile for columns WITH a panel tile - see k_chol_persist.)
+__device__ __forceinline__ bool tile_factor_inverse(double* T, double* Ti, int tid) { return tile_potrf_inv_sys(T, Ti, tid); }
 
 // acc (2x2 MFMA tiles of the wave's 32x32 quadrant) = As(rows wr..) * Bs(rows wc..)^T, K = 64.
 __device__ __forceinline__ void mfma_quadrant_nt(const double* As, const double* Bs, int wr, int wc,
@@ -1508,76 +1504,6 @@ __device__ __forceinline__ void quadrant_sub(d4 acc[2][2], const d4 p[2][2]) {
 }
 }  // namespace
 
-// The persistent chain's panel tile inside the systolic tile factorisation (tile_potrf_inv_sys, `Panel`): where the solved
-// rows go - system-scope 16-byte stores like store_tile_coh, 16 rows per wave - and how the tile is published.
-struct ChainPanel {
-  static constexpr bool enabled = true;
-  const double* As;  // the sub-diagonal tile A_{j, j-1} with every earlier update (LDS)
-  double* Cs;        // receives P = A L^-T (LDS, row-major)
-  double* Pg;        // P's place in the factor (memory)
-  size_t ld;
-  unsigned* lflag;   // P's flag
-  unsigned ep;
-  bool sub;          // false: a node's first column - no panel tile
-  __device__ __forceinline__ void store_rows(int wv, int lane) const {
-    const __amdgpu_buffer_rsrc_t r = tile_rsrc(Pg);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = lane + 64 * q;
-      const int row = 16 * wv + (idx >> 5), c2 = (idx & 31) * 2;
-      const i4v v = *reinterpret_cast<const i4v*>(Cs + row * GLD + c2);
-      __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(((size_t)row * ld + c2) * 8), 0, kCoherent);
-    }
-  }
-  __device__ __forceinline__ void publish(int lane) const { if (lane == 0) mavba::publish(lflag, ep); }
-  // the next column's tiles: sub-diagonal -> As, diagonal -> Cs (which is the NEXT column's T: the chain swaps the two)
-  const double* next_sub; size_t next_sub_ld; bool next_sub_coh;
-  const double* next_diag; size_t next_diag_ld; bool next_diag_coh;
-  const unsigned* next_f0; const unsigned* next_f1;  // the helpers' flags of the two tiles (null: nothing to wait for)
-  int* loaded;  // (LDS) set to 1 when both tiles are in place
-  bool more;
-  __device__ __forceinline__ int prefetch_poll() const {
-    if (!more) return 0;
-    int r = 1;
-    if (next_f0 && __hip_atomic_load(next_f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) r = 0;
-    if (next_f1 && __hip_atomic_load(next_f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) r = 0;
-    return r;
-  }
-  // one wave moves a 64x64 tile: 32 x (64 lanes x 16 B), eight requests in flight
-  __device__ __forceinline__ void wave_load_tile(const double* G, size_t gld, bool coherent, double* S, int lane) const {
-    const __amdgpu_buffer_rsrc_t r = tile_rsrc(G);
-#pragma unroll 1
-    for (int g = 0; g < 4; ++g) {
-      i4v v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = lane + 64 * (8 * g + q);
-        const int row = idx >> 5, c2 = (idx & 31) * 2;
-        const int off = (int)(((size_t)row * gld + c2) * 8);
-        v[q] = coherent ? __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kCoherent) : __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = lane + 64 * (8 * g + q);
-        const int row = idx >> 5, c2 = (idx & 31) * 2;
-        *reinterpret_cast<i4v*>(S + row * GLD + c2) = v[q];
-      }
-    }
-  }
-  __device__ __forceinline__ void prefetch(int state, int lane) const {
-    if (!more) return;
-    state = __builtin_amdgcn_readfirstlane(state);
-    if (!state) state = __builtin_amdgcn_readfirstlane(prefetch_poll());  // (one more look: this wave has nothing else to do)
-    if (!state) return;
-    if (next_sub) wave_load_tile(next_sub, next_sub_ld, next_sub_coh, const_cast<double*>(As), lane);
-    wave_load_tile(next_diag, next_diag_ld, next_diag_coh, Cs, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) *reinterpret_cast<volatile int*>(loaded) = 1;
-  }
-};
-
-[[maybe_unused]] constexpr bool kSysPrefetch = false;
-
 struct CholPersistArgs {
   const double* M; double* L; double* inv; double* pre;
   int ld, nb;
@@ -1585,8 +1511,6 @@ struct CholPersistArgs {
   unsigned* lflag; unsigned* dflag; unsigned* pflag; unsigned* abort_flag;
   unsigned epoch;
   double* fail;
-  // the backward substitution as the launch's tail (round 5; bs_y == null: separate launch)
-  double* bs_y; unsigned* bs_flags; const int* bs_seg_of_tile; const int* bs_seg_first; int bs_nseg; const int* bs_scatter; double* bs_y_nat;
   int drop_wg;                // test hook (MAVBA_CHOL_TEST_DROP_WG): this work-group does nothing, as if it were never resident
   unsigned long long* trace;  // MAVBA_CHOL_TRACE: 100 MHz wall-clock stamps, [8 per chain column | 4 per task], else null
 };
@@ -1598,7 +1522,6 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
   __shared__ __attribute__((aligned(16))) double Ds[NB * GLD];  // the chain's diagonal tile (As still holds the sub-diagonal one)
   __shared__ int s_ok, s_ok2;
   __shared__ int s_rows[4];  // per wave: the chain column (+ 1) whose row block of the panel tile is complete in Cs
-  __shared__ int s_next;  // (systolic chain) the next column's tiles are in LDS
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
   const int nb = A.nb;
@@ -1695,13 +1618,11 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
     // travel while the matrix cores factorise; otherwise the chain waits for them afterwards.
     TileRegs Rsub, Rdiag;
     bool have_next = false;  // Rsub / Rdiag hold column j's tiles
-    bool next_in_lds = false;  // (systolic chain) wave 2 of the previous column has put them into As / the spare tile buffer
-    [[maybe_unused]] int sys_flip = 0;
     for (int j = T.i; j < T.j; ++j) {
       const int info = A.chain_info[j];
       const bool sub = j > T.i;
       stamp((size_t)8 * j);
-      if (!have_next && !next_in_lds) {
+      if (!have_next) {
         const unsigned* f0 = (sub && (info & 2)) ? A.pflag + 2 * j + 1 : nullptr;
         const unsigned* f1 = (info & 1) ? A.pflag + 2 * j : nullptr;
         if ((f0 || f1) && !wait2(f0, f1)) { alive = false; break; }
@@ -1728,50 +1649,16 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       // was built, tested and measured - 10.3 us per column against 9.2 + 1.5 for the round-3 arrangement that hides the
       // panel work inside the look-ahead variant's longer phases: wave 0 cannot start on the pivots before it has solved
       // its 16 rows of P and downdated block (0, 0) (56 matrix instructions, 4 100 ticks), and spreading that over the
-      // waves makes wave 1 late for ITS pivots (11.1 us). No gain: those columns keep the round-3 code;
-      // -DMAVBA_CHAIN_FUSED_PANEL=1 builds the fused form (scripts/_dbg A/B).
-#ifndef MAVBA_CHAIN_FUSED_PANEL
-#define MAVBA_CHAIN_FUSED_PANEL 0
-#endif
-      if (MAVBA_TILE_LA == 0 && (MAVBA_CHAIN_FUSED_PANEL != 0 || !sub)) {
+      // waves makes wave 1 late for ITS pivots (11.1 us). No gain: those columns keep the round-3 code; the fused form
+      // (ChainPanel) is in scripts/_dbg/pruned_r06.patch.
+      if (!sub) {
         (void)seq;
-        // (the diagonal tile is factorised in Tcur, the panel tile lands in Pcur; the two buffers swap roles every column
-        // because wave 2 prefetches the NEXT diagonal tile into Pcur while Tcur is still the factorisation's mailbox)
-        double* const Tcur = Ds;  // (with kSysPrefetch the two would swap roles every column: sys_flip; fixed pointers keep
-        double* const Pcur = Cs;  // every access a plain LDS access - through a runtime choice they became FLAT ones)
-        if (!next_in_lds) {
-          if (sub) tile_regs_to_lds(Rsub, As, tid);
-          tile_regs_to_lds(Rdiag, Tcur, tid);
-        }
-        if (tid == 0) s_next = 0;
+        tile_regs_to_lds(Rdiag, Ds, tid);
         __syncthreads();
         stamp((size_t)8 * j + 2);
         stamp_clk((size_t)8 * j + 3); stamp((size_t)8 * j + 5);
-#if MAVBA_CHAIN_FUSED_PANEL
-        ChainPanel cp;
-        cp.As = As; cp.Cs = Pcur; cp.Pg = sub ? A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB : nullptr; cp.ld = ld;
-        cp.lflag = sub ? A.lflag + A.tile_id[(size_t)j * nb + (j - 1)] : nullptr; cp.ep = ep; cp.sub = sub;
-        // (the prefetch by wave 2 is built but switched off: the helpers deliver a column's tiles just in time - their queues
-        // are list-scheduled against the chain -, so the flags are almost never up a third of a column ahead, and when they
-        // were, 64 system-scope loads by one wave took longer than the wave's idle time: 13.4 instead of 10.2 us per column)
-        cp.more = more && kSysPrefetch; cp.loaded = &s_next;
-        cp.next_sub = nullptr; cp.next_diag = nullptr; cp.next_f0 = cp.next_f1 = nullptr;
-        cp.next_sub_ld = cp.next_diag_ld = 0; cp.next_sub_coh = cp.next_diag_coh = false;
-        if (more) {
-          const int ni = A.chain_info[j + 1];
-          if (ni & 2) { cp.next_sub = A.pre + (size_t)(2 * (j + 1) + 1) * NB * NB; cp.next_sub_ld = NB; cp.next_sub_coh = true; cp.next_f0 = A.pflag + 2 * (j + 1) + 1; }
-          else { cp.next_sub = A.M + (size_t)(j + 1) * NB * ld + (size_t)j * NB; cp.next_sub_ld = ld; }
-          if (ni & 1) { cp.next_diag = A.pre + (size_t)(2 * (j + 1)) * NB * NB; cp.next_diag_ld = NB; cp.next_diag_coh = true; cp.next_f1 = A.pflag + 2 * (j + 1); }
-          else { cp.next_diag = A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB; cp.next_diag_ld = ld; }
-        }
         bool stalled = false;
-        const bool ok = tile_potrf_inv_sys<NoMark, 0, ChainPanel>(Tcur, Bs, tid, NoMark(), cp, &stalled);
-#else
-        // (the product build: only a node's FIRST column comes here - the plain tile factorisation, no panel code in the kernel)
-        (void)Pcur;
-        bool stalled = false;
-        const bool ok = tile_potrf_inv_sys(Tcur, Bs, tid, NoMark(), NoPanel(), &stalled);
-#endif
+        const bool ok = tile_potrf_inv_sys(Ds, Bs, tid, NoMark(), NoPanel(), &stalled);
         // (a wave of the tile that never got its record - ~64 k spins - is a stall of this launch, not a bad pivot: reported like
         // the launch's own time-outs, so the solve is repeated on the launch-per-panel schedule instead of being taken for "not
         // positive definite" - ADVICE r5)
@@ -1781,8 +1668,6 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         store_tile_coh(A.inv + (size_t)j * NB * NB, NB, Bs, tid);
         drain_stores();
         __syncthreads();
-        next_in_lds = *reinterpret_cast<volatile int*>(&s_next) != 0;
-        ++sys_flip;
         if (tid == 0) publish(A.dflag + j, ep);
         stamp((size_t)8 * j + 7);
         continue;
@@ -1889,100 +1774,6 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
     }
   }
   if (!alive && tid == 0) atomicAdd(A.fail, 1e30);
-  // ---- the backward substitution, same launch (round 5) ----
-  // k_chol_backsolve_all's rows, owned the same way (work-group b: rows nb-1-b, nb-1-b-G, ...), entered when this work-group's
-  // forward tasks are done. No cycle of waits: forward tasks never wait for a backward row, and a backward row waits for
-  // forward outputs and for rows ABOVE it only. What a separate launch got from the kernel boundary is explicit here: a row
-  // starts when its column's inverse and its right-hand-side tile are published (their flags), everything another CU wrote in
-  // THIS launch is read with system-scope loads, and the factor tiles of a row are complete once ANY x_i it needs is (x_i's
-  // owner waited for column i's inverse, and column i's diagonal tile needed every tile (i, k) before that).
-#ifdef MAVBA_BS_IN_LAUNCH  // (not in the product build: its mere presence costs the forward pass 1-2 us - scripts/_dbg/ab_bs_tail.sh)
-  if (A.bs_y != nullptr && alive) {
-    double (*part)[NB] = reinterpret_cast<double (*)[NB]>(As);   // 4 x NB
-    double (*xs)[16] = reinterpret_cast<double (*)[16]>(As + 4 * NB);
-    const double* z = A.L + (size_t)nb * NB * ld;
-    auto cload = [&](const double* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    for (int k = nb - 1 - (int)blockIdx.x; k >= 0 && alive; k -= (int)gridDim.x) {
-      if (!wait2(A.dflag + k, A.lflag + A.tile_id[(size_t)nb * nb + k])) { alive = false; break; }
-      const int sk = A.bs_seg_of_tile[k];
-      double acc = (wv == 0) ? cload(z + (size_t)k * NB + lane) : 0.0;
-      double li[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) li[q] = cload(A.inv + (size_t)k * NB * NB + (size_t)(16 * wv + q) * NB + lane);
-      int i = nb - 1;
-      while (i > k && A.bs_seg_first[i * A.bs_nseg + sk] > k) --i;
-      bool ok = true;
-      // (every wave polls for itself, as in the separate kernel; lane 0 decides, the wave follows)
-      auto wave_wait = [&](int row) {
-        int good = 1;
-        if (lane == 0) good = wait_flag(A.bs_flags + row, ep, A.abort_flag) ? 1 : 0;
-        return __builtin_amdgcn_readfirstlane(good) != 0;
-      };
-      double l[16];
-      if (i > k) {
-        ok = wave_wait(i);
-        const double* Lt = A.L + (size_t)i * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) l[q] = cload(Lt + (size_t)q * ld);
-      }
-      while (i > k && ok) {
-        int nx = i - 1;
-        while (nx > k && A.bs_seg_first[nx * A.bs_nseg + sk] > k) --nx;
-        double ln[16];
-        if (nx > k) {
-          const double* Lt = A.L + (size_t)nx * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) ln[q] = cload(Lt + (size_t)q * ld);
-        }
-        ok = wave_wait(i);
-        if (lane < 16) xs[wv][lane] = cload(A.bs_y + (size_t)i * NB + 16 * wv + lane);
-        wave_lds_sync();
-        const double* xi = xs[wv];
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; q += 2) {
-          a0 = __builtin_fma(l[q], xi[q], a0);
-          a1 = __builtin_fma(l[q + 1], xi[q + 1], a1);
-        }
-        acc -= a0 + a1;
-        wave_lds_sync();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) l[q] = ln[q];
-        i = nx;
-      }
-      part[wv][lane] = acc;
-      if (lane == 0 && !ok) s_ok = 0;  // (wait2 left 1 there; a wave whose wait was abandoned takes the whole work-group out)
-      __syncthreads();
-      if (s_ok == 0) { alive = false; break; }
-      const double r = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-      __syncthreads();
-      if (wv == 0) part[0][lane] = r;
-      __syncthreads();
-      double b0 = 0.0, b1 = 0.0;
-#pragma unroll
-      for (int q = 0; q < 16; q += 2) {
-        b0 = __builtin_fma(li[q], part[0][16 * wv + q], b0);
-        b1 = __builtin_fma(li[q + 1], part[0][16 * wv + q + 1], b1);
-      }
-      __syncthreads();
-      part[wv][lane] = b0 + b1;
-      __syncthreads();
-      if (wv == 0) {
-        const double x = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-        __hip_atomic_store(A.bs_y + (size_t)k * NB + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) __hip_atomic_store(&A.bs_flags[k], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (A.bs_scatter) {
-          const int t = A.bs_scatter[k * NB + lane];
-          if (t >= 0) A.bs_y_nat[t] = x;
-        }
-      }
-      __syncthreads();
-    }
-    if (!alive && tid == 0) atomicAdd(A.fail, 1e30);
-  }
-#endif
 }
 
 void CholStructure::release() {
@@ -2303,7 +2094,7 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   // ~12.2 us per chain column, 9.6 for a node's first): every update list is ordered by the time its inputs are ready, and
   // the helpers' queues are filled by list scheduling (below). Only the ORDER comes from the model, never correctness.
   // (round 5: a node's first column is the systolic tile factorisation - 7.4 us of factor + load and publish)
-  constexpr double cU = 3.5, cS = 3.1, cP = 1.0, cCol = 12.2, cColFirst = MAVBA_TILE_LA != 0 ? 9.6 : 7.4, cSub = 4.0;
+  constexpr double cU = 3.5, cS = 3.1, cP = 1.0, cCol = 12.2, cColFirst = 7.4, cSub = 4.0;
   std::vector<std::pair<int, int>> id_ij((size_t)nt, {0, 0});
   for (int k = 0; k < nb; ++k) {
     id_ij[tile_id[(size_t)k * nb + k]] = {k, k};
@@ -2859,27 +2650,15 @@ bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
     return with_update;
   }
   const unsigned epoch = ++cs.epoch;  // flags of this solve (forward hand-offs and backward substitution)
-  bool merged_backsolve = false;
   if (allow_persistent && cs.persist_ok) {
     CholPersistArgs A;
     A.M = M; A.L = L; A.inv = inv; A.pre = cs.d_pre; A.ld = ld; A.nb = nb;
     A.tasks = cs.d_tasks; A.wg_begin = cs.d_wg_begin; A.upd = cs.d_upd; A.tile_id = cs.d_tile_id; A.chain_info = cs.d_chain_info;
     A.lflag = cs.d_pflags; A.dflag = cs.d_pflags + cs.persist_tiles; A.pflag = A.dflag + nb; A.abort_flag = A.pflag + 2 * nb;
     A.epoch = epoch; A.fail = fail; A.trace = cs.d_trace;
-    // -DMAVBA_BS_IN_LAUNCH + MAVBA_CHOL_BACKSOLVE_IN_LAUNCH=1: the backward substitution as the tail of this launch (no second
-    // launch, no gap). Built in round 5 for the ~10 us of launch + gap, verified bit-identical to the separate launch, measured
-    // SLOWER and compiled out: inside the launch every factor tile has to be read with system-scope loads (another CU wrote it
-    // in the same launch; the separate kernel reads through the caches behind the kernel boundary) - C3 0.265 + 0.036 ->
-    // 0.310 + 0.005 ms, C2 0.105 + 0.015 -> 0.120 + 0.005 ms -, and the tail's mere presence in the kernel cost the forward
-    // pass 1-2 us (A/B in one visit, scripts/_dbg/ab_bs_tail.sh).
-#ifdef MAVBA_BS_IN_LAUNCH
-    const bool bs_in = [] { const char* e = std::getenv("MAVBA_CHOL_BACKSOLVE_IN_LAUNCH"); return e && std::atoi(e) != 0; }();
-#else
-    const bool bs_in = false;
-#endif
-    merged_backsolve = bs_in && nb <= kMaxBacksolveGroups && cs.persist_grid >= 1;
-    A.bs_y = merged_backsolve ? y : nullptr; A.bs_flags = cs.d_flags; A.bs_seg_of_tile = cs.d_seg_of_tile; A.bs_seg_first = cs.d_seg_first;
-    A.bs_nseg = cs.nseg; A.bs_scatter = y_scatter; A.bs_y_nat = y_nat;
+    // (Round 5 built the backward substitution as the tail of this launch - no second launch, no gap -, verified it bit-identical
+    // and measured it SLOWER: inside the launch every factor tile has to be read with system-scope loads, C3 0.265 + 0.036 ->
+    // 0.310 + 0.005 ms, and the tail's mere presence cost the forward pass 1-2 us. The code is in scripts/_dbg/pruned_r06.patch.)
     static const int drop = [] { const char* e = std::getenv("MAVBA_CHOL_TEST_DROP_WG"); return e ? std::atoi(e) : -1; }();
     A.drop_wg = drop;
     // Two persistent launches must never share the device (each needs every CU for its resident grid). Launches on ONE stream
@@ -2941,9 +2720,7 @@ bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
   }
   if (after_factor) (void)hipEventRecord(after_factor, st);
   double* z = L + (size_t)n_pad * ld;
-  if (merged_backsolve) {
-    // (done inside k_chol_persist)
-  } else if (nb <= kMaxBacksolveGroups) {
+  if (nb <= kMaxBacksolveGroups) {
     const int cus = device_cu_count();
     hipLaunchKernelGGL(k_chol_backsolve_all, dim3(std::min(nb, cus > 0 ? 2 * cus : 64)), dim3(256), 0, st, L, ld, nb, cs.nseg, cs.d_seg_of_tile, cs.d_seg_first,
                        inv, z, y, cs.d_flags, epoch, y_scatter, y_nat);

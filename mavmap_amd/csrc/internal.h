@@ -251,10 +251,8 @@ void launch_schur_chunks(hipStream_t st, int kind, int num_chunks, const SchurCh
                          double* partial);
 int schur_partial_stride(int kind);
 // front end + cluster kernel in one launch (problems whose every observed point is clustered; cluster shape 16 x 3):
-// a.sw.cost_partial gets one partial per cluster
-void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int num_clusters, const SchurCluster* clusters, const int* tab,
-                        const int* cl_lists,
-                        const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii);
+// a.sw.cost_partial gets one partial per cluster (k_schur_rows, schur_rows.hip; its round-3 predecessor k_schur_fused lives in
+// scripts/_dbg/pruned_r06.patch)
 void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, int num_clusters,
                        const SchurRowsCluster* clusters, const int* tab, const int* cl_lists, const unsigned short* obs_meta,
                        const unsigned long long* lanemap, const unsigned* emit_map, double* part_pp, double* part_ip, double* part_ii);
@@ -287,13 +285,6 @@ void launch_tiles_zero(hipStream_t st, int num_tiles, const int2* tiles, double*
 void launch_fix_diag(hipStream_t st, int n_mat, int ld, bool add_one, const int* col_var,
                      const double* scale_cam, double* S);
 
-void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radius, double dmin,
-                           double dmax, const int* pt_start, const int* obs_img, const int* q_start,
-                           const int* q_cam, const unsigned char* pt_free, const double* Epose,
-                           const double* Eintr, const double* y, const double* Gi, const double* h,
-                           const double* Cu, const double* gu, const double* scale_pt,
-                           const double* points, double* cand_points, double* delta_points,
-                           double* partial /*[grid][3]*/, int* grid_out);
 int backsub_points_grid(int NP);
 // the same from recomputed Jacobians (no entry records read); `a`: the sweep arguments of the CURRENT state,
 // delta_cam from launch_update_cameras (which runs first). cost_partial != null: the candidate's cost as well (one partial per

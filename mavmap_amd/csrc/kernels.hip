@@ -1723,386 +1723,6 @@ __global__ void __launch_bounds__(kClThreads, kClPipelined ? 1 : 2) k_schur_clus
     }
   }
 }
-// ---------------------------------------------------------------------------
-// The cluster kernel with the front end inside (k_schur_fused): for problems whose every observed point sits in a
-// cluster (global BA of short tracks: C2, C3) the Schur entry records never exist in HBM. Per batch of 32 points the
-// work-group (512 lanes, one observation each) evaluates residual + Jacobian in registers, sums Cu / gu / Wk per point
-// through LDS (the park buffer aliases E, which is only built afterwards), factorises the points' damped 3x3 blocks,
-// writes U_a = (Jc'^T Jp') Gi^T, Uk = (s_k Wk s_p) Gi^T and h straight into the stacked entry matrix E and runs
-// S_cl += E E^T on the matrix cores. Out: cost partial per cluster, Cu, gu, Gi, h per point (the back-substitution and
-// the gradient norm read them) and the cluster's block partials. Gone against k_point_front + k_schur_clusters: the
-// 192 B / observation + 288 B / (point, camera) of records written and read again, one launch.
-// ---------------------------------------------------------------------------
-namespace {
-constexpr int kFuPitch = kClThreads + 1;  // park row pitch
-template <int KMAX>
-struct FusedShape {
-  static constexpr int K3 = 3 * KMAX, NROWS = 9 + K3;
-  static constexpr int ESIZE = ClShape<16, 3>::rows * kClPitch;
-  static constexpr int ROUNDS = NROWS * kFuPitch <= ESIZE ? 1 : 2;
-  static constexpr int NR = (NROWS + ROUNDS - 1) / ROUNDS;
-  static_assert(NR * kFuPitch + 3 <= ESIZE, "the park buffer must fit the entry matrix it aliases (+ 3: the 4-wide summation reads run up to 3 elements past a full batch's last observation, masked)");
-  static_assert(NR >= 9, "point rows must fit the first round");
-};
-}  // namespace
-
-template <int KMAX, bool TRACE = false>
-__global__ void __launch_bounds__(kClThreads, 1) k_schur_fused(
-    FrontArgs a, const SchurCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ cl_lists,
-    const unsigned short* __restrict__ obs_meta, const unsigned short* __restrict__ q_meta, double* __restrict__ part_pp,
-    double* __restrict__ part_ip, double* __restrict__ part_ii) {
-  using SH = ClShape<16, 3>;
-  using FS = FusedShape<KMAX>;
-  // per-cluster tables (cl_lists: the cluster's 16 images, then its 3 cameras, -1 padded): camera records, intrinsics and
-  // column scales of the cluster's images are read from memory ONCE per cluster instead of once per observation - the
-  // dependent image -> camera -> intrinsics round trips sat at the head of every batch's Jacobian phase
-  __shared__ double s_rec[SH::images][9], s_kin[SH::images][9], s_sc[SH::images][6], s_ksc[SH::cams][9];
-  __shared__ int s_icam[SH::images], s_model[SH::images];
-  __shared__ __attribute__((aligned(16))) double E[SH::rows * kClPitch];  // park buffer of the sums, then the entry matrix
-  __shared__ double s_q[kClBatch * kClCamsMax * (FS::K3 > 0 ? FS::K3 : 1)];  // Wk sums of the batch's (point, camera) entries
-  __shared__ double s_sum[kClBatch * 9];
-  __shared__ double s_g[kClBatch * 12];                                      // Gi(6) h(3) scale(3)
-  __shared__ double s_red[8];
-  __shared__ int s_bounds[2][kClMaxBatches + 1];
-  __shared__ int s_tab[SH::tab];
-  __shared__ int s_pb[kClBatch + 1];
-  __shared__ int s_cam[kClThreads + 3];  // (+ 3: the masked 4-wide reads of the summation loop past the last observation of a full batch)
-  __shared__ int s_qcam[kClBatch * kClCamsMax], s_qpt[kClBatch * kClCamsMax], s_qm[kClBatch * kClCamsMax];
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const SweepArgs& w = a.sw;
-  const int NPs = a.NPs;
-  const SchurCluster cl = clusters[blockIdx.x];
-  const int nbatch = (cl.p1 - cl.p0 + kClBatch - 1) / kClBatch;
-  for (int i = tid; i <= nbatch; i += kClThreads) {
-    const int p = min(cl.p0 + i * kClBatch, cl.p1);
-    s_bounds[0][i] = a.pt_start[p];
-    s_bounds[1][i] = a.q_start[p];
-  }
-  for (int i = tid; i < SH::tab; i += kClThreads) s_tab[i] = tabs[(size_t)blockIdx.x * SH::tab + i];
-  {
-    const int* lists = cl_lists + (size_t)blockIdx.x * (SH::images + SH::cams);
-    if (tid < SH::images * 9) {
-      const int sl = tid / 9, e = tid - 9 * sl, img = lists[sl];
-      if (img >= 0) {
-        const int cam = a.sw.img_cam[img];
-        s_rec[sl][e] = a.sw.camrec[9 * img + e];
-        s_kin[sl][e] = a.sw.intr[9 * cam + e];
-        if (e < 6) s_sc[sl][e] = a.scale_cam[6 * img + e];
-        if (e == 0) { s_icam[sl] = cam; s_model[sl] = a.sw.cam_model[cam]; }
-      }
-    } else if (tid < SH::images * 9 + SH::cams * 9) {
-      const int t = tid - SH::images * 9, c = t / 9, k = t - 9 * c, cam = lists[SH::images + c];
-      if (cam >= 0) s_ksc[c][k] = a.scale_cam[6 * a.sw.NI + 9 * cam + k];
-    }
-  }
-  cl_d4 acc[SH::acc];
-#pragma unroll
-  for (int i = 0; i < SH::acc; ++i) acc[i] = (cl_d4){0.0, 0.0, 0.0, 0.0};
-  double cost = 0.0;
-  // (TRACE: s_memtime stamps of the cluster's SECOND batch - steady state - per wave; a separate instantiation)
-  long long stamp[TRACE ? 10 : 1];
-  int nstamp = 0;
-  bool tracing = false;
-  auto mark = [&]() { if constexpr (TRACE) { if (tracing && nstamp < 10) stamp[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); } };
-  __syncthreads();
-  // A batch's first loads - every lane's observation, the owner lanes' per-point inputs - are requested before the
-  // PREVIOUS batch's matrix instructions start, so they travel under those (~15 k cycles) instead of stalling the batch.
-  bool act_n = false, own_free_n = false;
-  int im_n = 0, pt_n = 0;
-  double2 m_n = make_double2(0.0, 0.0);
-  unsigned meta_n = 0xFFFFu;
-  double own_sp_n[3] = {0.0, 0.0, 0.0};
-  auto request_batch = [&](int bj) {
-    const int c0 = cl.p0 + bj * kClBatch, c1 = min(c0 + kClBatch, cl.p1);
-    const int oo0 = s_bounds[0][bj], oo1 = s_bounds[0][bj + 1];
-    act_n = oo0 + tid < oo1;
-    if (act_n) { im_n = w.obs_img[oo0 + tid]; pt_n = w.obs_pt[oo0 + tid]; m_n = w.uv[oo0 + tid]; meta_n = obs_meta[oo0 + tid]; }
-    own_free_n = false;
-    if (tid < c1 - c0) {
-      own_free_n = a.pt_free[c0 + tid] != 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) own_sp_n[k] = a.scale_pt[(size_t)k * NPs + c0 + tid];
-    }
-  };
-  if (nbatch > 0) request_batch(0);
-  for (int bi = 0; bi < nbatch; ++bi) {
-    const int b0 = cl.p0 + bi * kClBatch, b1 = min(b0 + kClBatch, cl.p1), np = b1 - b0;
-    const int o0 = s_bounds[0][bi], o1 = s_bounds[0][bi + 1];   // <= 16 observations per clustered point: o1 - o0 <= 512
-    const int q0 = s_bounds[1][bi], nq = KMAX > 0 ? s_bounds[1][bi + 1] - q0 : 0;
-    const bool act = act_n, own_free = own_free_n;
-    const int im = im_n, pt = pt_n;
-    const double2 m = m_n;
-    const unsigned meta = act ? meta_n : 0xFFFFu;
-    const double own_sp[3] = {own_sp_n[0], own_sp_n[1], own_sp_n[2]};
-    (void)o1;
-    if constexpr (TRACE) tracing = bi == 1;
-    mark();  // 0: top of the batch
-    for (int j = tid; j <= np; j += kClThreads) s_pb[j] = a.pt_start[b0 + j];
-    if constexpr (KMAX > 0) {
-      for (int q = tid; q < nq; q += kClThreads) { s_qcam[q] = a.q_cam[q0 + q]; s_qpt[q] = a.q_pt[q0 + q] - b0; s_qm[q] = q_meta[q0 + q]; }
-    }
-    double jc[12], jp[6];
-    double prod[FS::NROWS];
-    int cam = -1;
-    if (act) {
-      int model;
-      double rec[9], kin[9], X[3];
-      X[0] = w.points[3 * (long long)pt]; X[1] = w.points[3 * (long long)pt + 1]; X[2] = w.points[3 * (long long)pt + 2];
-      if (meta != 0xFFFFu) {  // an image of the cluster's list: everything but the point comes from LDS
-        const int sl = (int)(meta >> 8);
-        cam = s_icam[sl];
-        model = s_model[sl];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { rec[k] = s_rec[sl][k]; kin[k] = s_kin[sl][k]; }
-      } else {  // (constant pose: not in the list)
-        cam = w.img_cam[im];
-        model = w.cam_model[cam];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) rec[k] = w.camrec[9 * im + k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) kin[k] = w.intr[9 * cam + k];
-      }
-      double r[2], Jc[12], Jp[6], Jk[18];
-      obs_jacobian(model, rec, kin, X, m.x, m.y, r, Jc, Jp, Jk);
-      double wgt, half_rho;
-      cauchy_weight(r[0] * r[0] + r[1] * r[1], w.loss_b, w.loss_inv_b, wgt, half_rho);
-      cost += half_rho;
-      const double rr0 = wgt * r[0], rr1 = wgt * r[1];
-#pragma unroll
-      for (int e = 0; e < 12; ++e) jc[e] = wgt * Jc[e];
-#pragma unroll
-      for (int e = 0; e < 6; ++e) jp[e] = wgt * Jp[e];
-      prod[0] = jp[0] * jp[0] + jp[3] * jp[3]; prod[1] = jp[0] * jp[1] + jp[3] * jp[4]; prod[2] = jp[0] * jp[2] + jp[3] * jp[5];
-      prod[3] = jp[1] * jp[1] + jp[4] * jp[4]; prod[4] = jp[1] * jp[2] + jp[4] * jp[5]; prod[5] = jp[2] * jp[2] + jp[5] * jp[5];
-      prod[6] = jp[0] * rr0 + jp[3] * rr1; prod[7] = jp[1] * rr0 + jp[4] * rr1; prod[8] = jp[2] * rr0 + jp[5] * rr1;
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        const double k0 = wgt * Jk[k], k1 = wgt * Jk[9 + k];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) prod[9 + 3 * k + t] = k0 * jp[t] + k1 * jp[3 + t];
-      }
-    }
-    // ---- per-point sums: products parked in LDS (over the not yet built entry matrix), one lane per sum, a point's
-    // observations added in order (the same fixed sequential sums as k_point_front) ----
-    auto round = [&](auto rc) {
-      constexpr int R = decltype(rc)::value;
-      constexpr int lo = R * FS::NR, hi = (lo + FS::NR < FS::NROWS) ? lo + FS::NR : FS::NROWS;
-      constexpr int PR = R == 0 ? 9 : 0;
-      constexpr int wlo = (lo > 9 ? lo : 9) - 9, WR = hi - 9 - wlo;
-      lds_barrier();  // (R == 0: the previous batch's matrix instructions have read E, the batch's tables are written)
-      if (act) {
-        if (R == 0) s_cam[tid] = cam;
-#pragma unroll
-        for (int v = lo; v < hi; ++v) E[(v - lo) * kFuPitch + tid] = prod[v];
-      }
-      lds_barrier();
-      const int nit = np * PR + nq * WR;
-      for (int it = tid; it < nit; it += kClThreads) {
-        const bool is_pt = it < np * PR;
-        int j, c = -1;
-        const double* row;
-        double* dst;
-        if (is_pt) {
-          j = it / 9;
-          row = E + (it - 9 * j) * kFuPitch - o0;
-          dst = s_sum + it;
-        } else {
-          const int t2 = it - np * PR;
-          const int wr = WR > 0 ? WR : 1;
-          const int q = t2 / wr, vv = wlo + (t2 - q * wr);
-          j = s_qpt[q]; c = s_qcam[q];
-          row = E + (vv + 9 - lo) * kFuPitch - o0;
-          dst = s_q + q * FS::K3 + vv;
-        }
-        const int b = s_pb[j], e = s_pb[j + 1];
-        const int* camv = s_cam - o0;
-        // (every sum is written exactly once, in the round its row belongs to: it starts from zero. Reads past the point's last
-        // observation stay inside the park buffer / the camera list's LDS neighbourhood and are masked below.)
-        double acc1 = 0.0;
-        for (int i0 = b; i0 < e; i0 += 4) {
-          const int i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
-          double x0 = row[i0], x1 = row[i1], x2 = row[i2], x3 = row[i3];
-          if (WR > 0 && !is_pt) {
-            x0 = camv[i0] == c ? x0 : 0.0; x1 = camv[i1] == c ? x1 : 0.0; x2 = camv[i2] == c ? x2 : 0.0; x3 = camv[i3] == c ? x3 : 0.0;
-          }
-          acc1 += x0;
-          acc1 += i0 + 1 < e ? x1 : 0.0;
-          acc1 += i0 + 2 < e ? x2 : 0.0;
-          acc1 += i0 + 3 < e ? x3 : 0.0;
-        }
-        *dst = acc1;
-      }
-    };
-    mark();  // 1: Jacobian + products done
-    round(std::integral_constant<int, 0>{});
-    mark();  // 2
-    if constexpr (FS::ROUNDS > 1) round(std::integral_constant<int, 1>{});
-    lds_barrier();  // sums complete, the park buffer is free
-    mark();  // 3
-    // ---- owner lanes: Cu, gu out, damped 3x3 block factorised; everybody clears E ----
-    if (tid < np) {
-      const int p = b0 + tid;
-      double C6[6], g3[3];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) C6[k] = s_sum[tid * 9 + k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) g3[k] = s_sum[tid * 9 + 6 + k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) a.Cu[(size_t)k * NPs + p] = C6[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) a.gu[(size_t)k * NPs + p] = g3[k];
-      double G[6] = {0, 0, 0, 0, 0, 0}, hh[3] = {0, 0, 0}, sp[3] = {0, 0, 0};
-      if (own_free) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) sp[k] = own_sp[k];
-        double C[6];
-        C[0] = sp[0] * sp[0] * C6[0]; C[1] = sp[0] * sp[1] * C6[1]; C[2] = sp[0] * sp[2] * C6[2];
-        C[3] = sp[1] * sp[1] * C6[3]; C[4] = sp[1] * sp[2] * C6[4]; C[5] = sp[2] * sp[2] * C6[5];
-        const double inv_radius = 1.0 / a.radius;
-        C[0] = __builtin_fma(clampd(C[0], a.dmin, a.dmax), inv_radius, C[0]);
-        C[3] = __builtin_fma(clampd(C[3], a.dmin, a.dmax), inv_radius, C[3]);
-        C[5] = __builtin_fma(clampd(C[5], a.dmin, a.dmax), inv_radius, C[5]);
-        bool fin = chol3_inv_fast(C, G);
-        const double gs[3] = {sp[0] * g3[0], sp[1] * g3[1], sp[2] * g3[2]};
-        gi_mul(G, gs, hh);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) fin = fin && isfinite(G[k]);
-        if (!fin) atomicAdd(a.fail, 1.0);
-      }
-      if (s_pb[tid + 1] > s_pb[tid]) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a.Gi[(size_t)k * NPs + p] = G[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) a.h[(size_t)k * NPs + p] = hh[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s_g[tid * 12 + k] = G[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { s_g[tid * 12 + 6 + k] = hh[k]; s_g[tid * 12 + 9 + k] = sp[k]; }
-    }
-    for (int i = tid; i < SH::rows * kClPitch / 2; i += kClThreads) reinterpret_cast<double2*>(E)[i] = make_double2(0.0, 0.0);
-    lds_barrier();
-    mark();  // 4: owners + clear
-    // ---- the stacked entry matrix of the batch, straight from registers ----
-    if (act && meta != 0xFFFFu) {  // (0xFFFF: the image's pose is constant - it has no rows; the sums above included it)
-      const int lp = pt - b0;
-      const double* g = s_g + lp * 12;
-      double* Eo = E + 6 * (int)(meta >> 8) * kClPitch + 3 * (int)(meta & 255u);
-      double jps[6];
-#pragma unroll
-      for (int row = 0; row < 2; ++row)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) jps[row * 3 + k] = jp[row * 3 + k] * g[9 + k];
-      const double* scl = s_sc[meta >> 8];
-#pragma unroll
-      for (int e = 0; e < 6; ++e) {
-        const double sc = scl[e];
-        const double j0 = jc[e] * sc, j1 = jc[6 + e] * sc;
-        const double w0 = j0 * jps[0] + j1 * jps[3], w1 = j0 * jps[1] + j1 * jps[4], w2 = j0 * jps[2] + j1 * jps[5];
-        Eo[e * kClPitch] = w0 * g[0];
-        Eo[e * kClPitch + 1] = w0 * g[1] + w1 * g[2];
-        Eo[e * kClPitch + 2] = w0 * g[3] + w1 * g[4] + w2 * g[5];
-      }
-    }
-    if constexpr (KMAX > 0) {
-      for (int it = tid; it < nq * KMAX; it += kClThreads) {
-        const int q = it / KMAX, k = it - KMAX * q;
-        const unsigned qm = (unsigned)s_qm[q];
-        if (qm == 0xFFFFu) continue;
-        const double* g = s_g + s_qpt[q] * 12;
-        const double sk = s_ksc[qm >> 8][k];
-        const double* W = s_q + q * FS::K3 + 3 * k;
-        const double w0 = W[0] * sk * g[9], w1 = W[1] * sk * g[10], w2 = W[2] * sk * g[11];
-        double* Eo = E + (SH::cam_row0 + 9 * (int)(qm >> 8) + k) * kClPitch + 3 * (int)(qm & 255u);
-        Eo[0] = w0 * g[0];
-        Eo[1] = w0 * g[1] + w1 * g[2];
-        Eo[2] = w0 * g[3] + w1 * g[4] + w2 * g[5];
-      }
-    }
-    if (tid < np * 3) {
-      const int pp = tid / 3, t = tid - 3 * pp;
-      if (a.pt_free[b0 + pp] && s_pb[pp + 1] > s_pb[pp]) E[SH::hrow * kClPitch + tid] = s_g[pp * 12 + 6 + t];
-    }
-    lds_barrier();
-    mark();  // 5: entry matrix written
-    if (bi + 1 < nbatch) {
-      request_batch(bi + 1);
-      __builtin_amdgcn_sched_barrier(0);  // (keep the loads here: the scheduler would sink them to their use)
-    }
-    switch (wv) {
-      case 0: cluster_mfma<SH, 0>(E, lane, acc); break;
-      case 1: cluster_mfma<SH, 1>(E, lane, acc); break;
-      case 2: cluster_mfma<SH, 2>(E, lane, acc); break;
-      case 3: cluster_mfma<SH, 3>(E, lane, acc); break;
-      case 4: cluster_mfma<SH, 4>(E, lane, acc); break;
-      case 5: cluster_mfma<SH, 5>(E, lane, acc); break;
-      case 6: cluster_mfma<SH, 6>(E, lane, acc); break;
-      default: cluster_mfma<SH, 7>(E, lane, acc); break;
-    }
-    mark();  // 6: matrix instructions issued
-    // (the next batch's first lds_barrier comes after its loads and bookkeeping)
-  }
-  if constexpr (TRACE) {
-    if (a.trace && lane == 0 && blockIdx.x < 4096) {
-      long long* out = a.trace + ((size_t)blockIdx.x * 8 + wv) * 16;
-      out[0] = nstamp;
-      for (int i = 0; i < nstamp; ++i) out[1 + i] = stamp[i];
-    }
-  }
-  const int* tab = s_tab;
-  switch (wv) {
-    case 0: cluster_emit<SH, 0>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    case 1: cluster_emit<SH, 1>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    case 2: cluster_emit<SH, 2>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    case 3: cluster_emit<SH, 3>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    case 4: cluster_emit<SH, 4>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    case 5: cluster_emit<SH, 5>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    case 6: cluster_emit<SH, 6>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-    default: cluster_emit<SH, 7>(lane, acc, tab, part_pp, part_ip, part_ii); break;
-  }
-  // cost partial of the cluster (fixed tree: lanes -> waves -> work-group)
-  const double wsum = wave_sum(cost);
-  __syncthreads();
-  if (lane == 0) s_red[wv] = wsum;
-  __syncthreads();
-  if (tid == 0) w.cost_partial[blockIdx.x] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
-}
-void launch_schur_fused(hipStream_t st, const FrontArgs& a, int kmax_intr, int num_clusters, const SchurCluster* clusters, const int* tab,
-                        const int* cl_lists, const unsigned short* obs_meta, const unsigned short* q_meta, double* part_pp, double* part_ip, double* part_ii) {
-  if (num_clusters <= 0) return;
-  // MAVBA_FUSED_TRACE=<file>: the 5th launch of the process (widest model <= 8) records s_memtime stamps per wave (debugging aid)
-  static const char* trace_file = std::getenv("MAVBA_FUSED_TRACE");
-  static int trace_calls = 0;
-  if (trace_file && kmax_intr > 4 && kmax_intr <= 8 && ++trace_calls == 5) {
-    const size_t trace_n = (size_t)4096 * 8 * 16;
-    long long* tr = nullptr;
-    (void)hipMalloc(reinterpret_cast<void**>(&tr), trace_n * 8);
-    (void)hipMemsetAsync(tr, 0, trace_n * 8, st);
-    FrontArgs b = a;
-    b.trace = tr;
-    hipLaunchKernelGGL((k_schur_fused<8, true>), dim3(num_clusters), dim3(kClThreads), 0, st, b, clusters, tab, cl_lists, obs_meta, q_meta, part_pp, part_ip, part_ii);
-    std::vector<long long> hst(trace_n);
-    (void)hipStreamSynchronize(st);
-    (void)hipMemcpy(hst.data(), tr, trace_n * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(tr);
-    if (FILE* fp = std::fopen(trace_file, "w")) {
-      for (int g = 0; g < std::min(num_clusters, 4096); ++g)
-        for (int wv = 0; wv < 8; ++wv) {
-          const long long* r = hst.data() + ((size_t)g * 8 + wv) * 16;
-          if (r[0] <= 0) continue;
-          std::fprintf(fp, "%d %d", g, wv);
-          for (int i = 0; i < (int)r[0]; ++i) std::fprintf(fp, " %lld", r[1 + i]);
-          std::fprintf(fp, "\n");
-        }
-      std::fclose(fp);
-    }
-    return;
-  }
-#define MAVBA_FUSED(K) hipLaunchKernelGGL((k_schur_fused<K>), dim3(num_clusters), dim3(kClThreads), 0, st, a, clusters, tab, cl_lists, obs_meta, q_meta, part_pp, part_ip, part_ii)
-  if (kmax_intr <= 0) MAVBA_FUSED(0); else if (kmax_intr <= 4) MAVBA_FUSED(4); else if (kmax_intr <= 8) MAVBA_FUSED(8); else MAVBA_FUSED(9);
-#undef MAVBA_FUSED
-}
-
 #define MAVBA_CL_S12 ClShape<12, 2>
 #define MAVBA_CL_S16 ClShape<16, 3>
 void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters, const SchurCluster* clusters, const int* tab,
@@ -2327,82 +1947,8 @@ void launch_fix_diag(hipStream_t st, int n_mat, int ld, bool add_one, const int*
 // partial[b] = { |delta|^2, model-change part, |X_cand|^2 } over free points, where the
 // model cost change is 1/2 sum_j y_j (g_j + D_j^2 y_j)  (== -(J step).(r + J step/2) when
 // (J^T J + D^2) y = g, which the direct solve guarantees to round-off).
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_backsub_points(
-    int NP, int NPs, int NI, int gp, double radius, double dmin, double dmax, const int* __restrict__ pt_start,
-    const int* __restrict__ obs_img, const int* __restrict__ q_start, const int* __restrict__ q_cam,
-    const unsigned char* __restrict__ pt_free, const double* __restrict__ Epose, const double* __restrict__ Eintr,
-    const double* __restrict__ y, const double* __restrict__ Gi, const double* __restrict__ h,
-    const double* __restrict__ Cu, const double* __restrict__ gu, const double* __restrict__ scale_pt,
-    const double* __restrict__ points, double* __restrict__ cand_points, double* __restrict__ delta_points,
-    double* __restrict__ partial) {
-  __shared__ double s_red[4];
-  // 16 lanes per point: lane g takes observation b + g, b + g + 16, ... (consecutive 192-byte records
-  // -> the row reads one contiguous run), then a DPP row reduction of the three sums.
-  const int g = threadIdx.x & 15;
-  double a_step = 0.0, a_model = 0.0, a_x2 = 0.0;
-  for (int p = blockIdx.x * 16 + (threadIdx.x >> 4); p < NP; p += gp * 16) {
-    const bool fr = pt_free[p] != 0;
-    double t[3] = {0, 0, 0};
-    if (fr) {
-      for (int o = pt_start[p] + g; o < pt_start[p + 1]; o += 16) {
-        const double2* U = reinterpret_cast<const double2*>(Epose + (size_t)o * kPoseRec);
-        const double* yc = y + 6 * obs_img[o];
-        double u[18];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { const double2 v = U[k]; u[2 * k] = v.x; u[2 * k + 1] = v.y; }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          const double yr = yc[r];
-          t[0] += u[3 * r] * yr; t[1] += u[3 * r + 1] * yr; t[2] += u[3 * r + 2] * yr;
-        }
-      }
-      for (int q = q_start[p] + g; q < q_start[p + 1]; q += 16) {
-        const double* U = Eintr + (size_t)q * kIntrRec;
-        const double* yc = y + 6 * NI + 9 * q_cam[q];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-          const double yr = yc[r];
-          t[0] += U[3 * r] * yr; t[1] += U[3 * r + 1] * yr; t[2] += U[3 * r + 2] * yr;
-        }
-      }
-    }
-    t[0] = row16_sum(t[0]); t[1] = row16_sum(t[1]); t[2] = row16_sum(t[2]);
-    if (g == 0) {
-      double X[3] = {points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2]};
-      double d[3] = {0, 0, 0};
-      if (fr) {
-        const double tt[3] = {h[p] - t[0], h[NPs + p] - t[1], h[2 * NPs + p] - t[2]};
-        const double G[6] = {Gi[p], Gi[NPs + p], Gi[2 * NPs + p], Gi[3 * NPs + p], Gi[4 * NPs + p], Gi[5 * NPs + p]};
-        double yp[3];
-        git_mul(G, tt, yp);
-        const int dg[3] = {0, 3, 5};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double s = scale_pt[k * NPs + p];
-          const double D2 = clampd(s * s * Cu[dg[k] * NPs + p], dmin, dmax) / radius;
-          const double gs = s * gu[k * NPs + p];
-          a_model += 0.5 * yp[k] * (gs + D2 * yp[k]);
-          d[k] = -yp[k] * s;
-          a_step += d[k] * d[k];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double xn = X[k] + d[k];
-        cand_points[3 * (size_t)p + k] = xn;
-        delta_points[3 * (size_t)p + k] = d[k];
-        if (fr) a_x2 += xn * xn;
-      }
-    }
-  }
-  const double s0 = block_sum_256(a_step, s_red);
-  const double s1 = block_sum_256(a_model, s_red);
-  const double s2 = block_sum_256(a_x2, s_red);
-  if (threadIdx.x == 0) { partial[3 * blockIdx.x] = s0; partial[3 * blockIdx.x + 1] = s1; partial[3 * blockIdx.x + 2] = s2; }
-}
-// The same back-substitution WITHOUT reading the entry records: for every observation of the point the Jacobian is
-// recomputed (20 bytes of input instead of a 144-byte record + the intrinsics records) and
+// WITHOUT entry records (the round-1 kernel that read them - 144 B per observation + the intrinsics records - lives in
+// scripts/_dbg/pruned_r06.patch): for every observation of the point the Jacobian is recomputed (20 bytes of input) and
 //   sum_a U_a^T y_a + sum_q Uk_q^T y_q = Gi ( s_p o sum_obs Jp^T (Jc (s y)_cam + Jk (s y)_intr) ),
 // with (s y) = -delta_cam from k_update_cameras (which therefore runs first).
 // ONE observation per lane: a work-group takes `ppb` consecutive points (~224 observations) at a time, every lane computes its
@@ -2615,21 +2161,6 @@ void launch_backsub_points_jvp(hipStream_t st, int NP, int NPs, int NI, double r
                      a.loss_inv_b, pt_start, a.obs_img, a.obs_pt, a.uv, a.img_cam, a.cam_model, a.camrec, a.intr, delta_cam, pt_free,
                      Gi, h, Cu, gu, scale_pt, a.points, cand_points, delta_points, partial, cand_camrec, cand_intr, a.pt_active,
                      cost_partial);
-}
-void launch_backsub_points(hipStream_t st, int NP, int NPs, int NI, double radius, double dmin,
-                           double dmax, const int* pt_start, const int* obs_img, const int* q_start,
-                           const int* q_cam, const unsigned char* pt_free, const double* Epose,
-                           const double* Eintr, const double* y, const double* Gi, const double* h,
-                           const double* Cu, const double* gu, const double* scale_pt,
-                           const double* points, double* cand_points, double* delta_points,
-                           double* partial, int* grid_out) {
-  int gp = (NP + 15) / 16;
-  if (gp > 1024) gp = 1024;
-  if (gp < 1) gp = 1;
-  hipLaunchKernelGGL(k_backsub_points, dim3(gp), dim3(256), 0, st, NP, NPs, NI, gp, radius, dmin, dmax, pt_start,
-                     obs_img, q_start, q_cam, pt_free, Epose, Eintr, y, Gi, h, Cu, gu, scale_pt, points, cand_points,
-                     delta_points, partial);
-  *grid_out = gp;
 }
 
 // Camera columns: step = -y, delta = s * step, candidate parameters (update_cameras_body, lm_bodies.h: work-group b takes

@@ -299,7 +299,7 @@ struct mavba_session {
   DevBuf<FrontTile> d_tail_tiles;  // tiles over the points [tail_begin, NP): what the fused kernel does not cover
   int num_tail_tiles = 0, tail_begin = 0;
   bool front_ok = false;
-  bool fused_ok = false;        // every observed point before tail_begin is clustered: their front end runs inside the cluster kernel (k_schur_fused), the tail's in k_point_front
+  bool fused_ok = false;        // every observed point before tail_begin is clustered: their front end runs inside the cluster kernel (k_schur_rows), the tail's in k_point_front
   int eval_rows = 0;            // cost partials the last evaluation pass wrote
   bool front_valid = false;     // Cu, gu, Gi, h and the entry records match the current x, scales and front_radius
   double front_radius = 0.0;
@@ -313,7 +313,7 @@ struct mavba_session {
   DevBuf<SchurChunk> d_chunks[3];
   DevBuf<SchurCluster> d_clusters;
   // k_schur_rows (round 4): the clusters with their row counts, sorted by row class then length; rows_ok: the set-up built
-  // them and the clusters take k_schur_rows instead of k_schur_fused
+  // them and the clusters take k_schur_rows (otherwise: k_point_front + k_schur_clusters)
   DevBuf<SchurRowsCluster> d_rows_clusters;
   DevBuf<int> d_rows_lists;                 // k_schur_rows: kRowsLists ints per cluster (internal.h)
   DevBuf<unsigned> d_rows_emit;             // k_schur_rows: the emit maps of the cluster shapes present (rows_emit_map)
@@ -519,8 +519,8 @@ void intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::v
   void build_front_tiles(const std::vector<int>& q_start);
   void build_tiles(const std::vector<int>& q_start, int first, DevBuf<FrontTile>& out, int& count);
   void ensure_planes();
-  // (k_schur_rows masks filtered points itself; k_schur_fused has no masked instantiation)
-  bool fused_now() const { return fused_ok && (rows_ok || h_pt_removed.empty()); }
+  // (the front end runs inside the cluster kernel - k_schur_rows, which masks filtered points itself)
+  bool fused_now() const { return fused_ok && rows_ok; }
   int eval_cost_rows() const { return front_ok ? eval_rows : (N > 0 ? jacobian_sweep_grid(N) : 0); }
   void take_evaluation(const double* h) { cost = h[SC_COST]; grad_max = h[SC_GRAD_MAX]; x_norm = std::sqrt(h[SC_XNORM2]); }
   void assemble(double r);

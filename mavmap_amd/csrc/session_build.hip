@@ -583,9 +583,13 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   int forced = -1, max_depth = 2;
   if (const char* e = std::getenv("MAVBA_ND_PARTS")) forced = std::atoi(e);  // 0/1 = off, n = force n flat parts
   // Depth of the recursive bisection. The persistent factorisation has no barrier between tree levels, so what counts is
-  // the longest root-to-leaf path and a third level pays (C3: 0.44 -> 0.41 ms); large systems run the launch-per-panel
-  // schedule, whose per-level launches make depth 3 slightly slower (C5: 3.46 -> 3.58 ms).
-  if (tiles0 <= 96) max_depth = 3;
+  // the longest root-to-leaf path and a third level pays (C3: 0.44 -> 0.41 ms, round 3). Round 3 kept depth 2 above 96 tile
+  // columns because such systems ran the launch-per-panel schedule, whose per-level launches made depth 3 slower (C5: 3.46 ->
+  // 3.58 ms); since round 4 they run the persistent launch too and the rule was never revisited - round 6,
+  // profiles/r06_nd_depth_sweep.txt: C5 at depth 3 has 8 concurrent fronts instead of 4 and 4 104 envelope tiles instead of
+  // 5 041, k_chol_persist 1.96 -> 1.53 ms, 186 -> 203 LM iterations/s (a fourth level changes nothing at C5, C3 or C2: a split
+  // must pay). Depth 2 stays where the launch-per-panel schedule is certain (more than 512 tile columns).
+  if (tiles0 <= 512) max_depth = 3;
   if (const char* e = std::getenv("MAVBA_ND_DEPTH")) max_depth = std::atoi(e);
   const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && max_depth > 0 && (world == 1 || NI <= 4096);
   if (can_dissect) {
@@ -770,7 +774,7 @@ void mavba_session::finish_structure() {
   // rows = 10 images + 2 cameras + h: 15 tiles of matrix instructions; 96 rows: 21; 128 rows: 36), so clusters are formed
   // from runs of points with one image set by estimated cost (do_range_rows) instead of "until 16 images are full". The
   // point order keeps equal image sets together (the hash in the key). Chosen when the front end can run inside the
-  // cluster kernel at all; otherwise - and with MAVBA_FUSED_V1 - the clusters of rounds 1-3.
+  // cluster kernel at all; otherwise the clusters of rounds 1-3 (k_point_front + k_schur_clusters).
   std::vector<int> cl_ni, cl_nc;
   const bool no_fuse_env = std::getenv("MAVBA_NO_FUSE") != nullptr;  // (read per session: the tests switch paths)
   auto build_clusters = [&](bool rows_mode) {
@@ -967,7 +971,7 @@ void mavba_session::finish_structure() {
            all_clustered == head_clustered && (long long)clusters.size() <= kFrontMaxGrid;
   };
   rows_ok = false;
-  if (front_ok && !no_fuse_env && cl_shape.images == 16 && std::getenv("MAVBA_FUSED_V1") == nullptr) {
+  if (front_ok && !no_fuse_env && cl_shape.images == 16) {
     build_clusters(true);
     rows_ok = fusable();
   }

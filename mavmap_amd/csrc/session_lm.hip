@@ -56,12 +56,8 @@ void mavba_session::launch_front(double r, bool entries, const LmSpec& spec) {
     // every observed point sits in a cluster: the cluster kernel evaluates the Jacobians itself and leaves the block
     // partials of S for this radius (no entry records in HBM)
     timed("schur_fused", [&] {
-      if (rows_ok)
-        launch_schur_rows(st, f, Q > 0 ? KMAX : 0, rows_generic, num_clusters, d_rows_clusters.p, d_cl_tab.p, d_rows_lists.p, d_obs_meta.p,
-                          d_rows_lanes.p, d_rows_emit.p, d_part[0].p, d_part[1].p, d_part[2].p);
-      else
-        launch_schur_fused(st, f, Q > 0 ? KMAX : 0, num_clusters, d_clusters.p, d_cl_tab.p, d_cl_lists.p, d_obs_meta.p, d_q_meta.p, d_part[0].p, d_part[1].p,
-                           d_part[2].p);
+      launch_schur_rows(st, f, Q > 0 ? KMAX : 0, rows_generic, num_clusters, d_rows_clusters.p, d_cl_tab.p, d_rows_lists.p, d_obs_meta.p,
+                        d_rows_lanes.p, d_rows_emit.p, d_part[0].p, d_part[1].p, d_part[2].p);
     });
     eval_rows = num_clusters;
     if (num_tail_tiles > 0) {
@@ -330,24 +326,16 @@ void mavba_session::candidate_enqueue(double r, ReduceTasks* tail, int* tail_cou
                             d_ccamrec.p);  // (+ the candidate's camera records: no separate cam_prepare launch)
     });
   cameras_updated = false;
-  static const bool from_entries = std::getenv("MAVBA_BACKSUB_ENTRIES") != nullptr;
   // (round 4: for launch-bound problems the candidate's cost is summed by the back-substitution kernel itself - the observations
   // of a block's points are in its caches, the new points in its LDS -, one launch less: a 10-image window 2.30 -> 2.19 ms. At
   // C3 / C5 the streaming k_cost_only is the faster way to do that pass (0.091 + 0.023 against 0.123 ms), so large problems keep
   // it. MAVBA_COST_FUSE_MAX_OBS moves the switch, 0 = never fuse)
   static const long long fuse_max_obs = [] { const char* e = std::getenv("MAVBA_COST_FUSE_MAX_OBS"); return e ? std::atoll(e) : 200000ll; }();
-  const bool cost_separate = from_entries || (long long)N > fuse_max_obs;
+  const bool cost_separate = (long long)N > fuse_max_obs;
   timed("backsub_points", [&] {
-    if (from_entries) {
-      int rows_check = 0;
-      launch_backsub_points(st, NP, NPs, NI, r, dmin, dmax, d_pt_start.p, d_obs_img.p, d_q_start.p, d_q_cam.p,
-                            d_pt_free.p, d_Epose.p, d_Eintr.p, d_y.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p,
-                            d_points.p, d_cpoints.p, d_delta_pts.p, d_step_partial.p, &rows_check);
-    } else {
-      launch_backsub_points_jvp(st, NP, NPs, NI, r, dmin, dmax, sweep_args(d_camrec.p, d_intr.p, d_points.p), d_pt_start.p,
-                                d_delta_cam.p, d_pt_free.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p, d_cpoints.p,
-                                d_delta_pts.p, d_step_partial.p, d_ccamrec.p, d_cintr.p, cost_separate ? nullptr : d_sweep_partial.p);
-    }
+    launch_backsub_points_jvp(st, NP, NPs, NI, r, dmin, dmax, sweep_args(d_camrec.p, d_intr.p, d_points.p), d_pt_start.p,
+                              d_delta_cam.p, d_pt_free.p, d_Gi.p, d_h.p, d_Cu.p, d_gu.p, d_scale_pt.p, d_cpoints.p,
+                              d_delta_pts.p, d_step_partial.p, d_ccamrec.p, d_cintr.p, cost_separate ? nullptr : d_sweep_partial.p);
   });
   SweepArgs a = sweep_args(d_ccamrec.p, d_cintr.p, d_cpoints.p);
   if (cost_separate) timed("cost_only", [&] { launch_cost_only(st, a); });

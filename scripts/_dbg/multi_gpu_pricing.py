@@ -36,7 +36,12 @@ COLL_LATENCY_US = 20.0  # launch + completion of one RCCL collective
 MEASURED = {
     "C3": dict(iteration=0.855, sharded=0.47, factor=0.27, backsolve=0.037, other_replicated=0.078, packed_tiles_mb=19.0),
     "C5": dict(iteration=5.82, sharded=3.30, factor=2.09, backsolve=0.13, other_replicated=0.30, packed_tiles_mb=164.0),
+    # round 6: C5 with a depth-3 elimination tree (the default since then; tests/golden/chol_structure_C5d3.txt, dumped with
+    # MAVBA_CHOL_DUMP; profiles/r06_nd_depth_sweep.txt: 4.92 ms per iteration, factor 1.53, back-substitution 0.10)
+    "C5d3": dict(iteration=4.92, sharded=2.95, factor=1.53, backsolve=0.10, other_replicated=0.34, packed_tiles_mb=134.0),
 }
+SCENE = {"C5d3": "C5"}    # the synthetic scene a structure belongs to
+DEPTH = {"C5d3": 3}       # depth of the elimination tree to ask for (default: the session's rule of rounds 3-5)
 
 
 def ring_allreduce_us(nbytes, ranks):
@@ -49,7 +54,7 @@ def ring_allreduce_us(nbytes, ranks):
 # ---------------------------------------------------------------------------------------------------------------------
 # (i) sharding: which tiles does a rank touch
 # ---------------------------------------------------------------------------------------------------------------------
-def image_tree(p):
+def image_tree(p, tree_depth=None):
     """node_of_image, parent[], depth[], column tile of every image / camera block (the session's layout: nodes in elimination
     order, 6 columns per image, the intrinsics at the end of the root, every node padded to whole 64-column tiles)."""
     NI, NC = p.num_images, p.num_cameras
@@ -58,7 +63,7 @@ def image_tree(p):
     m = adj.row < adj.col
     pairs = np.stack([adj.row[m], adj.col[m]], axis=1).astype(np.int32)
     tiles0 = (6 * NI + 9 * NC + 63) // 64
-    node, parent = api.elimination_tree(NI, NC, pairs, max_depth=3 if tiles0 <= 96 else 2)
+    node, parent = api.elimination_tree(NI, NC, pairs, max_depth=tree_depth if tree_depth else (3 if tiles0 <= 96 else 2))
     nn = len(parent)
     depth = np.zeros(nn, int)
     for n in range(nn - 1, -1, -1):   # parents come after their children
@@ -93,7 +98,7 @@ def touched_tiles(inc_rows, img_tile, cam_tile, img_cam, nbt):
 
 
 def sharding_report(name, p, ranks_list):
-    node, parent, depth, img_tile, cam_tile, node_tiles, inc = image_tree(p)
+    node, parent, depth, img_tile, cam_tile, node_tiles, inc = image_tree(p, DEPTH.get(name))
     nn = len(parent)
     nbt = node_tiles[-1][1]
     img_cam = np.asarray(p.image_camera)
@@ -305,7 +310,7 @@ if __name__ == "__main__":
         t0 = time.time()
         shard = None
         if "--no-shards" not in sys.argv:
-            p = synth.make_config(name)
+            p = synth.make_config(SCENE.get(name, name))
             print(f"[{name}] scene: {p.num_images} images, {p.num_points} points, {p.num_obs} observations ({time.time() - t0:.0f} s)")
             shard = sharding_report(name, p, ranks)
         fact = factor_report(name, ranks)

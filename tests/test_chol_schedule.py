@@ -195,12 +195,14 @@ def _load_structure(name):
     return nb, rows[1:1 + nn], rows[1 + nn:1 + nn + npairs]
 
 
-@pytest.mark.parametrize("name,measured_us", [("C2", None), ("C3", 258.5), ("C5", 1955.4)])
+@pytest.mark.parametrize("name,measured_us", [("C2", None), ("C3", 258.5), ("C5", 1955.4), ("C5d3", 1520.8)])
 def test_the_schedules_of_the_benchmark_configurations(name, measured_us):
     """The tile structures of C2 / C3 / C5 as the sessions hand them to CholStructure::build on the GPU box (dumped there with
     MAVBA_CHOL_DUMP; tests/golden/chol_structure_*.txt): their queues run to the end, the persistent launch is modelled faster
     than the launch-per-panel schedule, and the model stays near what MAVBA_CHOL_TRACE measured for the forward pass on the
-    MI355X (profiles/r05_chol_trace_C3.txt, r04_chol_trace_C5.txt) - the schedule is only as good as that agreement."""
+    MI355X (profiles/r05_chol_trace_C3.txt, r04_chol_trace_C5.txt) - the schedule is only as good as that agreement.
+    C5d3: C5 with the depth-3 elimination tree that is the default since round 6 (195 tile columns, 15 nodes, 8 concurrent leaves;
+    profiles/r06_chol_trace_C5.txt); "C5" is the depth-2 structure of rounds 3-5, kept for the digests below."""
     nb, nodes, pairs = _load_structure(name)
     s = api.debug_chol_schedule(nb, nodes, pairs, cus=256)
     assert s["ok"] and s["nodes"] == len(nodes) and s["grid"] <= 256
