@@ -84,31 +84,53 @@ inline unsigned image_set_mix(unsigned x) {
 
 // ---- k_schur_rows (schur_rows.hip): the fused front end + cluster Schur complement of round 4 ----
 // A point owns a 16-lane DPP row, a batch is 16 points (K = 48 columns of the entry matrix). The entry matrix of a cluster
-// has rows 6 * slot + e for its `ni` image slots, then 9 * slot + k for its `nc` camera slots, then the h row; clusters
-// are launched per ROW CLASS (16-row blocks NT of the matrix): 80 rows hold 10 images + 2 cameras + h (15 tiles), 96 rows
-// 12 + 2 (21 tiles), 128 rows the general 16 x 3 list (36 tiles). Slot tables and image / camera lists keep the 16 x 3 layout of
-// ClusterShape{16, 3}: a cluster of k_schur_rows is also a valid cluster of k_schur_clusters / k_schur_fused.
+// has rows 6 * slot + e for its `ni` image slots, then the parameters of its `nc` camera slots (4 / 8 / 9 rows each), then the
+// h row; the cluster's ROW CLASS (16-row blocks NT of the matrix) selects the batch loop: 80 rows hold 11 images + a PINHOLE and
+// an OPENCV camera + h (15 tiles), 96 rows 13 images (21 tiles), 128 rows the general 16 x 3 list (36 tiles). Slot tables and
+// image / camera lists keep the 16 x 3 layout of ClusterShape{16, 3}: a cluster of k_schur_rows is also a valid cluster of
+// k_schur_clusters.
 constexpr int kRowsBatch = 16;
 constexpr int kRowsMaxPoints = 256;
 constexpr int kRowsClasses = 3;
 constexpr int kRowsClassNT[kRowsClasses] = {5, 6, 8};
 // emit_off / emit_n: the cluster's emit map (rows_emit_map below) - where every element of its block partials comes from in the
-// packed lower triangle of its product; one map per (ni, nc), passes as in the kernel (a 128-row triangle leaves in two).
+// packed lower triangle of its product; one map per cluster shape, passes as in the kernel (a 128-row triangle leaves in two).
+// flags: bit 0 = kRowsUnplaced; bits 8-15 / 16-23 = first row of camera slot 1 / 2 inside the camera rows, bits 24-31 = camera
+// rows in all. Round 6: a camera slot takes as many rows as its model has parameters (4 / 8 / 9), not 9 - the common cluster of
+// 11 images + a PINHOLE and an OPENCV camera has 66 + 12 + 1 = 79 rows (15 tiles) instead of 85 (21 tiles).
 struct SchurRowsCluster { int p0, p1, ni, nc, emit_off, emit_n[2], flags; };
+constexpr int kRowsUnplaced = 1;  // flags: two camera slots, but some point has more than 8 observations of one of them (see lanemap)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int rows_cam_off(int flags, int lc) { return lc <= 0 ? 0 : lc >= 3 ? (flags >> 24) & 255 : (flags >> (8 * lc)) & 255; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int rows_cam_rows(int flags) { return (flags >> 24) & 255; }
+// k[lc]: parameters of the camera model in slot lc (nc slots)
+inline int rows_pack_flags(bool unplaced, const int* k, int nc) {
+  int off[4] = {0, 0, 0, 0};
+  for (int c = 0; c < 3; ++c) off[c + 1] = off[c] + (c < nc ? k[c] : 0);
+  return (unplaced ? kRowsUnplaced : 0) | off[1] << 8 | off[2] << 16 | off[3] << 24;
+}
+// One entry of an emit map: source index in the pass's packed triangle (13 bits; kRowsEmitZero: no source row - a parameter the
+// slot's model does not have - the partial's element is written as 0), offset inside the destination partial (7 bits), index of
+// the partial's slot in the cluster's slot table (8 bits).
+constexpr unsigned kRowsEmitZero = 8191u;
+constexpr unsigned rows_emit_entry(int src, int o, int tab_index) { return (unsigned)src | (unsigned)o << 13 | (unsigned)tab_index << 20; }
 // the lists of a k_schur_rows cluster: 16 image slots, the camera of each, 3 camera slots, 1 pad
 constexpr int kRowsListsCam = kClImagesMax, kRowsListsCams = 2 * kClImagesMax, kRowsLists = 2 * kClImagesMax + kClCamsMax + 1;
-constexpr int kRowsUnplaced = 1;  // flags: two camera slots, but some point has more than 8 observations of one of them (see lanemap)
-// One entry of an emit map: source index in the pass's packed triangle (13 bits), offset inside the destination partial
-// (7 bits), index of the partial's slot in the cluster's slot table (8 bits).
-constexpr unsigned rows_emit_entry(int src, int o, int tab_index) { return (unsigned)src | (unsigned)o << 13 | (unsigned)tab_index << 20; }
 constexpr int kRowsPassSplit = 96;  // rows [0, 96) and [96, 128) of a 128-row product are staged one after the other
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline int rows_class_of(int ni, int nc) {
-  const int rows = 6 * ni + 9 * nc + 1;
-  return rows <= 16 * kRowsClassNT[0] ? 0 : rows <= 16 * kRowsClassNT[1] ? 1 : 2;
-}
+inline int rows_class_of_rows(int rows) { return rows <= 16 * kRowsClassNT[0] ? 0 : rows <= 16 * kRowsClassNT[1] ? 1 : 2; }
+// rows of a cluster's entry matrix: 6 per image slot, the camera slots' parameters, the h row
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int rows_count(int ni, int cam_rows) { return 6 * ni + cam_rows + 1; }
 
 // Scalars exchanged with the host every LM iteration (device array of doubles).
 // Two groups, reduced over ranks SEPARATELY (an evaluation enqueued behind an accepted step and the next candidate
@@ -259,7 +281,7 @@ void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool g
 // The emit map of a cluster shape (host): for pass 0 and pass 1, in the order the lanes walk them, one rows_emit_entry per
 // element of the block partials the shape can touch - pose x pose (42 per image pair: the 6 x 6 block, lower triangle only on
 // the diagonal, + the h row's 6 on the diagonal), intrinsics x pose (54), intrinsics x intrinsics (90: 9 x 9 + the h row's 9).
-void rows_emit_map(int ni, int nc, std::vector<unsigned>& pass0, std::vector<unsigned>& pass1);
+void rows_emit_map(int ni, int nc, int flags, std::vector<unsigned>& pass0, std::vector<unsigned>& pass1);
 // lanemap: per point, nibble i = which of the point's observations lane i of its 16-lane row takes (kRowsLanesIdentity: lane i takes
 // observation i). In a cluster with two camera slots the observations of slot 0 sit in lanes 0-7, those of slot 1 in lanes 8-15.
 constexpr unsigned long long kRowsLanesIdentity = 0xFEDCBA9876543210ull;

@@ -208,7 +208,11 @@ __device__ __forceinline__ void f2_write_blocks(const double* __restrict__ T, in
     double* d[U];
     double v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { d[u] = e0 + u * kF2Threads < n ? s_dst[m[u] >> 20] : nullptr; v[u] = T[m[u] & 8191u]; }
+    for (int u = 0; u < U; ++u) {
+      d[u] = e0 + u * kF2Threads < n ? s_dst[m[u] >> 20] : nullptr;
+      const unsigned src = m[u] & 8191u;
+      v[u] = src == kRowsEmitZero ? 0.0 : T[src];  // (kRowsEmitZero: a parameter the camera slot's model does not have)
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) if (d[u]) d[u][(m[u] >> 13) & 127u] = v[u];
   }
@@ -246,7 +250,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   const int cidx = blockIdx.x;
   const SchurRowsCluster cl = clusters[cidx];
   const int npts = cl.p1 - cl.p0, nbatch = (npts + kRowsBatch - 1) / kRowsBatch;
-  const int P0 = 6 * cl.ni, H = P0 + 9 * cl.nc;
+  const int P0 = 6 * cl.ni, H = P0 + rows_cam_rows(cl.flags);  // first camera row, the h row
   for (int j = tid; j <= npts; j += kF2Threads) s_pstart[j] = a.pt_start[cl.p0 + j];
   for (int j = tid; j < npts; j += kF2Threads) s_lanes[j] = lanemap[cl.p0 + j];
   if (tid < kF2Tab) {
@@ -458,10 +462,13 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     // ---- intrinsics entries: Wk = sum over the camera's observations of P, reduce-scattered over the row; the lane that ends
     // with the three sums of an entry row (camera slot lc, parameter k) writes U = (s_k Wk) Gi^T ----
     if constexpr (KMAX > 0 && !(MAVBA_ROWS_SKIP & 2)) {
+      // (slot lc's rows: one per parameter of ITS model - a lane whose parameter the model does not have writes nothing)
       auto write_row = [&](int lc, int k, const double* W) {
+        const int r0 = rows_cam_off(cl.flags, lc);
+        if (k >= rows_cam_off(cl.flags, lc + 1) - r0) return;
         const double sk = s_ksc[lc][k];
         const double w0 = W[0] * sk, w1 = W[1] * sk, w2 = W[2] * sk;
-        double* Eo = col + (P0 + 9 * lc + k) * kF2Pitch;
+        double* Eo = col + (P0 + r0 + k) * kF2Pitch;
         Eo[0] = w0 * G[0];
         Eo[1] = w0 * G[1] + w1 * G[2];
         Eo[2] = w0 * G[3] + w1 * G[4] + w2 * G[5];
@@ -556,7 +563,7 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   }
   };  // run
   static_assert(kRowsClasses == 3, "one instantiation of the batch loop per row class");
-  switch (rows_class_of(cl.ni, cl.nc)) {  // (uniform over the work-group)
+  switch (rows_class_of_rows(H + 1)) {  // (uniform over the work-group)
     case 0: run(std::integral_constant<int, kRowsClassNT[0]>{}); break;
     case 1: run(std::integral_constant<int, kRowsClassNT[1]>{}); break;
     default: run(std::integral_constant<int, kRowsClassNT[2]>{}); break;
@@ -572,18 +579,25 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
       long long* out = a.trace + ((size_t)blockIdx.x * kF2Waves + wv) * 16;
       out[9] = t_entry; out[10] = t_loop0; out[11] = t_loop1; out[12] = (long long)__builtin_amdgcn_s_memtime();
       out[13] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID | XCC_ID << 32: where the wave ran
-      out[14] = ((long long)nbatch << 8) | rows_class_of(cl.ni, cl.nc);
+      out[14] = ((long long)nbatch << 8) | rows_class_of_rows(H + 1);
     }
   }
 }
 
-void rows_emit_map(int ni, int nc, std::vector<unsigned>& pass0, std::vector<unsigned>& pass1) {
+void rows_emit_map(int ni, int nc, int flags, std::vector<unsigned>& pass0, std::vector<unsigned>& pass1) {
   pass0.clear(); pass1.clear();
-  const bool two = kRowsClassNT[rows_class_of(ni, nc)] > 6;  // (the kernel stages a product of more than 96 rows in two passes)
-  const int P0 = 6 * ni, H = P0 + 9 * nc;
+  const int P0 = 6 * ni, H = P0 + rows_cam_rows(flags);
+  const bool two = kRowsClassNT[rows_class_of_rows(H + 1)] > 6;  // (the kernel stages a product of more than 96 rows in two passes)
+  auto koff = [&](int lc) { return rows_cam_off(flags, lc); };
+  auto kcnt = [&](int lc) { return koff(lc + 1) - koff(lc); };
   auto put = [&](int R, int C, int o, int tab_index) {
     const int pass = two && R >= kRowsPassSplit ? 1 : 0;
     (pass ? pass1 : pass0).push_back(rows_emit_entry(f2_tri(R) - (pass ? f2_tri(kRowsPassSplit) : 0) + C, o, tab_index));
+  };
+  // (an element without a source row: written as zero, in the pass that writes the slot's other elements of that row block)
+  auto put_zero = [&](int R_near, int o, int tab_index) {
+    const int pass = two && R_near >= kRowsPassSplit ? 1 : 0;
+    (pass ? pass1 : pass0).push_back(rows_emit_entry((int)kRowsEmitZero, o, tab_index));
   };
   for (int la = 0; la < ni; ++la)  // pose x pose (+ the h row's part of the diagonal blocks)
     for (int lb = 0; lb <= la; ++lb)
@@ -593,12 +607,24 @@ void rows_emit_map(int ni, int nc, std::vector<unsigned>& pass0, std::vector<uns
       }
   for (int lc = 0; lc < nc; ++lc)  // intrinsics x pose
     for (int la = 0; la < ni; ++la)
-      for (int o = 0; o < 54; ++o) put(P0 + 9 * lc + o / 6, 6 * la + o % 6, o, kF2TabIP + lc * 16 + la);
+      for (int o = 0; o < 54; ++o) {
+        const int r = o / 6;
+        if (r < kcnt(lc)) put(P0 + koff(lc) + r, 6 * la + o % 6, o, kF2TabIP + lc * 16 + la);
+        else put_zero(P0 + koff(lc), o, kF2TabIP + lc * 16 + la);
+      }
   for (int lc = 0; lc < nc; ++lc)  // intrinsics x intrinsics (+ the h row's part)
     for (int lc2 = 0; lc2 <= lc; ++lc2)
       for (int o = 0; o < 90; ++o) {
-        if (o < 81) { const int r = o / 9, c = o % 9; if (lc == lc2 && r < c) continue; put(P0 + 9 * lc + r, P0 + 9 * lc2 + c, o, kF2TabII + f2_tri(lc) + lc2); }
-        else if (lc == lc2) put(H, P0 + 9 * lc + (o - 81), o, kF2TabII + f2_tri(lc) + lc2);
+        const int t = kF2TabII + f2_tri(lc) + lc2;
+        if (o < 81) {
+          const int r = o / 9, c = o % 9;
+          if (lc == lc2 && r < c) continue;
+          if (r < kcnt(lc) && c < kcnt(lc2)) put(P0 + koff(lc) + r, P0 + koff(lc2) + c, o, t);
+          else put_zero(P0 + koff(lc), o, t);
+        } else if (lc == lc2) {
+          if (o - 81 < kcnt(lc)) put(H, P0 + koff(lc) + (o - 81), o, t);
+          else put_zero(H, o, t);
+        }
       }
 }
 

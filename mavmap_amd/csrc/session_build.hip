@@ -2,6 +2,8 @@
 // structure, elimination order of the reduced system (reference semantics: src/base3d/bundle_adjustment.cc:228-549
 // for what the caller's flat problem means; everything here is indexing for the device kernels).
 #include "session.h"
+#include <array>
+#include <map>
 
 using namespace mavba;
 
@@ -775,10 +777,11 @@ void mavba_session::finish_structure() {
   // from runs of points with one image set by estimated cost (do_range_rows) instead of "until 16 images are full". The
   // point order keeps equal image sets together (the hash in the key). Chosen when the front end can run inside the
   // cluster kernel at all; otherwise the clusters of rounds 1-3 (k_point_front + k_schur_clusters).
-  std::vector<int> cl_ni, cl_nc;
+  std::vector<int> cl_ni, cl_nc, cl_kr;  // image slots, camera slots, camera rows (the slots' model parameters) of every cluster
+  auto cam_rows_of = [&](const std::vector<int>& cams) { int k = 0; for (int c : cams) k += model_k(h_cam_model[c]); return k; };
   const bool no_fuse_env = std::getenv("MAVBA_NO_FUSE") != nullptr;  // (read per session: the tests switch paths)
   auto build_clusters = [&](bool rows_mode) {
-    clusters.clear(); cl_imgs.clear(); cl_cams.clear(); cl_ni.clear(); cl_nc.clear();
+    clusters.clear(); cl_imgs.clear(); cl_cams.clear(); cl_ni.clear(); cl_nc.clear(); cl_kr.clear();
     std::fill(pt_mode.begin(), pt_mode.end(), 0);
     bool use_clusters = true;
     if (const char* e = std::getenv("MAVBA_CLUSTERS")) use_clusters = std::atoi(e) != 0;
@@ -806,7 +809,7 @@ void mavba_session::finish_structure() {
     const int kRange = 2048;
     const int nranges = (NP + kRange - 1) / kRange;
     std::vector<std::vector<SchurCluster>> r_clusters(nranges);
-    std::vector<std::vector<int>> r_imgs(nranges), r_cams(nranges), r_ni(nranges), r_nc(nranges);
+    std::vector<std::vector<int>> r_imgs(nranges), r_cams(nranges), r_ni(nranges), r_nc(nranges), r_kr(nranges);
     // Membership of an image in the open cluster / in the current point is an epoch tag per image (one table per host
     // thread's range, reused): a point costs its observations, not a set union (2.6 -> ~1 ms at C3). Same greedy rule as
     // before - the cluster closes when the UNION of its images and the point's would not fit - so the clusters are the same.
@@ -823,7 +826,7 @@ void mavba_session::finish_structure() {
       int cur_p0 = r0, cur_n = 0;
       auto close = [&](int p_end) {
         if (cur_n > 0) {
-          r_ni[rg].push_back((int)cur_i.size()); r_nc[rg].push_back((int)cur_c.size());
+          r_ni[rg].push_back((int)cur_i.size()); r_nc[rg].push_back((int)cur_c.size()); r_kr[rg].push_back(cam_rows_of(cur_c));
           std::sort(cur_i.begin(), cur_i.end());
           std::sort(cur_c.begin(), cur_c.end());
           r_clusters[rg].push_back(SchurCluster{cur_p0, p_end});
@@ -898,12 +901,12 @@ void mavba_session::finish_structure() {
         else runs.push_back(Run{p, p + 1, 1, pi, pc});
       }
       auto batches = [](int n) { return (n + kRowsBatch - 1) / kRowsBatch; };
-      auto cost = [&](int n, int ni, int nc) { return kCostF + batches(n) * kCostB[rows_class_of(ni, nc)]; };
+      auto cost = [&](int n, int ni, int kr) { return kCostF + batches(n) * kCostB[rows_class_of_rows(rows_count(ni, kr))]; };
       std::vector<int> cur_i, cur_c;
       int cl_serial = rg * (kRange + 1), cur_p0 = r0, cur_n = 0;
       auto close = [&](int p_end) {
         if (cur_n > 0) {
-          r_ni[rg].push_back((int)cur_i.size()); r_nc[rg].push_back((int)cur_c.size());
+          r_ni[rg].push_back((int)cur_i.size()); r_nc[rg].push_back((int)cur_c.size()); r_kr[rg].push_back(cam_rows_of(cur_c));
           std::sort(cur_i.begin(), cur_i.end());
           std::sort(cur_c.begin(), cur_c.end());
           r_clusters[rg].push_back(SchurCluster{cur_p0, p_end});
@@ -919,14 +922,14 @@ void mavba_session::finish_structure() {
         cur_n += n;
       };
       for (const Run& R : runs) {
-        const int rni = (int)R.imgs.size(), rnc = (int)R.cams.size();
+        const int rni = (int)R.imgs.size();
         bool join = false;
         if (cur_n > 0 && cur_n + R.n <= kMaxPoints && R.p1 - cur_p0 <= kRowsMaxPoints) {
-          int ni = (int)cur_i.size(), nc = (int)cur_c.size();
+          int ni = (int)cur_i.size(), nc = (int)cur_c.size(), kr = cam_rows_of(cur_c);
           for (int i : R.imgs) ni += in_cluster[i] != cl_serial;
-          for (int c : R.cams) nc += std::find(cur_c.begin(), cur_c.end(), c) == cur_c.end();
+          for (int c : R.cams) if (std::find(cur_c.begin(), cur_c.end(), c) == cur_c.end()) { ++nc; kr += model_k(h_cam_model[c]); }
           join = ni <= kClImages && nc <= kClCams &&
-                 cost(cur_n + R.n, ni, nc) <= cost(cur_n, (int)cur_i.size(), (int)cur_c.size()) + cost(R.n, rni, rnc);
+                 cost(cur_n + R.n, ni, kr) <= cost(cur_n, (int)cur_i.size(), cam_rows_of(cur_c)) + cost(R.n, rni, cam_rows_of(R.cams));
         }
         if (join) { add(R, R.p0, R.n); continue; }
         close(R.p0);
@@ -960,6 +963,7 @@ void mavba_session::finish_structure() {
       cl_cams.insert(cl_cams.end(), r_cams[rg].begin(), r_cams[rg].end());
       cl_ni.insert(cl_ni.end(), r_ni[rg].begin(), r_ni[rg].end());
       cl_nc.insert(cl_nc.end(), r_nc[rg].begin(), r_nc[rg].end());
+      cl_kr.insert(cl_kr.end(), r_kr[rg].begin(), r_kr[rg].end());
     }
   };
   // can the front end run inside the cluster kernel? every observed point before the tail clustered, nothing else clustered
@@ -981,7 +985,7 @@ void mavba_session::finish_structure() {
   for (size_t c = 0; c < clusters.size(); ++c) {  // batches x k-steps x lower tiles x 2*16*16*4
     const int np = clusters[c].p1 - clusters[c].p0;
     if (rows_ok) {
-      const int nt = kRowsClassNT[rows_class_of(cl_ni[c], cl_nc[c])];
+      const int nt = kRowsClassNT[rows_class_of_rows(rows_count(cl_ni[c], cl_kr[c]))];
       cluster_flops += (double)((np + kRowsBatch - 1) / kRowsBatch) * (3 * kRowsBatch / 4) * (double)(nt * (nt + 1) / 2) * 2048.0;
     } else {
       cluster_flops += (double)((np + kClBatch - 1) / kClBatch) * (3 * kClBatch / 4) * (double)((sh.rows() / 16) * (sh.rows() / 16 + 1) / 2) * 2048.0;
@@ -1324,7 +1328,7 @@ void mavba_session::finish_structure() {
     // the slot order and does not change
     std::vector<int> order(num_clusters);
     for (int c = 0; c < num_clusters; ++c) order[c] = c;
-    auto row_class = [&](int c) { return rows_ok ? rows_class_of(cl_ni[c], cl_nc[c]) : 0; };
+    auto row_class = [&](int c) { return rows_ok ? rows_class_of_rows(rows_count(cl_ni[c], cl_kr[c])) : 0; };
     // (k_schur_rows: longest = most matrix instructions first - batches x tiles of the cluster's row class)
     auto weight = [&](int c) {
       const int np = clusters[c].p1 - clusters[c].p0;
@@ -1339,20 +1343,22 @@ void mavba_session::finish_structure() {
       rows_generic = false;
       for (int c = 0; c < num_clusters; ++c) rows_generic = rows_generic || cl_nc[c] > 2;
       d_rows_lanes.upload(rows_lanes, st);
-      // the emit maps of the shapes present: one per (ni, nc), concatenated
+      // the emit maps of the shapes present: one per (image slots, camera slots' rows), concatenated
       std::vector<unsigned> emit_all, e0, e1;
-      int emit_of[kClImagesMax + 1][kClCamsMax + 1][3];
-      for (auto& x : emit_of) for (auto& y : x) y[0] = -1;
+      std::map<std::pair<int, int>, std::array<int, 3>> emit_of;
       for (int c = 0; c < num_clusters; ++c) {
         const int o = order[c];
-        int* eo = emit_of[cl_ni[o]][cl_nc[o]];
-        if (eo[0] < 0) {
-          rows_emit_map(cl_ni[o], cl_nc[o], e0, e1);
-          eo[0] = (int)emit_all.size(); eo[1] = (int)e0.size(); eo[2] = (int)e1.size();
+        int kslot[kClCamsMax] = {0, 0, 0};
+        for (int k = 0; k < cl_nc[o] && k < kClCamsMax; ++k) kslot[k] = model_k(h_cam_model[cl_cams[(size_t)o * kClCams + k]]);  // (slot order = the cluster's sorted camera list)
+        const int flags = rows_pack_flags(cl_unplaced[o] != 0, kslot, cl_nc[o]);
+        auto it = emit_of.find({cl_ni[o], flags >> 8});
+        if (it == emit_of.end()) {
+          rows_emit_map(cl_ni[o], cl_nc[o], flags, e0, e1);
+          it = emit_of.emplace(std::make_pair(cl_ni[o], flags >> 8), std::array<int, 3>{(int)emit_all.size(), (int)e0.size(), (int)e1.size()}).first;
           emit_all.insert(emit_all.end(), e0.begin(), e0.end());
           emit_all.insert(emit_all.end(), e1.begin(), e1.end());
         }
-        rc[c] = SchurRowsCluster{clusters[o].p0, clusters[o].p1, cl_ni[o], cl_nc[o], eo[0], {eo[1], eo[2]}, cl_unplaced[o] ? kRowsUnplaced : 0};
+        rc[c] = SchurRowsCluster{clusters[o].p0, clusters[o].p1, cl_ni[o], cl_nc[o], it->second[0], {it->second[1], it->second[2]}, flags};
         rows_class_count[row_class(o)]++;
       }
       d_rows_clusters.upload(rc, st);
