@@ -93,7 +93,7 @@ REPLICATED = {"chol_factor", "chol_backsolve", "schur_finalize", "update_cameras
               "cam_prepare", "rot_prior"}
 
 
-PMC_ROUNDS = ("r05", "r04")  # newest first: the committed counter passes (scripts/measure_all.sh, scripts/_dbg/evidence_c5.sh)
+PMC_ROUNDS = ("r06", "r05", "r04")  # newest first: the committed counter passes (scripts/measure_all.sh, scripts/_dbg/evidence_c5.sh)
 
 
 def pmc_file(kind, config):
@@ -445,7 +445,7 @@ def main():
         dominant = next((r for r in table if r.get("bound")), None)
         mdl = info.get("chol_model_forward_us", 0.0)
         chain_note = (f" (persistent launch: the host-side timing model that fills its task queues predicts {mdl:.0f} us for the forward pass"
-                      f" - 12.2 us per dependent tile column, 9-12 us per child -> parent hand-off, profiles/r05_chol_trace_C3.txt)") if mdl > 0 else \
+                      f" - 12.2 us per dependent tile column, 9-12 us per child -> parent hand-off, profiles/r06_chol_trace_C3.txt)") if mdl > 0 else \
                      f" (launch-per-panel schedule: {info['chain_steps']} dependent 64-column panel steps)"
         roofline = None
         if dominant:
@@ -472,7 +472,7 @@ def main():
                                 mfma_counters=None if not mfma else mfma.get("schur_fused"))
                 roofline["note"] = ("k_schur_rows: Jacobian evaluation, per-point sums, 3x3 factors AND the Schur complement of the point "
                                     "clusters (E E^T on v_mfma_f64_16x16x4_f64) in one kernel, no Jacobian and no entry records in HBM. "
-                                    "FP64 vector and matrix instructions share the SIMD's pipe (profiles/r04_pipe_bench_fp64.txt), so the kernel is bound by their SUM; "
+                                    "While a v_mfma_f64_16x16x4 executes no vector instruction of either wave issues on its SIMD, and two waves' vector instructions do not overlap either (profiles/r06_issue_bench.txt), so the kernel is bound by the SUM of both; "
                                     "achieved / frac price only SURVEY 8(d)'s Schur-formation flops sum_p (6 L_p + K_p)^2 * 6 over the "
                                     "kernel's time; executed_* = matrix-instruction flops really issued; sweep_equivalent_* = SURVEY "
                                     "8(d)'s Jacobian-sweep bytes (J counted as if written) over the same time")
@@ -487,6 +487,13 @@ def main():
                                     f"time. Bound by the dependent chain of tile columns and child -> parent hand-offs, not by matrix "
                                     f"throughput{chain_note}. dense_equivalent_tflops prices SURVEY 8(d)'s n^3/3 + 2 n^2 = "
                                     f"{info['dense_factor_flops'] / 1e9:.2f} GFLOP and is NOT a roofline (> peak at C5)")
+        # (C3: k_schur_rows and k_chol_persist are within a few per cent of each other - which one leads changes from run to run;
+        # the runner-up's figures are carried beside the dominant kernel's)
+        second = next((r for r in table if r.get("bound") and r is not dominant), None)
+        if roofline is not None and second is not None:
+            roofline["runner_up"] = dict(kernel=second["kernel"], rocprof_kernel=PMC_KERNEL.get(second["kernel"]), bound=second["bound"],
+                                         achieved=second["achieved"], peak=second["peak"], unit=second["unit"], frac=second["frac"],
+                                         avg_ms=second["avg_ms"], share=second["share"])
         chol = next((r for r in table if r["kernel"] == "chol_factor"), None)
         back = next((r for r in table if r["kernel"] == "chol_backsolve"), None)
         reduced_solve = None
@@ -574,8 +581,9 @@ def main():
                     "REDUNDANTLY on every rank (chol_factor, chol_backsolve, schur_finalize, ...), only the per-point work shards. "
                     "expected_speedup_with_exchange adds the all-reduce of the packed tiles + right-hand side and two small "
                     "collectives per iteration, priced as 20 us + 2 (R-1)/R bytes / min(50 (R-1), 300) GB/s (one xGMI link per "
-                    "peer): the honest expectation for this design. profiles/r05_multi_gpu_pricing.txt prices the alternatives "
-                    "(subtree-aligned shards, subtree-to-rank factorisation: 1.36x at C3, 2.35x at C5 on 8 ranks) on the real structures"}
+                    "peer): the honest expectation for this design. profiles/r05_multi_gpu_pricing.txt and r06_multi_gpu_pricing_C5_depth3.txt price the "
+                    "alternatives on the real structures (subtree-aligned shards + subtree-to-rank factorisation: 1.36x at C3; C5 with its "
+                    "depth-3 tree 1.68 / 2.20 / 2.68x at 2 / 4 / 8 ranks - designed in DESIGN.md section 7, not built: no multi-GPU node to run it on)"}
         # the other single-GPU configurations of BASELINE.json, short passes (the driver times only this command: C2 and C5,
         # whose dominant kernel is the factorisation, would otherwise be builder-only numbers)
         other_configs = None
