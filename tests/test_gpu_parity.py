@@ -717,3 +717,32 @@ def test_merged_evaluation_tail_of_a_large_problem_equals_the_four_launches(mavb
         for x, y in zip(a, b):
             assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
 
+
+
+def test_lane_placement_and_its_fallback_match_the_oracle(mavba, oracle, monkeypatch, capfd):
+    """k_schur_rows, round 6: in a cluster with two camera slots the set-up places a point's observations in the 8-lane half of
+    their camera's slot; a point with more than 8 observations of ONE slot cannot be placed, its cluster keeps the
+    reduce-scatter's first halving with the selects. Three of four images on the first camera: both kinds of cluster occur
+    (the set-up's statistics say so), and the reduced system, the step and a complete solve are the oracle's."""
+    image_camera = np.array([0, 0, 0, 1] * 12, np.int32)
+    p = synth.make_scene(num_images=48, num_points=4000, track_len=12, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=61,
+                         spacing=5.0, image_camera=image_camera)
+    monkeypatch.setenv("MAVBA_CLUSTER_STATS", "1")
+    ref = oracle.linear_step(p, 1e4)
+    with mavba.Session(p) as s:
+        S, v = s.reduced_system(1e4)
+        st = s.linear_step(1e4)
+    err = capfd.readouterr().err
+    line = [l for l in err.splitlines() if "clusters that keep the selects" in l]
+    assert line, err[-2000:]
+    kept = int(line[-1].rsplit(":", 1)[1])
+    total = sum(int(tok.split("/")[0]) for tok in line[-1].split(";")[0].split() if "/" in tok and tok[0].isdigit())
+    assert 0 < kept < total, line[-1]  # both the placed and the unplaced form ran
+    assert rel_err(S, ref["S"]) < 1e-9 and rel_err(v, ref["v"]) < 1e-9
+    assert rel_err(st["d_poses"], ref["d_poses"]) < 1e-8 and rel_err(st["d_intr"], ref["d_intr"]) < 1e-8
+    assert rel_err(st["d_points"], ref["d_points"]) < 1e-8
+    monkeypatch.delenv("MAVBA_CLUSTER_STATS")
+    po, ro, eo, pg, rg, eg = _solve_both(mavba, oracle, p, **global_opts())
+    assert ro["num_successful_steps"] == rg["num_successful_steps"] and ro["termination"] == rg["termination"]
+    assert abs(rg["final_cost"] - ro["final_cost"]) <= 1e-6 * abs(ro["final_cost"])
+    assert_params_close(pg, po)
