@@ -1,6 +1,7 @@
 // host_util.hip - process-wide helpers of the host side: caching device allocator, stream cache, worker threads.
 #include "session.h"
 #include <atomic>
+#include <cstdint>
 #include <cstring>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -250,8 +251,117 @@ constexpr size_t kStagedCopyMin = (size_t)128 << 10, kStagedChunk = (size_t)32 <
 struct Parked { std::mutex m; std::unordered_map<hipStream_t, std::vector<void*>> by_stream; };
 Parked& parked() { static Parked* p = new Parked; return *p; }
 }  // namespace
+// ---- batched small uploads (round 6) ---------------------------------------------------------------------------------
+// A local-window session uploads ~50 small tables and clears ~8 small arrays while it is set up; every one of them was a
+// hipMemcpyAsync / hipMemsetAsync of its own - 4-8 us of host time each, a third of a 0.8 ms set-up. While a batch is open on
+// the calling thread, copies below kStagedCopyMin and clears below kBatchZeroMax on the batch's stream are only RECORDED
+// (payload copied into one page-locked arena); the flush enqueues ONE host-to-device copy of the arena and ONE kernel
+// that deals the segments to their destinations (a work-group per 16 KB piece). Stream order is kept as long as nothing
+// that reads the destinations is enqueued before the flush - the host-only set-up path of small problems (session_build.hip).
+namespace {
+struct UploadSeg { unsigned long long dst; long long src; unsigned bytes; unsigned pad; };  // src < 0: zeros
+constexpr size_t kBatchArena = (size_t)2 << 20, kBatchZeroMax = (size_t)1 << 20, kBatchPiece = (size_t)16 << 10;
+struct UploadBatch {
+  hipStream_t st = nullptr;
+  char* host = nullptr;
+  size_t used = 0;
+  std::vector<UploadSeg> segs;
+};
+thread_local UploadBatch* g_batch = nullptr;
+struct ParkedDev { std::mutex m; std::unordered_map<hipStream_t, std::vector<void*>> by_stream; };
+ParkedDev& parked_dev() { static ParkedDev* p = new ParkedDev; return *p; }
+
+__global__ void __launch_bounds__(256) k_upload_scatter(const char* __restrict__ arena, const UploadSeg* __restrict__ segs) {
+  const UploadSeg s = segs[blockIdx.x];
+  unsigned* d = reinterpret_cast<unsigned*>(s.dst);
+  const unsigned words = s.bytes >> 2;
+  if (s.src < 0) {
+    for (unsigned i = threadIdx.x; i < words; i += 256) d[i] = 0u;
+    if (threadIdx.x < (s.bytes & 3u)) reinterpret_cast<unsigned char*>(d + words)[threadIdx.x] = 0;
+  } else {
+    const unsigned* a = reinterpret_cast<const unsigned*>(arena + s.src);
+    for (unsigned i = threadIdx.x; i < words; i += 256) d[i] = a[i];
+    if (threadIdx.x < (s.bytes & 3u))
+      reinterpret_cast<unsigned char*>(d + words)[threadIdx.x] = reinterpret_cast<const unsigned char*>(a + words)[threadIdx.x];
+  }
+}
+
+// enqueue what the batch holds (the batch stays open, empty)
+hipError_t batch_emit(UploadBatch& B) {
+  if (B.segs.empty()) return hipSuccess;
+  const size_t table_off = (B.used + 15) & ~(size_t)15, table_bytes = B.segs.size() * sizeof(UploadSeg);
+  // (the arena has kBatchArena of payload + room for the table of the pieces that fit into it)
+  std::memcpy(B.host + table_off, B.segs.data(), table_bytes);
+  void* dev = nullptr;
+  hipError_t e = device_alloc(&dev, table_off + table_bytes);
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(dev, B.host, table_off + table_bytes, hipMemcpyHostToDevice, B.st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_upload_scatter, dim3((unsigned)B.segs.size()), dim3(256), 0, B.st, static_cast<const char*>(dev),
+                       reinterpret_cast<const UploadSeg*>(static_cast<const char*>(dev) + table_off));
+    e = hipGetLastError();
+  }
+  // both arenas are in use until the stream has passed the kernel: parked, freed by release_staged
+  { std::lock_guard<std::mutex> g(parked().m); parked().by_stream[B.st].push_back(B.host); }
+  { std::lock_guard<std::mutex> g(parked_dev().m); parked_dev().by_stream[B.st].push_back(dev); }
+  B.host = nullptr; B.used = 0; B.segs.clear();
+  return e;
+}
+constexpr size_t batch_table_room() { return (kBatchArena / 256 + kBatchArena / kBatchPiece + 64) * sizeof(UploadSeg); }
+// records one copy (src != nullptr) or clear; false = not taken (no arena): the caller issues it directly
+bool batch_add(UploadBatch& B, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return true;
+  if ((reinterpret_cast<uintptr_t>(dst) & 3u) != 0) return false;
+  const size_t need = src ? ((bytes + 15) & ~(size_t)15) : 0;
+  const size_t max_segs = batch_table_room() / sizeof(UploadSeg);
+  const size_t pieces = (bytes + kBatchPiece - 1) / kBatchPiece;
+  // a destination written twice (a buffer freed and handed out again inside the batch): the pieces of one flush run side by
+  // side, so the earlier write has to leave first
+  bool overlap = false;
+  const unsigned long long d0 = reinterpret_cast<unsigned long long>(dst), d1 = d0 + bytes;
+  for (const UploadSeg& s : B.segs) overlap = overlap || (s.dst < d1 && d0 < s.dst + s.bytes);
+  if (B.host && (overlap || B.used + need > kBatchArena || B.segs.size() + pieces > max_segs))
+    if (batch_emit(B) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (!B.host) {
+    void* h = nullptr;
+    if (pinned_alloc(&h, kBatchArena + 16 + batch_table_room()) != hipSuccess) { (void)hipGetLastError(); return false; }
+    B.host = static_cast<char*>(h);
+    B.used = 0;
+  }
+  long long at = -1;
+  if (src) { at = (long long)B.used; std::memcpy(B.host + B.used, src, bytes); B.used += need; }
+  for (size_t off = 0; off < bytes; off += kBatchPiece)
+    B.segs.push_back(UploadSeg{reinterpret_cast<unsigned long long>(static_cast<char*>(dst) + off), src ? at + (long long)off : -1,
+                               (unsigned)std::min(kBatchPiece, bytes - off), 0u});
+  return true;
+}
+}  // namespace
+bool upload_batch_begin(hipStream_t st) {
+  if (g_batch) return false;
+  g_batch = new UploadBatch;
+  g_batch->st = st;
+  return true;
+}
+hipError_t upload_batch_end(bool emit) {
+  if (!g_batch) return hipSuccess;
+  UploadBatch* B = g_batch;
+  g_batch = nullptr;
+  hipError_t e = hipSuccess;
+  if (emit) e = batch_emit(*B);
+  if (B->host) pinned_free(B->host);  // (aborted, or nothing recorded)
+  delete B;
+  return e;
+}
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (g_batch && g_batch->st == st && bytes <= kBatchZeroMax && batch_add(*g_batch, p, nullptr, bytes)) return hipSuccess;
+  return hipMemsetAsync(p, 0, bytes, st);
+}
+
 hipError_t copy_h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t st) {
-  if (bytes < kStagedCopyMin) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  if (bytes < kStagedCopyMin) {
+    if (g_batch && g_batch->st == st && batch_add(*g_batch, dst, src, bytes)) return hipSuccess;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  }
   for (size_t off = 0; off < bytes; off += kStagedChunk) {
     const size_t len = std::min(kStagedChunk, bytes - off);
     void* stage = nullptr;
@@ -269,10 +379,16 @@ void release_staged(hipStream_t st) {
   {
     std::lock_guard<std::mutex> g(parked().m);
     auto it = parked().by_stream.find(st);
-    if (it == parked().by_stream.end()) return;
-    blocks.swap(it->second);
+    if (it != parked().by_stream.end()) blocks.swap(it->second);
   }
   for (void* b : blocks) pinned_free(b);
+  std::vector<void*> dblocks;
+  {
+    std::lock_guard<std::mutex> g(parked_dev().m);
+    auto it = parked_dev().by_stream.find(st);
+    if (it != parked_dev().by_stream.end()) dblocks.swap(it->second);
+  }
+  for (void* b : dblocks) device_free(b);
 }
 hipError_t copy_d2h_staged_sync(void* dst, const void* src, size_t bytes, hipStream_t st) {
   if (bytes < kStagedCopyMin) {

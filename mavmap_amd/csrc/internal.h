@@ -371,6 +371,12 @@ void device_free(void* p);
 hipError_t copy_h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t st);       // asynchronous; staging released by release_staged
 hipError_t copy_d2h_staged_sync(void* dst, const void* src, size_t bytes, hipStream_t st);  // returns with the data in dst
 void release_staged(hipStream_t st);  // call behind a synchronisation of st
+// Batched small uploads (host_util.hip): between upload_batch_begin(st) and upload_batch_end on ONE host thread, copies
+// below 128 KiB through copy_h2d_staged and clears through zero_async on st are recorded and leave as one copy + one
+// kernel at the end (emit = false drops them: error paths). Nothing that READS the destinations may be enqueued in between.
+bool upload_batch_begin(hipStream_t st);      // false: the thread already has one open (the outer one keeps collecting)
+hipError_t upload_batch_end(bool emit);
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
 // host worker threads of the set-up passes (host_util.hip): body(0 .. T-1), T <= host_threads(); calls are serialised, never nest them
 int host_threads();
 void host_run(int T, const std::function<void(int)>& body);

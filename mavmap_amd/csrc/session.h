@@ -69,7 +69,7 @@ struct DevBuf {
     alloc(std::max<size_t>(count, 1));
     if (count) HIP_OK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st));
   }
-  void zero(hipStream_t st) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
+  void zero(hipStream_t st) { if (n) HIP_OK(zero_async(p, n * sizeof(T), st)); }
 };
 
 // session_build.hip: elimination tree of the reduced camera system (host only)
@@ -350,6 +350,7 @@ struct mavba_session {
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
+  bool setup_batched = false;    // build() collects the set-up's small uploads (upload_batch_begin): finish_structure does not synchronise
   bool M_is_clean = false;       // d_M holds zeros outside the entries the assembly writes
   bool M_outside_clean = false;  // d_M was cleared as a whole since it was allocated: only tiles inside the envelope can be dirty
   // cleared when a persistent factorisation launch had to give up; a session created within the next

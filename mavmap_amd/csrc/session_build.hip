@@ -47,6 +47,9 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
                                   std::unique_ptr<PinnedBuf<double2>>& im_uv_h, std::unique_ptr<PinnedBuf<int>>& im_pt_h) {
   const bool all_kept = keptp == nullptr;
   auto kept_at = [keptp](long long k) { return keptp ? keptp[k] : k; };
+  const bool tt = std::getenv("MAVBA_SETUP_TIMING") != nullptr;
+  double tl = now_s();
+  auto lap = [&](const char* what) { if (tt) { const double t = now_s(); std::fprintf(stderr, "[setup]   host: %-20s %8.3f ms\n", what, 1e3 * (t - tl)); tl = t; } };
   // ---- internal point order ----
   // One stable counting sort of the kept observations by (caller's) point gives every point's bucket; the
   // point-major order is the buckets concatenated in the new point order.
@@ -66,6 +69,7 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
                            });
       if (all_kept)
       for (int p = 0; p < NP; ++p) { h_pt_count_all[p] = cstart[p + 1] - cstart[p]; h_pt_used[p] = h_pt_count_all[p] > 0; }
+    lap("buckets by point");
     // Order: the 8 smallest DISTINCT images that see the point, 16 bits each in one 128-bit key (0xFFFF padded: a point
     // nobody sees sorts last), ties by the caller's point index - a strict total order, so the result does not depend on
     // the number of threads, and the same definition as k_point_keys + the radix sort of the device path.
@@ -98,6 +102,7 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
         keyed[p] = kk;
       }
     });
+    lap("point keys");
     auto before = [&](const KeyId& x, const KeyId& y) {
       if (x.tail != y.tail) return x.tail < y.tail;
       if (x.hi != y.hi) return x.hi < y.hi;
@@ -119,9 +124,53 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
         for (long long k = k0; k < k1; ++k) std::sort(dealt.data() + fstart[nonempty[k]], dealt.data() + fstart[nonempty[k] + 1], before);
       }, 2);
       parallel_ranges(NP, [&](long long b0, long long b1) { for (long long q = b0; q < b1; ++q) keyed[q] = dealt[q]; }, 20000);
+    } else if (NI <= 31 && !std::getenv("MAVBA_ORDER_GENERAL")) {  // (the switch: tests compare the two sorts)
+      // A local window (round 6): with at most 31 images the eight smallest images of a point are a 31-bit set (image 0 = the
+      // most significant bit) and the lexicographic order of the 0xFFFF-padded ascending lists is the DESCENDING order of
+      // those sets - at the first position where two lists differ, the smaller image is a bit one set has and the other has
+      // not, and every higher bit is common. So (tail, hi, lo, hash) packs into one 64-bit integer and the sort moves 16-byte
+      // pairs with a trivial comparison instead of 40-byte records with a five-level one (0.15 of a 0.3 ms ordering block at
+      // 2 500 points); the order is the same, ties by the caller's index as before.
+      std::vector<std::pair<unsigned long long, int>> packed(NP);
+      for (int p = 0; p < NP; ++p) {
+        const KeyId& kk = keyed[p];
+        unsigned set = 0;
+        for (int t = 0; t < 4; ++t) {
+          const unsigned a = (unsigned)(kk.hi >> (48 - 16 * t)) & 0xFFFFu, b2 = (unsigned)(kk.lo >> (48 - 16 * t)) & 0xFFFFu;
+          if (a != 0xFFFFu) set |= 1u << (30 - a);
+          if (b2 != 0xFFFFu) set |= 1u << (30 - b2);
+        }
+        packed[p] = {(unsigned long long)kk.tail << 63 | (unsigned long long)(~set & 0x7FFFFFFFu) << 32 | kk.hash, kk.id};
+      }
+      if (NI <= 12) {
+        // ... and with at most 12 images (tail, set) is one of 8 192 values: a stable counting sort puts the points of one
+        // image set together in the caller's order; only a set whose points differ in the hash - an image seen twice by some
+        // of them, more than eight images - needs a sort of its own (0.125 -> 0.03 ms at 2 500 points)
+        const int shift = 31 - NI, nbuckets = 2 << NI;
+        std::vector<int> start((size_t)nbuckets + 1, 0);
+        auto bucket_of = [&](unsigned long long key) { return (int)(key >> 63) << NI | (int)((unsigned)(key >> 32) & 0x7FFFFFFFu) >> shift; };
+        for (int p = 0; p < NP; ++p) start[(size_t)bucket_of(packed[p].first) + 1]++;
+        for (int b2 = 0; b2 < nbuckets; ++b2) start[b2 + 1] += start[b2];
+        std::vector<std::pair<unsigned long long, int>> dealt(NP);
+        {
+          std::vector<int> cur(start.begin(), start.end() - 1);
+          for (int p = 0; p < NP; ++p) dealt[cur[bucket_of(packed[p].first)]++] = packed[p];  // (ids ascend inside a bucket: keyed[] is in the caller's order)
+        }
+        for (int b2 = 0; b2 < nbuckets; ++b2) {
+          const int q0 = start[b2], q1 = start[b2 + 1];
+          bool same = true;
+          for (int q = q0 + 1; q < q1 && same; ++q) same = dealt[q].first == dealt[q0].first;
+          if (!same) std::sort(dealt.begin() + q0, dealt.begin() + q1);
+        }
+        packed.swap(dealt);
+      } else {
+        std::sort(packed.begin(), packed.end());
+      }
+      for (int q = 0; q < NP; ++q) keyed[q].id = packed[q].second;
     } else {
       std::sort(keyed.data(), keyed.data() + NP, before);
     }
+    lap("sort");
     h_pt_orig.resize(NP);
     for (int q = 0; q < NP; ++q) h_pt_orig[q] = keyed[q].id;
     for (int q = 0; q < NP; ++q) pt_new[h_pt_orig[q]] = q;
@@ -135,6 +184,7 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
     permute(h_points0, 3); permute(h_pt_const_in, 1); permute(h_pt_count_all, 1); permute(h_pt_used, 1);
   }
 
+  lap("permute point arrays");
   // ---- point-major order: the buckets in the new point order ----
   h_pt_start.assign(NP + 1, 0);
   for (int q = 0; q < NP; ++q) h_pt_start[q + 1] = h_pt_start[q] + (cstart[h_pt_orig[q] + 1] - cstart[h_pt_orig[q]]);
@@ -158,6 +208,7 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
     }
   });
 
+  lap("point-major order");
   // ---- image-major view for the camera sweep ----
   im_uv_h.reset(new PinnedBuf<double2>(N));
   im_pt_h.reset(new PinnedBuf<int>(N));
@@ -165,6 +216,7 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
   PinnedBuf<int>& im_pt = *im_pt_h;
   counting_sort_parallel(N, NI, [&](long long a) { return h_oimg[a]; }, img_start,
                          [&](long long a, int at) { im_uv[at] = uv[a]; im_pt[at] = opt_[a]; });
+  lap("image-major order");
 }
 
 void mavba_session::build(const mavba_problem* P, const DeviceRaw* raw) {
@@ -296,6 +348,14 @@ void mavba_session::build(const mavba_problem* P, const DeviceRaw* raw) {
 
   // ---- internal point order and the two observation orders: on the device (device_setup.hip) unless all-constant
   // residual blocks were dropped (the host walks the kept list then) or the problem is small ----
+  // Small problems on the host path: nothing of the set-up below runs on the device, so its ~50 small uploads and clears are
+  // collected and leave as ONE copy + ONE kernel before reset_state (upload_batch_begin, host_util.hip; MAVBA_UPLOAD_BATCH=0: off)
+  struct BatchScope { bool open = false; ~BatchScope() { if (open) (void)upload_batch_end(false); } } batch;
+  {
+    const char* e = std::getenv("MAVBA_UPLOAD_BATCH");
+    if (!device_order && N < 50000 && !(e && std::atoi(e) == 0)) batch.open = upload_batch_begin(st);
+  }
+  setup_batched = batch.open;
   std::vector<int> img_start;
   std::unique_ptr<PinnedBuf<double2>> uv_h, im_uv_h;   // host path: page-locked staging of the arrays uploaded below
   std::unique_ptr<PinnedBuf<int>> opt_h, im_pt_h;
@@ -382,6 +442,8 @@ void mavba_session::build(const mavba_problem* P, const DeviceRaw* raw) {
   derive_free_flags();
   finish_structure();
   lap("finish_structure total");
+  setup_batched = false;
+  if (batch.open) { batch.open = false; HIP_OK(upload_batch_end(true)); }
   reset_state();
   sync();
   lap("reset + sync");
@@ -956,7 +1018,7 @@ void mavba_session::finish_structure() {
         if (rows_mode) do_range_rows((int)g, in_cluster, in_point);
         else do_range((int)g, in_cluster, in_point);
       }
-    }, 2);
+    }, 8);  // (a handful of ranges: waking the worker threads costs more than the walk)
     for (int rg = 0; rg < nranges; ++rg) {
       clusters.insert(clusters.end(), r_clusters[rg].begin(), r_clusters[rg].end());
       cl_imgs.insert(cl_imgs.end(), r_imgs[rg].begin(), r_imgs[rg].end());
@@ -981,6 +1043,7 @@ void mavba_session::finish_structure() {
   }
   if (!rows_ok) build_clusters(false);
   num_clusters = (int)clusters.size();
+  lap("  clusters: greedy");
   cluster_flops = 0.0;
   for (size_t c = 0; c < clusters.size(); ++c) {  // batches x k-steps x lower tiles x 2*16*16*4
     const int np = clusters[c].p1 - clusters[c].p0;
@@ -1067,7 +1130,7 @@ void mavba_session::finish_structure() {
         }
       }
     }
-  }, 64);
+  }, 512);
   clustered_points = 0;
   for (int p = 0; p < NP; ++p) clustered_points += pt_mode[p] == 1;
   if (std::getenv("MAVBA_CLUSTER_STATS")) {  // debugging aid: how many 16-row blocks of the pose rows a 32-point batch really touches
@@ -1414,7 +1477,7 @@ void mavba_session::finish_structure() {
     }
     rows_ok = rows_ok && fused_ok;  // (if not: the clusters built for k_schur_rows are valid - only shorter - clusters of k_schur_clusters)
   }
-  sync();
+  if (!setup_batched) sync();  // (a batched set-up has nothing in flight yet: build() flushes and synchronises once)
   lap("upload terms");
 }
 

@@ -9,12 +9,13 @@ p.pose_const[:2] = A.CONST_POSE
 p.intr_const[:] = 1
 opts = dict(max_num_iterations=100, function_tolerance=1e-4, gradient_tolerance=1e-8)
 print("images %d points %d obs %d" % (p.num_images, p.num_points, p.num_obs))
-ts = []
-for rep in range(30):
+ts, su, so = [], [], []
+for rep in range(60):
     q = p.copy()
     t = time.perf_counter(); cost, res = mavmap_amd.bundle_adjustment(q, opts); ts.append(time.perf_counter() - t)
+    su.append(res["setup_seconds"]); so.append(res["solve_seconds"])
 it = res["num_successful_steps"] + res["num_unsuccessful_steps"]
-print("mavba_solve: median %.3f ms, min %.3f ms, iterations %d, setup %.3f ms, solve %.3f ms" % (1e3 * np.median(ts[5:]), 1e3 * min(ts), it, 1e3 * res["setup_seconds"], 1e3 * res["solve_seconds"]))
+print("mavba_solve: median %.3f ms, min %.3f ms, iterations %d, setup median %.3f ms (min %.3f), solve median %.3f ms" % (1e3 * np.median(ts[5:]), 1e3 * min(ts), it, 1e3 * np.median(su[5:]), 1e3 * min(su), 1e3 * np.median(so[5:])))
 with mavmap_amd.Session(p, dict(opts, profile_kernels=1)) as s:
     t = time.perf_counter(); s.iterate(1000); dt = time.perf_counter() - t
     print("session solve with event timers %.3f ms" % (1e3 * dt))

@@ -71,3 +71,42 @@ def test_device_setup_reports_a_bad_observation_index(mavba, monkeypatch):
     with pytest.raises(mavba.MavbaError) as e:
         mavba.Session(p, global_opts())
     assert e.value.code == A.ERR_BAD_INDEX
+
+
+@pytest.mark.parametrize("kind", ["window", "window_long_tracks"])
+def test_window_setup_shortcuts_change_nothing(mavba, monkeypatch, kind):
+    """Round 6, the set-up of a local window (host path): the point order sorted on packed 64-bit keys (at most 31 images) and
+    the small uploads / clears collected into one copy + one scatter kernel (upload_batch_begin, host_util.hip). Switched
+    off - MAVBA_ORDER_GENERAL=1, MAVBA_UPLOAD_BATCH=0 - the session must be the same to the last bit: same point order (every
+    sum follows from it), same tables on the device."""
+    if kind == "window":
+        p = synth.make_scene(num_images=10, num_points=2500, track_len=4, models=[A.MODEL_OPENCV], seed=3, refine_camera_params=False)
+        p.pose_const[:2] = A.CONST_POSE
+        p.intr_const[:] = 1
+    else:
+        # tracks through all 12 images (more than the key's eight), an image seen twice, a constant point, free intrinsics
+        p = synth.make_scene(num_images=12, num_points=900, track_len=6, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=41,
+                             long_track_frac=0.2, long_track_len=12)
+        p.obs_image[5] = p.obs_image[4] if p.obs_point[5] == p.obs_point[4] else p.obs_image[5]
+        p.point_const[11] = 1
+    out = {}
+    for mode in ("shortcuts", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("MAVBA_ORDER_GENERAL", "1")
+            monkeypatch.setenv("MAVBA_UPLOAD_BATCH", "0")
+        q = p.copy()
+        with mavba.Session(q, global_opts()) as s:
+            info = s.info()
+            res = s.solve()
+            x = s.get_params()
+            perr = s.point_errors()
+        out[mode] = (info, res, x, perr)
+    ia, ra, xa, ea = out["shortcuts"]
+    ib, rb, xb, eb = out["plain"]
+    for k in ("num_clusters", "clustered_points", "cluster_partials", "schur_blocks", "intr_entries"):
+        assert ia[k] == ib[k], k
+    for k in ("termination", "num_successful_steps", "num_unsuccessful_steps", "final_cost", "initial_cost", "num_residuals"):
+        assert ra[k] == rb[k], k
+    for a, b in zip(xa, xb):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ea, eb, equal_nan=True)
