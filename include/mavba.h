@@ -451,6 +451,9 @@ typedef struct mavba_session_info {
   int64_t cluster_partials;    /* (cluster, block) partials the clusters emit per linear solve  */
   double cluster_flops;        /* FP64 MFMA flops k_schur_clusters executes per linear solve (E E^T incl. structural zeros) */
   double chol_model_forward_us; /* the host-side timing model's forward factorisation on the persistent schedule (0: other schedule) */
+  int64_t reduced_store_bytes; /* device bytes of the reduced system S | v (as many again for its factor): the envelope's tiles + one
+                                  right-hand-side tile per tile column, 32 KiB each - what SPARSE_SCHUR's sparse storage is to Ceres
+                                  (reference src/base3d/bundle_adjustment.cc:555); a dense (n + 64) n array is matrix_dim^2 * 8 */
 } mavba_session_info;
 int mavba_session_get_info(mavba_session* s, mavba_session_info* out);
 

@@ -92,7 +92,7 @@ class CSessionInfo(C.Structure):
                 ("dense_factor_flops", C.c_double), ("matrix_dim", C.c_int32), ("nd_parts", C.c_int32),
                 ("chain_steps", C.c_int32), ("num_clusters", C.c_int32),
                 ("clustered_points", C.c_int64), ("cluster_partials", C.c_int64),
-                ("cluster_flops", C.c_double), ("chol_model_forward_us", C.c_double)]
+                ("cluster_flops", C.c_double), ("chol_model_forward_us", C.c_double), ("reduced_store_bytes", C.c_int64)]
 
 
 class CKernelStat(C.Structure):

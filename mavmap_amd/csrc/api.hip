@@ -378,10 +378,21 @@ int mavba_session_reduced_system(mavba_session* s, double radius, double* Sout, 
   if (!s->evaluated) s->evaluate();
   s->assemble(radius);
   // the device matrix is in elimination order; hand it out in the variables' order
-  const int n = s->n_full, m = s->n_mat;
-  std::vector<double> h((size_t)(m + 1) * m);
-  s->download(h.data(), s->d_M.p, h.size() * 8);
+  const int n = s->n_full, m = s->n_mat, nbt = m / 64;
+  // the device keeps the envelope's tiles only (tile store, internal.h): spread them into the dense (m + 1) x m form
+  std::vector<double> store(s->chol_struct.store_doubles());
+  s->download(store.data(), s->d_M.p, store.size() * 8);
   s->sync();
+  std::vector<double> h((size_t)(m + 1) * m, 0.0);
+  const std::vector<int>& slot = s->chol_struct.tile_slot;
+  for (int tr = 0; tr <= nbt; ++tr)
+    for (int tc = 0; tc < nbt; ++tc) {
+      const int sl = slot[(size_t)tr * nbt + tc];
+      if (sl < 0) continue;
+      const double* T = &store[(size_t)sl << 12];
+      const int rows = tr < nbt ? 64 : 1;  // (tile row nbt: the right-hand side, first row)
+      for (int r = 0; r < rows; ++r) std::memcpy(&h[(size_t)(64 * tr + r) * m + 64 * tc], T + 64 * r, 64 * 8);
+    }
   std::vector<int> var_col(n, 0);
   for (int t = 0; t < m; ++t) if (s->h_col_var[t] >= 0) var_col[s->h_col_var[t]] = t;
   if (Sout)
@@ -571,6 +582,7 @@ int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
   out->cluster_partials = s->cluster_partials;
   out->cluster_flops = s->cluster_flops;
   out->chol_model_forward_us = cs.persist_ok ? cs.predicted_forward_us : 0.0;
+  out->reduced_store_bytes = (int64_t)(cs.store_doubles() * sizeof(double));
   const double n = (double)s->n_full;
   out->dense_factor_flops = n * n * n / 3.0 + 2.0 * n * n;
   return MAVBA_OK;
@@ -774,16 +786,21 @@ int mavba_dense_spd_solve(int32_t n, const double* A, const double* b, double* x
   (void)hipGetDevice(&st_dev);
   struct Release { hipStream_t st; int dev; ~Release() { (void)hipStreamSynchronize(st); release_staged(st); stream_release(st, dev); } } rel{st, st_dev};
   const int n_pad = std::max(64, round_up(n, 64));
-  std::vector<double> M((size_t)(n_pad + 64) * n_pad, 0.0);
-  for (int i = 0; i < n_pad; ++i) M[(size_t)i * n_pad + i] = 1.0;
-  for (int i = 0; i < n; ++i) std::memcpy(&M[(size_t)i * n_pad], &A[(size_t)i * n], (size_t)n * 8);
-  std::memcpy(&M[(size_t)n_pad * n_pad], b, (size_t)n * 8);
   int rc = MAVBA_OK;
   {
-    DevBuf<double> dM, dL, dy, dws, dfail;
-    dM.upload(M, st); dL.alloc(M.size()); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
     CholStructure cs;
     HIP_OK(cs.build_dense(n_pad / 64));
+    // the caller's dense matrix into the tile store of a dense structure (every lower tile + the right-hand-side row)
+    const int nbt = n_pad / 64;
+    std::vector<double> M(cs.store_doubles(), 0.0);
+    auto at = [&](int r, int c) -> double& { return M[((size_t)cs.tile_slot[(size_t)(r >> 6) * nbt + (c >> 6)] << 12) + (r & 63) * 64 + (c & 63)]; };
+    for (int i = 0; i < n_pad; ++i) at(i, i) = 1.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j)
+        if ((i >> 6) >= (j >> 6)) at(i, j) = A[(size_t)i * n + j];
+    for (int j = 0; j < n; ++j) at(n_pad, j) = b[j];
+    DevBuf<double> dM, dL, dy, dws, dfail;
+    dM.upload(M, st); dL.alloc(M.size()); dy.alloc(n_pad); dws.alloc((size_t)2 * n_pad * 64); dfail.alloc(1); dfail.zero(st);
     std::vector<double> y(n_pad);
     double fail = 0.0;
     for (int attempt = 0; attempt < 2; ++attempt) {

@@ -936,6 +936,8 @@ __device__ __forceinline__ void mfma_quadrant_nt(const double* As, const double*
   }
 }
 
+// Tile store (internal.h): tile (i, k) of the matrix / the factor = store + slot[i * nb + k] * 4096, row-major with pitch NB.
+__device__ __forceinline__ size_t tile_at(const int* __restrict__ slot, int nb, int i, int k) { return (size_t)slot[(size_t)i * nb + k] << 12; }
 // 64x64 tile, global (leading dimension ld) -> LDS (pitch GLD), 256 threads, 16 B accesses.
 __device__ __forceinline__ void load_tile(const double* __restrict__ G, size_t ld, double* S, int tid) {
 #pragma unroll
@@ -958,7 +960,7 @@ __device__ __forceinline__ void store_tile(double* __restrict__ G, size_t ld, co
 
 // Factor + invert the diagonal tiles listed in `tiles` (one work-group each): the first tile of every
 // front. Block 0 also clears the backward substitution's flags for this solve.
-__global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M, int ld, const int* __restrict__ tiles,
+__global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M, const int* __restrict__ slot, int nb, const int* __restrict__ tiles,
                                                     double* __restrict__ inv, double* __restrict__ fail,
                                                     unsigned* __restrict__ flags, int nflags) {
   __shared__ __attribute__((aligned(16))) double T[NB * GLD];
@@ -967,7 +969,7 @@ __global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M
   const int t = tiles[blockIdx.x];
   if (blockIdx.x == 0)
     for (int f = tid; f < nflags; f += 256) flags[f] = 0u;
-  load_tile(M + (size_t)t * NB * ld + (size_t)t * NB, ld, T, tid);
+  load_tile(M + tile_at(slot, nb, t, t), NB, T, tid);
   __syncthreads();
   const bool ok = tile_factor_inverse(T, Ti, tid);
   if (tid == 0 && !ok) atomicAdd(fail, 1.0);
@@ -976,7 +978,7 @@ __global__ void __launch_bounds__(256) k_chol_diag0(const double* __restrict__ M
 
 // Panel solve, front blockIdx.z: row block blockIdx.x of the front's active list (the last one is the
 // right-hand-side block):   A_ik <- A_ik L_kk^-T = A_ik (L_kk^-1)^T
-__global__ void __launch_bounds__(256) k_chol_trsm(const double* __restrict__ M, double* __restrict__ Lout, int ld,
+__global__ void __launch_bounds__(256) k_chol_trsm(const double* __restrict__ M, double* __restrict__ Lout, const int* __restrict__ slot, int nb,
                                                    const CholFront* __restrict__ fronts,
                                                    const double* __restrict__ inv, const int* __restrict__ rows,
                                                    int aug) {
@@ -987,9 +989,10 @@ __global__ void __launch_bounds__(256) k_chol_trsm(const double* __restrict__ M,
   const int tid = threadIdx.x;
   const int k = F.k;
   const int i = (int)blockIdx.x < F.na ? rows[F.act_off + blockIdx.x] : aug;  // active row block, or the right-hand side
-  const double* Ain = M + (size_t)i * NB * ld + (size_t)k * NB;
-  double* A = Lout + (size_t)i * NB * ld + (size_t)k * NB;
-  load_tile(Ain, ld, As, tid);
+  const size_t at = tile_at(slot, nb, i, k);
+  const double* Ain = M + at;
+  double* A = Lout + at;
+  load_tile(Ain, NB, As, tid);
   load_tile(inv + (size_t)k * NB * NB, NB, Bs, tid);
   __syncthreads();
   const int wv = tid >> 6, lane = tid & 63;
@@ -1004,7 +1007,7 @@ __global__ void __launch_bounds__(256) k_chol_trsm(const double* __restrict__ M,
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        A[(size_t)(wr + 16 * m + lk + 4 * r) * ld + wc + 16 * n + li] = acc[m][n][r];
+        A[(wr + 16 * m + lk + 4 * r) * NB + wc + 16 * n + li] = acc[m][n][r];
 }
 
 // store the wave's 2x2 MFMA tiles (D layout) of a 64x64 product into an LDS tile (pitch GLD)
@@ -1026,7 +1029,7 @@ __device__ __forceinline__ void quadrant_to_lds(double* S, int wr, int wc, int l
 // Column j == k+1 work-groups store P_i (the final L_ik, needed by the backward substitution);
 // the owner of tile (k+1, k+1) then factorises + inverts it for the next panel.
 template <bool FUSED>
-__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, double* __restrict__ Lout, int ld,
+__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, double* __restrict__ Lout, const int* __restrict__ slot, int nb,
                                                      const CholFront* __restrict__ fronts,
                                                      double* __restrict__ inv, double* __restrict__ fail,
                                                      const int* __restrict__ rows, int aug,
@@ -1047,8 +1050,8 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
   const int li = lane & 15, lk = lane >> 4;
   // the tile being updated (ancestor columns of a front with a shadow: that front's shadow block);
   // its loads are issued first so that their latency hides behind the products
-  double* C = M + (size_t)i * NB * ld + (size_t)j * NB;
-  size_t ldc = (size_t)ld;
+  double* C = M + tile_at(slot, nb, i, j);
+  size_t ldc = (size_t)NB;
   if (F.sh_off >= 0 && j >= F.sh_begin) {
     ldc = (size_t)(aug - F.sh_begin) * NB;
     C = shadow + F.sh_off + (size_t)(i - F.sh_begin) * NB * ldc + (size_t)(j - F.sh_begin) * NB;
@@ -1062,9 +1065,9 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
       for (int r = 0; r < 4; ++r) cin[m][n][r] = C[(size_t)(wr + 16 * m + lk + 4 * r) * ldc + wc + 16 * n + li];
   d4 acc[2][2];
   if constexpr (FUSED) {
-    load_tile(M + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
+    load_tile(M + tile_at(slot, nb, i, k), NB, As, tid);
     load_tile(inv + (size_t)k * NB * NB, NB, Bs, tid);
-    if (i != j) load_tile(M + (size_t)j * NB * ld + (size_t)k * NB, ld, Cs, tid);
+    if (i != j) load_tile(M + tile_at(slot, nb, j, k), NB, Cs, tid);
     __syncthreads();
     mfma_quadrant_nt(As, Bs, wr, wc, lane, acc);      // P_i
     d4 accj[2][2];
@@ -1075,11 +1078,11 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
     __syncthreads();
     // L_ik is final; it goes to the second matrix (the raw tile is still being read by the
     // other work-groups of this launch)
-    if (blockIdx.x == 0) store_tile(Lout + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
+    if (blockIdx.x == 0) store_tile(Lout + tile_at(slot, nb, i, k), NB, As, tid);
   } else {
     // panel tiles were already solved by k_chol_trsm into the second matrix
-    load_tile(Lout + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
-    if (i != j) load_tile(Lout + (size_t)j * NB * ld + (size_t)k * NB, ld, Cs, tid);
+    load_tile(Lout + tile_at(slot, nb, i, k), NB, As, tid);
+    if (i != j) load_tile(Lout + tile_at(slot, nb, j, k), NB, Cs, tid);
     __syncthreads();
   }
   const double* Pj = (i != j) ? Cs : As;
@@ -1112,15 +1115,17 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ M, dou
 
 // End of a tree level: M[i][j] += sum of the level's shadow blocks that cover tile (i, j) (i may be the
 // right-hand-side row). A shadow with origin o covers tiles i, j >= o. grid = (nb - begin, nb - begin + 1).
-__global__ void __launch_bounds__(256) k_chol_merge(double* __restrict__ M, int ld, const double* __restrict__ shadow,
+__global__ void __launch_bounds__(256) k_chol_merge(double* __restrict__ M, const int* __restrict__ slot, int nb, const double* __restrict__ shadow,
                                                     const CholMerge* __restrict__ merges, int num_merges, int begin,
                                                     int aug) {
   const int j = begin + blockIdx.x, i = begin + blockIdx.y;
   if (j > i) return;
-  double* C = M + (size_t)i * NB * ld + (size_t)j * NB;
+  const int sl = slot[(size_t)i * nb + j];
+  if (sl < 0) return;  // (outside the envelope: no shadow block writes there either)
+  double* C = M + ((size_t)sl << 12);
   for (int e = threadIdx.x; e < NB * NB / 2; e += 256) {
     const int row = e >> 5, c2 = (e & 31) * 2;
-    double2 v = *reinterpret_cast<const double2*>(C + (size_t)row * ld + c2);
+    double2 v = *reinterpret_cast<const double2*>(C + row * NB + c2);
     for (int q = 0; q < num_merges; ++q) {
       const int o = merges[q].sh_begin;
       if (j < o) continue;  // (i >= j >= o)
@@ -1129,20 +1134,20 @@ __global__ void __launch_bounds__(256) k_chol_merge(double* __restrict__ M, int 
       const double2 w = *reinterpret_cast<const double2*>(Sh + (size_t)row * lds + c2);
       v.x += w.x; v.y += w.y;
     }
-    *reinterpret_cast<double2*>(C + (size_t)row * ld + c2) = v;
+    *reinterpret_cast<double2*>(C + row * NB + c2) = v;
   }
 }
 
 // Backward substitution, tile k (fallback for very many tile rows, single segment only):
 // y_k = L_kk^-T z_k; then z_j -= L_kj^T y_k for j < k.
 // grid = k + 1: block k stores y_k, block j < k updates z_j (disjoint segments).
-__global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict__ M, int ld, int k, int first,
+__global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict__ M, const int* __restrict__ slot, int nb, int k, int first,
                                                        const double* __restrict__ inv,
                                                        double* __restrict__ z, double* __restrict__ y) {
   __shared__ double zk[NB];
   __shared__ double yk[NB];
   const int lane = threadIdx.x;
-  zk[lane] = z[k * NB + lane];
+  zk[lane] = z[tile_at(slot, nb, nb, k) + lane];  // (z = the factor's store: the forward-substituted right-hand side is the first row of tile (nb, k))
   __syncthreads();
   const double* Li = inv + (size_t)k * NB * NB;  // L_kk^-1, lower, compact 64x64
   double acc0 = 0.0, acc1 = 0.0;
@@ -1156,14 +1161,16 @@ __global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict_
   if (j == k) { y[k * NB + lane] = mine; return; }
   yk[lane] = mine;
   __syncthreads();
-  const double* L = M + (size_t)k * NB * ld + (size_t)j * NB;
+  const int sl = slot[(size_t)k * nb + j];
+  if (sl < 0) return;  // (inside [first, k) but outside the envelope: structurally zero)
+  const double* L = M + ((size_t)sl << 12);
   double a0 = 0.0, a1 = 0.0;
 #pragma unroll 8
   for (int m = 0; m < NB; m += 2) {
-    a0 += L[(size_t)m * ld + lane] * yk[m];
-    a1 += L[(size_t)(m + 1) * ld + lane] * yk[m + 1];
+    a0 += L[m * NB + lane] * yk[m];
+    a1 += L[(m + 1) * NB + lane] * yk[m + 1];
   }
-  z[j * NB + lane] -= a0 + a1;
+  z[tile_at(slot, nb, nb, j) + lane] -= a0 + a1;
 }
 __global__ void k_scatter_y(int n, const int* __restrict__ scatter, const double* __restrict__ y, double* __restrict__ y_nat) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1177,11 +1184,11 @@ __global__ void k_scatter_y(int n, const int* __restrict__ scatter, const double
 // are fetched BEFORE the wait, so a step of the chain is {flag + 64 values of x, 16 FMAs, two LDS
 // reductions}, not a kernel launch. Tile (i, k) takes part iff k is inside row i's envelope for k's
 // segment - uncoupled parts of a nested-dissection ordering therefore never wait for each other.
-__global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __restrict__ L, int ld, int nb, int nseg,
+__global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __restrict__ L, const int* __restrict__ slot, int nb, int nseg,
                                                             const int* __restrict__ seg_of_tile,
                                                             const int* __restrict__ seg_first,
                                                             const double* __restrict__ inv,
-                                                            const double* __restrict__ z, double* y,
+                                                            double* y,
                                                             unsigned* flags, unsigned epoch, const int* __restrict__ scatter,
                                                             double* __restrict__ y_nat) {
   __shared__ double part[4][NB];
@@ -1192,7 +1199,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
   // dispatch order.
   for (int k = nb - 1 - (int)blockIdx.x; k >= 0; k -= (int)gridDim.x) {
   const int sk = seg_of_tile[k];
-  double acc = (wv == 0) ? z[(size_t)k * NB + lane] : 0.0;
+  double acc = (wv == 0) ? L[tile_at(slot, nb, nb, k) + lane] : 0.0;  // (right-hand side: first row of tile (nb, k))
   // this wave's 16 rows of L_kk^-1 (lower, compact 64 x 64)
   double li[16];
 #pragma unroll
@@ -1201,18 +1208,18 @@ __global__ void __launch_bounds__(256) k_chol_backsolve_all(const double* __rest
   while (i > k && seg_first[i * nseg + sk] > k) --i;  // tiles outside the envelope are structurally zero
   double l[16];
   if (i > k) {
-    const double* Lt = L + (size_t)i * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
+    const double* Lt = L + tile_at(slot, nb, i, k) + (16 * wv) * NB + lane;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) l[q] = Lt[(size_t)q * ld];
+    for (int q = 0; q < 16; ++q) l[q] = Lt[q * NB];
   }
   while (i > k) {
     int nx = i - 1;
     while (nx > k && seg_first[nx * nseg + sk] > k) --nx;
     double ln[16];
     if (nx > k) {
-      const double* Lt = L + (size_t)nx * NB * ld + (size_t)k * NB + (size_t)(16 * wv) * ld + lane;
+      const double* Lt = L + tile_at(slot, nb, nx, k) + (16 * wv) * NB + lane;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) ln[q] = Lt[(size_t)q * ld];
+      for (int q = 0; q < 16; ++q) ln[q] = Lt[q * NB];
     }
     // hand-off: the owner wrote x_i with system-scope (write-through) stores, drained them and raised the flag; the
     // poll is relaxed and the values are read with system-scope loads - no fences (an agent-scope release / acquire
@@ -1505,8 +1512,8 @@ __device__ __forceinline__ void quadrant_sub(d4 acc[2][2], const d4 p[2][2]) {
 }  // namespace
 
 struct CholPersistArgs {
-  const double* M; double* L; double* inv; double* pre;
-  int ld, nb;
+  const double* M; double* L; double* inv; double* pre;  // M, L: tile stores (slot = tile_id)
+  int nb;
   const CholTask* tasks; const int* wg_begin; const int* upd; const int* tile_id; const int* chain_info;
   unsigned* lflag; unsigned* dflag; unsigned* pflag; unsigned* abort_flag;
   unsigned epoch;
@@ -1527,7 +1534,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
   const int nb = A.nb;
   if (tid < 4) s_rows[tid] = 0;
   __syncthreads();
-  const size_t ld = (size_t)A.ld;
+  constexpr size_t ld = NB;  // (pitch inside a tile of the store)
   const unsigned ep = A.epoch;
   // waits: lane 0 polls, everyone learns the outcome behind a barrier (which also orders the LDS reuse)
   auto wait2 = [&](const unsigned* f0, const unsigned* f1) -> bool {
@@ -1556,7 +1563,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       const int i = T.i, j = T.j;
       d4 acc[2][2], p[2][2];
       {
-        const double* C = A.M + (size_t)i * NB * ld + (size_t)j * NB;  // written before this launch: plain loads
+        const double* C = A.M + ((size_t)A.tile_id[(size_t)i * nb + j] << 12);  // written before this launch: plain loads
         const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1572,11 +1579,12 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       // it lost at C5 too. C5's helpers are bound by the 4.7 GB of system-scope tile reads, not by their latency.)
       for (int u = T.ub; u < T.ue; ++u) {
         const int k = A.upd[u];
-        const unsigned* f0 = A.lflag + A.tile_id[(size_t)i * nb + k];
-        const unsigned* f1 = i != j ? A.lflag + A.tile_id[(size_t)j * nb + k] : nullptr;
+        const int s_ik = A.tile_id[(size_t)i * nb + k], s_jk = i != j ? A.tile_id[(size_t)j * nb + k] : 0;  // flag index = slot
+        const unsigned* f0 = A.lflag + s_ik;
+        const unsigned* f1 = i != j ? A.lflag + s_jk : nullptr;
         if (!wait2(f0, f1)) { alive = false; break; }
-        load_tile_coh(A.L + (size_t)i * NB * ld + (size_t)k * NB, ld, As, tid);
-        if (i != j) load_tile_coh(A.L + (size_t)j * NB * ld + (size_t)k * NB, ld, Bs, tid);
+        load_tile_coh(A.L + ((size_t)s_ik << 12), ld, As, tid);
+        if (i != j) load_tile_coh(A.L + ((size_t)s_jk << 12), ld, Bs, tid);
         __syncthreads();
         mfma_quadrant_nt(As, i != j ? Bs : As, wr, wc, lane, p);
         quadrant_sub(acc, p);
@@ -1592,10 +1600,11 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         __syncthreads();
         trsm_lower_tri(As, Bs, Cs, wv, lane);
         __syncthreads();
-        store_tile_coh(A.L + (size_t)i * NB * ld + (size_t)j * NB, ld, Cs, tid);
+        const int s_ij = A.tile_id[(size_t)i * nb + j];
+        store_tile_coh(A.L + ((size_t)s_ij << 12), ld, Cs, tid);
         drain_stores();
         __syncthreads();
-        if (tid == 0) publish(A.lflag + A.tile_id[(size_t)i * nb + j], ep);
+        if (tid == 0) publish(A.lflag + s_ij, ep);
         stamp(tslot + 3);
       } else {
         // PRE: the chain's tile with every update but the chain's own; slot 2 j (diagonal) / 2 j + 1 (sub-diagonal)
@@ -1618,9 +1627,13 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
     // travel while the matrix cores factorise; otherwise the chain waits for them afterwards.
     TileRegs Rsub, Rdiag;
     bool have_next = false;  // Rsub / Rdiag hold column j's tiles
-    for (int j = T.i; j < T.j; ++j) {
+    // slots (tile store) of the column's diagonal and sub-diagonal tile: looked up a column ahead, so that the dependent
+    // scalar load is long done when the chain needs the address (tile store, round 6: + 0.4 us per column without this)
+    int s_diag = A.tile_id[(size_t)T.i * nb + T.i], s_sub = 0, s_ndiag = 0, s_nsub = 0;
+    for (int j = T.i; j < T.j; ++j, s_diag = s_ndiag, s_sub = s_nsub) {
       const int info = A.chain_info[j];
       const bool sub = j > T.i;
+      if (j + 1 < T.j) { s_ndiag = A.tile_id[(size_t)(j + 1) * nb + (j + 1)]; s_nsub = A.tile_id[(size_t)(j + 1) * nb + j]; }
       stamp((size_t)8 * j);
       if (!have_next) {
         const unsigned* f0 = (sub && (info & 2)) ? A.pflag + 2 * j + 1 : nullptr;
@@ -1628,10 +1641,10 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         if ((f0 || f1) && !wait2(f0, f1)) { alive = false; break; }
         if (sub) {
           if (info & 2) load_tile_regs(A.pre + (size_t)(2 * j + 1) * NB * NB, NB, Rsub, tid, true);
-          else load_tile_regs(A.M + (size_t)j * NB * ld + (size_t)(j - 1) * NB, ld, Rsub, tid, false);
+          else load_tile_regs(A.M + ((size_t)s_sub << 12), ld, Rsub, tid, false);
         }
         if (info & 1) load_tile_regs(A.pre + (size_t)(2 * j) * NB * NB, NB, Rdiag, tid, true);
-        else load_tile_regs(A.M + (size_t)j * NB * ld + (size_t)j * NB, ld, Rdiag, tid, false);
+        else load_tile_regs(A.M + ((size_t)s_diag << 12), ld, Rdiag, tid, false);
       }
       have_next = false;
       stamp((size_t)8 * j + 1);
@@ -1676,7 +1689,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
         tile_regs_to_lds(Rsub, As, tid);
         tile_regs_to_lds(Rdiag, Ds, tid);
         __syncthreads();
-        double* Pg = A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB;
+        double* Pg = A.L + ((size_t)s_sub << 12);
         // rows 0..31 of P now, 20 matrix instructions per wave: blocks (0,0)+(1,3) | (0,1)+(1,2) | (0,2)+(1,1) | (0,3)+(1,0)
         d4 p0, p1;
         switch (wv) {
@@ -1707,9 +1720,9 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
       auto request_next = [&]() {
         const int ni = A.chain_info[j + 1];
         if (ni & 2) load_tile_regs(A.pre + (size_t)(2 * (j + 1) + 1) * NB * NB, NB, Rsub, tid, true);
-        else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)j * NB, ld, Rsub, tid, false);
+        else load_tile_regs(A.M + ((size_t)s_nsub << 12), ld, Rsub, tid, false);
         if (ni & 1) load_tile_regs(A.pre + (size_t)(2 * (j + 1)) * NB * NB, NB, Rdiag, tid, true);
-        else load_tile_regs(A.M + (size_t)(j + 1) * NB * ld + (size_t)(j + 1) * NB, ld, Rdiag, tid, false);
+        else load_tile_regs(A.M + ((size_t)s_ndiag << 12), ld, Rdiag, tid, false);
         have_next = true;
       };
       // hook(ph): every thread, right after the barrier that ends phase ph of the factorisation
@@ -1724,7 +1737,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
           if (sub) drain_stores();
           if (more && tid == 192) s_ok = next_ready();
         } else if (ph == 1) {
-          if (sub && tid == 0) publish(A.lflag + A.tile_id[(size_t)j * nb + (j - 1)], ep);
+          if (sub && tid == 0) publish(A.lflag + s_sub, ep);
           if (more && s_ok) request_next();
         } else if (ph == 2) {
           if (more && !have_next && tid == 192) s_ok2 = next_ready();
@@ -1745,7 +1758,7 @@ __global__ void __launch_bounds__(256) k_chol_persist(CholPersistArgs A) {
             syrk16_own(Ds, Cs, 1, lane);  // (1, 0), (1, 1): rows 0..31 of P are complete
             if (lane == 0) lds_flag_set(&s_rows[1], seq);  // (this wave does not read Bs in phase 0)
           } else {
-            double* Pg = A.L + (size_t)j * NB * ld + (size_t)(j - 1) * NB;
+            double* Pg = A.L + ((size_t)s_sub << 12);
             d4 c[4];
             trsm_row16(As, Bs, wv, lane, c);
 #pragma unroll
@@ -1809,8 +1822,8 @@ void CholStructure::release() {
   if (d_pints) device_free(d_pints);
   if (d_pflags) device_free(d_pflags);
   if (d_pre) device_free(d_pre);
-  if (d_env_tiles) device_free(d_env_tiles);
-  d_env_tiles = nullptr; num_env_tiles = 0;
+  if (d_tile_slot) device_free(d_tile_slot);
+  d_tile_slot = nullptr;
   d_ints = nullptr; d_fronts = nullptr; d_shadow = nullptr; d_merges = nullptr;
   d_tasks = nullptr; d_pints = nullptr; d_pflags = nullptr; d_pre = nullptr;
   persist_ok = false;
@@ -1965,6 +1978,41 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
     steps.push_back(Mg);
   }
 
+  // rows that couple to every column, schedule step of every column
+  std::vector<std::vector<int>> col_rows(nb);
+  std::vector<int> col_step(nb, 0);
+  {
+    int ordinal = 0;
+    for (const CholStep& S : steps) {
+      if (S.kind != 0) continue;
+      for (int f = S.front_off; f < S.front_off + S.nf + S.nf0; ++f) {
+        const CholFront& F = fronts[f];
+        col_rows[F.k].assign(rows.begin() + F.act_off, rows.begin() + F.act_off + F.na);
+        col_step[F.k] = ordinal;
+      }
+      ++ordinal;
+    }
+  }
+  // Tile store (round 6): the matrix and the factor keep the envelope's tiles only - per column the diagonal tile, the coupled
+  // rows, the right-hand-side tile (tile row nb). The slot is also the tile's flag index in the persistent launch.
+  tile_slot.assign((size_t)(nb + 1) * nb, -1);
+  num_tiles = 0;
+  for (int k = 0; k < nb; ++k) {
+    tile_slot[(size_t)k * nb + k] = (int)num_tiles++;
+    for (int i : col_rows[k]) tile_slot[(size_t)i * nb + k] = (int)num_tiles++;
+    tile_slot[(size_t)nb * nb + k] = (int)num_tiles++;
+  }
+  // (the launch-per-panel schedule updates tile (i, j) for every pair of a front's rows: all of them must be in the store)
+  for (const CholFront& F : fronts)
+    for (int a = 0; a < F.na; ++a)
+      for (int b2 = 0; b2 <= a; ++b2) {
+        const int i = rows[(size_t)F.act_off + a], j = rows[(size_t)F.act_off + b2];
+        if (tile_slot[(size_t)std::max(i, j) * nb + std::min(i, j)] < 0) {
+          std::fprintf(stderr, "mavba: factorisation envelope is not closed under its own updates (tile %d, %d of front %d)\n", i, j, F.k);
+          release();
+          return hipErrorInvalidValue;
+        }
+      }
   // device copies: rows | seg_of_tile | seg_first | init_tiles | flags
   std::vector<int> pack(rows);
   const size_t o_seg = pack.size();
@@ -1987,16 +2035,8 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
     e = copy_h2d_staged(d_merges, merges.data(), merges.size() * sizeof(CholMerge), st);
   if (e == hipSuccess && shadow_doubles)
     e = device_alloc(reinterpret_cast<void**>(&d_shadow), shadow_doubles * sizeof(double));
-  // the tiles the in-place (launch-per-panel) factorisation writes: tile (k, k) of every front and its active rows below.
-  // Between two solves only these need clearing - not the whole dense array (C5: 5 041 of 18 145 tiles, 1.18 GB per memset)
-  std::vector<int2> env;
-  for (const CholFront& F : fronts) {
-    env.push_back(make_int2(F.k, F.k));
-    for (int j = 0; j < F.na; ++j) env.push_back(make_int2(rows[(size_t)F.act_off + j], F.k));
-  }
-  num_env_tiles = (int)env.size();
-  if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_env_tiles), std::max<size_t>(env.size(), 1) * sizeof(int2));
-  if (e == hipSuccess && !env.empty()) e = copy_h2d_staged(d_env_tiles, env.data(), env.size() * sizeof(int2), st);
+  if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_tile_slot), tile_slot.size() * sizeof(int));
+  if (e == hipSuccess) e = copy_h2d_staged(d_tile_slot, tile_slot.data(), tile_slot.size() * sizeof(int), st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging vectors go out of scope
   release_staged(st);
   if (e != hipSuccess) { release(); return e; }
@@ -2006,19 +2046,7 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   d_init = d_ints + o_init;
   d_flags = reinterpret_cast<unsigned*>(d_ints + o_flags);
   }  // (!host_only)
-  // persistent schedule: rows that couple to every column, schedule step of every column
-  std::vector<std::vector<int>> col_rows(nb);
-  std::vector<int> col_step(nb, 0);
-  int ordinal = 0;
-  for (const CholStep& S : steps) {
-    if (S.kind != 0) continue;
-    for (int f = S.front_off; f < S.front_off + S.nf + S.nf0; ++f) {
-      const CholFront& F = fronts[f];
-      col_rows[F.k].assign(rows.begin() + F.act_off, rows.begin() + F.act_off + F.na);
-      col_step[F.k] = ordinal;
-    }
-    ++ordinal;
-  }
+  // persistent schedule
   e = build_persistent(col_rows, col_step, height, st);
   if (e != hipSuccess) { release(); return e; }
   return hipSuccess;
@@ -2059,13 +2087,9 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   int G = host_only ? host_only_cus : device_cu_count();
   if (grid_cap > 0) G = std::min(G, grid_cap);
   // ---- tiles with a 'published' flag: diagonal, coupled rows, right-hand-side row of every column ----
-  std::vector<int> tile_id((size_t)(nb + 1) * nb, -1);
-  long long nt = 0;
-  for (int k = 0; k < nb; ++k) {
-    tile_id[(size_t)k * nb + k] = (int)nt++;
-    for (int i : col_rows[k]) tile_id[(size_t)i * nb + k] = (int)nt++;
-    tile_id[(size_t)nb * nb + k] = (int)nt++;
-  }
+  // (= the slots of the tile store, CholStructure::build: a tile's flag and its place in memory share one index)
+  const std::vector<int>& tile_id = tile_slot;
+  const long long nt = num_tiles;
   // ---- the updates every tile receives, in a fixed order: by availability (schedule step of k), then k ----
   std::vector<std::vector<int>> upd_of((size_t)nt);
   std::vector<int> R;
@@ -2531,8 +2555,13 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
 // the inverted diagonal tiles). M is only read.
 // UPD (round 4): the work-group goes on to the camera update of the LM step (k_update_cameras' work: it reads the solution
 // this work-group has just written) - one launch less on the 75 us iteration of a local window.
+struct SmallSlots { int s00, s10, s11, r0, r1; };  // tiles (0,0), (1,0), (1,1) and the right-hand side's two tiles; < 0: not in the store (zero)
+__device__ __forceinline__ void load_tile_or_zero(const double* __restrict__ M, int slot, double* S, int tid) {
+  if (slot >= 0) { load_tile(M + ((size_t)slot << 12), NB, S, tid); return; }
+  for (int e = tid; e < NB * NB; e += 256) S[(e >> 6) * GLD + (e & 63)] = 0.0;
+}
 template <bool UPD>
-__global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M, int ld, int nb_all, int nb,
+__global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M, SmallSlots sl, int nb_all, int nb,
                                                     double* __restrict__ fail, double* __restrict__ y,
                                                     const int* __restrict__ scatter, double* y_nat, CamUpdateArgs U) {
   // nb (1 or 2): the leading tile columns that hold free parameters; columns beyond them (up to nb_all tiles) are unit
@@ -2544,9 +2573,9 @@ __global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M
   __shared__ double vv[2 * NB], zz[2 * NB], xx[2 * NB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
-  load_tile(M, ld, W, tid);
-  if (nb > 1) load_tile(M + (size_t)NB * ld, ld, P, tid);
-  if (tid < nb * NB) vv[tid] = M[(size_t)nb_all * NB * ld + tid];
+  load_tile_or_zero(M, sl.s00, W, tid);
+  if (nb > 1) load_tile_or_zero(M, sl.s10, P, tid);
+  if (tid < nb * NB) { const int rs = tid < NB ? sl.r0 : sl.r1; vv[tid] = rs >= 0 ? M[((size_t)rs << 12) + (tid & 63)] : 0.0; }
   __syncthreads();
   bool ok = tile_factor_inverse(W, I0, tid);
   __syncthreads();
@@ -2570,7 +2599,7 @@ __global__ void __launch_bounds__(256) k_chol_small(const double* __restrict__ M
   if (nb > 1) {
     d4 acc[2][2];
     mfma_quadrant_nt(P, I0, wr, wc, lane, acc);  // L10 = A10 (L00^-1)^T
-    load_tile(M + (size_t)NB * ld + NB, ld, W, tid);  // A11 (W's L00 is not needed any more)
+    load_tile_or_zero(M, sl.s11, W, tid);  // A11 (W's L00 is not needed any more)
     __syncthreads();
     quadrant_to_lds(P, wr, wc, lane, acc);
     __syncthreads();
@@ -2637,22 +2666,25 @@ bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
                             double* diag_ws, double* L, const CholStructure& cs,
                             const int* y_scatter, double* y_nat, bool allow_persistent, hipEvent_t after_factor,
                             const CamUpdateArgs* upd) {
-  const int nb = n_pad / NB, ld = n_pad;
+  const int nb = n_pad / NB;
+  const int* slot = cs.d_tile_slot;
   double* inv = diag_ws;
   const int nb_active = cs.active_tiles > 0 ? std::min(cs.active_tiles, nb) : nb;
   if (dense_spd_solve_is_small(n_pad, cs)) {
     const bool with_update = upd != nullptr && y_scatter != nullptr && y_nat != nullptr;
+    auto hs = [&](int i, int k) { return i <= nb && k < nb ? cs.tile_slot[(size_t)i * nb + k] : -1; };
+    const SmallSlots sl{hs(0, 0), nb > 1 ? hs(1, 0) : -1, nb > 1 ? hs(1, 1) : -1, hs(nb, 0), nb > 1 ? hs(nb, 1) : -1};
     if (with_update)
-      hipLaunchKernelGGL(k_chol_small<true>, dim3(1), dim3(256), 0, st, M, ld, nb, nb_active, fail, y, y_scatter, y_nat, *upd);
+      hipLaunchKernelGGL(k_chol_small<true>, dim3(1), dim3(256), 0, st, M, sl, nb, nb_active, fail, y, y_scatter, y_nat, *upd);
     else
-      hipLaunchKernelGGL(k_chol_small<false>, dim3(1), dim3(256), 0, st, M, ld, nb, nb_active, fail, y, y_scatter, y_nat, CamUpdateArgs{});
+      hipLaunchKernelGGL(k_chol_small<false>, dim3(1), dim3(256), 0, st, M, sl, nb, nb_active, fail, y, y_scatter, y_nat, CamUpdateArgs{});
     if (after_factor) (void)hipEventRecord(after_factor, st);  // (one launch does both halves)
     return with_update;
   }
   const unsigned epoch = ++cs.epoch;  // flags of this solve (forward hand-offs and backward substitution)
   if (allow_persistent && cs.persist_ok) {
     CholPersistArgs A;
-    A.M = M; A.L = L; A.inv = inv; A.pre = cs.d_pre; A.ld = ld; A.nb = nb;
+    A.M = M; A.L = L; A.inv = inv; A.pre = cs.d_pre; A.nb = nb;
     A.tasks = cs.d_tasks; A.wg_begin = cs.d_wg_begin; A.upd = cs.d_upd; A.tile_id = cs.d_tile_id; A.chain_info = cs.d_chain_info;
     A.lflag = cs.d_pflags; A.dflag = cs.d_pflags + cs.persist_tiles; A.pflag = A.dflag + nb; A.abort_flag = A.pflag + 2 * nb;
     A.epoch = epoch; A.fail = fail; A.trace = cs.d_trace;
@@ -2692,42 +2724,41 @@ bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
   if (cs.shadow_doubles) (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);
   static const int fuse_below = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE"); return e ? std::atoi(e) : kFuseBelow; }();  // tuning knobs
   static const int fuse_tasks = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE_TASKS"); return e ? std::atoi(e) : kFuseTasks; }();
-  hipLaunchKernelGGL(k_chol_diag0, dim3(cs.num_leaf_init), dim3(256), 0, st, M, ld, cs.d_init, inv, fail, cs.d_flags, nb);
+  hipLaunchKernelGGL(k_chol_diag0, dim3(cs.num_leaf_init), dim3(256), 0, st, M, slot, nb, cs.d_init, inv, fail, cs.d_flags, nb);
   for (const CholStep& S : cs.steps) {
     if (S.kind == 1) {
       const int nt = nb - S.merge_begin;
       if (S.nf > 0)
-        hipLaunchKernelGGL(k_chol_merge, dim3(nt, nt + 1), dim3(256), 0, st, M, ld, cs.d_shadow, cs.d_merges + S.front_off, S.nf,
+        hipLaunchKernelGGL(k_chol_merge, dim3(nt, nt + 1), dim3(256), 0, st, M, slot, nb, cs.d_shadow, cs.d_merges + S.front_off, S.nf,
                            S.merge_begin, nb);
-      hipLaunchKernelGGL(k_chol_diag0, dim3(S.nf0), dim3(256), 0, st, M, ld, cs.d_init + S.init_off, inv, fail, cs.d_flags, 0);
+      hipLaunchKernelGGL(k_chol_diag0, dim3(S.nf0), dim3(256), 0, st, M, slot, nb, cs.d_init + S.init_off, inv, fail, cs.d_flags, 0);
       continue;
     }
     const CholFront* F = cs.d_fronts + S.front_off;
     if (S.max_na > fuse_below || S.tasks > fuse_tasks) {
       // much trailing work (more tile updates than one round of the CUs absorbs): one panel solve, then a lean
       // update (one product per work-group, 2 work-groups per CU)
-      hipLaunchKernelGGL(k_chol_trsm, dim3(S.max_na + 1, 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, cs.d_rows, nb);
-      hipLaunchKernelGGL((k_chol_update<false>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, fail,
+      hipLaunchKernelGGL(k_chol_trsm, dim3(S.max_na + 1, 1, S.nf), dim3(256), 0, st, M, L, slot, nb, F, inv, cs.d_rows, nb);
+      hipLaunchKernelGGL((k_chol_update<false>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, slot, nb, F, inv, fail,
                          cs.d_rows, nb, cs.d_shadow);
     } else if (S.max_na > 0) {
       // small trailing matrix: latency matters, fold the panel solve into the update launch
-      hipLaunchKernelGGL((k_chol_update<true>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, ld, F, inv, fail,
+      hipLaunchKernelGGL((k_chol_update<true>), dim3(S.max_na, S.max_na + 1, S.nf), dim3(256), 0, st, M, L, slot, nb, F, inv, fail,
                          cs.d_rows, nb, cs.d_shadow);
     }
     if (S.nf0)  // fronts with nothing below their tile: only the right-hand-side block is left
-      hipLaunchKernelGGL(k_chol_trsm, dim3(1, 1, S.nf0), dim3(256), 0, st, M, L, ld, F + S.nf, inv, cs.d_rows, nb);
+      hipLaunchKernelGGL(k_chol_trsm, dim3(1, 1, S.nf0), dim3(256), 0, st, M, L, slot, nb, F + S.nf, inv, cs.d_rows, nb);
   }
   }
   if (after_factor) (void)hipEventRecord(after_factor, st);
-  double* z = L + (size_t)n_pad * ld;
   if (nb <= kMaxBacksolveGroups) {
     const int cus = device_cu_count();
-    hipLaunchKernelGGL(k_chol_backsolve_all, dim3(std::min(nb, cus > 0 ? 2 * cus : 64)), dim3(256), 0, st, L, ld, nb, cs.nseg, cs.d_seg_of_tile, cs.d_seg_first,
-                       inv, z, y, cs.d_flags, epoch, y_scatter, y_nat);
+    hipLaunchKernelGGL(k_chol_backsolve_all, dim3(std::min(nb, cus > 0 ? 2 * cus : 64)), dim3(256), 0, st, L, slot, nb, cs.nseg, cs.d_seg_of_tile, cs.d_seg_first,
+                       inv, y, cs.d_flags, epoch, y_scatter, y_nat);
   } else {
     // more tile rows than work-groups that are certainly resident: one small launch per tile (single segment)
     for (int k = nb - 1; k >= 0; --k)
-      hipLaunchKernelGGL(k_chol_backsolve, dim3(k - cs.seg_first[k] + 1), dim3(64), 0, st, L, ld, k, cs.seg_first[k], inv, z, y);
+      hipLaunchKernelGGL(k_chol_backsolve, dim3(k - cs.seg_first[k] + 1), dim3(64), 0, st, L, slot, nb, k, cs.seg_first[k], inv, L, y);
     if (y_scatter) hipLaunchKernelGGL(k_scatter_y, dim3((n_pad + 255) / 256), dim3(256), 0, st, n_pad, y_scatter, y, y_nat);
   }
   return false;

@@ -296,15 +296,18 @@ void launch_schur_clusters(hipStream_t st, ClusterShape shape, int num_clusters,
 // (the matrix is assembled in the factorisation's elimination order, the vectors keep the variables' order).
 void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blocks,
                            const double* part_pp, const double* part_ip, const double* part_ii,
-                           int NI, int NC, int ld, bool add_base, double radius, double dmin,
+                           int NI, int NC, const int* slot, int nb, bool add_base, double radius, double dmin,
                            double dmax, const int* img_cam, const double* img_rec,
                            const double* cam_rec, const double* scale_cam, const int* off_img, const int* off_cam,
-                           double* S, double* v);
-void launch_tiles_copy(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, double* buf, bool to_buf);
-// zeroes the listed 64x64 tiles of M and the `tail_rows` rows below row ld (the right-hand-side block)
-void launch_tiles_zero(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, int tail_rows);
+                           double* S);
+// Tile store of the reduced system (round 6): the matrix and its factor are kept as the 64 x 64 tiles of the factorisation's
+// ENVELOPE only - tile (i, k), k <= i, lives at store + slot[i * nb + k] * 4096 (row-major, pitch 64), slot < 0 = outside the
+// envelope (structurally zero, never touched); tile row nb holds the right-hand side in the first row of its tiles.
+// CholStructure::tile_slot / d_tile_slot is the table (dense_chol.hip), shared by the assembly, the exchange and the solve.
+// pack: tiles[t] (a slot) -> buf[t * 4096 ...] and the right-hand side -> buf[num_tiles * 4096 + c]; unpack: the reverse.
+void launch_tiles_copy(hipStream_t st, int num_tiles, const int* tiles, const int* slot, int nb, double* M, double* buf, bool to_buf);
 // col_var[t]: variable (index into scale_cam) held by matrix column t, -1 for padding columns.
-void launch_fix_diag(hipStream_t st, int n_mat, int ld, bool add_one, const int* col_var,
+void launch_fix_diag(hipStream_t st, int n_mat, const int* slot, bool add_one, const int* col_var,
                      const double* scale_cam, double* S);
 
 int backsub_points_grid(int NP);
@@ -442,8 +445,13 @@ struct CholStructure {
   CholFront* d_fronts = nullptr;
   CholMerge* d_merges = nullptr;
   double* d_shadow = nullptr;
-  int2* d_env_tiles = nullptr;    // (row tile, column tile) of every tile inside the envelope: what the in-place factorisation overwrites
-  int num_env_tiles = 0;
+  // Tile store (round 6): slot of tile (i, k) = tile_slot[i * nb + k], i in [0, nb] (row nb: the right-hand side), -1 outside the
+  // envelope; per column k: the diagonal tile, the coupled rows ascending, the right-hand-side tile. Also the index of the
+  // tile's 'published' flag in the persistent launch.
+  std::vector<int> tile_slot;
+  int* d_tile_slot = nullptr;
+  long long num_tiles = 0;
+  size_t store_doubles() const { return (size_t)std::max<long long>(num_tiles, 1) * 4096; }
   // persistent schedule
   int active_tiles = 0;  // leading tile columns that hold a free parameter (0: all); the rest is identity with a zero right-hand side
   bool persist_ok = false;        // a schedule exists (structure consistent, fits the resident grid)
@@ -491,6 +499,7 @@ struct CamUpdateArgs {
   double* cand_poses; double* cand_intr; double* delta_cam; double* partial3; double* cand_camrec;
 };
 bool dense_spd_solve_is_small(int n_pad, const CholStructure& cs);  // the one-work-group path will be taken
+// M, L: tile stores of cs (cs.store_doubles() doubles each).
 bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, double* fail,
                             double* diag_ws, double* L, const CholStructure& cs,
                             const int* y_scatter = nullptr, double* y_nat = nullptr, bool allow_persistent = true,

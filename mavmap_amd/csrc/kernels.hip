@@ -1814,11 +1814,11 @@ void launch_partial_reduce(hipStream_t st, int num_tasks, const PartialReduce* t
 // base (only when add_base, i.e. on one rank): scaled F^T F + D^2 from the camera sums.
 __global__ void __launch_bounds__(256) k_schur_finalize(
     int num_blocks, const SchurBlock* __restrict__ blocks, const double* __restrict__ part_pp,
-    const double* __restrict__ part_ip, const double* __restrict__ part_ii, int NI, int NC, int ld,
+    const double* __restrict__ part_ip, const double* __restrict__ part_ii, int NI, int NC, const int* __restrict__ slot, int nb,
     int add_base, double radius, double dmin, double dmax, const int* __restrict__ img_cam,
     const double* __restrict__ img_rec, const double* __restrict__ cam_rec,
     const double* __restrict__ scale_cam, const int* __restrict__ off_img, const int* __restrict__ off_cam,
-    double* __restrict__ S, double* __restrict__ v) {
+    double* __restrict__ S) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bid = blockIdx.x * 4 + wv;
   if (bid >= num_blocks) return;
@@ -1859,8 +1859,10 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
       // (what k_fix_diag does for the columns no block covers)
       if (is_diag && r == c && scale_cam[gr] == 0.0) val = add_base ? 1.0 : 0.0;
       if (!is_diag || r >= c) {
-        S[(size_t)(prow0 + r) * ld + pcol0 + c] = val;
-        S[(size_t)(pcol0 + c) * ld + prow0 + r] = val;
+        // (tile store: only the lower tiles exist; an element of a diagonal tile is written on both sides of the diagonal)
+        const int R = prow0 + r, C = pcol0 + c;
+        if ((R >> 6) >= (C >> 6)) S[((size_t)slot[(R >> 6) * nb + (C >> 6)] << 12) + (R & 63) * 64 + (C & 63)] = val;
+        if ((C >> 6) >= (R >> 6)) S[((size_t)slot[(C >> 6) * nb + (R >> 6)] << 12) + (C & 63) * 64 + (R & 63)] = val;
       }
     } else if (is_diag) {
       const int r = idx - NA;
@@ -1871,7 +1873,8 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
                                           : cam_rec[(size_t)B.row_ent * kCamRec + 45 + r];
         base = scale_cam[gr] * g;
       }
-      v[prow0 + r] = base - s;
+      const int C = prow0 + r;  // right-hand side: first row of tile (nb, C / 64)
+      S[((size_t)slot[nb * nb + (C >> 6)] << 12) + (C & 63)] = base - s;
     }
   };
   // one lane per element; the block's chunk partials are added in a fixed order (strided_sum16)
@@ -1879,65 +1882,48 @@ __global__ void __launch_bounds__(256) k_schur_finalize(
 }
 void launch_schur_finalize(hipStream_t st, int num_blocks, const SchurBlock* blocks,
                            const double* part_pp, const double* part_ip, const double* part_ii,
-                           int NI, int NC, int ld, bool add_base, double radius, double dmin,
+                           int NI, int NC, const int* slot, int nb, bool add_base, double radius, double dmin,
                            double dmax, const int* img_cam, const double* img_rec,
                            const double* cam_rec, const double* scale_cam, const int* off_img, const int* off_cam,
-                           double* S, double* v) {
+                           double* S) {
   if (num_blocks <= 0) return;
   hipLaunchKernelGGL(k_schur_finalize, dim3((num_blocks + 3) / 4), dim3(256), 0, st, num_blocks, blocks, part_pp,
-                     part_ip, part_ii, NI, NC, ld, add_base ? 1 : 0, radius, dmin, dmax, img_cam, img_rec, cam_rec,
-                     scale_cam, off_img, off_cam, S, v);
+                     part_ip, part_ii, NI, NC, slot, nb, add_base ? 1 : 0, radius, dmin, dmax, img_cam, img_rec, cam_rec,
+                     scale_cam, off_img, off_cam, S);
 }
-// Multi-rank exchange of the reduced system: only the structurally non-zero lower 64x64 tiles (and the
-// right-hand-side row) travel. pack: tile t of the list -> buf[t * 4096 ...]; unpack: the reverse.
-__global__ void __launch_bounds__(256) k_tiles_copy(int num_tiles, const int2* __restrict__ tiles, double* __restrict__ M,
-                                                    int ld, double* __restrict__ buf, int to_buf) {
-  const int t = blockIdx.x;
-  if (t >= num_tiles) return;
-  const int2 rc = tiles[t];
-  double* tile = M + (size_t)rc.x * 64 * ld + (size_t)rc.y * 64;
-  double* lin = buf + (size_t)t * 4096;
-  for (int e = threadIdx.x; e < 2048; e += 256) {
-    const int row = e >> 5, c2 = (e & 31) * 2;
-    double2* a = reinterpret_cast<double2*>(tile + (size_t)row * ld + c2);
-    double2* b = reinterpret_cast<double2*>(lin + row * 64 + c2);
-    if (to_buf) *b = *a; else *a = *b;
-  }
-}
-__global__ void __launch_bounds__(256) k_tiles_zero(int num_tiles, const int2* __restrict__ tiles, double* __restrict__ M, int ld, int tail_rows) {
+// Multi-rank exchange of the reduced system: only the structurally non-zero lower 64x64 tiles and the right-hand side
+// travel. pack: tile tiles[t] of the store -> buf[t * 4096 ...], right-hand side (first rows of the tiles of tile row nb)
+// -> buf[num_tiles * 4096 + c]; unpack: the reverse.
+__global__ void __launch_bounds__(256) k_tiles_copy(int num_tiles, const int* __restrict__ tiles, const int* __restrict__ slot, int nb,
+                                                    double* __restrict__ M, double* __restrict__ buf, int to_buf) {
   const int t = blockIdx.x;
   if (t < num_tiles) {
-    const int2 rc = tiles[t];
-    double* tile = M + (size_t)rc.x * 64 * ld + (size_t)rc.y * 64;
-    for (int e = threadIdx.x; e < 2048; e += 256) {
-      const int row = e >> 5, c2 = (e & 31) * 2;
-      *reinterpret_cast<double2*>(tile + (size_t)row * ld + c2) = make_double2(0.0, 0.0);
+    double2* a = reinterpret_cast<double2*>(M + ((size_t)tiles[t] << 12));
+    double2* b = reinterpret_cast<double2*>(buf + ((size_t)t << 12));
+    for (int e = threadIdx.x; e < 2048; e += 256) { if (to_buf) b[e] = a[e]; else a[e] = b[e]; }
+  } else {
+    double* rhs = buf + ((size_t)num_tiles << 12);
+    for (int c = (t - num_tiles) * 256 + threadIdx.x; c < nb * 64; c += (gridDim.x - num_tiles) * 256) {
+      double* a = M + ((size_t)slot[nb * nb + (c >> 6)] << 12) + (c & 63);
+      if (to_buf) rhs[c] = *a; else *a = rhs[c];
     }
-  } else {  // the rows below the matrix (right-hand side), spread over the remaining work-groups
-    double2* tail = reinterpret_cast<double2*>(M + (size_t)ld * ld);
-    const size_t n2 = (size_t)tail_rows * ld / 2;
-    for (size_t e = (size_t)(t - num_tiles) * 256 + threadIdx.x; e < n2; e += (size_t)(gridDim.x - num_tiles) * 256) tail[e] = make_double2(0.0, 0.0);
   }
 }
-void launch_tiles_zero(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, int tail_rows) {
-  const int extra = std::max(1, std::min(64, (int)(((size_t)tail_rows * ld / 2 + 4095) / 4096)));
-  hipLaunchKernelGGL(k_tiles_zero, dim3(num_tiles + extra), dim3(256), 0, st, num_tiles, tiles, M, ld, tail_rows);
-}
-void launch_tiles_copy(hipStream_t st, int num_tiles, const int2* tiles, double* M, int ld, double* buf, bool to_buf) {
-  if (num_tiles <= 0) return;
-  hipLaunchKernelGGL(k_tiles_copy, dim3(num_tiles), dim3(256), 0, st, num_tiles, tiles, M, ld, buf, to_buf ? 1 : 0);
+void launch_tiles_copy(hipStream_t st, int num_tiles, const int* tiles, const int* slot, int nb, double* M, double* buf, bool to_buf) {
+  const int extra = std::max(1, std::min(16, (nb * 64 + 1023) / 1024));
+  hipLaunchKernelGGL(k_tiles_copy, dim3(num_tiles + extra), dim3(256), 0, st, num_tiles, tiles, slot, nb, M, buf, to_buf ? 1 : 0);
 }
 
 // Constant / unused / padding columns: unit diagonal (their rows and columns are zero).
-__global__ void k_fix_diag(int n_mat, int ld, int add_one, const int* __restrict__ col_var,
+__global__ void k_fix_diag(int n_mat, const int* __restrict__ slot, int add_one, const int* __restrict__ col_var,
                            const double* __restrict__ scale_cam, double* __restrict__ S) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_mat) return;
   const int j = col_var[t];  // the variable in matrix column t, -1 for padding
-  if (j < 0 || scale_cam[j] == 0.0) S[(size_t)t * ld + t] = add_one ? 1.0 : 0.0;
+  if (j < 0 || scale_cam[j] == 0.0) S[((size_t)slot[(t >> 6) * (n_mat >> 6) + (t >> 6)] << 12) + (t & 63) * 65] = add_one ? 1.0 : 0.0;
 }
-void launch_fix_diag(hipStream_t st, int n_mat, int ld, bool add_one, const int* col_var, const double* scale_cam, double* S) {
-  hipLaunchKernelGGL(k_fix_diag, dim3((n_mat + 255) / 256), dim3(256), 0, st, n_mat, ld, add_one ? 1 : 0, col_var, scale_cam, S);
+void launch_fix_diag(hipStream_t st, int n_mat, const int* slot, bool add_one, const int* col_var, const double* scale_cam, double* S) {
+  hipLaunchKernelGGL(k_fix_diag, dim3((n_mat + 255) / 256), dim3(256), 0, st, n_mat, slot, add_one ? 1 : 0, col_var, scale_cam, S);
 }
 
 // ---------------------------------------------------------------------------

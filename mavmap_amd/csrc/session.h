@@ -352,7 +352,6 @@ struct mavba_session {
   CholStructure chol_struct;
   bool setup_batched = false;    // build() collects the set-up's small uploads (upload_batch_begin): finish_structure does not synchronise
   bool M_is_clean = false;       // d_M holds zeros outside the entries the assembly writes
-  bool M_outside_clean = false;  // d_M was cleared as a whole since it was allocated: only tiles inside the envelope can be dirty
   // cleared when a persistent factorisation launch had to give up; a session created within the next
   // kPersistCooldownSessions sessions of the process starts without it (a device shared with another tenant would
   // otherwise pay the 0.3 s time-out once per bundle_adjustment() call). Decided in start(): only a single-rank session
@@ -370,7 +369,7 @@ struct mavba_session {
   DevBuf<int> d_off, d_col_var;
   DevBuf<double> d_ymat;
   // multi-rank: the structurally non-zero lower tiles of the matrix, packed for the all-reduce
-  DevBuf<int2> d_ar_tiles;
+  DevBuf<int> d_ar_tiles;   // slots (tile store) of the tiles that travel
   DevBuf<double> d_ar_buf;
   int num_ar_tiles = 0;
 

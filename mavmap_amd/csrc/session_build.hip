@@ -737,18 +737,27 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   chol_struct.active_tiles = active_cols >= 0 ? std::max(1, (active_cols + 63) / 64) : nbt;
   nd_parts = chol_struct.nseg > 1 ? chol_struct.num_fronts_max : 0;
   if (sharded()) {
-    std::vector<int2> tl;
+    // (slots of the tile store: diagonal tiles, then the structurally non-zero ones)
+    std::vector<int> tl;
     std::vector<unsigned char> have((size_t)nbt * nbt, 0);
-    for (int t = 0; t < nbt; ++t) { tl.push_back(make_int2(t, t)); have[(size_t)t * nbt + t] = 1; }
+    auto slot_of = [&](int tr, int tc) {
+      const int sl = chol_struct.tile_slot[(size_t)tr * nbt + tc];
+      if (sl < 0) throw Failure(MAVBA_ERR_HIP, "a structurally non-zero tile lies outside the factorisation's envelope");
+      return sl;
+    };
+    for (int t = 0; t < nbt; ++t) { tl.push_back(slot_of(t, t)); have[(size_t)t * nbt + t] = 1; }
     for (const auto& pr : tile_pairs)
-      if (!have[(size_t)pr.first * nbt + pr.second]) { have[(size_t)pr.first * nbt + pr.second] = 1; tl.push_back(make_int2(pr.first, pr.second)); }
+      if (!have[(size_t)pr.first * nbt + pr.second]) { have[(size_t)pr.first * nbt + pr.second] = 1; tl.push_back(slot_of(pr.first, pr.second)); }
     num_ar_tiles = (int)tl.size();
     d_ar_tiles.upload(tl, st);
     d_ar_buf.alloc((size_t)num_ar_tiles * 4096 + n_mat);
   }
-  d_M.alloc((size_t)(n_mat + 64) * n_mat); d_L.alloc((size_t)(n_mat + 64) * n_mat);
-  M_is_clean = false;
-  M_outside_clean = false;  // (fresh memory: the first assembly clears all of it)
+  // every block of S must land in a tile of the store
+  for (const auto& pr : tile_pairs)
+    if (chol_struct.tile_slot[(size_t)pr.first * nbt + pr.second] < 0)
+      throw Failure(MAVBA_ERR_HIP, "a structurally non-zero tile lies outside the factorisation's envelope");
+  d_M.alloc(chol_struct.store_doubles()); d_L.alloc(chol_struct.store_doubles());
+  M_is_clean = false;  // (fresh memory: the first assembly clears it)
   d_ymat.alloc(n_mat); d_diag_ws.alloc((size_t)n_mat * 64);
 }
 

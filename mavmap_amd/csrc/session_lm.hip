@@ -219,19 +219,13 @@ void mavba_session::assemble(double r) {
   // in place, makes a fresh clear necessary.
   if (!M_is_clean) {
     timed("memset_S", [&] {
-      // Outside the envelope nothing ever writes: after the first full clear only the envelope's tiles (which the in-place
-      // factorisation of the launch-per-panel schedule overwrote) and the right-hand-side rows are cleared again.
-      // (Sharded sessions too, round 6: what the exchange leaves behind - the SUM over ranks in tiles this rank's assembly does not
-      // rewrite - lies in the tiles that travel, all inside the envelope every rank agreed on; rounds 3-5 cleared the whole
-      // dense array before every solve of a sharded session: 90 MB at C3, 1.2 GB at C5 per LM iteration.)
-      if (M_outside_clean && chol_struct.num_env_tiles > 0)
-        launch_tiles_zero(st, chol_struct.num_env_tiles, chol_struct.d_env_tiles, d_M.p, n_mat, 64);
-      else
-        HIP_OK(hipMemsetAsync(d_M.p, 0, (size_t)(n_mat + 64) * n_mat * sizeof(double), st));
-      M_outside_clean = true;
+      // The store holds the envelope's tiles and nothing else (round 6; rounds 1-5: a dense (n + 64) n array of which the
+      // envelope was 11 % at C5): what the in-place factorisation of the launch-per-panel schedule - or, with shards, the
+      // exchange - left behind is cleared as one block.
+      HIP_OK(hipMemsetAsync(d_M.p, 0, chol_struct.store_doubles() * sizeof(double), st));
       // unit diagonal of the columns no block of S covers (padding, entirely constant blocks); the finalize pass
       // writes the diagonal of the constant parameters inside its blocks itself
-      launch_fix_diag(st, n_mat, n_mat, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
+      launch_fix_diag(st, n_mat, chol_struct.d_tile_slot, rank == 0, d_col_var.p, d_scale_cam.p, d_M.p);
     });
     M_is_clean = true;
   }
@@ -243,20 +237,17 @@ void mavba_session::assemble(double r) {
   if (num_chunks[0] > 0) timed("schur_chunks_pp", [&] { launch_schur_chunks(st, BLK_PP, num_chunks[0], d_chunks[0].p, d_terms[0].p, d_Epose.p, d_Eintr.p, d_part[0].p); });
   if (num_chunks[1] > 0) timed("schur_chunks_ip", [&] { launch_schur_chunks(st, BLK_IP, num_chunks[1], d_chunks[1].p, d_terms[1].p, d_Epose.p, d_Eintr.p, d_part[1].p); });
   if (num_chunks[2] > 0) timed("schur_chunks_ii", [&] { launch_schur_chunks(st, BLK_II, num_chunks[2], d_chunks[2].p, d_terms[2].p, d_Epose.p, d_Eintr.p, d_part[2].p); });
-  double* v = d_M.p + (size_t)n_mat * n_mat;
+  const int nbt = n_mat / 64;
   timed("schur_finalize", [&] {
     launch_partial_reduce(st, num_reduce_tasks, d_reduce_tasks.p, d_part[0].p, d_part[1].p, d_part[2].p);
-    launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, n_mat, rank == 0,
-                          r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p, v);
+    launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, chol_struct.d_tile_slot, nbt, rank == 0,
+                          r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p);
   });
   if (sharded()) {
     // only the tiles the factorisation reads (lower, inside the structure) and the right-hand side travel
-    double* rhs = d_ar_buf.p + (size_t)num_ar_tiles * 4096;
-    launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, d_M.p, n_mat, d_ar_buf.p, true);
-    HIP_OK(hipMemcpyAsync(rhs, v, (size_t)n_mat * 8, hipMemcpyDeviceToDevice, st));
+    launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, chol_struct.d_tile_slot, nbt, d_M.p, d_ar_buf.p, true);
     allreduce(d_ar_buf.p, (long long)num_ar_tiles * 4096 + n_mat, 0);
-    launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, d_M.p, n_mat, d_ar_buf.p, false);
-    HIP_OK(hipMemcpyAsync(v, rhs, (size_t)n_mat * 8, hipMemcpyDeviceToDevice, st));
+    launch_tiles_copy(st, num_ar_tiles, d_ar_tiles.p, chol_struct.d_tile_slot, nbt, d_M.p, d_ar_buf.p, false);
   }
   assembled = true;
 }

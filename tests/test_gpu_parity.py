@@ -311,6 +311,12 @@ def test_envelope_factorisation_on_a_banded_system(mavba, oracle):
         assert info["reduced_dim"] == 6 * 140 + 18 and info["padded_dim"] % 64 == 0
         assert info["envelope_tiles"] < info["dense_tiles"]
         assert info["factor_flops"] < 64.0 ** 3 * 2 * info["dense_tiles"] * 14  # sanity: finite, bounded
+        # round 6: the device keeps the envelope's tiles only (+ one right-hand-side tile per tile column), not a dense array
+        nb = info["matrix_dim"] // 64
+        assert info["reduced_store_bytes"] == (info["envelope_tiles"] + nb) * 64 * 64 * 8
+        assert info["reduced_store_bytes"] < (info["matrix_dim"] + 64) * info["matrix_dim"] * 8
+        S, v = s.reduced_system(1e4)   # (spread back into the dense form at the boundary)
+        assert np.array_equal(S, S.T) and np.all(np.diag(S) > 0)
         st = s.linear_step(1e4)
     ref = oracle.linear_step(p, 1e4)
     assert rel_err(st["d_poses"], ref["d_poses"]) < 1e-8
