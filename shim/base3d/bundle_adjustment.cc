@@ -362,7 +362,21 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
   }
   lap("2-D points with a 3-D point");
   std::vector<uint32_t> point3D_num_points2D(max_p3d + 1, 0);  // an image listed twice counts twice, as in the reference
-  for (const Entry& E : entries) for (size_t id : E.p3d) point3D_num_points2D[id] += 1;
+  size_t total_p3d = 0;
+  for (const Entry& E : entries) total_p3d += E.p3d.size();
+  // (round 6: big calls count on the worker threads with relaxed atomic increments - neighbouring images share points, but a
+  // counter line is only contended between the few entries that see it; the serial loop was 2 of the walk's 16 ms at C3)
+  // (MAVBA_SHIM_ASSEMBLY=serial | blocks forces one form: tests compare them on small scenes)
+  const char* asm_env = std::getenv("MAVBA_SHIM_ASSEMBLY");
+  const bool asm_serial = asm_env && std::string(asm_env) == "serial", asm_blocks = asm_env && std::string(asm_env) == "blocks";
+  const bool big_call = host_threads() > 1 && !asm_serial && (asm_blocks || total_p3d >= 200000);
+  if (big_call)
+    parallel_for(entries.size(), [&](size_t e0, size_t e1, int) {
+      for (size_t e = e0; e < e1; ++e)
+        for (size_t id : entries[e].p3d) __atomic_fetch_add(&point3D_num_points2D[id], 1u, __ATOMIC_RELAXED);
+    });
+  else
+    for (const Entry& E : entries) for (size_t id : E.p3d) point3D_num_points2D[id] += 1;
   parallel_for(entries.size(), [&](size_t e0, size_t e1, int) {
     for (size_t e = e0; e < e1; ++e) {
       Entry& E = entries[e];
@@ -388,12 +402,12 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
   std::vector<double> poses, intrinsics, points, obs_uv;
   std::vector<uint8_t> pose_const, intr_const, point_const;
   std::vector<int32_t> image_camera, camera_model, obs_image, obs_point;
-  {
-    size_t total = 0;
-    for (const Entry& E : entries) total += E.kept;
-    obs_uv.reserve(2 * total); obs_image.reserve(total); obs_point.reserve(total);
-  }
-  for (Entry& E : entries) {
+  // Per entry (a few hundred, serial): images and cameras by first appearance, constancy, where its observations go.
+  std::vector<int32_t> entry_img(entries.size(), -1);
+  std::vector<size_t> entry_off(entries.size() + 1, 0);
+  for (size_t e = 0; e < entries.size(); ++e) {
+    Entry& E = entries[e];
+    entry_off[e + 1] = entry_off[e] + E.kept;
     if (E.kept == 0) continue;  // no residual block: the image does not enter the problem here
     const size_t image_id = E.image_id;
     // An image id listed twice (in one list or in two) is ONE set of parameter blocks in the reference: its
@@ -426,21 +440,84 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
       poses.insert(poses.end(), r, r + 3);
       poses.insert(poses.end(), t, t + 3);
     }
-    for (size_t i = 0; i < E.kept; ++i) {
-      int32_t& ip = point_index[E.p3d[i]];
-      if (ip < 0) { ip = (int32_t)point_ids.size(); point_ids.push_back(E.p3d[i]); }
-      obs_uv.push_back(E.xy[2 * i]); obs_uv.push_back(E.xy[2 * i + 1]);
-      obs_image.push_back(img);
-      obs_point.push_back(ip);
-    }
+    entry_img[e] = img;
     // Constancy is applied only if the image contributed more than one residual (:361).
     if (E.kept > 1) {
       if (E.state == BA_POSE_FIXED) pose_const[img] |= MAVBA_CONST_POSE;
       if (E.state == BA_POSE_FIXED_X) pose_const[img] |= MAVBA_CONST_TX;
       if (!options.refine_camera_params) intr_const[image_camera[img]] = 1;
     }
-    std::vector<size_t>().swap(E.p2d); std::vector<size_t>().swap(E.p3d); std::vector<double>().swap(E.xy);
   }
+  const size_t total_obs = entry_off.back();
+  obs_uv.resize(2 * total_obs); obs_image.resize(total_obs); obs_point.resize(total_obs);
+  if (!big_call) {
+    // the observations concatenated in list order, points numbered by first appearance
+    for (size_t e = 0; e < entries.size(); ++e) {
+      Entry& E = entries[e];
+      for (size_t i = 0; i < E.kept; ++i) {
+        int32_t& ip = point_index[E.p3d[i]];
+        if (ip < 0) { ip = (int32_t)point_ids.size(); point_ids.push_back(E.p3d[i]); }
+        const size_t o = entry_off[e] + i;
+        obs_uv[2 * o] = E.xy[2 * i]; obs_uv[2 * o + 1] = E.xy[2 * i + 1];
+        obs_image[o] = entry_img[e];
+        obs_point[o] = ip;
+      }
+    }
+  } else {
+    // Round 6, the same arrays without the serial walk over 2 M observations (7 of the call's 35 ms at C3). The entries are
+    // cut into BLOCKS that are contiguous in list order. A point's first appearance lies in the lowest block that sees it
+    // (atomic minimum per point, pass A); the block that owns a point numbers it locally in the order it first meets it
+    // (pass B: only the owner writes the point's slot); a prefix sum over the blocks' counts turns local numbers into the
+    // serial walk's numbers (points first met in block b follow all points first met in earlier blocks, in b's own order of
+    // first appearance), and pass C writes the observations. No per-thread tables, no zero-fills beyond the two dense arrays.
+    const size_t nblk = std::min(entries.size(), (size_t)4 * host_threads());
+    auto blk_begin = [&](size_t b) { return entries.size() * b / nblk; };
+    std::vector<uint32_t> first_blk(max_p3d + 1, 0xFFFFFFFFu);
+    auto over_blocks = [&](const std::function<void(size_t)>& body) {
+      const int T = host_threads();
+      const std::function<void(int)> job = [&](int t) { for (size_t b = (size_t)t; b < nblk; b += (size_t)T) body(b); };
+      workers().run(T, job);
+    };
+    over_blocks([&](size_t b) {
+      for (size_t e = blk_begin(b); e < blk_begin(b + 1); ++e) {
+        const Entry& E = entries[e];
+        for (size_t i = 0; i < E.kept; ++i) {
+          uint32_t* f = &first_blk[E.p3d[i]];
+          uint32_t cur = __atomic_load_n(f, __ATOMIC_RELAXED);
+          while (cur > (uint32_t)b && !__atomic_compare_exchange_n(f, &cur, (uint32_t)b, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
+      }
+    });
+    std::vector<std::vector<size_t>> blk_points(nblk);
+    over_blocks([&](size_t b) {
+      std::vector<size_t>& mine = blk_points[b];
+      for (size_t e = blk_begin(b); e < blk_begin(b + 1); ++e) {
+        const Entry& E = entries[e];
+        for (size_t i = 0; i < E.kept; ++i) {
+          const size_t id = E.p3d[i];
+          if (first_blk[id] != (uint32_t)b || point_index[id] >= 0) continue;
+          point_index[id] = (int32_t)mine.size();
+          mine.push_back(id);
+        }
+      }
+    });
+    std::vector<size_t> blk_base(nblk + 1, 0);
+    for (size_t b = 0; b < nblk; ++b) blk_base[b + 1] = blk_base[b] + blk_points[b].size();
+    point_ids.resize(blk_base[nblk]);
+    over_blocks([&](size_t b) {
+      std::copy(blk_points[b].begin(), blk_points[b].end(), point_ids.begin() + blk_base[b]);
+      for (size_t e = blk_begin(b); e < blk_begin(b + 1); ++e) {
+        const Entry& E = entries[e];
+        for (size_t i = 0; i < E.kept; ++i) {
+          const size_t id = E.p3d[i], o = entry_off[e] + i;
+          obs_uv[2 * o] = E.xy[2 * i]; obs_uv[2 * o + 1] = E.xy[2 * i + 1];
+          obs_image[o] = entry_img[e];
+          obs_point[o] = (int32_t)(blk_base[first_blk[id]] + (size_t)point_index[id]);
+        }
+      }
+    });
+  }
+  for (Entry& E : entries) { std::vector<size_t>().swap(E.p2d); std::vector<size_t>().swap(E.p3d); std::vector<double>().swap(E.xy); }
   lap("assembly in list order");
   points.resize(3 * point_ids.size());
   point_const.resize(point_ids.size());

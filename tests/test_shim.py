@@ -425,6 +425,38 @@ def test_an_image_id_listed_twice_is_one_set_of_blocks(mock):
     assert int(np.sum(r["obs_image"] == i3)) == 2 * n3              # its residual blocks were added by both loops
 
 
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_block_wise_assembly_hands_over_the_serial_walks_problem(mock, monkeypatch, seed):
+    """Round 6: big calls assemble the flat problem on the worker threads - blocks of entries contiguous in list order, a
+    point's owner = the lowest block that sees it, local numbers + a prefix sum over the blocks = the numbers of the serial
+    "first appearance" walk (shim/base3d/bundle_adjustment.cc). MAVBA_SHIM_ASSEMBLY forces either form: on scenes with
+    unmatched 2-D points, a min_track_len that drops points, an image listed twice, GCPs and lists in scrambled order both
+    must hand over the SAME arrays - and the independent restatement's."""
+    rng = np.random.default_rng(seed)
+    p = synth.make_scene(num_images=40, num_points=1500, track_len=4, models=[A.MODEL_PINHOLE, A.MODEL_OPENCV], seed=seed,
+                         long_track_frac=0.05, long_track_len=9)
+    sc = Scene(p, extra_unmatched=200, rng=rng)
+    ids = rng.permutation(40)
+    free, fixed, fixed_x = list(ids[:30]), list(ids[30:36]) + [int(ids[3])], list(ids[36:39])   # (one image in two lists; one unused)
+    gcp = [5, 77, 300]
+    out = {}
+    for mode in ("serial", "blocks"):
+        monkeypatch.setenv("MAVBA_SHIM_ASSEMBLY", mode)
+        rc, *_ = run(mock, sc, free, fixed, fixed_x, gcp=gcp, min_track_len=3, refine_camera_params=1)
+        assert rc == 0
+        out[mode] = recorded(mock)
+    a, b = out["serial"], out["blocks"]
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # and once against the restatement (no image listed twice there: its rule is tested by the test above)
+    monkeypatch.setenv("MAVBA_SHIM_ASSEMBLY", "blocks")
+    fixed1 = list(ids[30:36])
+    rc, *_ = run(mock, sc, free, fixed1, fixed_x, gcp=gcp, min_track_len=3, refine_camera_params=1)
+    assert rc == 0
+    check_against_expected(mock, sc, expected_flat(sc, free, fixed1, fixed_x, gcp, 3, 1))
+
+
 @pytest.mark.gpu
 def test_shim_rotation_constraints_end_to_end_on_gpu(mavba, oracle):
     """constrain_rotation through the reference-signature call into the real library: global pre-rotation of the whole
