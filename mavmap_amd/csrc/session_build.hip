@@ -948,8 +948,18 @@ void mavba_session::finish_structure() {
       for (int p = std::max(r0, tail_begin); p < r_end; ++p)
         if (h_pt_free[p] && (h_pt_start[p + 1] > h_pt_start[p] || q_start[p + 1] > q_start[p])) pt_mode[p] = 2;
       const int r1 = std::min(r_end, std::max(r0, tail_begin));
-      struct Run { int p0, p1, n; std::vector<int> imgs, cams; };
+      // (a run's image / camera lists live in two flat arrays of the range: one heap block per list was 80 000 allocations on 16
+      // threads at C3)
+      struct Run {
+        int p0, p1, n, io, ni, co, nc;
+        const std::vector<int>* fi; const std::vector<int>* fc;
+        struct Span { const int* b; const int* e; const int* begin() const { return b; } const int* end() const { return e; } size_t size() const { return (size_t)(e - b); } };
+        Span imgs_span() const { return Span{fi->data() + io, fi->data() + io + ni}; }
+        Span cams_span() const { return Span{fc->data() + co, fc->data() + co + nc}; }
+      };
       std::vector<Run> runs;
+      std::vector<int> flat_i, flat_c;
+      flat_i.reserve((size_t)4 * kRange); flat_c.reserve((size_t)kRange);
       std::vector<int> pi, pc;
       for (int p = r0; p < r1; ++p) {
         if (!h_pt_free[p]) continue;
@@ -968,8 +978,17 @@ void mavba_session::finish_structure() {
         std::sort(pi.begin(), pi.end());
         for (int q = q_start[p]; q < q_start[p + 1]; ++q) pc.push_back(q_cam[q]);  // (ascending)
         pt_mode[p] = 1;
-        if (!runs.empty() && runs.back().imgs == pi && runs.back().cams == pc) { runs.back().p1 = p + 1; runs.back().n++; }
-        else runs.push_back(Run{p, p + 1, 1, pi, pc});
+        bool same_set = !runs.empty() && runs.back().ni == (int)pi.size() && runs.back().nc == (int)pc.size();
+        if (same_set) {
+          const Run& B = runs.back();
+          same_set = std::equal(pi.begin(), pi.end(), flat_i.begin() + B.io) && std::equal(pc.begin(), pc.end(), flat_c.begin() + B.co);
+        }
+        if (same_set) { runs.back().p1 = p + 1; runs.back().n++; }
+        else {
+          runs.push_back(Run{p, p + 1, 1, (int)flat_i.size(), (int)pi.size(), (int)flat_c.size(), (int)pc.size(), &flat_i, &flat_c});
+          flat_i.insert(flat_i.end(), pi.begin(), pi.end());
+          flat_c.insert(flat_c.end(), pc.begin(), pc.end());
+        }
       }
       auto batches = [](int n) { return (n + kRowsBatch - 1) / kRowsBatch; };
       auto cost = [&](int n, int ni, int kr) { return kCostF + batches(n) * kCostB[rows_class_of_rows(rows_count(ni, kr))]; };
@@ -986,21 +1005,22 @@ void mavba_session::finish_structure() {
         }
         cur_i.clear(); cur_c.clear(); cur_n = 0; cur_p0 = p_end; ++cl_serial;
       };
+      auto cam_rows_span = [&](const Run::Span& cams) { int k = 0; for (int c : cams) k += model_k(h_cam_model[c]); return k; };
       auto add = [&](const Run& R, int p_begin, int n) {
         if (cur_n == 0) cur_p0 = p_begin;
-        for (int i : R.imgs) if (in_cluster[i] != cl_serial) { in_cluster[i] = cl_serial; cur_i.push_back(i); }
-        for (int c : R.cams) if (std::find(cur_c.begin(), cur_c.end(), c) == cur_c.end()) cur_c.push_back(c);
+        for (int i : R.imgs_span()) if (in_cluster[i] != cl_serial) { in_cluster[i] = cl_serial; cur_i.push_back(i); }
+        for (int c : R.cams_span()) if (std::find(cur_c.begin(), cur_c.end(), c) == cur_c.end()) cur_c.push_back(c);
         cur_n += n;
       };
       for (const Run& R : runs) {
-        const int rni = (int)R.imgs.size();
+        const int rni = R.ni;
         bool join = false;
         if (cur_n > 0 && cur_n + R.n <= kMaxPoints && R.p1 - cur_p0 <= kRowsMaxPoints) {
           int ni = (int)cur_i.size(), nc = (int)cur_c.size(), kr = cam_rows_of(cur_c);
-          for (int i : R.imgs) ni += in_cluster[i] != cl_serial;
-          for (int c : R.cams) if (std::find(cur_c.begin(), cur_c.end(), c) == cur_c.end()) { ++nc; kr += model_k(h_cam_model[c]); }
+          for (int i : R.imgs_span()) ni += in_cluster[i] != cl_serial;
+          for (int c : R.cams_span()) if (std::find(cur_c.begin(), cur_c.end(), c) == cur_c.end()) { ++nc; kr += model_k(h_cam_model[c]); }
           join = ni <= kClImages && nc <= kClCams &&
-                 cost(cur_n + R.n, ni, kr) <= cost(cur_n, (int)cur_i.size(), cam_rows_of(cur_c)) + cost(R.n, rni, cam_rows_of(R.cams));
+                 cost(cur_n + R.n, ni, kr) <= cost(cur_n, (int)cur_i.size(), cam_rows_of(cur_c)) + cost(R.n, rni, cam_rows_span(R.cams_span()));
         }
         if (join) { add(R, R.p0, R.n); continue; }
         close(R.p0);

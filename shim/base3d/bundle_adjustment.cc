@@ -364,19 +364,32 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
   std::vector<uint32_t> point3D_num_points2D(max_p3d + 1, 0);  // an image listed twice counts twice, as in the reference
   size_t total_p3d = 0;
   for (const Entry& E : entries) total_p3d += E.p3d.size();
-  // (round 6: big calls count on the worker threads with relaxed atomic increments - neighbouring images share points, but a
-  // counter line is only contended between the few entries that see it; the serial loop was 2 of the walk's 16 ms at C3)
   // (MAVBA_SHIM_ASSEMBLY=serial | blocks forces one form: tests compare them on small scenes)
   const char* asm_env = std::getenv("MAVBA_SHIM_ASSEMBLY");
   const bool asm_serial = asm_env && std::string(asm_env) == "serial", asm_blocks = asm_env && std::string(asm_env) == "blocks";
   const bool big_call = host_threads() > 1 && !asm_serial && (asm_blocks || total_p3d >= 200000);
-  if (big_call)
-    parallel_for(entries.size(), [&](size_t e0, size_t e1, int) {
-      for (size_t e = e0; e < e1; ++e)
-        for (size_t id : entries[e].p3d) __atomic_fetch_add(&point3D_num_points2D[id], 1u, __ATOMIC_RELAXED);
-    });
-  else
-    for (const Entry& E : entries) for (size_t id : E.p3d) point3D_num_points2D[id] += 1;
+  // ONE contiguous block of entries per worker, cut at equal weights: neighbouring images see the same 3-D points, so a point's
+  // owner slot is shared by the threads of adjacent blocks only
+  auto block_bounds = [&](const std::function<size_t(const Entry&)>& weight) {
+    const size_t nblk = std::min(entries.size(), (size_t)host_threads());
+    std::vector<size_t> bound(nblk + 1, entries.size());
+    size_t total = 0, run = 0, b = 1;
+    for (const Entry& E : entries) total += weight(E);
+    bound[0] = 0;
+    for (size_t e = 0; e < entries.size() && b < nblk; ++e) {
+      run += weight(entries[e]);
+      while (b < nblk && run * nblk >= total * b) bound[b++] = e + 1;
+    }
+    return bound;
+  };
+  auto over_blocks = [&](const std::vector<size_t>& bound, const std::function<void(size_t, size_t, size_t)>& body) {
+    const size_t nblk = bound.size() - 1;
+    const std::function<void(int)> job = [&](int t) { if ((size_t)t < nblk) body((size_t)t, bound[t], bound[t + 1]); };
+    workers().run((int)nblk, job);
+  };
+  // (the counting stays serial: with relaxed atomic increments on the worker threads it took 9 ms instead of 3.5 on the GPU box's
+  // host, contiguous blocks or not - every increment is a locked read-modify-write on a line other cores also write)
+  for (const Entry& E : entries) for (size_t id : E.p3d) point3D_num_points2D[id] += 1;
   parallel_for(entries.size(), [&](size_t e0, size_t e1, int) {
     for (size_t e = e0; e < e1; ++e) {
       Entry& E = entries[e];
@@ -470,16 +483,11 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
     // (pass B: only the owner writes the point's slot); a prefix sum over the blocks' counts turns local numbers into the
     // serial walk's numbers (points first met in block b follow all points first met in earlier blocks, in b's own order of
     // first appearance), and pass C writes the observations. No per-thread tables, no zero-fills beyond the two dense arrays.
-    const size_t nblk = std::min(entries.size(), (size_t)4 * host_threads());
-    auto blk_begin = [&](size_t b) { return entries.size() * b / nblk; };
+    const std::vector<size_t> bound = block_bounds([](const Entry& E) { return E.kept; });
+    const size_t nblk = bound.size() - 1;
     std::vector<uint32_t> first_blk(max_p3d + 1, 0xFFFFFFFFu);
-    auto over_blocks = [&](const std::function<void(size_t)>& body) {
-      const int T = host_threads();
-      const std::function<void(int)> job = [&](int t) { for (size_t b = (size_t)t; b < nblk; b += (size_t)T) body(b); };
-      workers().run(T, job);
-    };
-    over_blocks([&](size_t b) {
-      for (size_t e = blk_begin(b); e < blk_begin(b + 1); ++e) {
+    over_blocks(bound, [&](size_t b, size_t e0, size_t e1) {
+      for (size_t e = e0; e < e1; ++e) {
         const Entry& E = entries[e];
         for (size_t i = 0; i < E.kept; ++i) {
           uint32_t* f = &first_blk[E.p3d[i]];
@@ -489,9 +497,9 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
       }
     });
     std::vector<std::vector<size_t>> blk_points(nblk);
-    over_blocks([&](size_t b) {
+    over_blocks(bound, [&](size_t b, size_t e0, size_t e1) {
       std::vector<size_t>& mine = blk_points[b];
-      for (size_t e = blk_begin(b); e < blk_begin(b + 1); ++e) {
+      for (size_t e = e0; e < e1; ++e) {
         const Entry& E = entries[e];
         for (size_t i = 0; i < E.kept; ++i) {
           const size_t id = E.p3d[i];
@@ -504,9 +512,9 @@ double bundle_adjustment(FeatureManager& fm, const std::vector<size_t>& free_ima
     std::vector<size_t> blk_base(nblk + 1, 0);
     for (size_t b = 0; b < nblk; ++b) blk_base[b + 1] = blk_base[b] + blk_points[b].size();
     point_ids.resize(blk_base[nblk]);
-    over_blocks([&](size_t b) {
+    over_blocks(bound, [&](size_t b, size_t e0, size_t e1) {
       std::copy(blk_points[b].begin(), blk_points[b].end(), point_ids.begin() + blk_base[b]);
-      for (size_t e = blk_begin(b); e < blk_begin(b + 1); ++e) {
+      for (size_t e = e0; e < e1; ++e) {
         const Entry& E = entries[e];
         for (size_t i = 0; i < E.kept; ++i) {
           const size_t id = E.p3d[i], o = entry_off[e] + i;
