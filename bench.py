@@ -636,7 +636,11 @@ def main():
                                "chain_steps": info["chain_steps"], "schur_clusters": info["num_clusters"],
                                "clustered_points": info["clustered_points"], "cluster_partials": info["cluster_partials"],
                                "factor_gflop_envelope": round(info["factor_flops"] / 1e9, 3),
-                               "factor_gflop_dense_equivalent": round(info["dense_factor_flops"] / 1e9, 3)},
+                               "factor_gflop_dense_equivalent": round(info["dense_factor_flops"] / 1e9, 3),
+                               "store_mb": round(info["reduced_store_bytes"] / 1e6, 2),
+                               "store_note": "device bytes of S | v as the envelope's 64 x 64 tiles (as many again for the factor); "
+                                             "a dense (n + 64) n array would be "
+                                             f"{(info['matrix_dim'] + 64) * info['matrix_dim'] * 8 / 1e6:.0f} MB"},
             "cpu_baseline": cpu_baseline,
             "scaling_model": scaling_model,
             "ranks": {"world": world, "confirmed_by_all_reduce": ranks_confirmed, "exchange": exchange, "per_rank": ranks,

@@ -393,6 +393,11 @@ int mavba_debug_elimination_tree(int32_t num_images, int32_t num_cameras, int64_
 /* Test entry of the set-up's device sort (device_setup.hip): order_out [n] = the stable ascending order of 0..n-1 by
  * keys[i] (the low `key_bytes` bytes are significant). */
 int mavba_debug_radix_sort(int32_t n, const uint32_t* keys, int32_t key_bytes, int32_t* order_out, int32_t device);
+/* Test entry of the set-up's batched small uploads (csrc/host_util.hip: one copy + one scatter kernel for the ~50 small tables of a
+ * local-window session): n buffers of |sizes[i]| bytes - sizes[i] < 0: dirtied, then cleared; every third one uploaded twice -
+ * inside one batch whose arena holds `arena_bytes` (small values exercise the arena-full path), read back and compared.
+ * Returns the number of wrong bytes (0 = pass), -1 on error. */
+int64_t mavba_debug_upload_batch(int32_t n, const int64_t* sizes, int64_t arena_bytes, int32_t device);
 /* Test entry: the LM accept / reject / terminate decision (csrc/lm_decide.h) by the host build and by the device build on
  * the same n cases (16 scalars + 8 parameters each, 6 doubles out each); the speculative evaluation needs them identical. */
 int mavba_debug_lm_decide(int32_t n, const double* cases, double* out_host, double* out_device, int32_t device);

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mavba_scene_get_camera", "mavba_scene_flatten", "mavba_scene_bundle_adjust",
     "mavba_rccl_unique_id", "mavba_session_set_rccl", "mavba_pose_refine_batch", "mavba_session_set_params", "mavba_session_restart", "mavba_session_filter_points", "mavba_solve_filter_solve",
     "mavba_debug_elimination_tree", "mavba_debug_radix_sort", "mavba_debug_lm_decide", "mavba_debug_chol_schedule",
-    "mavba_debug_inproc_comms",
+    "mavba_debug_inproc_comms", "mavba_debug_upload_batch",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
@@ -121,7 +121,7 @@ def load():
     L.mavba_debug_chol_schedule.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int64, i32p, i32p, C.c_int32, dp,
                                             i32p, C.c_int64, i64p, i32p, C.c_int64, i64p, i32p]
     for f in EXPORTED_SYMBOLS:
-        if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy", "mavba_scene_destroy"):
+        if f not in ("mavba_options_init", "mavba_last_error", "mavba_session_destroy", "mavba_scene_destroy", "mavba_debug_upload_batch"):
             getattr(L, f).restype = C.c_int
     _lib = L
     return L
@@ -565,6 +565,17 @@ def radix_sort_order(keys, key_bytes=4, device=-1):
     out = np.zeros(len(keys), np.int32)
     _check(load().mavba_debug_radix_sort(len(keys), A.ptr(keys, C.c_uint32), int(key_bytes), A.ptr(out, C.c_int32), device))
     return out
+
+
+def debug_upload_batch(sizes, arena_bytes=0, device=-1):
+    """Wrong bytes after a batch of small uploads / clears of the given sizes (negative: a clear) - 0 = pass."""
+    sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+    f = load().mavba_debug_upload_batch
+    f.restype = C.c_int64   # (wrong bytes, not a status)
+    r = f(C.c_int32(len(sizes)), A.ptr(sizes, C.c_int64), C.c_int64(int(arena_bytes)), C.c_int32(device))
+    if r < 0:
+        raise MavbaError(A.ERR_HIP, load().mavba_last_error().decode(errors="replace"))
+    return int(r)
 
 
 def debug_lm_decide(cases, device=-1):

@@ -561,6 +561,62 @@ int mavba_session_time_front(mavba_session* s, double radius, int32_t reps, floa
   MAVBA_CATCH
 }
 
+// Test entry of the batched small uploads (host_util.hip): `n` buffers of sizes[i] bytes get a pattern, a clear (sizes[i] < 0:
+// cleared, -sizes[i] bytes) or - every third one - a second upload over the first (the overlap rule), all inside ONE batch with an
+// arena of `arena_bytes` (small: the arena-full path); everything is read back and compared. Returns the number of wrong bytes.
+int64_t mavba_debug_upload_batch(int32_t n, const int64_t* sizes, int64_t arena_bytes, int32_t device) {
+  if (mavba_device_count() <= 0) { g_last_error = "no HIP device: the mavba backend has no CPU path"; return -1; }
+  int64_t wrong = -1;
+  try {
+    if (device >= 0) HIP_OK(hipSetDevice(device));
+    hipStream_t st;
+    HIP_OK(stream_acquire(&st));
+    int st_dev = 0;
+    (void)hipGetDevice(&st_dev);
+    struct Release { hipStream_t st; int dev; ~Release() { (void)hipStreamSynchronize(st); release_staged(st); stream_release(st, dev); upload_batch_debug_arena(0); } } rel{st, st_dev};
+    upload_batch_debug_arena((size_t)arena_bytes);
+    std::vector<std::unique_ptr<DevBuf<unsigned char>>> bufs;
+    std::vector<std::vector<unsigned char>> want;
+    if (!upload_batch_begin(st)) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "a batch is already open on this thread");
+    struct End { bool open = true; ~End() { if (open) (void)upload_batch_end(false); } } guard;
+    for (int i = 0; i < n; ++i) {
+      const bool clear = sizes[i] < 0;
+      const size_t bytes = (size_t)(clear ? -sizes[i] : sizes[i]);
+      bufs.emplace_back(new DevBuf<unsigned char>);
+      std::vector<unsigned char> h(bytes);
+      for (size_t k = 0; k < bytes; ++k) h[k] = (unsigned char)(1 + (k * 7 + (size_t)i * 13) % 251);
+      if (clear) {
+        bufs.back()->upload(std::vector<unsigned char>(std::max<size_t>(bytes, 1), 0xEE), st);  // dirty first, then the clear: same destination twice
+        bufs.back()->n = bytes;
+        bufs.back()->zero(st);
+        std::fill(h.begin(), h.end(), 0);
+      } else {
+        bufs.back()->upload(h, st);
+        if (i % 3 == 2) {  // once more with other content (pointer-stable: DevBuf::upload frees and re-allocates the same class)
+          for (size_t k = 0; k < bytes; ++k) h[k] = (unsigned char)(255 - h[k]);
+          bufs.back()->upload(h, st);
+        }
+      }
+      want.push_back(std::move(h));
+    }
+    guard.open = false;
+    HIP_OK(upload_batch_end(true));
+    wrong = 0;
+    for (int i = 0; i < n; ++i) {
+      std::vector<unsigned char> got(want[i].size());
+      if (!got.empty()) HIP_OK(copy_d2h_staged_sync(got.data(), bufs[i]->p, got.size(), st));
+      for (size_t k = 0; k < got.size(); ++k) wrong += got[k] != want[i][k];
+    }
+  } catch (const Failure& f) {
+    g_last_error = f.what();
+    return -1;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return -1;
+  }
+  return wrong;
+}
+
 int mavba_session_get_info(mavba_session* s, mavba_session_info* out) {
   MAVBA_SESSION_TRY(s)
   if (!out) throw Failure(MAVBA_ERR_INVALID_ARGUMENT, "null argument");

@@ -2033,8 +2033,6 @@ hipError_t CholStructure::build(int nb_, const std::vector<std::pair<int, int>>&
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_merges), std::max<size_t>(merges.size(), 1) * sizeof(CholMerge));
   if (e == hipSuccess && !merges.empty())
     e = copy_h2d_staged(d_merges, merges.data(), merges.size() * sizeof(CholMerge), st);
-  if (e == hipSuccess && shadow_doubles)
-    e = device_alloc(reinterpret_cast<void**>(&d_shadow), shadow_doubles * sizeof(double));
   if (e == hipSuccess) e = device_alloc(reinterpret_cast<void**>(&d_tile_slot), tile_slot.size() * sizeof(int));
   if (e == hipSuccess) e = copy_h2d_staged(d_tile_slot, tile_slot.data(), tile_slot.size() * sizeof(int), st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging vectors go out of scope
@@ -2083,7 +2081,10 @@ hipError_t CholStructure::build_persistent(const std::vector<std::vector<int>>& 
   static const int mode = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST"); return e ? std::atoi(e) : 1; }();
   const bool enabled = mode != 0;
   static const int grid_cap = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST_GRID"); return e ? std::atoi(e) : 0; }();
-  if (!enabled || nb < 1 || nb > 512) return hipSuccess;  // (dense tile-id table)
+  static const int max_nb = [] { const char* e = std::getenv("MAVBA_CHOL_PERSIST_MAX_NB"); return e ? std::atoi(e) : 1024; }();
+  // (round 6: 512 -> 1024 tile columns - the old limit belonged to a dense tile table; a 10 000-image scene, 943 columns: 64.7 ->
+  // 44.6 ms per LM iteration, the builder takes 55 ms of a 1.2 s set-up, profiles/r06_scale_probe.txt)
+  if (!enabled || nb < 1 || nb > max_nb) return hipSuccess;  // (larger systems: the launch-per-panel schedule; the builder below is O(updates))
   int G = host_only ? host_only_cus : device_cu_count();
   if (grid_cap > 0) G = std::min(G, grid_cap);
   // ---- tiles with a 'published' flag: diagonal, coupled rows, right-hand-side row of every column ----
@@ -2721,7 +2722,21 @@ bool dense_spd_solve_device(hipStream_t st, double* M, int n_pad, double* y, dou
       }
     }
   } else {
-  if (cs.shadow_doubles) (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);
+  if (cs.shadow_doubles) {
+    // the shadow blocks of the concurrent fronts - dense over the ancestors' tile range, far larger than the tile store itself -
+    // exist only once this schedule really runs (round 6; rounds 3-5 allocated them with the structure: 5 GB at C5 that the
+    // persistent launch never touched)
+    if (!cs.d_shadow && device_alloc(reinterpret_cast<void**>(&cs.d_shadow), cs.shadow_doubles * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      cs.d_shadow = nullptr;
+      static const double kNoMemory = 1e30;  // (reported like a time-out of the persistent launch: the step is invalid, nothing is read from a null block)
+      std::fprintf(stderr, "mavba: out of device memory for the launch-per-panel factorisation's shadow blocks (%.1f GB)\n", cs.shadow_doubles * 8e-9);
+      (void)hipMemcpyAsync(fail, &kNoMemory, sizeof(double), hipMemcpyHostToDevice, st);
+      if (after_factor) (void)hipEventRecord(after_factor, st);
+      return false;
+    }
+    (void)hipMemsetAsync(cs.d_shadow, 0, cs.shadow_doubles * sizeof(double), st);
+  }
   static const int fuse_below = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE"); return e ? std::atoi(e) : kFuseBelow; }();  // tuning knobs
   static const int fuse_tasks = [] { const char* e = std::getenv("MAVBA_CHOL_FUSE_TASKS"); return e ? std::atoi(e) : kFuseTasks; }();
   hipLaunchKernelGGL(k_chol_diag0, dim3(cs.num_leaf_init), dim3(256), 0, st, M, slot, nb, cs.d_init, inv, fail, cs.d_flags, nb);

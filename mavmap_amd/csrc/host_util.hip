@@ -260,7 +260,9 @@ Parked& parked() { static Parked* p = new Parked; return *p; }
 // that reads the destinations is enqueued before the flush - the host-only set-up path of small problems (session_build.hip).
 namespace {
 struct UploadSeg { unsigned long long dst; long long src; unsigned bytes; unsigned pad; };  // src < 0: zeros
-constexpr size_t kBatchArena = (size_t)2 << 20, kBatchZeroMax = (size_t)1 << 20, kBatchPiece = (size_t)16 << 10;
+constexpr size_t kBatchArenaDefault = (size_t)2 << 20, kBatchZeroMax = (size_t)1 << 20, kBatchPiece = (size_t)16 << 10;
+size_t g_batch_arena = kBatchArenaDefault;  // (mavba_debug_upload_batch shrinks it: the arena-full path)
+#define kBatchArena g_batch_arena
 struct UploadBatch {
   hipStream_t st = nullptr;
   char* host = nullptr;
@@ -307,12 +309,13 @@ hipError_t batch_emit(UploadBatch& B) {
   B.host = nullptr; B.used = 0; B.segs.clear();
   return e;
 }
-constexpr size_t batch_table_room() { return (kBatchArena / 256 + kBatchArena / kBatchPiece + 64) * sizeof(UploadSeg); }
+size_t batch_table_room() { return (kBatchArena / 256 + kBatchArena / kBatchPiece + 64) * sizeof(UploadSeg); }
 // records one copy (src != nullptr) or clear; false = not taken (no arena): the caller issues it directly
 bool batch_add(UploadBatch& B, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return true;
   if ((reinterpret_cast<uintptr_t>(dst) & 3u) != 0) return false;
   const size_t need = src ? ((bytes + 15) & ~(size_t)15) : 0;
+  if (need > kBatchArena) return false;  // (does not fit an arena at all)
   const size_t max_segs = batch_table_room() / sizeof(UploadSeg);
   const size_t pieces = (bytes + kBatchPiece - 1) / kBatchPiece;
   // a destination written twice (a buffer freed and handed out again inside the batch): the pieces of one flush run side by
@@ -352,16 +355,24 @@ hipError_t upload_batch_end(bool emit) {
   delete B;
   return e;
 }
+void upload_batch_debug_arena(size_t bytes) { g_batch_arena = bytes ? bytes : kBatchArenaDefault; }
+// An operation the open batch does not take is issued directly - BEHIND what the batch holds (stream order as the caller wrote it).
+static void batch_flush_before_direct(hipStream_t st) {
+  if (g_batch && g_batch->st == st) (void)batch_emit(*g_batch);
+}
 hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
   if (g_batch && g_batch->st == st && bytes <= kBatchZeroMax && batch_add(*g_batch, p, nullptr, bytes)) return hipSuccess;
+  batch_flush_before_direct(st);
   return hipMemsetAsync(p, 0, bytes, st);
 }
 
 hipError_t copy_h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t st) {
   if (bytes < kStagedCopyMin) {
     if (g_batch && g_batch->st == st && batch_add(*g_batch, dst, src, bytes)) return hipSuccess;
+    batch_flush_before_direct(st);
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
   }
+  batch_flush_before_direct(st);
   for (size_t off = 0; off < bytes; off += kStagedChunk) {
     const size_t len = std::min(kStagedChunk, bytes - off);
     void* stage = nullptr;

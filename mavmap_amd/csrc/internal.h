@@ -380,6 +380,7 @@ void release_staged(hipStream_t st);  // call behind a synchronisation of st
 bool upload_batch_begin(hipStream_t st);      // false: the thread already has one open (the outer one keeps collecting)
 hipError_t upload_batch_end(bool emit);
 hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
+void upload_batch_debug_arena(size_t bytes);  // tests: arena size of the batches that follow (0 = default)
 // host worker threads of the set-up passes (host_util.hip): body(0 .. T-1), T <= host_threads(); calls are serialised, never nest them
 int host_threads();
 void host_run(int T, const std::function<void(int)>& body);
@@ -444,7 +445,7 @@ struct CholStructure {
   unsigned* d_flags = nullptr;    // [nb] 'solution segment published' flags of the backward substitution
   CholFront* d_fronts = nullptr;
   CholMerge* d_merges = nullptr;
-  double* d_shadow = nullptr;
+  mutable double* d_shadow = nullptr;  // launch-per-panel schedule only: allocated by the first solve that takes it (C5: 5 GB, 10 000 images: 40 GB - a persistent session never needs it)
   // Tile store (round 6): slot of tile (i, k) = tile_slot[i * nb + k], i in [0, nb] (row nb: the right-hand side), -1 outside the
   // envelope; per column k: the diagonal tile, the coupled rows ascending, the right-hand-side tile. Also the index of the
   // tile's 'published' flag in the persistent launch.

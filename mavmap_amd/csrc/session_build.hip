@@ -652,8 +652,11 @@ void mavba_session::choose_elimination_order(const std::vector<SchurBlock>& bloc
   // 3.58 ms); since round 4 they run the persistent launch too and the rule was never revisited - round 6,
   // profiles/r06_nd_depth_sweep.txt: C5 at depth 3 has 8 concurrent fronts instead of 4 and 4 104 envelope tiles instead of
   // 5 041, k_chol_persist 1.96 -> 1.53 ms, 186 -> 203 LM iterations/s (a fourth level changes nothing at C5, C3 or C2: a split
-  // must pay). Depth 2 stays where the launch-per-panel schedule is certain (more than 512 tile columns).
-  if (tiles0 <= 512) max_depth = 3;
+  // must pay). Depth 2 stays where the launch-per-panel schedule is certain (more than MAVBA_CHOL_PERSIST_MAX_NB = 1024 tile columns).
+  {
+    const char* e = std::getenv("MAVBA_CHOL_PERSIST_MAX_NB");
+    if (tiles0 <= (e ? std::atoi(e) : 1024)) max_depth = 3;
+  }
   if (const char* e = std::getenv("MAVBA_ND_DEPTH")) max_depth = std::atoi(e);
   const bool can_dissect = NI >= 16 && tiles0 >= 8 && forced != 0 && forced != 1 && max_depth > 0 && (world == 1 || NI <= 4096);
   if (can_dissect) {

@@ -110,3 +110,14 @@ def test_window_setup_shortcuts_change_nothing(mavba, monkeypatch, kind):
     for a, b in zip(xa, xb):
         assert np.array_equal(a, b)
     assert np.array_equal(ea, eb, equal_nan=True)
+
+
+def test_batched_small_uploads_with_a_full_arena_and_destinations_written_twice(mavba):
+    """The upload batch of the small-problem set-up (csrc/host_util.hip) outside its usual sizes: an arena that fills up several
+    times over (pieces leave early, the batch stays open), buffers cleared after being written and uploaded twice (the earlier
+    write must leave first: the pieces of one flush run side by side), odd sizes (the tail bytes of a piece), empty buffers."""
+    rng = np.random.default_rng(5)
+    sizes = [int(x) for x in rng.integers(1, 40_000, size=60)]
+    sizes[7] = 0; sizes[11] = -3; sizes[12] = -70_001; sizes[20] = 131_071; sizes[21] = 1; sizes[22] = 16_385
+    assert mavba.debug_upload_batch(sizes, arena_bytes=64 << 10) == 0     # 64 KiB arena: ~15 flushes
+    assert mavba.debug_upload_batch(sizes, arena_bytes=0) == 0             # default arena: one flush (+ the overlaps)
