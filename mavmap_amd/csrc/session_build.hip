@@ -55,18 +55,44 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
   // point-major order is the buckets concatenated in the new point order.
   std::vector<int> pt_new(NP);
   std::vector<int> cstart;
-  HostBuf<long long> bucket(N);  // kept observation ids, grouped by caller's point, input order inside
+  // Small problems (serial anyway; round 6, a local window: 0.19 -> 0.15 ms): no buckets - ONE pass over the observations counts
+  // them per point and keeps every point's key up to date (the eight smallest distinct images and the hash do not depend on
+  // the order in which a point's observations arrive), and the point-major arrays are written by a second pass through
+  // per-point cursors (caller's order inside a point, as the stable counting sort gives it).
+  const bool streaming = N < 50000 && !std::getenv("MAVBA_ORDER_GENERAL");
+  HostBuf<long long> bucket(streaming ? 1 : N);  // kept observation ids, grouped by caller's point, input order inside
   // (pixel and image travel with it: the caller's arrays are read once, in order, instead of being gathered again)
-  HostBuf<double2> buv(N);
-  HostBuf<int> bimg(N);
+  HostBuf<double2> buv(streaming ? 1 : N);
+  HostBuf<int> bimg(streaming ? 1 : N);
   {
-    HostBuf<int> simg(N);
+    HostBuf<int> simg(streaming ? 1 : N);
+    HostBuf<unsigned short> k8(streaming ? (size_t)NP * 8 : 1);
+    std::vector<unsigned> hsum;
+    if (streaming) {
+      cstart.assign((size_t)NP + 1, 0);
+      hsum.assign(NP, 0u);
+      std::memset(k8.data(), 0xFF, (size_t)NP * 8 * sizeof(unsigned short));
+      for (long long k = 0; k < N; ++k) {
+        const long long o = kept_at(k);
+        const int p = P->obs_point[o];
+        unsigned x = (unsigned)P->obs_image[o];
+        cstart[(size_t)p + 1]++;
+        hsum[p] += image_set_mix(x);
+        unsigned short* kk = &k8[(size_t)p * 8];
+        bool dup = false;
+        for (int t = 0; t < 8; ++t) dup = dup || kk[t] == x;
+        if (dup) continue;
+        for (int t = 0; t < 8; ++t) if (x < kk[t]) { const unsigned y = kk[t]; kk[t] = (unsigned short)x; x = y; }
+      }
+      for (int p = 0; p < NP; ++p) cstart[(size_t)p + 1] += cstart[p];
+    } else {
     counting_sort_parallel(N, NP, [&](long long k) { return P->obs_point[kept_at(k)]; }, cstart,
                            [&](long long k, int at) {
                              const long long o = kept_at(k);
                              bucket[at] = o; simg[at] = bimg[at] = P->obs_image[o];
                              buv[at] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
                            });
+    }
       if (all_kept)
       for (int p = 0; p < NP; ++p) { h_pt_count_all[p] = cstart[p + 1] - cstart[p]; h_pt_used[p] = h_pt_count_all[p] > 0; }
     lap("buckets by point");
@@ -85,7 +111,8 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
       for (long long p = b0; p < b1; ++p) {
         unsigned k[8] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
         unsigned hash = 0;
-        for (int a2 = cstart[p]; a2 < cstart[p + 1]; ++a2) {
+        if (streaming) { for (int t = 0; t < 8; ++t) k[t] = k8[(size_t)p * 8 + t]; hash = hsum[p]; }
+        else for (int a2 = cstart[p]; a2 < cstart[p + 1]; ++a2) {
           unsigned x = (unsigned)simg[a2];
           hash += image_set_mix(x);
           bool dup = false;
@@ -196,6 +223,16 @@ void mavba_session::order_on_host(const mavba_problem* P, const long long* keptp
   PinnedBuf<double2>& uv = *uv_h;
   PinnedBuf<int>& opt_ = *opt_h;
   h_oimg.resize(N);
+  if (streaming) {
+    std::vector<int> cursor(h_pt_start.begin(), h_pt_start.end() - 1);
+    for (long long k = 0; k < N; ++k) {
+      const long long o = kept_at(k);
+      const int q = pt_new[P->obs_point[o]], a = cursor[q]++;
+      perm[a] = o;
+      uv[a] = make_double2(P->obs_uv[2 * o], P->obs_uv[2 * o + 1]);
+      h_oimg[a] = P->obs_image[o]; opt_[a] = q;
+    }
+  } else
   parallel_ranges(NP, [&](long long q0, long long q1) {
     for (long long q = q0; q < q1; ++q) {
       const int src = cstart[h_pt_orig[q]], cnt = h_pt_start[q + 1] - h_pt_start[q];
@@ -1368,7 +1405,8 @@ void mavba_session::finish_structure() {
   // long partial runs are pre-reduced in groups of 32 into extra slots; the block then points at those (launch-bound
   // problems - a local window has ~80 clusters - keep runs of up to 256 for the finalize pass itself: one launch less)
   std::vector<PartialReduce> reduce_tasks;
-  const int kPreReduceFrom = N < 200000 ? 256 : 64;
+  int kPreReduceFrom = N < 200000 ? 256 : 64;
+  if (const char* e = std::getenv("MAVBA_PRE_REDUCE_FROM")) kPreReduceFrom = std::max(32, std::atoi(e));  // tuning knob
   for (SchurBlock& B : blocks) {
     const int n = B.chunk_end - B.chunk_begin;
     if (n <= kPreReduceFrom) continue;

@@ -321,7 +321,7 @@ void mavba_session::candidate_enqueue(double r, ReduceTasks* tail, int* tail_cou
   // of a block's points are in its caches, the new points in its LDS -, one launch less: a 10-image window 2.30 -> 2.19 ms. At
   // C3 / C5 the streaming k_cost_only is the faster way to do that pass (0.091 + 0.023 against 0.123 ms), so large problems keep
   // it. MAVBA_COST_FUSE_MAX_OBS moves the switch, 0 = never fuse)
-  static const long long fuse_max_obs = [] { const char* e = std::getenv("MAVBA_COST_FUSE_MAX_OBS"); return e ? std::atoll(e) : 200000ll; }();
+  static const long long fuse_max_obs = [] { const char* e = std::getenv("MAVBA_COST_FUSE_MAX_OBS"); return e ? std::atoll(e) : 500000ll; }();  // (round 6: 200 000 -> 500 000 - C2, 300 000 observations: 4 058 -> 4 109 iter/s fused, A/B/A/B)
   const bool cost_separate = (long long)N > fuse_max_obs;
   timed("backsub_points", [&] {
     launch_backsub_points_jvp(st, NP, NPs, NI, r, dmin, dmax, sweep_args(d_camrec.p, d_intr.p, d_points.p), d_pt_start.p,
