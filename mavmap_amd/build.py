@@ -14,7 +14,7 @@ LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libmavba.so")
 OBJDIR = os.path.join(LIBDIR, "obj")
 SOURCES = ["kernels.hip", "schur_rows.hip", "dense_chol.hip", "pose_refine.hip", "host_util.hip", "session_build.hip", "session_lm.hip", "scene.hip", "multi_gpu.hip", "device_setup.hip", "api.hip"]
-HEADERS = ["ba_math.h", "dev_reduce.h", "internal.h", "session.h", "lm_decide.h", "lm_bodies.h", os.path.join("..", "..", "include", "mavba.h")]
+HEADERS = ["ba_math.h", "dev_reduce.h", "internal.h", "session.h", "lm_decide.h", "lm_bodies.h", "sweep_body.h", os.path.join("..", "..", "include", "mavba.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall",
          "-Wno-unused-result"]
 # Per-file additions. dense_chol.hip: matrix instructions with their accumulators in ordinary vector registers - the

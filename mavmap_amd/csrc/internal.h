@@ -277,7 +277,8 @@ int schur_partial_stride(int kind);
 // scripts/_dbg/pruned_r06.patch)
 void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, int num_clusters,
                        const SchurRowsCluster* clusters, const int* tab, const int* cl_lists, const unsigned short* obs_meta,
-                       const unsigned long long* lanemap, const unsigned* emit_map, double* part_pp, double* part_ip, double* part_ii);
+                       const unsigned long long* lanemap, const unsigned* emit_map, double* part_pp, double* part_ip, double* part_ii,
+                       const struct CamSweepArgs* with_sweep = nullptr /* local windows, constant intrinsics: the camera sweep's chunks as extra work-groups of this launch */);
 // The emit map of a cluster shape (host): for pass 0 and pass 1, in the order the lanes walk them, one rows_emit_entry per
 // element of the block partials the shape can touch - pose x pose (42 per image pair: the 6 x 6 block, lower triangle only on
 // the diagonal, + the h row's 6 on the diagonal), intrinsics x pose (54), intrinsics x intrinsics (90: 9 x 9 + the h row's 9).

@@ -33,6 +33,7 @@
 #include "ba_math.h"
 #include "dev_reduce.h"
 #include "lm_decide.h"
+#include "sweep_body.h"
 
 // MAVBA_ROWS_SKIP (debug builds only, scripts/_dbg/rows_variants.sh): bit mask of parts left out to time the rest - wrong results.
 #ifndef MAVBA_ROWS_SKIP
@@ -226,11 +227,16 @@ __device__ __forceinline__ void f2_write_blocks(const double* __restrict__ T, in
 // fewer - with both forms in one kernel the common one spilt ~70 registers per lane).
 // One launch for all row classes: the cluster's row count selects the instantiation of the batch loop (the registers and
 // the LDS of the kernel are those of the largest class either way: two work-groups per CU).
-template <int KMAX, bool GENERIC, bool TRACE = false>
+// SWEEP (round 6, local windows with constant intrinsics): work-groups behind the clusters' run the camera sweep's chunks
+// (camera_sweep_body<0>, sweep_body.h) - the evaluation's other pass over the observations, independent of this one - so that
+// a 65 us iteration has one launch less; the sweep's LDS scratch is this kernel's entry matrix.
+struct RowsSweep { CamSweepArgs cs; int first; };  // first: number of cluster work-groups in front of the sweep's
+template <int KMAX, bool GENERIC, bool TRACE = false, bool SWEEP = false>
 __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
     FrontArgs a, const SchurRowsCluster* __restrict__ clusters, const int* __restrict__ tabs, const int* __restrict__ cl_lists,
     const unsigned short* __restrict__ obs_meta, const unsigned long long* __restrict__ lanemap,
-    const unsigned* __restrict__ emit_map, double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii) {
+    const unsigned* __restrict__ emit_map, double* __restrict__ part_pp, double* __restrict__ part_ip, double* __restrict__ part_ii,
+    RowsSweep sweep) {
   using SHMAX = F2Shape<kRowsClassNT[kRowsClasses - 1]>;
   if (!lm_spec_go(a.spec, &a.radius)) return;  // (speculative evaluation: only behind an accepted step, with the radius it leaves)
   long long t_entry = 0, t_loop0 = 0, t_loop1 = 0;  // (TRACE: the cluster's time line - entry, tables ready, batches done, end)
@@ -240,6 +246,10 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   __shared__ double s_rec[kClImagesMax][9], s_kin[kClImagesMax][9], s_sc[kClImagesMax][6], s_ksc[kClCamsMax][9];
   __shared__ int s_icam[kClImagesMax], s_model[kClImagesMax], s_lc[kClImagesMax], s_clcam[4];
   __shared__ __attribute__((aligned(16))) double E[SHMAX::rows * kF2Pitch];
+  if constexpr (SWEEP) {
+    static_assert(kF2Threads == 256 && SHMAX::rows * kF2Pitch >= 4 * kSweepAcc, "the sweep's chunk layout and scratch");
+    if ((int)blockIdx.x >= sweep.first) { camera_sweep_body<0>(sweep.cs, (int)blockIdx.x - sweep.first, E); return; }
+  }
   __shared__ double s_red[kF2Waves];
   __shared__ double* s_dst[kF2Tab];  // the cluster's block partials by slot-table index (null: block not touched)
   __shared__ int s_pstart[kRowsMaxPoints + 1];
@@ -631,8 +641,18 @@ void rows_emit_map(int ni, int nc, int flags, std::vector<unsigned>& pass0, std:
 // generic: some cluster has three camera slots (the 9-parameter model always takes the general form of the intrinsics entries).
 void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool generic, int num_clusters,
                        const SchurRowsCluster* clusters, const int* tab, const int* cl_lists, const unsigned short* obs_meta,
-                       const unsigned long long* lanemap, const unsigned* emit_map, double* part_pp, double* part_ip, double* part_ii) {
+                       const unsigned long long* lanemap, const unsigned* emit_map, double* part_pp, double* part_ip, double* part_ii,
+                       const CamSweepArgs* with_sweep) {
   if (num_clusters <= 0) return;
+  RowsSweep sweep{};
+  sweep.first = num_clusters;
+  if (with_sweep) {
+    // (constant intrinsics only: camera_sweep_body<0>; the caller asks for it on local windows)
+    sweep.cs = *with_sweep;
+    hipLaunchKernelGGL((k_schur_rows<0, true, false, true>), dim3(num_clusters + with_sweep->num_chunks), dim3(kF2Threads), 0, st, a, clusters, tab,
+                       cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii, sweep);
+    return;
+  }
   // MAVBA_ROWS_TRACE=<file>: the 5th launch of the process (widest model <= 8) records s_memtime stamps per wave
   static const char* trace_file = std::getenv("MAVBA_ROWS_TRACE");
   static int trace_calls = 0;
@@ -643,7 +663,7 @@ void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool g
     (void)hipMemsetAsync(tr, 0, trace_n * 8, st);
     FrontArgs b = a;
     b.trace = tr;
-    hipLaunchKernelGGL((k_schur_rows<8, false, true>), dim3(num_clusters), dim3(kF2Threads), 0, st, b, clusters, tab, cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii);
+    hipLaunchKernelGGL((k_schur_rows<8, false, true>), dim3(num_clusters), dim3(kF2Threads), 0, st, b, clusters, tab, cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii, sweep);
     std::vector<long long> hst(trace_n);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(hst.data(), tr, trace_n * 8, hipMemcpyDeviceToHost);
@@ -663,7 +683,7 @@ void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool g
     }
     return;
   }
-#define MAVBA_ROWS(K, G) hipLaunchKernelGGL((k_schur_rows<K, G>), dim3(num_clusters), dim3(kF2Threads), 0, st, a, clusters, tab, cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii)
+#define MAVBA_ROWS(K, G) hipLaunchKernelGGL((k_schur_rows<K, G>), dim3(num_clusters), dim3(kF2Threads), 0, st, a, clusters, tab, cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii, sweep)
   if (kmax_intr <= 0) MAVBA_ROWS(0, true);
   else if (kmax_intr <= 4) { if (generic) MAVBA_ROWS(4, true); else MAVBA_ROWS(4, false); }
   else if (kmax_intr <= 8) { if (generic) MAVBA_ROWS(8, true); else MAVBA_ROWS(8, false); }

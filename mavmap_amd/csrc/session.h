@@ -350,6 +350,7 @@ struct mavba_session {
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
+  bool sweep_rode_along = false; // the last launch_front carried the camera sweep's chunks (k_schur_rows<.., SWEEP>): no separate sweep launch
   bool setup_batched = false;    // build() collects the set-up's small uploads (upload_batch_begin): finish_structure does not synchronise
   bool M_is_clean = false;       // d_M holds zeros outside the entries the assembly writes
   // cleared when a persistent factorisation launch had to give up; a session created within the next
@@ -502,7 +503,7 @@ void intr_entries_on_device(const std::vector<unsigned char>& cam_active, std::v
   // candidate point - every kernel returns at once unless k_lm_snapshot accepted the step, the front end takes the radius
   // from its decision (next_radius only says "with entries")
   void evaluate_enqueue(double next_radius = -1.0, const LmSpec& spec = lm_spec_off());
-  void launch_front(double r, bool entries, const LmSpec& spec = lm_spec_off());
+  void launch_front(double r, bool entries, const LmSpec& spec = lm_spec_off(), const CamSweepArgs* with_sweep = nullptr);
   // ---- speculative evaluation (lm_decide.h) ----
   DevBuf<double> d_lm_dec;       // {code, radius} of k_lm_snapshot's decision
   double* lm_pub = nullptr;      // host-mapped slot the snapshot kernel publishes to (null: the copy + synchronise read-back)

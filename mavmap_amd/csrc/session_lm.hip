@@ -37,7 +37,8 @@ void mavba_session::ensure_planes() {
 
 // The J-free front end at the current x: cost partials, Cu, gu and - with `entries` - the points' factors and the Schur
 // entry records for trust-region radius r.
-void mavba_session::launch_front(double r, bool entries, const LmSpec& spec) {
+void mavba_session::launch_front(double r, bool entries, const LmSpec& spec, const CamSweepArgs* with_sweep) {
+  sweep_rode_along = false;
   FrontArgs f;
   f.spec = spec;
   f.sw = sweep_args(d_camrec.p, d_intr.p, d_points.p);
@@ -55,10 +56,13 @@ void mavba_session::launch_front(double r, bool entries, const LmSpec& spec) {
   if (entries && fused_now()) {
     // every observed point sits in a cluster: the cluster kernel evaluates the Jacobians itself and leaves the block
     // partials of S for this radius (no entry records in HBM)
+    // (a local window with constant intrinsics: the camera sweep's chunks ride along as extra work-groups - one launch less)
+    const CamSweepArgs* ride = (with_sweep && Q == 0 && !any_intr_free) ? with_sweep : nullptr;
     timed("schur_fused", [&] {
       launch_schur_rows(st, f, Q > 0 ? KMAX : 0, rows_generic, num_clusters, d_rows_clusters.p, d_cl_tab.p, d_rows_lists.p, d_obs_meta.p,
-                        d_rows_lanes.p, d_rows_emit.p, d_part[0].p, d_part[1].p, d_part[2].p);
+                        d_rows_lanes.p, d_rows_emit.p, d_part[0].p, d_part[1].p, d_part[2].p, ride);
     });
+    sweep_rode_along = ride != nullptr;
     eval_rows = num_clusters;
     if (num_tail_tiles > 0) {
       // the points behind the clusters (long tracks with their generic term lists, constant points): sums, factors and
@@ -81,9 +85,17 @@ void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
   if (!camrec_current) timed("cam_prepare", [&] { launch_cam_prepare(st, NI, d_poses.p, d_camrec.p); });
   camrec_current = true;
   SweepArgs a = sweep_args(d_camrec.p, d_intr.p, d_points.p);
+  CamSweepArgs c;
+  c.NI = NI; c.NC = NC; c.chunks = d_sweep_chunks.p; c.num_chunks = num_sweep_chunks;
+  c.im_uv = d_im_uv.p; c.im_pt = d_im_pt.p; c.camrec = d_camrec.p; c.intr = d_intr.p;
+  c.img_cam = d_img_cam.p; c.cam_model = d_cam_model.p; c.points = d_points.p;
+  c.pt_active = a.pt_active;
+  c.loss_b = a.loss_b; c.loss_inv_b = a.loss_inv_b; c.partial = d_cam_partial.p;
+  c.spec = spec;
+  sweep_rode_along = false;
   if (front_ok) {
     // one pass: the evaluation's sums and (once the Jacobi scales exist and the next radius is known) the entries
-    launch_front(next_radius, scales_ready && next_radius > 0.0, spec);
+    launch_front(next_radius, scales_ready && next_radius > 0.0, spec, scales_ready && merge_small() && num_sweep_chunks > 0 ? &c : nullptr);
   } else {
     ensure_planes();
     front_valid = false;
@@ -93,14 +105,7 @@ void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
                           d_R.p, d_Jp.p, d_Jk.p, d_Cu.p, d_gu.p, d_Wk.p);
     });
   }
-  CamSweepArgs c;
-  c.NI = NI; c.NC = NC; c.chunks = d_sweep_chunks.p; c.num_chunks = num_sweep_chunks;
-  c.im_uv = d_im_uv.p; c.im_pt = d_im_pt.p; c.camrec = d_camrec.p; c.intr = d_intr.p;
-  c.img_cam = d_img_cam.p; c.cam_model = d_cam_model.p; c.points = d_points.p;
-  c.pt_active = a.pt_active;
-  c.loss_b = a.loss_b; c.loss_inv_b = a.loss_inv_b; c.partial = d_cam_partial.p;
-  c.spec = spec;
-  timed("camera_sweep", [&] { launch_camera_sweep(st, c, KMAX, any_intr_free); });
+  if (!sweep_rode_along) timed("camera_sweep", [&] { launch_camera_sweep(st, c, KMAX, any_intr_free); });
   if (num_priors > 0)
     timed("rot_prior", [&] {
       launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_poses.p, d_prior_res.p,
