@@ -245,10 +245,16 @@ __global__ void __launch_bounds__(kF2Threads, 2) k_schur_rows(
   // slots; -1 padded): camera records, intrinsics and column scales are read from memory once per cluster
   __shared__ double s_rec[kClImagesMax][9], s_kin[kClImagesMax][9], s_sc[kClImagesMax][6], s_ksc[kClCamsMax][9];
   __shared__ int s_icam[kClImagesMax], s_model[kClImagesMax], s_lc[kClImagesMax], s_clcam[4];
-  __shared__ __attribute__((aligned(16))) double E[SHMAX::rows * kF2Pitch];
+  // (SWEEP with free intrinsics: the Gram form's rows need 70 KB - still two work-groups per CU)
+  constexpr int kELen = (SWEEP && KMAX > 0 && kCsLdsDoubles > SHMAX::rows * kF2Pitch) ? kCsLdsDoubles : SHMAX::rows * kF2Pitch;
+  __shared__ __attribute__((aligned(16))) double E[kELen];
   if constexpr (SWEEP) {
     static_assert(kF2Threads == 256 && SHMAX::rows * kF2Pitch >= 4 * kSweepAcc, "the sweep's chunk layout and scratch");
-    if ((int)blockIdx.x >= sweep.first) { camera_sweep_body<0>(sweep.cs, (int)blockIdx.x - sweep.first, E); return; }
+    if ((int)blockIdx.x >= sweep.first) {
+      if constexpr (KMAX == 0) camera_sweep_body<0>(sweep.cs, (int)blockIdx.x - sweep.first, E);
+      else camera_sweep_gram_body<KMAX>(sweep.cs, (int)blockIdx.x - sweep.first, E);
+      return;
+    }
   }
   __shared__ double s_red[kF2Waves];
   __shared__ double* s_dst[kF2Tab];  // the cluster's block partials by slot-table index (null: block not touched)
@@ -647,10 +653,16 @@ void launch_schur_rows(hipStream_t st, const FrontArgs& a, int kmax_intr, bool g
   RowsSweep sweep{};
   sweep.first = num_clusters;
   if (with_sweep) {
-    // (constant intrinsics only: camera_sweep_body<0>; the caller asks for it on local windows)
+    // (the caller asks for it on local windows; the sweep's form follows the widest model like launch_camera_sweep's: the vector
+    // kernel's body without free intrinsics, the Gram form's with)
     sweep.cs = *with_sweep;
-    hipLaunchKernelGGL((k_schur_rows<0, true, false, true>), dim3(num_clusters + with_sweep->num_chunks), dim3(kF2Threads), 0, st, a, clusters, tab,
-                       cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii, sweep);
+#define MAVBA_ROWS_SWEEP(K, G) hipLaunchKernelGGL((k_schur_rows<K, G, false, true>), dim3(num_clusters + with_sweep->num_chunks), dim3(kF2Threads), 0, st, a, \
+                                                 clusters, tab, cl_lists, obs_meta, lanemap, emit_map, part_pp, part_ip, part_ii, sweep)
+    if (kmax_intr <= 0) MAVBA_ROWS_SWEEP(0, true);
+    else if (kmax_intr <= 4) { if (generic) MAVBA_ROWS_SWEEP(4, true); else MAVBA_ROWS_SWEEP(4, false); }
+    else if (kmax_intr <= 8) { if (generic) MAVBA_ROWS_SWEEP(8, true); else MAVBA_ROWS_SWEEP(8, false); }
+    else MAVBA_ROWS_SWEEP(9, true);
+#undef MAVBA_ROWS_SWEEP
     return;
   }
   // MAVBA_ROWS_TRACE=<file>: the 5th launch of the process (widest model <= 8) records s_memtime stamps per wave

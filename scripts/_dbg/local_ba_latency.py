@@ -16,6 +16,17 @@ for rep in range(60):
     su.append(res["setup_seconds"]); so.append(res["solve_seconds"])
 it = res["num_successful_steps"] + res["num_unsuccessful_steps"]
 print("mavba_solve: median %.3f ms, min %.3f ms, iterations %d, setup median %.3f ms (min %.3f), solve median %.3f ms" % (1e3 * np.median(ts[5:]), 1e3 * min(ts), it, 1e3 * np.median(su[5:]), 1e3 * min(su), 1e3 * np.median(so[5:])))
+# the reference's default for local BA refines the intrinsics as well (mapper.cc:883, local-ba-refine-camera-params = true)
+pr = synth.make_scene(num_images=10, num_points=2500, track_len=4, models=[A.MODEL_OPENCV], seed=3, refine_camera_params=True)
+pr.pose_const[:2] = A.CONST_POSE
+ts, su, so = [], [], []
+for rep in range(60):
+    q = pr.copy()
+    t = time.perf_counter(); cost, res = mavmap_amd.bundle_adjustment(q, opts); ts.append(time.perf_counter() - t)
+    su.append(res["setup_seconds"]); so.append(res["solve_seconds"])
+it = res["num_successful_steps"] + res["num_unsuccessful_steps"]
+print("mavba_solve, free intrinsics: median %.3f ms, min %.3f ms, iterations %d, setup median %.3f ms (min %.3f), solve median %.3f ms (%.1f us / iteration)" % (
+    1e3 * np.median(ts[5:]), 1e3 * min(ts), it, 1e3 * np.median(su[5:]), 1e3 * min(su), 1e3 * np.median(so[5:]), 1e6 * np.median(so[5:]) / max(it, 1)))
 with mavmap_amd.Session(p, dict(opts, profile_kernels=1)) as s:
     t = time.perf_counter(); s.iterate(1000); dt = time.perf_counter() - t
     print("session solve with event timers %.3f ms" % (1e3 * dt))
