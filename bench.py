@@ -434,6 +434,10 @@ def main():
                 ach = amount / (v["avg_ms"] * 1e-3) / 1e12
                 row.update(bound="mfma", achieved=round(ach, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                            frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4), algorithmic_flops=amount)
+            if name == "schur_fused" and per.get("camera_sweep", {}).get("launches", 0) * 2 < v["launches"]:
+                # (problems of up to 1 M observations: csrc/session_lm.hip, MAVBA_SWEEP_RIDE_MAX_OBS)
+                row["note"] = ("this launch also runs the camera sweep's chunks as extra work-groups (no separate k_camera_sweep "
+                               "launch per evaluation); achieved / frac still price the Schur-formation flops alone")
             table.append(row)
             log("  {kernel:18s} n={launches:5d} avg={avg_ms:9.4f} ms share={share:6.1%}  ".format(**row) +
                 (f"{row['achieved']} {row['unit']} ({row['frac']:.1%} of {row['bound']} peak)" if bound else ""))

@@ -98,7 +98,13 @@ void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
   sweep_rode_along = false;
   if (front_ok) {
     // one pass: the evaluation's sums and (once the Jacobi scales exist and the next radius is known) the entries
-    launch_front(next_radius, scales_ready && next_radius > 0.0, spec, scales_ready && merge_small() && num_sweep_chunks > 0 ? &c : nullptr);
+    // Beyond local windows, up to MAVBA_SWEEP_RIDE_MAX_OBS observations (default 1 000 000): the sweep's chunks fill the tail of the
+    // cluster launch - C2 4 095 -> 4 184 LM iterations/s, A/B/A/B, profiles/r06_ab_sweep_ride.txt. At C3 the merged launch is 19 us
+    // shorter than the two (1 285 -> 1 310 iter/s) and it stays OFF there by default: the cluster kernel is that configuration's
+    // dominant kernel and its roofline figures (time, flops, counters) are only meaningful for the kernel on its own; C5: no gain.
+    static const long long ride_max_obs = [] { const char* e = std::getenv("MAVBA_SWEEP_RIDE_MAX_OBS"); return e ? std::atoll(e) : 1000000ll; }();
+    const bool ride = scales_ready && num_sweep_chunks > 0 && (merge_small() || (merge_on && !sharded() && N <= ride_max_obs));
+    launch_front(next_radius, scales_ready && next_radius > 0.0, spec, ride ? &c : nullptr);
   } else {
     ensure_planes();
     front_valid = false;
