@@ -21,3 +21,4 @@ timeout 60 scripts/_dbg/pipe_bench > $OUT/pipe_bench_fp64.txt 2>&1
 timeout 60 scripts/_dbg/issue_bench > $OUT/issue_bench.txt 2>&1
 MAVBA_CHOL_TRACE=$OUT/chol_trace_raw.txt timeout 300 python scripts/chol_trace.py C2 > $OUT/chol_trace_C2.txt 2>&1; rm -f $OUT/chol_trace_raw.txt
 ls -la $OUT
+timeout 200 python scripts/_dbg/window_setup.py > $OUT/window_setup.log 2>&1
