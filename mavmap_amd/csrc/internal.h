@@ -42,6 +42,9 @@ struct SchurBlock {
 struct SchurChunk { int begin; int end; int slot; };
 // Pre-reduction of a long run of partials of one block: partial[dst] = sum partial[src_begin..src_end) (fixed order)
 struct PartialReduce { int kind, src_begin, src_end, dst; };
+// The pre-reduction's tasks as EXTRA work-groups of an evaluation kernel that runs right behind the cluster kernel and does not
+// depend on it (k_camera_reduce_img / k_eval_head, round 6): one launch less per linear solve. n == 0: nothing rides.
+struct PartialRide { int n = 0; const PartialReduce* tasks = nullptr; double* pp = nullptr; double* ip = nullptr; double* ii = nullptr; };
 void launch_partial_reduce(hipStream_t st, int num_tasks, const PartialReduce* tasks, double* part_pp, double* part_ip,
                            double* part_ii);  // term range; slot = index of the partial it writes
 
@@ -239,7 +242,7 @@ void launch_camera_sweep(hipStream_t st, const CamSweepArgs& a, int kmax, bool a
 void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_start,
                           const double* partial, const int* prior_start, const double* prior_res,
                           const double* prior_jac, const int* cam_img_start, const int* cam_imgs,
-                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams = true, const LmSpec& spec = lm_spec_off());
+                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams = true, const LmSpec& spec = lm_spec_off(), const PartialRide& ride = PartialRide());
 void launch_rot_prior(hipStream_t st, int n, const int* prior_img, const double* prior_R0, double w,
                       const double* poses, double* res, double* jac, double* cost_partial, const LmSpec& spec = lm_spec_off());
 
@@ -354,6 +357,7 @@ struct EvalSmallArgs {
   const unsigned char* pose_free; const unsigned char* intr_free; const unsigned char* pt_free;
   const double* poses; const double* intr; const double* points; const double* gu; double* norm_partial;
   ReduceTasks T; LmSpec spec;
+  PartialRide ride;  // k_eval_head only
 };
 void launch_eval_small(hipStream_t st, const EvalSmallArgs& a);
 // the same for problems of any size, as TWO launches (round 5): per-image sums and the points' norm groups side by side

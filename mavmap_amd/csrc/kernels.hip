@@ -838,11 +838,13 @@ void launch_rot_prior(hipStream_t st, int n, const int* prior_img, const double*
 
 // Per image: sum its chunks (fixed order) + its rotation priors -> img_rec[81] and
 // the image's intrinsics part -> img_intr_tmp[54]. One 64-lane group per image (camera_reduce_img_body, lm_bodies.h).
+__device__ void partial_reduce_task(const PartialReduce T, int lane, double* part_pp, double* part_ip, double* part_ii);  // (below, with k_partial_reduce)
 __global__ void __launch_bounds__(64) k_camera_reduce_img(
     int NI, const int* __restrict__ img_chunk_start, const double* __restrict__ partial,
     const int* __restrict__ prior_start, const double* __restrict__ prior_res,
-    const double* __restrict__ prior_jac, double* __restrict__ img_rec, double* __restrict__ img_intr_tmp, LmSpec spec) {
+    const double* __restrict__ prior_jac, double* __restrict__ img_rec, double* __restrict__ img_intr_tmp, LmSpec spec, PartialRide ride) {
   if (!lm_spec_go(spec, nullptr)) return;
+  if ((int)blockIdx.x >= NI) { partial_reduce_task(ride.tasks[blockIdx.x - NI], threadIdx.x, ride.pp, ride.ip, ride.ii); return; }
   camera_reduce_img_body(blockIdx.x, threadIdx.x, img_chunk_start, partial, prior_start, prior_res, prior_jac, img_rec, img_intr_tmp);
 }
 // Per camera: sum the intrinsics parts of its images (fixed order: 16 interleaved partial sums
@@ -881,10 +883,10 @@ __global__ void __launch_bounds__(1024) k_camera_reduce_cam(
 void launch_camera_reduce(hipStream_t st, int NI, int NC, const int* img_chunk_start,
                           const double* partial, const int* prior_start, const double* prior_res,
                           const double* prior_jac, const int* cam_img_start, const int* cam_imgs,
-                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams, const LmSpec& spec) {
-  if (NI > 0)
-    hipLaunchKernelGGL(k_camera_reduce_img, dim3(NI), dim3(64), 0, st, NI, img_chunk_start, partial,
-                       prior_start, prior_res, prior_jac, img_rec, img_intr_tmp, spec);
+                          double* img_rec, double* cam_rec, double* img_intr_tmp, bool with_cams, const LmSpec& spec, const PartialRide& ride) {
+  if (NI > 0 || ride.n > 0)
+    hipLaunchKernelGGL(k_camera_reduce_img, dim3(NI + ride.n), dim3(64), 0, st, NI, img_chunk_start, partial,
+                       prior_start, prior_res, prior_jac, img_rec, img_intr_tmp, spec, ride);
   if (NC > 0 && with_cams)  // (no free intrinsics: nobody reads the per-camera sums, they stay zero)
     hipLaunchKernelGGL(k_camera_reduce_cam, dim3(NC), dim3(1024), 0, st, cam_img_start, cam_imgs, img_intr_tmp, cam_rec, spec);
 }
@@ -1574,15 +1576,18 @@ __device__ __forceinline__ double strided_sum16(const double* __restrict__ part,
   }
   return (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) + (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
 }
+// one task = one 64-lane group (also run as extra work-groups of k_camera_reduce_img / k_eval_head: PartialRide)
+__device__ void partial_reduce_task(const PartialReduce T, int lane, double* part_pp, double* part_ip, double* part_ii) {
+  double* part = T.kind == BLK_PP ? part_pp : T.kind == BLK_IP ? part_ip : part_ii;
+  const int PS = T.kind == BLK_PP ? 42 : T.kind == BLK_IP ? 54 : 90;
+  for (int idx = lane; idx < PS; idx += 64) part[(size_t)T.dst * PS + idx] = strided_sum16(part, PS, idx, T.src_begin, T.src_end);
+}
 __global__ void __launch_bounds__(256) k_partial_reduce(int num_tasks, const PartialReduce* __restrict__ tasks,
                                                         double* __restrict__ part_pp, double* __restrict__ part_ip,
                                                         double* __restrict__ part_ii) {
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (task >= num_tasks) return;
-  const PartialReduce T = tasks[task];
-  double* part = T.kind == BLK_PP ? part_pp : T.kind == BLK_IP ? part_ip : part_ii;
-  const int PS = T.kind == BLK_PP ? 42 : T.kind == BLK_IP ? 54 : 90;
-  for (int idx = lane; idx < PS; idx += 64) part[(size_t)T.dst * PS + idx] = strided_sum16(part, PS, idx, T.src_begin, T.src_end);
+  partial_reduce_task(tasks[task], lane, part_pp, part_ip, part_ii);
 }
 void launch_partial_reduce(hipStream_t st, int num_tasks, const PartialReduce* tasks, double* part_pp, double* part_ip,
                            double* part_ii) {
@@ -2053,6 +2058,11 @@ __global__ void __launch_bounds__(256) k_eval_head(EvalSmallArgs a, int img_bloc
     if (i < a.NI) camera_reduce_img_body(i, threadIdx.x & 63, a.img_chunk_start, a.cam_partial, a.prior_start, a.prior_res, a.prior_jac, a.img_rec, a.img_intr_tmp);
     return;
   }
+  if ((int)blockIdx.x >= img_blocks + a.gp) {  // (the pre-reduction's tasks riding along, four per work-group)
+    const int task = 4 * ((int)blockIdx.x - img_blocks - a.gp) + (threadIdx.x >> 6);
+    if (task < a.ride.n) partial_reduce_task(a.ride.tasks[task], threadIdx.x & 63, a.ride.pp, a.ride.ip, a.ride.ii);
+    return;
+  }
   state_norms_body(blockIdx.x - img_blocks, a.gp, a.gc, a.NI, a.NC, a.NP, a.NPs, a.cam_part, a.pose_free, a.intr_free, a.pt_free, a.poses, a.intr,
                    a.points, a.img_rec, a.cam_rec, a.gu, a.norm_partial, s_red);
 }
@@ -2096,7 +2106,7 @@ __global__ void __launch_bounds__(1024) k_eval_tail(EvalSmallArgs a) {
 }
 void launch_eval_head_tail(hipStream_t st, const EvalSmallArgs& a) {
   const int img_blocks = (a.NI + 3) / 4;
-  hipLaunchKernelGGL(k_eval_head, dim3(img_blocks + a.gp), dim3(256), 0, st, a, img_blocks);
+  hipLaunchKernelGGL(k_eval_head, dim3(img_blocks + a.gp + (a.ride.n + 3) / 4), dim3(256), 0, st, a, img_blocks);
   EvalSmallArgs b = a;
   b.first_group = a.gp;
   hipLaunchKernelGGL(k_eval_tail, dim3(1), dim3(1024), 0, st, b);

@@ -350,6 +350,7 @@ struct mavba_session {
   double* d_img_rec = nullptr;
   double* d_cam_rec = nullptr;
   CholStructure chol_struct;
+  bool prereduced = false;       // the long runs of the current block partials are pre-reduced (k_partial_reduce's tasks rode in the evaluation: PartialRide)
   bool sweep_rode_along = false; // the last launch_front carried the camera sweep's chunks (k_schur_rows<.., SWEEP>): no separate sweep launch
   bool setup_batched = false;    // build() collects the set-up's small uploads (upload_batch_begin): finish_structure does not synchronise
   bool M_is_clean = false;       // d_M holds zeros outside the entries the assembly writes

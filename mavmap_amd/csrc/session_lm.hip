@@ -39,6 +39,7 @@ void mavba_session::ensure_planes() {
 // entry records for trust-region radius r.
 void mavba_session::launch_front(double r, bool entries, const LmSpec& spec, const CamSweepArgs* with_sweep) {
   sweep_rode_along = false;
+  prereduced = false;  // (new block partials: their long runs have to be pre-reduced again)
   FrontArgs f;
   f.spec = spec;
   f.sw = sweep_args(d_camrec.p, d_intr.p, d_points.p);
@@ -115,6 +116,16 @@ void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
     });
   }
   if (!sweep_rode_along) timed("camera_sweep", [&] { launch_camera_sweep(st, c, KMAX, any_intr_free); });
+  // The pre-reduction of the block partials the cluster kernel has just written (k_partial_reduce's tasks) rides in the next
+  // kernel of the evaluation that does not depend on them - one launch less per linear solve (round 6; C3 778 -> 773 us). Only
+  // when every partial of a pre-reduced run comes from the cluster kernel (no generic term lists: their chunk kernels run in
+  // assemble()), on one rank, and outside the profiled pass (the timers attribute the work to the kernel it belongs to).
+  PartialRide pride;
+  static const bool pride_on = [] { const char* e = std::getenv("MAVBA_PARTIAL_RIDE"); return !e || std::atoi(e) != 0; }();
+  if (pride_on && merge_on && front_ok && front_valid && fused_now() && num_reduce_tasks > 0 && num_chunks[0] + num_chunks[1] + num_chunks[2] == 0 &&
+      num_tail_tiles == 0 && !sharded() && !opt.profile_kernels) {
+    pride.n = num_reduce_tasks; pride.tasks = d_reduce_tasks.p; pride.pp = d_part[0].p; pride.ip = d_part[1].p; pride.ii = d_part[2].p;
+  }
   if (num_priors > 0)
     timed("rot_prior", [&] {
       launch_rot_prior(st, num_priors, d_prior_img.p, d_prior_R0.p, prior_weight, d_poses.p, d_prior_res.p,
@@ -164,8 +175,10 @@ void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
         e.T.t[2] = ReduceTask{d_sweep_partial.p, eval_cost_rows(), 1, 0, d_prior_cost.p, num_priors, d_scal.p + SC_COST};
         e.num_tasks = 3;
         e.spec = spec;
+        e.ride = pride;
         launch_eval_head_tail(st, e);
       });
+      prereduced = pride.n > 0;
       evaluated = true; assembled = false;
       return;
     }
@@ -173,8 +186,9 @@ void mavba_session::evaluate_enqueue(double next_radius, const LmSpec& spec) {
   timed("camera_reduce", [&] {
     launch_camera_reduce(st, NI, NC, d_img_chunk_start.p, d_cam_partial.p, num_priors > 0 ? d_prior_start.p : nullptr,
                          d_prior_res.p, d_prior_jac.p, d_cam_img_start.p, d_cam_imgs.p, d_img_rec, d_cam_rec,
-                         d_img_intr_tmp.p, any_intr_free, spec);
+                         d_img_intr_tmp.p, any_intr_free, spec, pride);
   });
+  prereduced = pride.n > 0;
   allreduce(d_camsum.p, (long long)NI * kImgRec + (long long)NC * kCamRec, 0);
   if (!scales_ready) {
     timed("scales", [&] {
@@ -253,7 +267,7 @@ void mavba_session::assemble(double r) {
   if (num_chunks[2] > 0) timed("schur_chunks_ii", [&] { launch_schur_chunks(st, BLK_II, num_chunks[2], d_chunks[2].p, d_terms[2].p, d_Epose.p, d_Eintr.p, d_part[2].p); });
   const int nbt = n_mat / 64;
   timed("schur_finalize", [&] {
-    launch_partial_reduce(st, num_reduce_tasks, d_reduce_tasks.p, d_part[0].p, d_part[1].p, d_part[2].p);
+    if (!(prereduced && front_valid && front_radius == r)) launch_partial_reduce(st, num_reduce_tasks, d_reduce_tasks.p, d_part[0].p, d_part[1].p, d_part[2].p);
     launch_schur_finalize(st, num_blocks, d_blocks.p, d_part[0].p, d_part[1].p, d_part[2].p, NI, NC, chol_struct.d_tile_slot, nbt, rank == 0,
                           r, dmin, dmax, d_img_cam.p, d_img_rec, d_cam_rec, d_scale_cam.p, d_off.p, d_off.p + NI, d_M.p);
   });
@@ -427,7 +441,7 @@ int mavba_session::iterate(int max_iters, int* done) {
     const LmSpec sp = lm_spec(pending_eval);
     bool speculated = false;
     // what the speculative evaluation changes in the session's books (restored if the step is not accepted)
-    struct Books { bool evaluated, assembled, front_valid, fail_slot_clean; double front_radius; int eval_rows; } books{};
+    struct Books { bool evaluated, assembled, front_valid, fail_slot_clean; double front_radius; int eval_rows; bool prereduced; } books{};
     if (speculate && lm_pub) {
       solve_linear(radius);
       lm_seq += 1.0;
@@ -440,7 +454,7 @@ int mavba_session::iterate(int max_iters, int* done) {
         candidate_enqueue(radius);
         timed("lm_snapshot", [&] { launch_lm_snapshot(st, sp, d_lm_dec.p, lm_pub, lm_seq, d_scal.p + SC_FAIL); });
       }
-      books = Books{evaluated, assembled, front_valid, fail_slot_clean, front_radius, eval_rows};
+      books = Books{evaluated, assembled, front_valid, fail_slot_clean, front_radius, eval_rows, prereduced};
       std::swap(d_poses.p, d_cposes.p); std::swap(d_intr.p, d_cintr.p); std::swap(d_points.p, d_cpoints.p);
       std::swap(d_camrec.p, d_ccamrec.p);
       LmSpec ks = sp;
@@ -462,7 +476,7 @@ int mavba_session::iterate(int max_iters, int* done) {
         std::swap(d_camrec.p, d_ccamrec.p);
         evaluated = books.evaluated; assembled = books.assembled;
         front_valid = false;  // (k_lm_snapshot has cleared SC_FAIL_FRONT too: the front end runs again and rewrites it)
-        fail_slot_clean = false; front_radius = books.front_radius; eval_rows = books.eval_rows;
+        fail_slot_clean = false; front_radius = books.front_radius; eval_rows = books.eval_rows; prereduced = false;
         speculated = false;
         std::fprintf(stderr, "mavba: persistent factorisation timed out, falling back to the launch-per-panel schedule\n");
         allow_persistent = false;
@@ -481,7 +495,7 @@ int mavba_session::iterate(int max_iters, int* done) {
       std::swap(d_camrec.p, d_ccamrec.p);
       evaluated = books.evaluated; assembled = books.assembled; front_valid = books.front_valid;
       fail_slot_clean = false;  // (the speculative front end's fill did run)
-      front_radius = books.front_radius; eval_rows = books.eval_rows;
+      front_radius = books.front_radius; eval_rows = books.eval_rows; prereduced = books.prereduced;
       speculated = false;
     };
     if (dec.code == LM_TERM_GTOL) {  // the previous iteration ended the solve: this one never happened

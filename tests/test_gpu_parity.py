@@ -725,6 +725,29 @@ def test_merged_evaluation_tail_of_a_large_problem_equals_the_four_launches(mavb
 
 
 
+@pytest.mark.parametrize("scale", [0.12, 0.4])
+def test_pre_reduction_riding_in_the_evaluation_changes_nothing(mavba, monkeypatch, scale):
+    """Round 6: the pre-reduction of long runs of block partials (k_partial_reduce's tasks) runs as extra work-groups of the
+    evaluation's next kernel - k_eval_head up to 160 images (scale 0.12: 60 images), k_camera_reduce_img above (scale 0.4: 200
+    images) - instead of a launch of its own before the finalize pass; a rejected step, whose speculative evaluation never
+    ran, and a repeated solve with another radius must find the books right. Same tasks, same order: bit-identical solves."""
+    p0 = synth.make_config("C3", scale=scale, seed=27)
+    assert p0.num_obs >= 200_000   # (from there runs of more than 64 partials are pre-reduced)
+    out = []
+    for ride in ("1", "0"):
+        monkeypatch.setenv("MAVBA_PARTIAL_RIDE", ride)
+        p = p0.copy()
+        with mavba.Session(p, global_opts()) as s:
+            a = s.linear_step(1e4)
+            b = s.linear_step(3e2)          # (another radius on the same evaluation: the front end runs again, without the evaluation)
+            r = s.solve()
+            x = s.get_params()
+        out.append((a["d_poses"], a["d_points"], b["d_poses"], b["d_points"], x[0], x[1], x[2], r["final_cost"], r["num_successful_steps"],
+                    r["num_unsuccessful_steps"], r["termination"]))
+    for u, v in zip(*out):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
 def test_lane_placement_and_its_fallback_match_the_oracle(mavba, oracle, monkeypatch, capfd):
     """k_schur_rows, round 6: in a cluster with two camera slots the set-up places a point's observations in the 8-lane half of
     their camera's slot; a point with more than 8 observations of ONE slot cannot be placed, its cluster keeps the
