@@ -806,13 +806,9 @@ __global__ void __launch_bounds__(256, 2) k_camera_sweep_gram(CamSweepArgs a) {
 void launch_camera_sweep(hipStream_t st, const CamSweepArgs& a, int kmax, bool any_intr_free) {
   if (a.num_chunks <= 0) return;
   const dim3 g(a.num_chunks), b(256);
-  static const bool vector_only = std::getenv("MAVBA_CAMSWEEP_VECTOR") != nullptr;
+  // (with free intrinsics the vector form - k_camera_sweep<4 / 8 / 9>, ~120 accumulators per lane - was 0.133 against the Gram
+  // form's 0.074 ms at C3, round 2; its switch MAVBA_CAMSWEEP_VECTOR went in round 6, the template keeps the code)
   if (!any_intr_free) hipLaunchKernelGGL((k_camera_sweep<0>), g, b, 0, st, a);  // 27 sums: the vector kernel is the cheaper one
-  else if (vector_only) {
-    if (kmax <= 4) hipLaunchKernelGGL((k_camera_sweep<4>), g, b, 0, st, a);
-    else if (kmax <= 8) hipLaunchKernelGGL((k_camera_sweep<8>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((k_camera_sweep<9>), g, b, 0, st, a);
-  }
   else if (kmax <= 4) hipLaunchKernelGGL((k_camera_sweep_gram<4>), g, b, 0, st, a);
   else if (kmax <= 8) hipLaunchKernelGGL((k_camera_sweep_gram<8>), g, b, 0, st, a);
   else hipLaunchKernelGGL((k_camera_sweep_gram<9>), g, b, 0, st, a);

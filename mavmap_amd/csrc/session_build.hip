@@ -1405,8 +1405,7 @@ void mavba_session::finish_structure() {
   // long partial runs are pre-reduced in groups of 32 into extra slots; the block then points at those (launch-bound
   // problems - a local window has ~80 clusters - keep runs of up to 256 for the finalize pass itself: one launch less)
   std::vector<PartialReduce> reduce_tasks;
-  int kPreReduceFrom = N < 200000 ? 256 : 64;
-  if (const char* e = std::getenv("MAVBA_PRE_REDUCE_FROM")) kPreReduceFrom = std::max(32, std::atoi(e));  // tuning knob
+  const int kPreReduceFrom = N < 200000 ? 256 : 64;  // (flat between 64 and 256 at C2 / C3: profiles/r06_ab_small_knobs.txt, item 3)
   for (SchurBlock& B : blocks) {
     const int n = B.chunk_end - B.chunk_begin;
     if (n <= kPreReduceFrom) continue;

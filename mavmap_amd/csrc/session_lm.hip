@@ -59,8 +59,7 @@ void mavba_session::launch_front(double r, bool entries, const LmSpec& spec, con
     // partials of S for this radius (no entry records in HBM)
     // (a local window with constant intrinsics: the camera sweep's chunks ride along as extra work-groups - one launch less)
     // (the sweep's form must be the one launch_camera_sweep would pick: constant intrinsics everywhere, or the Gram form of KMAX)
-    static const bool sweep_vector_only = std::getenv("MAVBA_CAMSWEEP_VECTOR") != nullptr;
-    const bool forms_agree = (Q == 0 && !any_intr_free) || (Q > 0 && any_intr_free && !sweep_vector_only);
+    const bool forms_agree = (Q == 0 && !any_intr_free) || (Q > 0 && any_intr_free);
     const CamSweepArgs* ride = (with_sweep && forms_agree) ? with_sweep : nullptr;
     timed("schur_fused", [&] {
       launch_schur_rows(st, f, Q > 0 ? KMAX : 0, rows_generic, num_clusters, d_rows_clusters.p, d_cl_tab.p, d_rows_lists.p, d_obs_meta.p,
